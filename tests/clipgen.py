@@ -1,0 +1,235 @@
+"""Seeded generators of ring pairs for the clip parity tests, plus ctypes bindings to the two CPU
+clip libraries used as checkers (TEST INFRASTRUCTURE):
+
+  oracle/_ref/libclipper_ref.so      the reference's own Clipper 6.4.2 (built by oracle/Makefile)
+  tests/hostsim/libvatti_host.so     the device sweep engine compiled for the host with g++
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCALE = float(2 ** 32)
+
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+
+
+def matlab_int64(v):
+    """MATLAB int64(double): round half away from zero, saturate (polyclip.m:66)."""
+    v = np.asarray(v, np.float64)
+    t = np.trunc(v)
+    frac = v - t
+    r = t + np.where(np.abs(frac) >= 0.5, np.sign(v), 0.0)
+    r = np.clip(r, -9.223372036854775808e18, 9.223372036854775807e18)
+    out = np.empty(r.shape, np.int64)
+    big = r >= 9.223372036854775807e18
+    out[~big] = r[~big].astype(np.int64)
+    out[big] = np.iinfo(np.int64).max
+    return out
+
+
+def to_fixed(x):
+    return matlab_int64(np.asarray(x, np.float64) * SCALE)
+
+
+class PairSet:
+    """CSR of ring pairs on int64 coordinates."""
+
+    def __init__(self):
+        self.ax, self.ay, self.aoff = [], [], [0]
+        self.bx, self.by, self.boff = [], [], [0]
+
+    def add(self, a, b, fixed=False):
+        a = np.asarray(a); b = np.asarray(b)
+        if not fixed:
+            a = np.stack([to_fixed(a[:, 0]), to_fixed(a[:, 1])], 1)
+            b = np.stack([to_fixed(b[:, 0]), to_fixed(b[:, 1])], 1)
+        self.ax.append(a[:, 0].astype(np.int64)); self.ay.append(a[:, 1].astype(np.int64))
+        self.bx.append(b[:, 0].astype(np.int64)); self.by.append(b[:, 1].astype(np.int64))
+        self.aoff.append(self.aoff[-1] + len(a)); self.boff.append(self.boff[-1] + len(b))
+
+    def arrays(self):
+        cat = lambda l: np.ascontiguousarray(np.concatenate(l)) if l else np.zeros(0, np.int64)
+        return (cat(self.ax), cat(self.ay), np.asarray(self.aoff, np.int32),
+                cat(self.bx), cat(self.by), np.asarray(self.boff, np.int32))
+
+    def __len__(self):
+        return len(self.aoff) - 1
+
+
+def load_shapes():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "floe_shapes.npz"))
+    off = d["off"]
+    return [np.stack([d["x"][off[i]:off[i + 1]], d["y"][off[i]:off[i + 1]]], 1) for i in range(len(off) - 1)], d["polygon_info"]
+
+
+def _rot(p, th):
+    c, s = np.cos(th), np.sin(th)
+    return p @ np.array([[c, s], [-s, c]])
+
+
+def shape_pairs(n, seed=0, max_verts=None):
+    """Pairs of real floe outlines (reference fixture FloeShapes.mat), second one rotated and moved
+    so the two overlap partially, at floe-scale coordinates (1e4..1e5 m)."""
+    rng = np.random.default_rng(seed)
+    shapes, _ = load_shapes()
+    if max_verts:
+        shapes = [s for s in shapes if len(s) <= max_verts]
+    ps = PairSet()
+    for _ in range(n):
+        a = shapes[rng.integers(len(shapes))]
+        b = shapes[rng.integers(len(shapes))]
+        ca, cb = a.mean(0), b.mean(0)
+        ra = np.sqrt(((a - ca) ** 2).sum(1).max()); rb = np.sqrt(((b - cb) ** 2).sum(1).max())
+        th = rng.uniform(0, 2 * np.pi)
+        d = rng.uniform(0.3, 1.1) * (ra + rb)
+        ang = rng.uniform(0, 2 * np.pi)
+        b2 = _rot(b - cb, th) + ca + d * np.array([np.cos(ang), np.sin(ang)])
+        # closed rings, as floe_interactions.m passes them (first vertex repeated)
+        ps.add(np.vstack([a, a[:1]]), np.vstack([b2, b2[:1]]))
+    return ps
+
+
+def convex_pairs(n, seed=0):
+    """Random convex polygons (6-9 vertices, km scale) like fresh Voronoi floes, overlapping a little."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+    for _ in range(n):
+        polys = []
+        for _k in range(2):
+            m = rng.integers(4, 10)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, m))
+            r = rng.uniform(800, 1500)
+            polys.append(np.stack([r * np.cos(ang), r * np.sin(ang)], 1))
+        c = rng.uniform(-9e4, 9e4, 2)
+        d = rng.uniform(0.6, 2.1) * 1200
+        a2 = rng.uniform(0, 2 * np.pi)
+        a = polys[0] + c
+        b = polys[1] + c + d * np.array([np.cos(a2), np.sin(a2)])
+        ps.add(np.vstack([a, a[:1]]), np.vstack([b, b[:1]]))
+    return ps
+
+
+def lattice_pairs(n, seed=0, grid=6, max_verts=9):
+    """Small polygons on a coarse integer lattice: shared edges, horizontal edges, touching vertices,
+    collinear runs, self-intersections -- the degenerate paths of the sweep (joins, horizontals)."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+    unit = 1 << 32
+    for _ in range(n):
+        polys = []
+        for _k in range(2):
+            m = rng.integers(3, max_verts + 1)
+            p = rng.integers(0, grid + 1, (m, 2)).astype(np.int64) * unit
+            polys.append(p)
+        ps.add(polys[0], polys[1], fixed=True)
+    return ps
+
+
+def rect_pairs(n, seed=0, grid=8):
+    """Axis-aligned rectangles and L-shapes on a lattice: every edge horizontal or vertical."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+    unit = 1 << 32
+
+    def rect():
+        x0, x1 = np.sort(rng.choice(grid + 1, 2, replace=False))
+        y0, y1 = np.sort(rng.choice(grid + 1, 2, replace=False))
+        p = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], np.int64)
+        if rng.random() < 0.5:
+            p = p[::-1]
+        if rng.random() < 0.4 and x1 - x0 >= 2 and y1 - y0 >= 2:
+            xm = rng.integers(x0 + 1, x1); ym = rng.integers(y0 + 1, y1)
+            p = np.array([[x0, y0], [x1, y0], [x1, ym], [xm, ym], [xm, y1], [x0, y1]], np.int64)
+        k = rng.integers(len(p))
+        return np.roll(p, k, 0) * unit
+
+    for _ in range(n):
+        ps.add(rect(), rect(), fixed=True)
+    return ps
+
+
+def _build_if_needed(path, cmd):
+    if not os.path.exists(path):
+        subprocess.check_call(cmd, cwd=ROOT)
+
+
+def ref_lib():
+    path = os.path.join(ROOT, "oracle", "_ref", "libclipper_ref.so")
+    if not os.path.exists(path):
+        if not os.path.isdir("/root/reference"):
+            return None
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    L = ctypes.CDLL(path)
+    L.ref_clip_batch.argtypes = [ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p, ctypes.c_int,
+                                 _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
+    return L
+
+
+def host_lib():
+    path = os.path.join(ROOT, "tests", "hostsim", "libvatti_host.so")
+    src = os.path.join(ROOT, "tests", "hostsim", "vatti_host.cpp")
+    hdr = os.path.join(ROOT, "subzero_amd", "csrc", "vatti.hpp")
+    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
+                               src, "-o", path])
+    L = ctypes.CDLL(path)
+    L.host_clip_batch.argtypes = [ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int,
+                                  _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
+    return L
+
+
+class ClipResult:
+    def __init__(self, x, y, ring_off, pair_ring_off, status):
+        self.x, self.y, self.ring_off, self.pair_ring_off, self.status = x, y, ring_off, pair_ring_off, status
+
+    def rings(self, p):
+        out = []
+        for r in range(self.pair_ring_off[p], self.pair_ring_off[p + 1]):
+            a, b = self.ring_off[r], self.ring_off[r + 1]
+            out.append(np.stack([self.x[a:b], self.y[a:b]], 1))
+        return out
+
+
+def _alloc(ps):
+    ax, ay, aoff, bx, by, boff = ps.arrays()
+    n = len(ps)
+    cap_v = int(16 * (len(ax) + len(bx)) + 64 * n + 64)
+    cap_r = int(4 * (len(ax) + len(bx)) + 8 * n + 8)
+    return (ax, ay, aoff, bx, by, boff, np.zeros(cap_v, np.int64), np.zeros(cap_v, np.int64), cap_v,
+            np.zeros(cap_r + 1, np.int32), cap_r, np.zeros(n + 1, np.int32), np.zeros(n, np.int32))
+
+
+def run_ref(ps, method):
+    L = ref_lib()
+    ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st = _alloc(ps)
+    rc = L.ref_clip_batch(len(ps), ax, ay, aoff, bx, by, boff, method, ox, oy, cap_v, roff, cap_r, proff, st)
+    assert rc == 0, rc
+    return ClipResult(ox, oy, roff, proff, st)
+
+
+def run_host(ps, method, fill_s=0, fill_c=0):
+    L = host_lib()
+    ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st = _alloc(ps)
+    rc = L.host_clip_batch(len(ps), ax, ay, aoff, bx, by, boff, method, fill_s, fill_c,
+                           ox, oy, cap_v, roff, cap_r, proff, st)
+    assert rc == 0, rc
+    return ClipResult(ox, oy, roff, proff, st)
+
+
+def compare(r1, r2, n):
+    """Bit-exact comparison: status, ring count, ring order, vertex order.  Returns list of bad pairs."""
+    bad = []
+    for p in range(n):
+        if r1.status[p] != r2.status[p]:
+            bad.append((p, "status", int(r1.status[p]), int(r2.status[p]))); continue
+        a, b = r1.rings(p), r2.rings(p)
+        if len(a) != len(b):
+            bad.append((p, "nrings", len(a), len(b))); continue
+        for k in range(len(a)):
+            if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
+                bad.append((p, "ring%d" % k, a[k].shape, b[k].shape)); break
+    return bad
