@@ -1,0 +1,128 @@
+/* subzero_hip.h -- C ABI of libsubzero_hip.so, the MI355X (gfx950) implementation of SubZero's
+ * per-timestep floe-interaction hot path.
+ *
+ * Two reference surfaces are replaced:
+ *
+ *  B1  the `clipper` mex                 /root/reference/private/mexclipper.cpp:83-305
+ *      called only from                  /root/reference/polyclip.m:73
+ *      -> szClipBatch / szPolyclipBatch / szOrientation
+ *
+ *  B2  the Floe struct-array step        /root/reference/floe_interactions_all.m:1-285
+ *      called from                       /root/reference/Subzero.m:133,301
+ *      -> szFloesUpload / szStep / szFloesDownload / szInteractionsDownload
+ *
+ * Conventions: plain C, plain pointers and sizes, caller owns every host buffer, the context owns all
+ * device memory.  Every function returns an int status (SZ_OK = 0) and never throws, exits or calls
+ * into MATLAB.  One context per process and GPU; a context is not thread-safe (the mex it replaces
+ * is called on MATLAB's interpreter thread only).
+ *
+ * There is no CPU fallback: without a usable gfx950 device szCreate fails with SZ_ERR_NO_DEVICE.
+ */
+#ifndef SUBZERO_HIP_H
+#define SUBZERO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZ_ABI_VERSION 1
+
+/* library status codes */
+enum {
+  SZ_OK = 0,
+  SZ_ERR_NO_DEVICE = -1,
+  SZ_ERR_BAD_ARG = -2,
+  SZ_ERR_HIP = -3,       /* a HIP runtime call failed; see szLastError */
+  SZ_ERR_CAPACITY = -4,  /* caller-provided output buffer too small */
+  SZ_ERR_WORKSPACE = -5, /* a device-side list outgrew every workspace tier (never silent) */
+  SZ_ERR_STATE = -6      /* call out of order (e.g. szStep before szFloesUpload) */
+};
+
+/* per-clip status, one per pair (what the mex would have done for that call) */
+enum {
+  SZ_CLIP_OK = 0,
+  SZ_CLIP_ERROR = 1,        /* mexErrMsgTxt("Clipper Error."), mexclipper.cpp:304 */
+  SZ_CLIP_BAD_ARG = 2,      /* bad method / fill type, mexclipper.cpp:229,259,282 */
+  SZ_CLIP_OUT_CAPACITY = 3, /* internal: result larger than its slot (retried, never returned) */
+  SZ_CLIP_RANGE = 4,        /* coordinate outside Clipper's range, clipper.cpp:883-896 */
+  SZ_CLIP_WORKSPACE = 5     /* internal: retried with a larger workspace, never returned */
+};
+
+/* boolean operation, numbered as the mex's third argument (mexclipper.cpp:215-230; polyclip.m:52-58) */
+enum { SZ_CLIP_DIFFERENCE = 0, SZ_CLIP_INTERSECTION = 1, SZ_CLIP_XOR = 2, SZ_CLIP_UNION = 3 };
+/* fill rule, numbered as the mex's 4th/5th argument (mexclipper.cpp:243-287); default even-odd */
+enum { SZ_FILL_EVENODD = 0, SZ_FILL_NONZERO = 1, SZ_FILL_POSITIVE = 2, SZ_FILL_NEGATIVE = 3 };
+
+typedef struct szContext szContext;
+
+int szAbiVersion(void);
+/* device = HIP device ordinal.  Fails with SZ_ERR_NO_DEVICE when no gfx950 GPU is usable. */
+int szCreate(szContext **ctx, int device);
+int szDestroy(szContext *ctx);
+/* text of the last failure on this context (static storage inside the context) */
+const char *szLastError(const szContext *ctx);
+
+/* ---- B1: boolean clipping, batched ---------------------------------------------------------
+ * npairs independent calls of  clipper(Subj, Clip, method, subj_fill, clip_fill)  with single-ring
+ * Subj and Clip (polyclip.m:72 asserts exactly that).  Rings are given as CSR over one vertex pool:
+ * pair p's subject is (ax,ay)[aoff[p] .. aoff[p+1]), its clip (bx,by)[boff[p] .. boff[p+1]).
+ * int64 coordinates as produced by polyclip.m:66.
+ *
+ * Results, in the order the mex returns them (ring order, first vertex, direction all identical):
+ *   pair p owns rings   pair_ring_off[p] .. pair_ring_off[p+1]
+ *   ring r owns vertices ring_off[r] .. ring_off[r+1]   of (outx,outy)
+ * status[p] is SZ_CLIP_OK / SZ_CLIP_ERROR / SZ_CLIP_BAD_ARG / SZ_CLIP_RANGE.
+ * Returns SZ_ERR_CAPACITY if out_cap / ring_cap are too small (nothing partial is promised).
+ * All pointers are HOST pointers. */
+int szClipBatch(szContext *ctx, int npairs,
+                const int64_t *ax, const int64_t *ay, const int32_t *aoff,
+                const int64_t *bx, const int64_t *by, const int32_t *boff,
+                int method, int subj_fill, int clip_fill,
+                int64_t *outx, int64_t *outy, int64_t out_cap,
+                int32_t *ring_off, int64_t ring_cap,
+                int32_t *pair_ring_off, int32_t *status);
+
+/* polyclip.m:63-80 in one call: doubles in (metres), x2^32 fixed-point conversion with MATLAB int64()
+ * semantics (round half away from zero, saturating), clip, back to doubles (/2^32). Same layout. */
+int szPolyclipBatch(szContext *ctx, int npairs,
+                    const double *ax, const double *ay, const int32_t *aoff,
+                    const double *bx, const double *by, const int32_t *boff,
+                    int method,
+                    double *outx, double *outy, int64_t out_cap,
+                    int32_t *ring_off, int64_t ring_cap,
+                    int32_t *pair_ring_off, int32_t *status);
+
+/* Device-resident form used by the step path and by bench.py: inputs already in HBM (device
+ * pointers), results stay in HBM in per-pair slots; only counters come back.  See DESIGN.md. */
+typedef struct {
+  double kernel_ms;      /* HIP-event time of the clip kernel(s) on the context's stream */
+  int64_t pairs;         /* pairs processed */
+  int64_t input_vertices;/* sum of na+nb */
+  int64_t rings_out;     /* rings produced */
+  int64_t vertices_out;  /* vertices produced */
+  int64_t retried;       /* pairs that needed a larger workspace tier */
+  int64_t failed;        /* pairs with status != SZ_CLIP_OK */
+} szClipStats;
+
+int szClipBatchDevice(szContext *ctx, int npairs,
+                      const int64_t *d_ax, const int64_t *d_ay, const int32_t *d_aoff,
+                      const int64_t *d_bx, const int64_t *d_by, const int32_t *d_boff,
+                      int total_a, int total_b, int method, szClipStats *stats);
+
+/* clipper(P) orientation mode (mexclipper.cpp:134-145): 1 if Area(P) >= 0 else 0.  Host arithmetic
+ * on n vertices (an O(n) sum; there is nothing to accelerate). */
+int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation);
+
+/* raw device memory helpers for callers without a HIP binding (bench.py, tests) */
+int szDeviceAlloc(szContext *ctx, void **dptr, int64_t bytes);
+int szDeviceFree(szContext *ctx, void *dptr);
+int szCopyToDevice(szContext *ctx, void *dst, const void *src, int64_t bytes);
+int szCopyToHost(szContext *ctx, void *dst, const void *src, int64_t bytes);
+int szSynchronize(szContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBZERO_HIP_H */

@@ -1,0 +1,78 @@
+// capi.hip -- context management and raw device-memory helpers of include/subzero_hip.h.
+#include "context.hpp"
+
+void sz_step_destroy(szContext *ctx); // step.hip
+
+extern "C" {
+
+int szAbiVersion(void) { return SZ_ABI_VERSION; }
+
+int szCreate(szContext **out, int device) {
+  if (!out) return SZ_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SZ_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SZ_ERR_NO_DEVICE;
+  // the code objects in this library are gfx950 only
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SZ_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return SZ_ERR_NO_DEVICE;
+  szContext *ctx = new szContext();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return SZ_ERR_HIP;
+  }
+  *out = ctx;
+  return SZ_OK;
+}
+
+int szDestroy(szContext *ctx) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  sz_step_destroy(ctx);
+  DevBuf *bufs[] = {&ctx->ws, &ctx->ovx, &ctx->ovy, &ctx->oroff, &ctx->ov_base, &ctx->or_base,
+                    &ctx->nrings, &ctx->status, &ctx->retry_list, &ctx->counters,
+                    &ctx->in_ax, &ctx->in_ay, &ctx->in_aoff, &ctx->in_bx, &ctx->in_by, &ctx->in_boff,
+                    &ctx->in_fax, &ctx->in_fay, &ctx->in_fbx, &ctx->in_fby};
+  for (DevBuf *b : bufs) sz_release(*b);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SZ_OK;
+}
+
+const char *szLastError(const szContext *ctx) { return ctx ? ctx->err : "null context"; }
+
+int szDeviceAlloc(szContext *ctx, void **dptr, int64_t bytes) {
+  if (!ctx || !dptr || bytes < 0) return SZ_ERR_BAD_ARG;
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  SZ_HIP(ctx, hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 16)));
+  return SZ_OK;
+}
+int szDeviceFree(szContext *ctx, void *dptr) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  if (dptr) SZ_HIP(ctx, hipFree(dptr));
+  return SZ_OK;
+}
+int szCopyToDevice(szContext *ctx, void *dst, const void *src, int64_t bytes) {
+  if (!ctx || bytes < 0) return SZ_ERR_BAD_ARG;
+  if (bytes) SZ_HIP(ctx, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+  return SZ_OK;
+}
+int szCopyToHost(szContext *ctx, void *dst, const void *src, int64_t bytes) {
+  if (!ctx || bytes < 0) return SZ_ERR_BAD_ARG;
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (bytes) SZ_HIP(ctx, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return SZ_OK;
+}
+int szSynchronize(szContext *ctx) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,66 @@
+// context.hpp -- the szContext behind the C ABI (include/subzero_hip.h): one HIP device, one stream,
+// a pair of timing events and growable device buffers owned by the context.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/subzero_hip.h"
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct szContext {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[512] = {0};
+  std::vector<DevBuf *> owned;
+  struct StepState *step = nullptr; // floe state for the B2 surface (step.hip)
+
+  // clip path buffers
+  DevBuf ws, ovx, ovy, oroff, ov_base, or_base, nrings, status, retry_list, counters;
+  DevBuf in_ax, in_ay, in_aoff, in_bx, in_by, in_boff;
+  DevBuf in_fax, in_fay, in_fbx, in_fby; // double inputs of szPolyclipBatch
+};
+
+inline int sz_fail(szContext *ctx, int code, const char *fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define SZ_HIP(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return sz_fail(ctx, SZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                     __FILE__, __LINE__);                                                        \
+  } while (0)
+
+// grow-only device buffer; contents are NOT preserved on growth
+inline int sz_reserve(szContext *ctx, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return SZ_OK;
+  if (b.p) {
+    SZ_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 4 + 256;
+  SZ_HIP(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return SZ_OK;
+}
+inline void sz_release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}

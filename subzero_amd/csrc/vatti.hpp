@@ -263,17 +263,19 @@ struct CrossLess {
 struct Caps {
   int edges, minima, beams, rings, pts, joins, ghosts, crosses;
 };
-// Capacities for a clip whose inputs total nv vertices.  Generous; any overflow is ST_WORKSPACE.
+// Capacities for a clip whose inputs total nv vertices.  Enough for simple polygons (floe outlines);
+// heavily self-intersecting input can outgrow them: that is ST_WORKSPACE, and the caller retries with
+// a larger nv (never a silent truncation).
 SZ_HD Caps caps_for(int nv) {
   Caps c;
   c.edges = nv + 2;
-  c.minima = nv / 2 + 4;
-  c.beams = nv + 4;
-  c.rings = 2 * nv + 16;
-  c.pts = 6 * nv + 32;
-  c.joins = 2 * nv + 16;
-  c.ghosts = nv + 8;
-  c.crosses = 4 * nv + 32;
+  c.minima = nv / 2 + 2;
+  c.beams = nv + 2;
+  c.rings = 2 * nv + 4;
+  c.pts = 6 * nv + 8;
+  c.joins = 2 * nv + 4;
+  c.ghosts = nv + 4;
+  c.crosses = 4 * nv + 8;
   return c;
 }
 SZ_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -284,6 +286,9 @@ SZ_HD size_t workspace_bytes(int nv) {
          align16(sizeof(OutPt) * c.pts) + align16(sizeof(Join) * c.joins) +
          align16(sizeof(Join) * c.ghosts) + align16(sizeof(Cross) * c.crosses);
 }
+// Linear upper bound of workspace_bytes(nv), so that per-pair workspace offsets follow in closed form
+// from the CSR offsets of the inputs: offset(p) = WS_PER_VERTEX * (verts before p) + WS_PER_CLIP * p.
+enum { WS_PER_VERTEX = 528, WS_PER_CLIP = 1024 };
 
 struct Sweep {
   // storage

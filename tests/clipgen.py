@@ -233,3 +233,36 @@ def compare(r1, r2, n):
             if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
                 bad.append((p, "ring%d" % k, a[k].shape, b[k].shape)); break
     return bad
+
+
+GOLDEN_SETS = ["shapes", "convex", "lattice", "rect", "clipper_test_m"]
+
+
+def load_golden(name):
+    """(PairSet-like arrays, {method: ClipResult}) from tests/golden/clip_golden.npz."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "clip_golden.npz"))
+    inp = tuple(np.ascontiguousarray(d["%s/%s" % (name, k)]) for k in ("ax", "ay", "aoff", "bx", "by", "boff"))
+    res = {}
+    for m in range(4):
+        res[m] = ClipResult(d["%s/m%d/x" % (name, m)], d["%s/m%d/y" % (name, m)], d["%s/m%d/ring_off" % (name, m)],
+                            d["%s/m%d/pair_ring_off" % (name, m)], d["%s/m%d/status" % (name, m)])
+    return inp, res
+
+
+class ArraysPairSet:
+    """Adapter so arrays loaded from a fixture can be passed where a PairSet is expected."""
+
+    def __init__(self, arrays):
+        self._a = arrays
+
+    def arrays(self):
+        return self._a
+
+    def __len__(self):
+        return len(self._a[2]) - 1
+
+
+def run_gpu(ctx, ps, method, fill_s=0, fill_c=0):
+    ax, ay, aoff, bx, by, boff = ps.arrays()
+    ox, oy, roff, proff, st = ctx.clip_batch(ax, ay, aoff, bx, by, boff, method, fill_s, fill_c)
+    return ClipResult(ox, oy, roff, proff, st)

@@ -1,0 +1,67 @@
+"""CPU suite for the clip primitive (no GPU):
+  * the oracle (reference Clipper build, oracle/_ref) reproduces the committed golden vectors and the
+    reference's own known answer (private/clipper_test.m:2-12);
+  * the device sweep engine, compiled for the host (tests/hostsim), is bit-identical to the golden
+    vectors and to the live reference on fresh random input;
+  * libstdc++-order sort restatement agrees with std::sort on ties (through the >16 element cases).
+"""
+import numpy as np
+import pytest
+
+import clipgen as g
+
+HAVE_REF = g.ref_lib() is not None
+
+
+def test_known_answer_clipper_test_m():
+    # private/clipper_test.m:2-12 -> intersection is the square (0.5..1)^2, area 0.25
+    inp, res = g.load_golden("clipper_test_m")
+    r = res[1]
+    rings = r.rings(0)
+    assert len(rings) == 1
+    xy = rings[0] / g.SCALE
+    assert np.array_equal(xy, np.array([[1, 1], [0.5, 1], [0.5, 0.5], [1, 0.5]]))
+    x, y = xy[:, 0], xy[:, 1]
+    area = 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+    assert area == 0.25
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built and /root/reference absent")
+@pytest.mark.parametrize("name", g.GOLDEN_SETS)
+def test_reference_build_reproduces_golden(name):
+    inp, res = g.load_golden(name)
+    ps = g.ArraysPairSet(inp)
+    for m in range(4):
+        r = g.run_ref(ps, m)
+        assert g.compare(res[m], r, len(ps)) == []
+
+
+@pytest.mark.parametrize("name", g.GOLDEN_SETS)
+def test_device_engine_on_host_matches_golden(name):
+    inp, res = g.load_golden(name)
+    ps = g.ArraysPairSet(inp)
+    for m in range(4):
+        h = g.run_host(ps, m)
+        assert g.compare(res[m], h, len(ps)) == []
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built and /root/reference absent")
+@pytest.mark.parametrize("gen,n,kw", [
+    (g.convex_pairs, 4000, {}),
+    (g.shape_pairs, 600, {}),
+    (g.lattice_pairs, 4000, {}),
+    (g.lattice_pairs, 1500, {"grid": 10, "max_verts": 30}),   # >16 crossings / minima: sort tie order
+    (g.lattice_pairs, 3000, {"grid": 3, "max_verts": 12}),    # dense coincidences: joins, horizontals
+    (g.rect_pairs, 3000, {}),
+])
+def test_device_engine_on_host_matches_live_reference(gen, n, kw):
+    ps = gen(n, seed=4242, **kw)
+    for m in range(4):
+        r, h = g.run_ref(ps, m), g.run_host(ps, m)
+        assert g.compare(r, h, len(ps)) == []
+
+
+def test_matlab_int64_rounding():
+    v = np.array([0.5, -0.5, 1.5, -1.5, 2.4999, -2.5, 1e30, -1e30, 0.49999999999999994])
+    out = g.matlab_int64(v)
+    assert out.tolist() == [1, -1, 2, -2, 2, -3, 2 ** 63 - 1, -2 ** 63, 0]
