@@ -1,0 +1,985 @@
+// TEST INFRASTRUCTURE ONLY (oracle).  Never linked, imported or called by the product path
+// (subzero_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+// checker / the timed CPU baseline.
+//
+// CPU restatement of SubZero's per-timestep floe-interaction hot path, following the reference's
+// MATLAB text function by function and line by line (quirks included):
+//
+//   or_step                 floe_interactions_all.m:9-285
+//   floe_interactions       collisions/floe_interactions.m:1-199
+//   polyclip                polyclip.m:63-80   (clip itself = the reference's own Clipper, oracle/_ref)
+//   interx                  collisions/InterX.m:54-81
+//   p_poly_dist             polygon_operations/p_poly_dist.m:111-288
+//   inpolygon               polygon_operations/inpolygon.m:64-224
+//   calc_trajectory         calc_trajectory.m:1-241
+//
+// MathWorks builtins that are not in the reference repo are replaced by their documented definitions
+// (SURVEY.md section 8c): polyshape area/centroid = shoelace (pinned against MATLAB's own cached values
+// in the FloeShapes.mat fixture), polyarea = its published one-liner, dsearchn = brute-force nearest
+// vertex, interp2 = bilinear, cart2pol = atan2/hypot, unique(...,'rows') = lexicographic sort + dedupe,
+// sum/mean = left-to-right.  sin/cos/atan2 come from or_math.h (self-contained, <= 1-2 ulp).
+//
+// PARITY STATUS: the C++ clip is pinned by the reference's own known answer (private/clipper_test.m)
+// and by being the reference's own source.  The MATLAB layers are "parity unpinned" by the reference
+// (it ships no golden output and no MATLAB/Octave exists here); they are pinned only through the
+// FloeShapes.mat area/centroid values and by review against the .m text cited at each function.
+#include "subzero_oracle.h"
+#include "or_math.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <limits>
+#include <utility>
+#include <vector>
+
+namespace {
+
+typedef std::vector<double> Vec;
+const double INF = std::numeric_limits<double>::infinity();
+const double NaN = std::numeric_limits<double>::quiet_NaN();
+const double EPS = 2.220446049250313e-16;
+
+struct Ring {
+  Vec x, y;
+};
+
+// ---------------------------------------------------------------------------------------------
+// clip function (dlopen'ed so the oracle itself has no link-time dependency on either checker)
+// ---------------------------------------------------------------------------------------------
+typedef int (*ref_clip_fn)(const int64_t *, const int64_t *, const int32_t *, int, const int64_t *,
+                           const int64_t *, const int32_t *, int, int, int, int, int64_t *, int64_t *, int,
+                           int32_t *, int, int32_t *);
+typedef int (*host_clip_fn)(int, const int64_t *, const int64_t *, const int32_t *, const int64_t *,
+                            const int64_t *, const int32_t *, int, int, int, int64_t *, int64_t *, int64_t,
+                            int32_t *, int64_t, int32_t *, int32_t *);
+ref_clip_fn g_ref_clip = nullptr;
+host_clip_fn g_host_clip = nullptr;
+
+// MATLAB int64(v * 2^32): round half away from zero, saturate (polyclip.m:63,66)
+int64_t to_fixed(double v) {
+  double s = v * 4294967296.0;
+  if (s != s) return 0;
+  if (s >= 9223372036854775807.0) return INT64_MAX;
+  if (s <= -9223372036854775808.0) return INT64_MIN;
+  double t = trunc(s);
+  double f = s - t;
+  if (f >= 0.5) t += 1.0;
+  else if (f <= -0.5) t -= 1.0;
+  return (int64_t)t;
+}
+
+// polyclip.m:63-80.  method: 0 'dif', 1 'int', 2 'xor', 3 'union'.  ok=false -> the mex would have raised.
+std::vector<Ring> polyclip(const Vec &x1, const Vec &y1, const Vec &x2, const Vec &y2, int method, bool &ok) {
+  std::vector<Ring> out;
+  ok = true;
+  int n1 = (int)x1.size(), n2 = (int)x2.size();
+  std::vector<int64_t> ax(n1), ay(n1), bx(n2), by(n2);
+  for (int i = 0; i < n1; ++i) { ax[i] = to_fixed(x1[i]); ay[i] = to_fixed(y1[i]); }
+  for (int i = 0; i < n2; ++i) { bx[i] = to_fixed(x2[i]); by[i] = to_fixed(y2[i]); }
+  int cap = 4 * (n1 + n2) + 64;
+  for (int attempt = 0; attempt < 6; ++attempt, cap *= 8) {
+    std::vector<int64_t> ox(cap), oy(cap);
+    std::vector<int32_t> roff(cap + 1);
+    int32_t aoff[2] = {0, n1}, boff[2] = {0, n2};
+    int32_t nr = 0;
+    int rc, st = 0;
+    if (g_ref_clip) {
+      rc = g_ref_clip(ax.data(), ay.data(), aoff, 1, bx.data(), by.data(), boff, 1, method, 0, 0, ox.data(),
+                      oy.data(), cap, roff.data(), cap, &nr);
+      if (rc == 3) continue;
+      st = rc;
+    } else {
+      int32_t proff[2] = {0, 0};
+      int32_t stat = 0;
+      rc = g_host_clip(1, ax.data(), ay.data(), aoff, bx.data(), by.data(), boff, method, 0, 0, ox.data(),
+                       oy.data(), cap, roff.data(), cap, proff, &stat);
+      if (rc == 3) continue;
+      st = stat;
+      nr = proff[1];
+    }
+    if (st != 0) { ok = false; return out; }
+    out.resize(nr);
+    for (int r = 0; r < nr; ++r) {
+      for (int v = roff[r]; v < roff[r + 1]; ++v) {
+        out[r].x.push_back((double)ox[v] / 4294967296.0); // polyclip.m:67
+        out[r].y.push_back((double)oy[v] / 4294967296.0);
+      }
+    }
+    return out;
+  }
+  ok = false;
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MathWorks builtins, by definition
+// ---------------------------------------------------------------------------------------------
+// area(polyshape(X,Y)) of one ring: |shoelace|, evaluated relative to the first vertex
+double ring_area_signed(const double *x, const double *y, int n) {
+  if (n < 3) return 0;
+  double s = 0;
+  for (int i = 0; i < n; ++i) {
+    int k = (i + 1 == n) ? 0 : i + 1;
+    double ax = x[i] - x[0], ay = y[i] - y[0], bx = x[k] - x[0], by = y[k] - y[0];
+    s += ax * by - bx * ay;
+  }
+  return 0.5 * s;
+}
+double ring_area(const double *x, const double *y, int n) { return fabs(ring_area_signed(x, y, n)); }
+
+// centroid(polyshape(X,Y)) of one ring, relative to the first vertex
+void ring_centroid(const double *x, const double *y, int n, double &cx, double &cy) {
+  double s = 0, sx = 0, sy = 0;
+  for (int i = 0; i < n; ++i) {
+    int k = (i + 1 == n) ? 0 : i + 1;
+    double ax = x[i] - x[0], ay = y[i] - y[0], bx = x[k] - x[0], by = y[k] - y[0];
+    double w = ax * by - bx * ay;
+    s += w;
+    sx += (ax + bx) * w;
+    sy += (ay + by) * w;
+  }
+  cx = x[0] + sx / (3.0 * s);
+  cy = y[0] + sy / (3.0 * s);
+}
+
+// polyarea.m: abs(sum((x([2:n 1]) - x) .* (y([2:n 1]) + y)) / 2)
+double polyarea(const double *x, const double *y, int n) {
+  double s = 0;
+  for (int i = 0; i < n; ++i) {
+    int k = (i + 1 == n) ? 0 : i + 1;
+    s += (x[k] - x[i]) * (y[k] + y[i]);
+  }
+  return fabs(s / 2);
+}
+
+double hyp(double a, double b) { return sqrt(a * a + b * b); }
+
+// ---------------------------------------------------------------------------------------------
+// InterX.m:54-81 -- all crossings of two polylines (here: closed rings), sorted unique rows
+// ---------------------------------------------------------------------------------------------
+void interx(const double *x1, const double *y1, int n1, const double *x2, const double *y2, int n2,
+            Vec &px, Vec &py) {
+  px.clear(); py.clear();
+  int m1 = n1 - 1, m2 = n2 - 1;
+  if (m1 < 1 || m2 < 1) return;
+  Vec dx1(m1), dy1(m1), S1(m1), dx2(m2), dy2(m2), S2(m2);
+  for (int i = 0; i < m1; ++i) {
+    dx1[i] = x1[i + 1] - x1[i]; dy1[i] = y1[i + 1] - y1[i];
+    S1[i] = dx1[i] * y1[i] - dy1[i] * x1[i];           // :60
+  }
+  for (int j = 0; j < m2; ++j) {
+    dx2[j] = x2[j + 1] - x2[j]; dy2[j] = y2[j + 1] - y2[j];
+    S2[j] = dx2[j] * y2[j] - dy2[j] * x2[j];           // :61
+  }
+  std::vector<std::pair<double, double> > pts;
+  // [i,j] = find(C1 & C2): column-major, j outer
+  for (int j = 0; j < m2; ++j) {
+    for (int i = 0; i < m1; ++i) {
+      double a = dx1[i] * y2[j] - dy1[i] * x2[j];          // :63
+      double b = dx1[i] * y2[j + 1] - dy1[i] * x2[j + 1];
+      bool C1 = ((a - S1[i]) * (b - S1[i])) <= 0;
+      double c = y1[i] * dx2[j] - x1[i] * dy2[j];          // :64
+      double d = y1[i + 1] * dx2[j] - x1[i + 1] * dy2[j];
+      bool C2 = ((c - S2[j]) * (d - S2[j])) <= 0;
+      if (!(C1 && C2)) continue;
+      double L = dy2[j] * dx1[i] - dy1[i] * dx2[j];        // :72
+      if (L == 0) continue;                                 // :73
+      double X = (dx2[j] * S1[i] - dx1[i] * S2[j]) / L;    // :76-77
+      double Y = (dy2[j] * S1[i] - dy1[i] * S2[j]) / L;
+      pts.push_back(std::make_pair(X, Y));
+    }
+  }
+  std::sort(pts.begin(), pts.end());
+  for (size_t k = 0; k < pts.size(); ++k) {
+    if (k > 0 && pts[k].first == pts[k - 1].first && pts[k].second == pts[k - 1].second) continue;
+    px.push_back(pts[k].first); py.push_back(pts[k].second);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inpolygon.m:64-224 (vendored copy of the MathWorks routine), single loop, one point at a time
+// ---------------------------------------------------------------------------------------------
+bool inpolygon1(double x, double y, const Vec &xv0, const Vec &yv0) {
+  int n = (int)xv0.size();
+  if (n == 0) return false;
+  double mnx = xv0[0], mxx = xv0[0], mny = yv0[0], mxy = yv0[0];
+  for (int k = 1; k < n; ++k) {
+    mnx = std::min(mnx, xv0[k]); mxx = std::max(mxx, xv0[k]);
+    mny = std::min(mny, yv0[k]); mxy = std::max(mxy, yv0[k]);
+  }
+  if (!(x >= mnx && x <= mxx && y >= mny && y <= mxy)) return false; // :76-81
+  Vec xv = xv0, yv = yv0;
+  if (n >= 3 && (xv[0] != xv[n - 1] || yv[0] != yv[n - 1])) { xv.push_back(xv[0]); yv.push_back(yv[0]); } // close_loops
+  int Nv = (int)xv.size();
+  double sumdq = 0;
+  bool on = false;
+  for (int m = 0; m + 1 < Nv; ++m) {
+    double avx = fabs(0.5 * (xv[m] + xv[m + 1]));          // :165-168
+    double avy = fabs(0.5 * (yv[m] + yv[m + 1]));
+    double sf = std::max(avx, avy);
+    sf = std::max(sf, avx * avy);
+    double ax = xv[m] - x, ay = yv[m] - y, bx = xv[m + 1] - x, by = yv[m + 1] - y; // :171-172
+    int qa, qb;
+    { bool px = ax > 0, py = ay > 0; qa = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+    { bool px = bx > 0, py = by > 0; qb = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+    double cp = ax * by - bx * ay;                           // :188
+    double scp = (cp > 0) ? 1 : (cp < 0 ? -1 : 0);
+    if (fabs(cp) < sf * EPS * 3) scp = 0;                    // :196-198
+    double dp = ax * bx + ay * by;                           // :200
+    double dq = qb - qa;                                     // :203
+    if (fabs(dq) == 3) dq = -dq / 3;                         // :208-209
+    if (fabs(dq) == 2) dq = 2 * scp;                         // :210-211
+    sumdq += dq;
+    if (scp == 0 && dp <= 0) on = true;                      // :222
+  }
+  return (sumdq != 0) || on;
+}
+
+// ---------------------------------------------------------------------------------------------
+// p_poly_dist.m:111-288 with find_in_out = true (4 inputs, 1 output -> :115-116); only |d_min| is
+// consumed by the caller (floe_interactions.m:127), so the sign (inpolygon, :285-288) is applied too
+// but is immaterial.
+// ---------------------------------------------------------------------------------------------
+void p_poly_dist(const Vec &xp, const Vec &yp, const Vec &xv0, const Vec &yv0, Vec &dmin) {
+  Vec xv = xv0, yv = yv0;
+  int nv = (int)xv.size();
+  if (xv[0] != xv[nv - 1] || yv[0] != yv[nv - 1]) { xv.push_back(xv[0]); yv.push_back(yv[0]); nv++; } // :133-141
+  int np = (int)xp.size();
+  dmin.assign(np, 0.0);
+  int ns = nv - 1;
+  Vec vds(ns), ct(ns), st(ns), p1r1(ns), p1r2(ns);
+  for (int k = 0; k < ns; ++k) {
+    double dvx = xv[k + 1] - xv[k], dvy = yv[k + 1] - yv[k];
+    vds[k] = hyp(dvx, dvy);                                  // :163
+    ct[k] = dvx / vds[k]; st[k] = dvy / vds[k];              // :185-186
+    p1r1[k] = ct[k] * xv[k] + st[k] * yv[k];                 // :195-196
+    p1r2[k] = -st[k] * xv[k] + ct[k] * yv[k];
+  }
+  for (int j = 0; j < np; ++j) {
+    double dpv_min = INF; int I_dpv = 0;
+    for (int k = 0; k < nv; ++k) {                           // :151-155
+      double d = hyp(xv[k] - xp[j], yv[k] - yp[j]);
+      if (d < dpv_min) { dpv_min = d; I_dpv = k; }
+    }
+    double cr_min = NaN; int I_cr = 0;
+    for (int k = 0; k < ns; ++k) {
+      double r = (xp[j] * ct[k] + yp[j] * st[k]) - p1r1[k];  // :210,214
+      double cr = (xp[j] * (-st[k]) + yp[j] * ct[k]) - p1r2[k]; // :211,215
+      if (r > 0 && r < vds[k]) {                             // :256
+        double a = fabs(cr);
+        if (cr_min != cr_min || a < cr_min) { cr_min = a; I_cr = k; } // :264
+      }
+    }
+    bool cond1 = (cr_min != cr_min);                         // :271
+    bool cond2 = (I_cr != I_dpv) && ((cr_min - dpv_min) > 0);// :275
+    double d = (cond1 || cond2) ? dpv_min : cr_min;          // :280-281
+    if (inpolygon1(xp[j], yp[j], xv, yv)) d = -d;            // :285-288
+    dmin[j] = d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// collisions/floe_interactions.m
+// ---------------------------------------------------------------------------------------------
+struct Body { // the fields of floe1 / potentialInteractions(k) / floebound that the function reads
+  double Xi, Yi, Ui, Vi, ksi_ice, h, area;
+};
+struct Contact {
+  double fx, fy, px, py, overlap;
+};
+
+// returns false if the clipper failed (MATLAB would have raised an error)
+bool floe_interactions(const Vec &c1x_in, const Vec &c1y_in, const Body &f1, const Vec &c2x_in,
+                       const Vec &c2y_in, const Body &f2, bool boundary, const double *c2b, bool PERIODIC,
+                       double Modulus, double dt, double mu, double nu, std::vector<Contact> &rows) {
+  rows.clear();
+  // :10-21
+  double h1 = f1.h, h2 = f2.h;
+  double r1 = sqrt(f1.area), r2 = sqrt(f2.area);
+  double Force_factor = Modulus * (h1 * h2) / (h1 * r2 + h2 * r1);
+  double overlap0 = 0;
+  if (boundary) Force_factor = Modulus * h1 / r1;              // :13-14 (floebound has field 'alive')
+  else if (r1 > 1e5 || r2 > 1e5) {                             // :15-19
+    r1 = std::min(r1, r2);
+    h1 = std::min(h1, h2);
+    Force_factor = Modulus * h1 / r1;
+  }
+  double G = Modulus / (2 * (1 + nu));                         // :21
+
+  Vec c1x = c1x_in, c1y = c1y_in, c2x = c2x_in, c2y = c2y_in;  // :25-27
+  bool ok;
+  std::vector<Ring> reg = polyclip(c1x, c1y, c2x, c2y, boundary ? 0 : 1, ok); // :29 / :34
+  if (!ok) return false;
+  if (boundary && !reg.empty()) {                              // :35-40
+    if (polyarea(reg[0].x.data(), reg[0].y.data(), (int)reg[0].x.size()) / f1.area > 0.75) overlap0 = INF;
+  }
+  Vec Ar;
+  if (reg.empty()) Ar.push_back(0);                            // :43-44
+  else for (size_t k = 0; k < reg.size(); ++k) Ar.push_back(ring_area(reg[k].x.data(), reg[k].y.data(), (int)reg[k].x.size())); // :46-50
+
+  // :54-60 merge flags
+  {
+    double mx1 = c1x[0], mn1 = c1x[0], my1 = c1y[0], mny1 = c1y[0];
+    for (size_t k = 1; k < c1x.size(); ++k) {
+      mx1 = std::max(mx1, c1x[k]); mn1 = std::min(mn1, c1x[k]);
+      my1 = std::max(my1, c1y[k]); mny1 = std::min(mny1, c1y[k]);
+    }
+    double bxmax = c2b[0], bxmin = c2b[0], bymax = c2b[1], bymin = c2b[1];
+    for (int k = 1; k < 5; ++k) {
+      bxmax = std::max(bxmax, c2b[2 * k]); bxmin = std::min(bxmin, c2b[2 * k]);
+      bymax = std::max(bymax, c2b[2 * k + 1]); bymin = std::min(bymin, c2b[2 * k + 1]);
+    }
+    double bx[4] = {c2b[0], c2b[2], c2b[4], c2b[6]}, by[4] = {c2b[1], c2b[3], c2b[5], c2b[7]};
+    double barea = ring_area(bx, by, 4);
+    bool inside = (mx1 < bxmax && mn1 > bxmin && my1 < bymax && mny1 > bymin);
+    if (inside || f2.area < 0.95 * barea || PERIODIC) {
+      double sumAr = 0;
+      for (size_t k = 0; k < Ar.size(); ++k) sumAr += Ar[k];
+      if (sumAr / f1.area > 0.55) overlap0 = INF;
+      else if (sumAr / f2.area > 0.55) overlap0 = -INF;
+    }
+  }
+  // :62-67 close the rings
+  if (hyp(c1x[0] - c1x.back(), c1y[0] - c1y.back()) > 1) { c1x.push_back(c1x[0]); c1y.push_back(c1y[0]); }
+  if (hyp(c2x[0] - c2x.back(), c2y[0] - c2y.back()) > 1) { c2x.push_back(c2x[0]); c2y.push_back(c2y[0]); }
+
+  Vec Px, Py;
+  interx(c1x.data(), c1y.data(), (int)c1x.size(), c2x.data(), c2y.data(), (int)c2x.size(), Px, Py); // :70
+  if (Px.size() < 2 || std::isinf(overlap0) || reg.empty()) {  // :71-74
+    Contact c = {0, 0, 0, 0, overlap0};
+    rows.push_back(c);
+    return true;
+  }
+  int N1 = (int)c1x.size() - 1, N2 = (int)c2x.size() - 1;      // :78-79
+  double Amin = std::min(N1, N2) * 100 / 1.75;
+  {                                                             // :83
+    std::vector<Ring> r2v; Vec a2;
+    for (size_t k = 0; k < reg.size(); ++k) if (!(Ar[k] < Amin)) { r2v.push_back(reg[k]); a2.push_back(Ar[k]); }
+    reg.swap(r2v); Ar.swap(a2);
+  }
+  int N_contact = (int)reg.size();
+  for (int k = 0; k < N_contact; ++k) {
+    const Vec &X = reg[k].x, &Y = reg[k].y;
+    int nr = (int)X.size();
+    double cx, cy;
+    ring_centroid(X.data(), Y.data(), nr, cx, cy);              // :96-97
+    // :98-100 dsearchn: nearest region vertex of every crossing point
+    Vec ppx, ppy;
+    for (size_t q = 0; q < Px.size(); ++q) {
+      double best = INF; int bi = 0;
+      for (int v = 0; v < nr; ++v) {
+        double ddx = X[v] - Px[q], ddy = Y[v] - Py[q];
+        double d2 = ddx * ddx + ddy * ddy;
+        if (d2 < best) { best = d2; bi = v; }
+      }
+      if (sqrt(best) < 1) { ppx.push_back(X[bi]); ppy.push_back(Y[bi]); }
+    }
+    int m = (int)ppx.size();
+    double fdx = 0, fdy = 0, dl = 0, pcx = cx, pcy = cy;
+    if (Ar[k] == 0) { fdx = fdy = 0; pcx = pcy = 0; dl = 0; }   // :103-106
+    else if (m == 2) {                                          // :107-112
+      double xgh = ppx[1] - ppx[0], ygh = ppy[1] - ppy[0];
+      double b = sqrt(xgh * xgh + ygh * ygh);
+      fdx = -ygh / b; fdy = xgh / b;
+      dl = b;
+    } else if (m == 0) { fdx = fdy = 0; dl = 0; }               // :113-116
+    else {                                                      // :117-137
+      Vec xv = X, yv = Y; xv.push_back(X[0]); yv.push_back(Y[0]);
+      Vec xm(nr), ym(nr), b(nr), nx(nr), ny(nr);
+      for (int e = 0; e < nr; ++e) {
+        double xgh = xv[e + 1] - xv[e], ygh = yv[e + 1] - yv[e];
+        xm[e] = (xv[e + 1] + xv[e]) / 2; ym[e] = (yv[e + 1] + yv[e]) / 2;
+        b[e] = sqrt(xgh * xgh + ygh * ygh);
+        nx[e] = -ygh / b[e]; ny[e] = xgh / b[e];
+        double xt = xm[e] + nx[e] / 100, yt = ym[e] + ny[e] / 100;
+        if (!inpolygon1(xt, yt, xv, yv)) { nx[e] = -nx[e]; ny[e] = -ny[e]; }   // :123-124
+      }
+      Vec d;
+      p_poly_dist(xm, ym, c1x, c1y, d);                         // :126
+      int non = 0;
+      double sfx = 0, sfy = 0, sb = 0;
+      for (int e = 0; e < nr; ++e) {
+        if (fabs(d[e]) < 1e-8) {                                // :127
+          ++non;
+          sfx += (-Force_factor * b[e]) * nx[e];                // :125,129  Fn = -Force_factor*(b*[1 1]).*n
+          sfy += (-Force_factor * b[e]) * ny[e];
+          sb += b[e];
+        }
+      }
+      if (non < nr && non > 0) {                                // :128-131
+        double nrm = sqrt(sfx * sfx + sfy * sfy);
+        fdx = sfx / nrm; fdy = sfy / nrm;
+        dl = sb / non;
+      } else { fdx = fdy = 0; dl = 0; }
+    }
+    // :140-155 direction check by re-clipping the ring shifted 1 m along the force direction
+    Vec X1n = c1x, Y1n = c1y;
+    if (dl < 0.1) { fdx = 0; fdy = 0; }
+    else for (size_t q = 0; q < X1n.size(); ++q) { X1n[q] = c1x[q] + fdx; Y1n[q] = c1y[q] + fdy; }
+    std::vector<Ring> regn = polyclip(X1n, Y1n, c2x, c2y, boundary ? 0 : 1, ok);
+    if (!ok) return false;
+    for (size_t ii = 0; ii < regn.size(); ++ii) {               // :156-165
+      std::vector<Ring> rn = polyclip(regn[ii].x, regn[ii].y, X, Y, 1, ok);
+      if (!ok) return false;
+      if (!rn.empty()) {
+        double Anew = polyarea(regn[ii].x.data(), regn[ii].y.data(), (int)regn[ii].x.size());
+        if (Anew / Ar[k] - 1 > 0) { fdx = -fdx; fdy = -fdy; }
+      }
+    }
+    double Fx = fdx * Ar[k] * Force_factor, Fy = fdy * Ar[k] * Force_factor; // :167
+    // :170-183 tangential force
+    double v1x = f1.Ui + f1.ksi_ice * (pcx - f1.Xi), v1y = f1.Vi + f1.ksi_ice * (pcy - f1.Yi);
+    double v2x = f2.Ui + f2.ksi_ice * (pcx - f2.Xi), v2y = f2.Vi + f2.ksi_ice * (pcy - f2.Yi);
+    double vtx = v1x - v2x, vty = v1y - v2y;
+    double dtx, dty;
+    if (std::max(fabs(vtx), fabs(vty)) == 0) { dtx = 0; dty = 0; }
+    else { double nv = sqrt(vtx * vtx + vty * vty); dtx = vtx / nv; dty = vty / nv; }
+    double vn = sqrt(vtx * vtx + vty * vty);
+    double coef = -(dtx * vtx + dty * vty) * dl * G * vn;       // :178, left to right
+    double ftx = coef * dtx * dt, fty = coef * dty * dt;
+    double nF = sqrt(Fx * Fx + Fy * Fy);
+    if (sqrt(ftx * ftx + fty * fty) > mu * nF) {                // :180-181
+      ftx = -mu * nF * dtx; fty = -mu * nF * dty;
+    }
+    Contact c = {Fx + ftx, Fy + fty, pcx, pcy, Ar[k]};          // :186-187
+    rows.push_back(c);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// calc_trajectory.m
+// ---------------------------------------------------------------------------------------------
+double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, const double *V, double xq, double yq) {
+  // V is ny x nx column-major.  NaN outside the grid, as interp2 does.
+  if (!(xq >= Xo[0] && xq <= Xo[nx - 1] && yq >= Yo[0] && yq <= Yo[ny - 1])) return NaN;
+  int ix = (int)floor((xq - Xo[0]) / (Xo[1] - Xo[0]));
+  int iy = (int)floor((yq - Yo[0]) / (Yo[1] - Yo[0]));
+  if (ix > nx - 2) ix = nx - 2;
+  if (iy > ny - 2) iy = ny - 2;
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  while (ix > 0 && xq < Xo[ix]) --ix;
+  while (ix < nx - 2 && xq > Xo[ix + 1]) ++ix;
+  while (iy > 0 && yq < Yo[iy]) --iy;
+  while (iy < ny - 2 && yq > Yo[iy + 1]) ++iy;
+  double tx = (xq - Xo[ix]) / (Xo[ix + 1] - Xo[ix]);
+  double ty = (yq - Yo[iy]) / (Yo[iy + 1] - Yo[iy]);
+  double v00 = V[iy + (size_t)ny * ix], v01 = V[iy + (size_t)ny * (ix + 1)];
+  double v10 = V[iy + 1 + (size_t)ny * ix], v11 = V[iy + 1 + (size_t)ny * (ix + 1)];
+  double a = v00 * (1 - tx) + v01 * tx;
+  double b = v10 * (1 - tx) + v11 * tx;
+  return a * (1 - ty) + b * ty;
+}
+
+struct FloeRef {
+  OrFloes *f;
+  int i;
+};
+
+// returns: 0 updated, 1 floe removed (tmp = []), -3 unsupported (Monte-Carlo regeneration needs rand)
+int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, int nrows) {
+  const double dt = P->dt;
+  double ext_fx = F->collision_force[2 * i], ext_fy = F->collision_force[2 * i + 1]; // :3
+  double ext_torque = F->collision_torque[i];                                         // :4
+  const double HFo = P->HFo;                                                          // :5
+  const int Nz = F->n_stress;
+  double *SH = F->StressH + (size_t)i * Nz * 4;
+  // :9-29 stress
+  double S[4] = {0, 0, 0, 0}; // column-major 2x2: [xx, yx, xy, yy]
+  if (nrows > 0) {
+    double r1 = F->Xi[i], r2 = F->Yi[i];
+    double s11 = 0, s12 = 0, s21 = 0, s22 = 0, t11 = 0, t12 = 0, t21 = 0, t22 = 0;
+    for (int k = 0; k < nrows; ++k) {
+      const double *a = rows + 7 * k;
+      s11 += (a[3] - r1) * a[1]; s12 += (a[4] - r2) * a[1];
+      s21 += (a[3] - r1) * a[2]; s22 += (a[4] - r2) * a[2];
+      t11 += a[1] * (a[3] - r1); t12 += a[2] * (a[3] - r1);
+      t21 += a[1] * (a[4] - r2); t22 += a[2] * (a[4] - r2);
+    }
+    double c = 1 / (2 * F->area[i] * F->h[i]);
+    S[0] = c * (s11 + t11); S[1] = c * (s21 + t21); S[2] = c * (s12 + t12); S[3] = c * (s22 + t22);
+  }
+  if (F->StressCount[i] > Nz) F->StressCount[i] = 1;
+  for (int q = 0; q < 4; ++q) SH[(size_t)(F->StressCount[i] - 1) * 4 + q] = S[q];
+  F->StressCount[i] += 1;
+  for (int q = 0; q < 4; ++q) {                               // :20 mean(StressH,3)
+    double s = 0;
+    for (int z = 0; z < Nz; ++z) s += SH[(size_t)z * 4 + q];
+    F->Stress[4 * i + q] = s / Nz;
+  }
+  // :36-41
+  if (F->h[i] > 10) F->h[i] = 10;
+  else if (F->mass[i] < 100) { F->mass[i] = 1e3; F->alive[i] = 0; }
+  // :42-46
+  while (std::max(fabs(ext_fx), fabs(ext_fy)) > F->mass[i] / (5 * dt)) {
+    ext_fx = ext_fx / 10; ext_fy = ext_fy / 10; ext_torque = ext_torque / 10;
+  }
+  const double *Xo = P->Xo, *Yo = P->Yo;
+  const int nxo = P->nxo, nyo = P->nyo;
+  const double rho0 = 1027, Cd = 3e-3, rho_air = 1.2, Cd_atm = 1e-3; // :58-64
+  const double fc = P->fCoriolis;
+  const double floe_area = F->area[i];
+  double floe_mass = F->mass[i];
+  double h = F->h[i];
+  double floe_inertia = F->inertia_moment[i];
+  // :76-80
+  double dh = HFo * dt / h;
+  floe_mass = (h - dh) / h * floe_mass; F->mass[i] = floe_mass;
+  floe_inertia = (h - dh) / h * floe_inertia; F->inertia_moment[i] = floe_inertia;
+  F->h[i] = h - dh;
+  if (F->Xi[i] != F->Xi[i]) return 1;                          // :89
+  const int v0 = F->vert_off[i], nvr = F->vert_off[i + 1] - v0;
+  const int nmc = F->n_mc;
+  const bool doforce = P->doInt || F->h[i] < 0.1;              // :94,121 (FxOA is never empty here)
+  Vec xr1, xr2;
+  if (doforce) {
+    double sa, ca;
+    orm_sincos(F->alpha_i[i], &sa, &ca);                        // :97
+    const double *mx = F->mcX + (size_t)i * nmc, *my = F->mcY + (size_t)i * nmc;
+    xr1.resize(nmc); xr2.resize(nmc);
+    for (int q = 0; q < nmc; ++q) { xr1[q] = ca * mx[q] + (-sa) * my[q]; xr2[q] = sa * mx[q] + ca * my[q]; } // :98
+    int cnt = 0;
+    for (int q = 0; q < nmc; ++q) cnt += F->mcA[(size_t)i * nmc + q] ? 1 : 0;
+    if (cnt == 0) return -3;                                    // :100-110 needs rand()
+  }
+  // :116 out of the ocean grid
+  {
+    double mxx = F->cax[v0], mnx = F->cax[v0], mxy = F->cay[v0], mny = F->cay[v0];
+    for (int k = 1; k < nvr; ++k) {
+      mxx = std::max(mxx, F->cax[v0 + k]); mnx = std::min(mnx, F->cax[v0 + k]);
+      mxy = std::max(mxy, F->cay[v0 + k]); mny = std::min(mny, F->cay[v0 + k]);
+    }
+    double Xomax = Xo[0], Xomin = Xo[0], Yomax = Yo[0], Yomin = Yo[0];
+    for (int k = 1; k < nxo; ++k) { Xomax = std::max(Xomax, Xo[k]); Xomin = std::min(Xomin, Xo[k]); }
+    for (int k = 1; k < nyo; ++k) { Yomax = std::max(Yomax, Yo[k]); Yomin = std::min(Yomin, Yo[k]); }
+    if (mxx + F->Xi[i] > Xomax || mnx + F->Xi[i] < Xomin || mxy + F->Yi[i] > Yomax || mny + F->Yi[i] < Yomin)
+      return 1;
+  }
+  if (F->alive[i] != 1) return 0;                              // :118
+  if (doforce) {                                               // :121-166
+    const double Xi = F->Xi[i], Yi = F->Yi[i];
+    const double ta = P->turn_angle;
+    double sta, cta;
+    orm_sincos(ta, &sta, &cta);
+    const uint8_t *A = F->mcA + (size_t)i * nmc;
+    // U10, V10: mean of the interpolated winds over the points inside the floe (:139)
+    double su = 0, sv = 0; int cnt = 0;
+    Vec Uo(nmc), Vo(nmc), th(nmc), rho(nmc);
+    for (int q = 0; q < nmc; ++q) {
+      double Xg = xr1[q] + Xi, Yg = xr2[q] + Yi;                // :122
+      th[q] = orm_atan2(xr2[q], xr1[q]); rho[q] = hyp(xr1[q], xr2[q]); // :124
+      Uo[q] = interp2_linear(Xo, nxo, Yo, nyo, P->Uocn, Xg, Yg);
+      Vo[q] = interp2_linear(Xo, nxo, Yo, nyo, P->Vocn, Xg, Yg);
+      if (A[q]) {
+        su += interp2_linear(Xo, nxo, Yo, nyo, P->Uwind, Xg, Yg);
+        sv += interp2_linear(Xo, nxo, Yo, nyo, P->Vwind, Xg, Yg);
+        ++cnt;
+      }
+    }
+    double U10 = su / cnt, V10 = sv / cnt;
+    double w10 = sqrt(U10 * U10 + V10 * V10);
+    double Fx_atm = rho_air * Cd_atm * w10 * U10;               // :140-141
+    double Fy_atm = rho_air * Cd_atm * w10 * V10;
+    double sFx = 0, sFy = 0, sT = 0;
+    for (int q = 0; q < nmc; ++q) {
+      double sth, cth;
+      orm_sincos(th[q], &sth, &cth);
+      double Uice = F->Ui[i] - rho[q] * F->ksi_ice[i] * sth;    // :127-128
+      double Vice = F->Vi[i] + rho[q] * F->ksi_ice[i] * cth;
+      double Fx_p = -(floe_mass / floe_area) * fc * Vo[q];      // :143-144
+      double Fy_p = +(floe_mass / floe_area) * fc * Uo[q];
+      double du = Uo[q] - Uice, dv = Vo[q] - Vice;              // :146
+      double sp = sqrt(du * du + dv * dv);
+      double tauX = rho0 * Cd * sp * (cta * du - sta * dv);     // :148-149
+      double tauY = rho0 * Cd * sp * (sta * du + cta * dv);
+      double Fx = tauX + Fx_atm + Fx_p;                         // :151-152
+      double Fy = tauY + Fy_atm + Fy_p;
+      double tq = (-Fx * sth + Fy * cth) * rho[q];              // :156
+      Fx = Fx + (floe_mass / floe_area) * fc * F->Vi[i];        // :159-160
+      Fy = Fy - (floe_mass / floe_area) * fc * F->Ui[i];
+      if (A[q]) { sFx += Fx; sFy += Fy; sT += tq; }
+    }
+    F->FxOA[i] = sFx / cnt; F->FyOA[i] = sFy / cnt; F->torqueOA[i] = sT / cnt; // :163-165
+  }
+  // :174-177 positions, Adams-Bashforth 2
+  double dx = 1.5 * dt * F->Ui[i] - 0.5 * dt * F->dXi_p[i];
+  double dy = 1.5 * dt * F->Vi[i] - 0.5 * dt * F->dYi_p[i];
+  F->Xi[i] = F->Xi[i] + dx; F->dXi_p[i] = F->Ui[i];
+  F->Yi[i] = F->Yi[i] + dy; F->dYi_p[i] = F->Vi[i];
+  F->alpha_i[i] = F->alpha_i[i] + 1.5 * dt * F->ksi_ice[i] - 0.5 * dt * F->dalpha_i_p[i];
+  F->dalpha_i_p[i] = F->ksi_ice[i];
+  // :181-208 velocities
+  const double hh = F->h[i];
+  double numU = F->FxOA[i] * floe_area + ext_fx, numV = F->FyOA[i] * floe_area + ext_fy;
+  double dUi_dt = numU / floe_mass, dVi_dt = numV / floe_mass;
+  bool have_frac = false;
+  double frac = 0;
+  bool bigU = fabs(dt * dUi_dt) > 0.5 * hh, bigV = fabs(dt * dVi_dt) > 0.5 * hh;
+  bool smallU = fabs(dt * dUi_dt) < 0.5 * hh, smallV = fabs(dt * dVi_dt) < 0.5 * hh;
+  auto sgn = [](double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+  if (bigU && bigV) {
+    double a = sgn(dUi_dt) * 0.5 * hh / dt, b = sgn(dVi_dt) * 0.5 * hh / dt;
+    double frac1 = a / numU * floe_mass, frac2 = b / numV * floe_mass;
+    frac = std::min(frac1, frac2); have_frac = true;
+  } else if (bigU && smallV) {
+    double a = sgn(dUi_dt) * 0.5 * hh / dt;
+    frac = a / numU * floe_mass; have_frac = true;
+  } else if (smallU && bigV) {
+    double b = sgn(dVi_dt) * 0.5 * hh / dt;
+    frac = b / numV * floe_mass; have_frac = true;
+  }
+  if (have_frac) { dUi_dt = frac * (numU / floe_mass); dVi_dt = frac * (numV / floe_mass); }
+  F->Ui[i] = F->Ui[i] + 1.5 * dt * dUi_dt - 0.5 * dt * F->dUi_p[i];
+  F->Vi[i] = F->Vi[i] + 1.5 * dt * dVi_dt - 0.5 * dt * F->dVi_p[i];
+  F->dUi_p[i] = dUi_dt; F->dVi_p[i] = dVi_dt;
+  // :210-219 angular velocity
+  double dksi = (F->torqueOA[i] * floe_area + ext_torque) / floe_inertia;
+  if (have_frac) dksi = frac * dksi;
+  double ksi = F->ksi_ice[i] + 1.5 * dt * dksi - 0.5 * dt * F->dksi_ice_p[i];
+  if (fabs(ksi) > 1e-5) ksi = sgn(ksi) * 1e-5;
+  F->ksi_ice[i] = ksi;
+  F->dksi_ice_p[i] = dksi;
+  // :221-222 rotate the ring
+  double sa, ca;
+  orm_sincos(F->alpha_i[i], &sa, &ca);
+  for (int k = 0; k < nvr; ++k) {
+    F->cax[v0 + k] = ca * F->c0x[v0 + k] + (-sa) * F->c0y[v0 + k];
+    F->cay[v0 + k] = sa * F->c0x[v0 + k] + ca * F->c0y[v0 + k];
+  }
+  if (P->doInt) {                                              // :224-234 strain
+    Vec Uice(nvr), Vice(nvr);
+    for (int k = 0; k < nvr; ++k) {
+      double th = orm_atan2(F->cay[v0 + k], F->cax[v0 + k]), rh = hyp(F->cax[v0 + k], F->cay[v0 + k]);
+      double sth, cth;
+      orm_sincos(th, &sth, &cth);
+      Uice[k] = F->Ui[i] - rh * F->ksi_ice[i] * sth;
+      Vice[k] = F->Vi[i] + rh * F->ksi_ice[i] * cth;
+    }
+    double sudy = 0, sudx = 0, svdy = 0, svdx = 0;
+    for (int k = 0; k < nvr; ++k) {
+      int k2 = (k + 1 == nvr) ? 0 : k + 1;
+      double dU = Uice[k2] - Uice[k], dV = Vice[k2] - Vice[k];
+      double dcy = F->cay[v0 + k2] - F->cay[v0 + k], dcx = F->cax[v0 + k2] - F->cax[v0 + k];
+      sudy += dU * dcy; sudx += dU * dcx; svdy += dV * dcy; svdx += dV * dcx;
+    }
+    double du_dx = 0.5 * sudy / floe_area, du_dy = 0.5 * sudx / floe_area;
+    double dv_dx = 0.5 * svdy / floe_area, dv_dy = 0.5 * svdx / floe_area;
+    // strain = 1/2*([du_dx du_dy; dv_dx dv_dy] + [du_dx dv_dx; du_dy dv_dy]), column-major
+    F->strain[4 * i + 0] = 0.5 * (du_dx + du_dx);
+    F->strain[4 * i + 1] = 0.5 * (dv_dx + du_dy);
+    F->strain[4 * i + 2] = 0.5 * (du_dy + dv_dx);
+    F->strain[4 * i + 3] = 0.5 * (dv_dy + dv_dy);
+  }
+  return 0;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+int or_set_clipper(const char *path, int kind) {
+  void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return -2;
+  g_ref_clip = nullptr; g_host_clip = nullptr;
+  if (kind == 0) g_ref_clip = (ref_clip_fn)dlsym(h, "ref_clip");
+  else g_host_clip = (host_clip_fn)dlsym(h, "host_clip_batch");
+  return (g_ref_clip || g_host_clip) ? 0 : -2;
+}
+
+double or_ring_area(const double *x, const double *y, int n) { return ring_area(x, y, n); }
+void or_ring_centroid(const double *x, const double *y, int n, double *cx, double *cy) { ring_centroid(x, y, n, *cx, *cy); }
+double or_polyarea(const double *x, const double *y, int n) { return polyarea(x, y, n); }
+int or_interx(const double *x1, const double *y1, int n1, const double *x2, const double *y2, int n2,
+              double *px, double *py, int cap) {
+  Vec a, b;
+  interx(x1, y1, n1, x2, y2, n2, a, b);
+  int n = (int)a.size();
+  for (int k = 0; k < n && k < cap; ++k) { px[k] = a[k]; py[k] = b[k]; }
+  return n;
+}
+void or_p_poly_dist(const double *xp, const double *yp, int np, const double *xv, const double *yv, int nv, double *dmin) {
+  Vec a(xp, xp + np), b(yp, yp + np), c(xv, xv + nv), d(yv, yv + nv), out;
+  p_poly_dist(a, b, c, d, out);
+  for (int k = 0; k < np; ++k) dmin[k] = out[k];
+}
+void or_inpolygon(const double *x, const double *y, int np, const double *xv, const double *yv, int nv, uint8_t *in) {
+  Vec c(xv, xv + nv), d(yv, yv + nv);
+  for (int k = 0; k < np; ++k) in[k] = inpolygon1(x[k], y[k], c, d) ? 1 : 0;
+}
+int or_floe_interactions(const double *c1x, const double *c1y, int n1, const double *s1, const double *c2x,
+                         const double *c2y, int n2, const double *s2, int floe2_is_boundary,
+                         const double *c2_boundary, int periodic, double Modulus, double dt, double mu,
+                         double nu, double *force, double *pcontact, double *overlap, int cap) {
+  if (!g_ref_clip && !g_host_clip) return -2;
+  Body b1 = {s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6]}, b2 = {s2[0], s2[1], s2[2], s2[3], s2[4], s2[5], s2[6]};
+  std::vector<Contact> rows;
+  Vec a(c1x, c1x + n1), b(c1y, c1y + n1), c(c2x, c2x + n2), d(c2y, c2y + n2);
+  if (!floe_interactions(a, b, b1, c, d, b2, floe2_is_boundary != 0, c2_boundary, periodic != 0, Modulus, dt, mu, nu, rows)) return -4;
+  int n = (int)rows.size();
+  for (int k = 0; k < n && k < cap; ++k) {
+    force[2 * k] = rows[k].fx; force[2 * k + 1] = rows[k].fy;
+    pcontact[2 * k] = rows[k].px; pcontact[2 * k + 1] = rows[k].py;
+    overlap[k] = rows[k].overlap;
+  }
+  return n;
+}
+void or_sincos(double x, double *s, double *c) { orm_sincos(x, s, c); }
+double or_atan2(double y, double x) { return orm_atan2(y, x); }
+int64_t or_matlab_int64_scaled(double v) { return to_fixed(v); }
+
+// floe_interactions_all.m:9-285
+int or_step(OrFloes *F, const OrParams *P, int32_t *inter_off, double *inter, int64_t inter_cap,
+            int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext,
+            int32_t threads) {
+  if (!g_ref_clip && !g_host_clip) return -2;
+  const int N0 = F->n, Nb = F->nb;
+  const double *c2b = P->c2_boundary;
+  double Lx = c2b[0], Ly = c2b[1];                              // :9-10
+  for (int k = 1; k < 5; ++k) { Lx = std::max(Lx, c2b[2 * k]); Ly = std::max(Ly, c2b[2 * k + 1]); }
+  const bool PERIODIC = P->PERIODIC != 0, COLLISION = P->COLLISION != 0;
+
+  // extended list: real floes then ghosts.  Ghosts copy their source's state at creation (:33-37,:54-58)
+  struct Ext { int src; double x, y; int floenum; }; // src = real floe whose ring/state it carries
+  std::vector<Ext> ext(N0);
+  for (int i = 0; i < N0; ++i) { ext[i].src = i; ext[i].x = F->Xi[i]; ext[i].y = F->Yi[i]; ext[i].floenum = i + 1; }
+  std::vector<int> parent; // 0-based index into ext of each ghost's parent (:36,:57)
+  auto max_abs_coord = [&](int e, int dim) {
+    int s = ext[e].src, v0 = F->vert_off[s], nv = F->vert_off[s + 1] - v0;
+    double m = 0;
+    for (int k = 0; k < nv; ++k) {
+      double v = (dim == 0) ? F->cax[v0 + k] + ext[e].x : F->cay[v0 + k] + ext[e].y;
+      m = std::max(m, fabs(v));
+    }
+    return m;
+  };
+  auto sgn = [](double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+  if (PERIODIC) {
+    int n1 = (int)ext.size();
+    for (int i = 0; i < n1; ++i) {                              // :29-42
+      if (F->alive[ext[i].src] && max_abs_coord(i, 0) > Lx) {
+        Ext g = ext[i];
+        g.x = ext[i].x - 2 * Lx * sgn(ext[i].x);
+        g.floenum = -abs(ext[i].floenum);
+        ext.push_back(g); parent.push_back(i);
+      }
+    }
+    int n2 = (int)ext.size();
+    for (int i = 0; i < n2; ++i) {                              // :50-62
+      if (F->alive[ext[i].src] && max_abs_coord(i, 1) > Ly) {
+        Ext g = ext[i];
+        g.y = ext[i].y - 2 * Ly * sgn(ext[i].y);
+        g.floenum = -abs(ext[i].floenum);
+        ext.push_back(g); parent.push_back(i);
+      }
+    }
+  }
+  const int N = (int)ext.size();
+  *n_ext = N;
+  auto alive = [&](int e) { return F->alive[ext[e].src] != 0; };
+  auto rmax = [&](int e) { return F->rmax[ext[e].src]; };
+
+  // ---- :76-120 broad-phase ----
+  std::vector<std::vector<int> > pot(N); // accepted partner indices (1-based), ascending
+  for (int i = Nb; i < N; ++i) {
+    std::vector<double> mems;
+    if (ext[i].floenum < 0) {                                  // :94-99
+      int num = abs(ext[i].floenum) - 1;
+      for (size_t q = 0; q < pot[num].size(); ++q) mems.push_back((double)pot[num][q]);
+    }
+    if (alive(i) && !(ext[i].x != ext[i].x) && COLLISION) {   // :101
+      for (int j = i + 1; j < N; ++j) {                        // :102-103 (j > i)
+        if (!alive(j)) continue;
+        double ddx = ext[i].x - ext[j].x, ddy = ext[i].y - ext[j].y;
+        if (!(sqrt(ddx * ddx + ddy * ddy) < (rmax(i) + rmax(j)))) continue;
+        double key = (double)abs(ext[j].floenum);
+        bool member = std::find(mems.begin(), mems.end(), key) != mems.end();
+        if (!(!member || 2 * (rmax(i) + rmax(j)) > std::min(2 * Lx, 2 * Ly))) continue;
+        pot[i].push_back(j + 1);                               // :104
+        mems.push_back((double)ext[j].floenum);                // :113
+      }
+    }
+  }
+  int64_t np = 0;
+  for (int i = 0; i < N; ++i)
+    for (size_t q = 0; q < pot[i].size(); ++q) {
+      if (np < pair_cap) { pair_i[np] = i + 1; pair_j[np] = pot[i][q]; }
+      ++np;
+    }
+  *npairs_out = np;
+  if (np > pair_cap) return -1;
+
+  // ---- :123-174 narrow-phase ----
+  typedef std::vector<double> Rows; // 7 doubles per row
+  std::vector<Rows> inter_rows(N);
+  std::vector<double> overlapArea(N, 0.0);
+  std::vector<int> kill(N, 0), transfer(N, 0);
+  std::vector<int> alive_new(N0);
+  for (int i = 0; i < N0; ++i) alive_new[i] = F->alive[i];
+  int err = 0;
+  auto ring_of = [&](int e, Vec &x, Vec &y) {
+    int s = ext[e].src, v0 = F->vert_off[s], nv = F->vert_off[s + 1] - v0;
+    x.resize(nv); y.resize(nv);
+    for (int k = 0; k < nv; ++k) { x[k] = F->cax[v0 + k] + ext[e].x; y[k] = F->cay[v0 + k] + ext[e].y; } // :105 / floe_interactions.m:25
+  };
+  auto body_of = [&](int e) {
+    int s = ext[e].src;
+    Body b = {ext[e].x, ext[e].y, F->Ui[s], F->Vi[s], F->ksi_ice[s], F->h[s], F->area[s]};
+    return b;
+  };
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads > 0 ? threads : 1)
+  for (int i = Nb; i < N; ++i) {
+    Vec c1x, c1y, c2x, c2y;
+    std::vector<Contact> rows;
+    ring_of(i, c1x, c1y);
+    Body b1 = body_of(i);
+    for (size_t q = 0; q < pot[i].size(); ++q) {               // :129-147
+      int j = pot[i][q] - 1;
+      ring_of(j, c2x, c2y);
+      Body b2 = body_of(j);
+      if (!floe_interactions(c1x, c1y, b1, c2x, c2y, b2, false, c2b, PERIODIC, P->Modulus, P->dt, P->mu, P->nu, rows)) {
+#pragma omp atomic write
+        err = -4;
+        continue;
+      }
+      double sabs = 0;
+      for (size_t r = 0; r < rows.size(); ++r) sabs += fabs(rows[r].fx) + fabs(rows[r].fy);
+      if (sabs != 0) {                                          // :135-137
+        double so = 0;
+        for (size_t r = 0; r < rows.size(); ++r) {
+          double row[7] = {(double)(j + 1), rows[r].fx, rows[r].fy, rows[r].px, rows[r].py, 0, rows[r].overlap};
+          inter_rows[i].insert(inter_rows[i].end(), row, row + 7);
+          so += rows[r].overlap;
+        }
+        overlapArea[i] = so + overlapArea[i];
+      } else if (!rows.empty() && std::isinf(rows[0].overlap) && i + 1 > Nb) {   // :138-145
+        // kill/transfer start as 1 x N0 (:123) and grow when a ghost row (i > N0) assigns into them
+        if (i + 1 <= N0 && rows[0].overlap > 0) { kill[i] = i + 1; transfer[i] = j + 1; }
+        else if (j + 1 <= N0) kill[i] = j + 1;
+      }
+    }
+    if (!PERIODIC) {                                            // :150-172
+      Vec bx(4), by(4);
+      for (int k = 0; k < 4; ++k) { bx[k] = c2b[2 * k]; by[k] = c2b[2 * k + 1]; }
+      Body fb = {P->fb_Xi, P->fb_Yi, P->fb_Ui, P->fb_Vi, P->fb_ksi_ice, P->fb_h, P->fb_area};
+      if (!floe_interactions(c1x, c1y, b1, bx, by, fb, true, c2b, PERIODIC, P->Modulus, P->dt, P->mu, P->nu, rows)) {
+#pragma omp atomic write
+        err = -4;
+        continue;
+      }
+      Vec b5x(5), b5y(5);
+      for (int k = 0; k < 5; ++k) { b5x[k] = c2b[2 * k]; b5y[k] = c2b[2 * k + 1]; }
+      if (!inpolygon1(ext[i].x, ext[i].y, b5x, b5y)) alive_new[i] = 0;     // :152-155 (non-periodic: no ghosts)
+      double sabs = 0;
+      for (size_t r = 0; r < rows.size(); ++r) sabs += fabs(rows[r].fx) + fabs(rows[r].fy);
+      if (sabs != 0) {
+        double so = 0;
+        for (size_t r = 0; r < rows.size(); ++r) {
+          double fx = rows[r].fx, fy = rows[r].fy;
+          if (fabs(rows[r].py) == Ly) fx = 0;                   // :160-162
+          if (fabs(rows[r].px) == Lx) fy = 0;                   // :163-165
+          double row[7] = {INF, fx, fy, rows[r].px, rows[r].py, 0, rows[r].overlap};
+          inter_rows[i].insert(inter_rows[i].end(), row, row + 7);
+          so += rows[r].overlap;
+        }
+        overlapArea[i] = so + overlapArea[i];
+      }
+    }
+  }
+  if (err) return err;
+  for (int i = 0; i < N0; ++i) F->alive[i] = alive_new[i];
+  for (int i = 0; i < N; ++i)                                   // :175-179
+    if (abs(kill[i] - (i + 1)) > 0 && kill[i] > 0) transfer[kill[i] - 1] = i + 1;
+
+  // ---- :187-214 mirror, sequential ----
+  for (int i = 0; i < N; ++i) {
+    size_t nrow = inter_rows[i].size() / 7; // rows present when floe i is visited (own + mirrored from lower i)
+    for (size_t r = 0; r < nrow; ++r) {
+      double a[7];
+      memcpy(a, &inter_rows[i][7 * r], sizeof(a));
+      if (a[0] <= N && a[0] > i + 1) {
+        int j = (int)a[0] - 1;
+        double row[7] = {(double)(i + 1), -a[1], -a[2], a[3], a[4], 0, a[6]};
+        inter_rows[j].insert(inter_rows[j].end(), row, row + 7);
+        overlapArea[j] = overlapArea[j] + a[6];
+      }
+    }
+  }
+
+  // ---- :218-246 torques and sums of ghosts, then added to parents ----
+  std::vector<double> cfx(N, 0.0), cfy(N, 0.0), ctq(N, 0.0);
+  auto torque_and_sums = [&](int i, double &sfx, double &sfy, double &stq) {
+    Rows &a = inter_rows[i];
+    size_t nrow = a.size() / 7;
+    sfx = sfy = stq = 0;
+    for (size_t r = 0; r < nrow; ++r) {
+      double *w = &a[7 * r];
+      // cross([P - r, 0], [F, 0]) (3) = (Px - x) * Fy - (Py - y) * Fx   (:230,:258)
+      w[5] = (w[3] - ext[i].x) * w[2] - (w[4] - ext[i].y) * w[1];
+    }
+    for (size_t r = 0; r < nrow; ++r) { sfx += a[7 * r + 1]; sfy += a[7 * r + 2]; stq += a[7 * r + 5]; }
+  };
+  if (PERIODIC) {
+    for (int i = N0; i < N; ++i) {
+      if (!inter_rows[i].empty()) { double a, b, c; torque_and_sums(i, a, b, c); cfx[i] = a; cfy[i] = b; ctq[i] = c; }
+    }
+    for (size_t g = 0; g < parent.size(); ++g) {                // :242-245
+      int p = parent[g], gi = N0 + (int)g;
+      cfx[p] = cfx[p] + cfx[gi]; cfy[p] = cfy[p] + cfy[gi]; ctq[p] = ctq[p] + ctq[gi];
+    }
+  }
+
+  // ---- :249-285 real floes: torque, sums, wrap, integrate ----
+  int rc_all = 0;
+  for (int i = Nb; i < N0; ++i) {
+    if (!inter_rows[i].empty()) {
+      double a, b, c;
+      torque_and_sums(i, a, b, c);
+      cfx[i] = a + cfx[i]; cfy[i] = b + cfy[i]; ctq[i] = c + ctq[i];   // :262-263
+    }
+    F->collision_force[2 * i] = cfx[i]; F->collision_force[2 * i + 1] = cfy[i];
+    F->collision_torque[i] = ctq[i];
+    F->OverlapArea[i] = overlapArea[i];
+    if (PERIODIC) {                                             // :267-277
+      if (fabs(F->Xi[i]) > Lx) F->Xi[i] = F->Xi[i] - 2 * Lx * sgn(F->Xi[i]);
+      if (fabs(F->Yi[i]) > Ly) F->Yi[i] = F->Yi[i] - 2 * Ly * sgn(F->Yi[i]);
+    }
+    if (F->alive[i]) {                                          // :280-283
+      double x_before = ext[i].x;
+      // tmp = calc_trajectory(...): when tmp is [] the stored Floe(i) keeps its pre-call fields (:282)
+      const int Nz = F->n_stress;
+      int sc0 = F->StressCount[i] > Nz ? 1 : F->StressCount[i];
+      double slot0[4], st0[4];
+      for (int q = 0; q < 4; ++q) { slot0[q] = F->StressH[((size_t)i * Nz + (sc0 - 1)) * 4 + q]; st0[q] = F->Stress[4 * i + q]; }
+      int cnt0 = F->StressCount[i], alive0 = F->alive[i];
+      double h0 = F->h[i], m0 = F->mass[i], in0 = F->inertia_moment[i];
+      int rc = calc_trajectory(F, i, P, inter_rows[i].empty() ? nullptr : &inter_rows[i][0], (int)(inter_rows[i].size() / 7));
+      if (rc < 0) rc_all = rc;
+      if (rc == 1) {
+        for (int q = 0; q < 4; ++q) { F->StressH[((size_t)i * Nz + (sc0 - 1)) * 4 + q] = slot0[q]; F->Stress[4 * i + q] = st0[q]; }
+        F->StressCount[i] = cnt0; F->alive[i] = alive0; F->h[i] = h0; F->mass[i] = m0; F->inertia_moment[i] = in0;
+      }
+      if (rc == 1 || x_before != x_before) kill[i] = i + 1;
+    }
+  }
+  for (int i = 0; i < Nb; ++i) { F->collision_force[2 * i] = 0; F->collision_force[2 * i + 1] = 0; F->collision_torque[i] = 0; F->OverlapArea[i] = 0; }
+  for (int i = 0; i < N; ++i) { F->kill[i] = kill[i]; F->transfer[i] = transfer[i]; } // caller sizes both 4*n
+
+  // contact rows of the real floes, CSR
+  int64_t tot = 0;
+  inter_off[0] = 0;
+  for (int i = 0; i < N0; ++i) {
+    int64_t nrow = (int64_t)(inter_rows[i].size() / 7);
+    if (tot + nrow > inter_cap) return -1;
+    if (nrow) memcpy(inter + 7 * tot, &inter_rows[i][0], sizeof(double) * 7 * nrow);
+    tot += nrow;
+    inter_off[i + 1] = (int32_t)tot;
+  }
+  return rc_all;
+}
+
+} // extern "C"

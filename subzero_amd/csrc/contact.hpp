@@ -1,0 +1,429 @@
+// contact.hpp -- one candidate pair of the narrow-phase: the contact model of the reference's
+// collisions/floe_interactions.m:1-199 for one lane, on top of the sweep in vatti.hpp.
+//
+// Everything a pair needs lives in one scratch slice (PairScratch): the sweep workspace, the two rings
+// in 2^32 fixed point, the shifted ring of the direction check, two region slots and the crossing
+// points.  Arithmetic follows the .m text operation by operation (IEEE double, no FMA) so that contact
+// rows agree with the CPU oracle to the last bit:
+//   spring constants                       floe_interactions.m:10-21
+//   overlap regions, 'int' / 'dif'         :25-41      (polyclip.m:63-80 fixed-point round trip)
+//   region areas, merge flags              :43-60
+//   ring closure, crossings P              :62-70      (InterX.m:54-81)
+//   small-region filter                    :78-83
+//   per region: centroid, contact points   :95-100
+//               force direction            :103-137    (p_poly_dist.m:111-288, inpolygon.m:150-224)
+//               direction check by re-clip :140-165
+//               normal + tangential force  :167-187
+#pragma once
+#include <math.h>
+#include "vatti.hpp"
+
+#if defined(__HIPCC__)
+#define SZ_HD_NOINLINE static __host__ __device__ __attribute__((noinline))
+#else
+#define SZ_HD_NOINLINE static __attribute__((noinline))
+#endif
+
+namespace szc {
+
+using szv::i64;
+using szv::Pt;
+
+SZ_HD double absd(double v) { return v < 0 ? -v : v; }
+SZ_HD double mind(double a, double b) { return b < a ? b : a; }   // std::min(a, b)
+SZ_HD double maxd(double a, double b) { return a < b ? b : a; }   // std::max(a, b)
+SZ_HD double hyp(double a, double b) { return ::sqrt(a * a + b * b); }
+SZ_HD bool is_inf(double v) { return v > 1.7976931348623157e308 || v < -1.7976931348623157e308; }
+#define SZC_INF (__builtin_huge_val())
+#define SZC_EPS 2.220446049250313e-16
+
+// MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
+SZ_HD i64 to_fixed(double v) {
+  double s = v * 4294967296.0;
+  if (s != s) return 0;
+  if (s >= 9223372036854775807.0) return 0x7FFFFFFFFFFFFFFFLL;
+  if (s <= -9223372036854775808.0) return (i64)0x8000000000000000ULL;
+  double t = (double)(i64)s; // trunc
+  double f = s - t;
+  if (f >= 0.5) t += 1.0;
+  else if (f <= -0.5) t -= 1.0;
+  return (i64)t;
+}
+SZ_HD double from_fixed(i64 v) { return (double)v / 4294967296.0; } // polyclip.m:67
+
+// ---- one shared, non-inlined instance of the sweep for all three clips of a pair ----
+struct FixedRing {
+  const i64 *x, *y;
+  SZ_HD Pt operator()(int i) const { Pt p; p.x = x[i]; p.y = y[i]; return p; }
+};
+struct RegionSink { // stores rings, or only counts them when ox == nullptr
+  i64 *ox, *oy;
+  int *roff;
+  int cap_v, cap_r, nv, nr;
+  SZ_HD bool ring_begin() { return ox == nullptr || nr < cap_r; }
+  SZ_HD bool vertex(const Pt &p) {
+    if (ox == nullptr) return true;
+    if (nv >= cap_v) return false;
+    ox[nv] = p.x; oy[nv] = p.y; ++nv;
+    return true;
+  }
+  SZ_HD bool ring_end() { ++nr; if (ox != nullptr) roff[nr] = nv; return true; }
+};
+SZ_HD_NOINLINE int clip_fixed(void *ws, int cap_nv, const i64 *ax, const i64 *ay, int na, const i64 *bx,
+                           const i64 *by, int nb, int op, RegionSink *sink) {
+  FixedRing a = {ax, ay}, b = {bx, by};
+  sink->nv = 0; sink->nr = 0;
+  if (sink->ox != nullptr) sink->roff[0] = 0;
+  return szv::clip_rings(ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
+}
+
+// ---- rings in metres: c_alpha + (Xi, Yi), optionally closed by one more vertex (:62-67) ----
+struct RingD {
+  const double *x, *y; // c_alpha of the floe (or the box)
+  double ox, oy;       // floe position (0 for the box)
+  int n;               // stored vertices
+  int extra;           // 1 when the ring had to be closed (index n maps to vertex 0)
+  SZ_HD int len() const { return n + extra; }
+  SZ_HD double X(int k) const { return x[k >= n ? 0 : k] + ox; }
+  SZ_HD double Y(int k) const { return y[k >= n ? 0 : k] + oy; }
+};
+
+struct Body { // floe_interactions.m reads these of floe1 / floe2
+  double Xi, Yi, Ui, Vi, ksi_ice, h, area;
+};
+
+struct PairScratch {
+  void *ws; int cap_nv;           // sweep workspace
+  i64 *f1x, *f1y, *f2x, *f2y;     // rings in fixed point (cap n1 + 1, n2 + 1)
+  i64 *fsx, *fsy;                 // ring 1 shifted by the unit force direction
+  i64 *r1x, *r1y; int *r1off;     // regions of clip 1
+  i64 *r2x, *r2y; int *r2off;     // regions of clip 2
+  int cap_v, cap_r;               // capacity of each region slot
+  double *px, *py; int cap_p;     // crossings P
+  double *rows; int cap_rows;     // output: 5 doubles per contact row [Fx, Fy, Px, Py, overlap]
+};
+
+struct PairOut {
+  int nrows;        // contact rows written
+  double sentinel;  // the `overlap` of the no-contact return: 0, +Inf or -Inf (:71-74); only when nrows == 0
+  int has_sentinel; // 1 when the function returned the [0 0],[0 0],overlap form
+};
+
+// area(polyshape(X,Y)): |shoelace| relative to the first vertex
+SZ_HD double region_area(const i64 *rx, const i64 *ry, int n) {
+  if (n < 3) return 0;
+  double x0 = from_fixed(rx[0]), y0 = from_fixed(ry[0]);
+  double s = 0;
+  for (int i = 0; i < n; ++i) {
+    int k = (i + 1 == n) ? 0 : i + 1;
+    double ax = from_fixed(rx[i]) - x0, ay = from_fixed(ry[i]) - y0;
+    double bx = from_fixed(rx[k]) - x0, by = from_fixed(ry[k]) - y0;
+    s += ax * by - bx * ay;
+  }
+  return absd(0.5 * s);
+}
+SZ_HD void region_centroid(const i64 *rx, const i64 *ry, int n, double &cx, double &cy) {
+  double x0 = from_fixed(rx[0]), y0 = from_fixed(ry[0]);
+  double s = 0, sx = 0, sy = 0;
+  for (int i = 0; i < n; ++i) {
+    int k = (i + 1 == n) ? 0 : i + 1;
+    double ax = from_fixed(rx[i]) - x0, ay = from_fixed(ry[i]) - y0;
+    double bx = from_fixed(rx[k]) - x0, by = from_fixed(ry[k]) - y0;
+    double w = ax * by - bx * ay;
+    s += w;
+    sx += (ax + bx) * w;
+    sy += (ay + by) * w;
+  }
+  cx = x0 + sx / (3.0 * s);
+  cy = y0 + sy / (3.0 * s);
+}
+// polyarea.m
+SZ_HD double region_polyarea(const i64 *rx, const i64 *ry, int n) {
+  double s = 0;
+  for (int i = 0; i < n; ++i) {
+    int k = (i + 1 == n) ? 0 : i + 1;
+    s += (from_fixed(rx[k]) - from_fixed(rx[i])) * (from_fixed(ry[k]) + from_fixed(ry[i]));
+  }
+  return absd(s / 2);
+}
+
+// inpolygon.m:150-224 for one point against the closed region ring (nr vertices + closing one)
+SZ_HD bool in_region(double x, double y, const i64 *rx, const i64 *ry, int nr) {
+  double mnx = from_fixed(rx[0]), mxx = mnx, mny = from_fixed(ry[0]), mxy = mny;
+  for (int k = 1; k < nr; ++k) {
+    double vx = from_fixed(rx[k]), vy = from_fixed(ry[k]);
+    mnx = mind(mnx, vx); mxx = maxd(mxx, vx); mny = mind(mny, vy); mxy = maxd(mxy, vy);
+  }
+  if (!(x >= mnx && x <= mxx && y >= mny && y <= mxy)) return false;
+  double sumdq = 0;
+  bool on = false;
+  for (int m = 0; m < nr; ++m) {
+    int m1 = (m + 1 == nr) ? 0 : m + 1;
+    double xa = from_fixed(rx[m]), ya = from_fixed(ry[m]), xb = from_fixed(rx[m1]), yb = from_fixed(ry[m1]);
+    double avx = absd(0.5 * (xa + xb)), avy = absd(0.5 * (ya + yb));
+    double sf = maxd(avx, avy);
+    sf = maxd(sf, avx * avy);
+    double ax = xa - x, ay = ya - y, bx = xb - x, by = yb - y;
+    int qa, qb;
+    { bool px = ax > 0, py = ay > 0; qa = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+    { bool px = bx > 0, py = by > 0; qb = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+    double cp = ax * by - bx * ay;
+    double scp = (cp > 0) ? 1 : (cp < 0 ? -1 : 0);
+    if (absd(cp) < sf * SZC_EPS * 3) scp = 0;
+    double dp = ax * bx + ay * by;
+    double dq = qb - qa;
+    if (absd(dq) == 3) dq = -dq / 3;
+    if (absd(dq) == 2) dq = 2 * scp;
+    sumdq += dq;
+    if (scp == 0 && dp <= 0) on = true;
+  }
+  return (sumdq != 0) || on;
+}
+
+// |p_poly_dist| of one point against the closed ring c (p_poly_dist.m:143-281)
+SZ_HD double dist_to_ring(double xp, double yp, const RingD &c) {
+  int nv = c.len();
+  double dpv_min = SZC_INF; int I_dpv = 0;
+  for (int k = 0; k < nv; ++k) {
+    double d = hyp(c.X(k) - xp, c.Y(k) - yp);
+    if (d < dpv_min) { dpv_min = d; I_dpv = k; }
+  }
+  double cr_min = 0; int I_cr = 0; bool have = false;
+  for (int k = 0; k + 1 < nv; ++k) {
+    double x0 = c.X(k), y0 = c.Y(k);
+    double dvx = c.X(k + 1) - x0, dvy = c.Y(k + 1) - y0;
+    double vds = hyp(dvx, dvy);
+    double ct = dvx / vds, st = dvy / vds;
+    double p1r1 = ct * x0 + st * y0;
+    double p1r2 = -st * x0 + ct * y0;
+    double r = (xp * ct + yp * st) - p1r1;
+    double cr = (xp * (-st) + yp * ct) - p1r2;
+    if (r > 0 && r < vds) {
+      double a = absd(cr);
+      if (!have || a < cr_min) { cr_min = a; I_cr = k; have = true; }
+    }
+  }
+  bool cond1 = !have;
+  bool cond2 = have && (I_cr != I_dpv) && ((cr_min - dpv_min) > 0);
+  return (cond1 || cond2) ? dpv_min : cr_min;
+}
+
+// InterX.m:54-81.  Returns the number of unique crossings (sorted by x, then y), or -1 on overflow.
+SZ_HD int crossings(const RingD &c1, const RingD &c2, double *px, double *py, int cap) {
+  int m1 = c1.len() - 1, m2 = c2.len() - 1;
+  int np = 0;
+  for (int j = 0; j < m2; ++j) {
+    double x2a = c2.X(j), y2a = c2.Y(j), x2b = c2.X(j + 1), y2b = c2.Y(j + 1);
+    double dx2 = x2b - x2a, dy2 = y2b - y2a;
+    double S2 = dx2 * y2a - dy2 * x2a;
+    for (int i = 0; i < m1; ++i) {
+      double x1a = c1.X(i), y1a = c1.Y(i), x1b = c1.X(i + 1), y1b = c1.Y(i + 1);
+      double dx1 = x1b - x1a, dy1 = y1b - y1a;
+      double S1 = dx1 * y1a - dy1 * x1a;
+      double a = dx1 * y2a - dy1 * x2a;
+      double b = dx1 * y2b - dy1 * x2b;
+      if (!(((a - S1) * (b - S1)) <= 0)) continue;
+      double c = y1a * dx2 - x1a * dy2;
+      double d = y1b * dx2 - x1b * dy2;
+      if (!(((c - S2) * (d - S2)) <= 0)) continue;
+      double L = dy2 * dx1 - dy1 * dx2;
+      if (L == 0) continue;
+      double X = (dx2 * S1 - dx1 * S2) / L;
+      double Y = (dy2 * S1 - dy1 * S2) / L;
+      // insertion into the sorted unique list (unique(...,'rows'))
+      int k = np;
+      while (k > 0 && (px[k - 1] > X || (px[k - 1] == X && py[k - 1] > Y))) --k;
+      if (k > 0 && px[k - 1] == X && py[k - 1] == Y) continue;
+      if (np >= cap) return -1;
+      for (int q = np; q > k; --q) { px[q] = px[q - 1]; py[q] = py[q - 1]; }
+      px[k] = X; py[k] = Y;
+      ++np;
+    }
+  }
+  return np;
+}
+
+// The contact model for one pair.  Returns a szv::Status (ST_WORKSPACE / ST_OUT_CAPACITY ask for a
+// larger scratch tier; ST_CLIP_ERROR is the reference's "Clipper Error.").
+SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+                       const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
+                       PairScratch &S, PairOut &out) {
+  out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
+  // :10-21
+  double h1 = f1.h, h2 = f2.h;
+  double r1 = ::sqrt(f1.area), r2 = ::sqrt(f2.area);
+  double Force_factor = Modulus * (h1 * h2) / (h1 * r2 + h2 * r1);
+  double overlap0 = 0;
+  if (boundary) Force_factor = Modulus * h1 / r1;
+  else if (r1 > 1e5 || r2 > 1e5) {
+    r1 = mind(r1, r2);
+    h1 = mind(h1, h2);
+    Force_factor = Modulus * h1 / r1;
+  }
+  double G = Modulus / (2 * (1 + nu));
+
+  const int n1 = ring1.n, n2 = ring2.n;
+  for (int k = 0; k < n1; ++k) { S.f1x[k] = to_fixed(ring1.X(k)); S.f1y[k] = to_fixed(ring1.Y(k)); }
+  for (int k = 0; k < n2; ++k) { S.f2x[k] = to_fixed(ring2.X(k)); S.f2y[k] = to_fixed(ring2.Y(k)); }
+  const int op = boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION;
+  RegionSink s1 = {S.r1x, S.r1y, S.r1off, S.cap_v, S.cap_r, 0, 0};
+  int st = clip_fixed(S.ws, S.cap_nv, S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, op, &s1);   // :29 / :34
+  if (st != szv::ST_OK) return st;
+  int nreg = s1.nr;
+  if (boundary && nreg > 0) {                                                          // :35-40
+    if (region_polyarea(S.r1x, S.r1y, S.r1off[1]) / f1.area > 0.75) overlap0 = SZC_INF;
+  }
+  // :54-60 merge flags (sum of the region areas, :43-51)
+  {
+    double mx1 = ring1.X(0), mn1 = mx1, my1 = ring1.Y(0), mny1 = my1;
+    for (int k = 1; k < n1; ++k) {
+      double vx = ring1.X(k), vy = ring1.Y(k);
+      mx1 = maxd(mx1, vx); mn1 = mind(mn1, vx); my1 = maxd(my1, vy); mny1 = mind(mny1, vy);
+    }
+    double bxmax = c2b[0], bxmin = c2b[0], bymax = c2b[1], bymin = c2b[1];
+    for (int k = 1; k < 5; ++k) {
+      bxmax = maxd(bxmax, c2b[2 * k]); bxmin = mind(bxmin, c2b[2 * k]);
+      bymax = maxd(bymax, c2b[2 * k + 1]); bymin = mind(bymin, c2b[2 * k + 1]);
+    }
+    // area(polyshape(c2_boundary')): shoelace of the 4 corners relative to the first
+    double barea;
+    {
+      double s = 0;
+      for (int i = 0; i < 4; ++i) {
+        int k = (i + 1 == 4) ? 0 : i + 1;
+        double ax = c2b[2 * i] - c2b[0], ay = c2b[2 * i + 1] - c2b[1];
+        double bx = c2b[2 * k] - c2b[0], by = c2b[2 * k + 1] - c2b[1];
+        s += ax * by - bx * ay;
+      }
+      barea = absd(0.5 * s);
+    }
+    bool inside = (mx1 < bxmax && mn1 > bxmin && my1 < bymax && mny1 > bymin);
+    if (inside || f2.area < 0.95 * barea || periodic) {
+      double sumAr = 0;
+      if (nreg == 0) sumAr += 0;
+      for (int k = 0; k < nreg; ++k)
+        sumAr += region_area(S.r1x + S.r1off[k], S.r1y + S.r1off[k], S.r1off[k + 1] - S.r1off[k]);
+      if (sumAr / f1.area > 0.55) overlap0 = SZC_INF;
+      else if (sumAr / f2.area > 0.55) overlap0 = -SZC_INF;
+    }
+  }
+  // :62-67 close the rings
+  RingD c1 = ring1, c2 = ring2;
+  if (hyp(c1.X(0) - c1.X(n1 - 1), c1.Y(0) - c1.Y(n1 - 1)) > 1) c1.extra = 1;
+  if (hyp(c2.X(0) - c2.X(n2 - 1), c2.Y(0) - c2.Y(n2 - 1)) > 1) c2.extra = 1;
+
+  int np = crossings(c1, c2, S.px, S.py, S.cap_p);                                     // :70
+  if (np < 0) return szv::ST_WORKSPACE;
+  if (np < 2 || is_inf(overlap0) || nreg == 0) {                                       // :71-74
+    out.has_sentinel = 1;
+    out.sentinel = overlap0;
+    return szv::ST_OK;
+  }
+  int N1 = c1.len() - 1, N2 = c2.len() - 1;                                            // :78-79
+  double Amin = (double)(N1 < N2 ? N1 : N2) * 100 / 1.75;
+  const int nc1 = c1.len();
+  for (int k = 0; k < nreg; ++k) {
+    const i64 *RX = S.r1x + S.r1off[k], *RY = S.r1y + S.r1off[k];
+    const int nr = S.r1off[k + 1] - S.r1off[k];
+    double Ar = region_area(RX, RY, nr);
+    if (Ar < Amin) continue;                                                           // :83
+    double cx, cy;
+    region_centroid(RX, RY, nr, cx, cy);                                               // :96-97
+    // :98-100 nearest region vertex of each crossing; keep those closer than 1 m
+    int m = 0;
+    double p0x = 0, p0y = 0, p1x = 0, p1y = 0;
+    for (int q = 0; q < np; ++q) {
+      double best = SZC_INF; int bi = 0;
+      for (int v = 0; v < nr; ++v) {
+        double ddx = from_fixed(RX[v]) - S.px[q], ddy = from_fixed(RY[v]) - S.py[q];
+        double d2 = ddx * ddx + ddy * ddy;
+        if (d2 < best) { best = d2; bi = v; }
+      }
+      if (::sqrt(best) < 1) {
+        if (m == 0) { p0x = from_fixed(RX[bi]); p0y = from_fixed(RY[bi]); }
+        else if (m == 1) { p1x = from_fixed(RX[bi]); p1y = from_fixed(RY[bi]); }
+        ++m;
+      }
+    }
+    double fdx = 0, fdy = 0, dl = 0, pcx = cx, pcy = cy;
+    if (Ar == 0) { fdx = fdy = 0; pcx = pcy = 0; dl = 0; }                             // :103-106
+    else if (m == 2) {                                                                 // :107-112
+      double xgh = p1x - p0x, ygh = p1y - p0y;
+      double b = ::sqrt(xgh * xgh + ygh * ygh);
+      fdx = -ygh / b; fdy = xgh / b;
+      dl = b;
+    } else if (m == 0) { fdx = fdy = 0; dl = 0; }                                      // :113-116
+    else {                                                                             // :117-137
+      int non = 0;
+      double sfx = 0, sfy = 0, sb = 0;
+      for (int e = 0; e < nr; ++e) {
+        int e1 = (e + 1 == nr) ? 0 : e + 1;
+        double xa = from_fixed(RX[e]), ya = from_fixed(RY[e]), xb = from_fixed(RX[e1]), yb = from_fixed(RY[e1]);
+        double xgh = xb - xa, ygh = yb - ya;
+        double xm = (xb + xa) / 2, ym = (yb + ya) / 2;
+        double b = ::sqrt(xgh * xgh + ygh * ygh);
+        double nx = -ygh / b, ny = xgh / b;
+        double xt = xm + nx / 100, yt = ym + ny / 100;
+        if (!in_region(xt, yt, RX, RY, nr)) { nx = -nx; ny = -ny; }
+        double d = dist_to_ring(xm, ym, c1);
+        if (d < 1e-8) {
+          ++non;
+          sfx += (-Force_factor * b) * nx;
+          sfy += (-Force_factor * b) * ny;
+          sb += b;
+        }
+      }
+      if (non < nr && non > 0) {
+        double nrm = ::sqrt(sfx * sfx + sfy * sfy);
+        fdx = sfx / nrm; fdy = sfy / nrm;
+        dl = sb / non;
+      } else { fdx = fdy = 0; dl = 0; }
+    }
+    // :140-155 shift ring 1 by the unit direction and clip again
+    if (dl < 0.1) { fdx = 0; fdy = 0; }
+    for (int q = 0; q < nc1; ++q) {
+      if (dl < 0.1) { S.fsx[q] = to_fixed(c1.X(q)); S.fsy[q] = to_fixed(c1.Y(q)); }
+      else { S.fsx[q] = to_fixed(c1.X(q) + fdx); S.fsy[q] = to_fixed(c1.Y(q) + fdy); }
+    }
+    // ring 2 after closure (clip 1 used the unclosed one; the closing vertex is a duplicate either way)
+    const int nc2 = c2.len();
+    if (c2.extra) { S.f2x[n2] = S.f2x[0]; S.f2y[n2] = S.f2y[0]; }
+    RegionSink s2 = {S.r2x, S.r2y, S.r2off, S.cap_v, S.cap_r, 0, 0};
+    st = clip_fixed(S.ws, S.cap_nv, S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, &s2);
+    if (st != szv::ST_OK) return st;
+    for (int ii = 0; ii < s2.nr; ++ii) {                                               // :156-165
+      const i64 *TX = S.r2x + S.r2off[ii], *TY = S.r2y + S.r2off[ii];
+      const int nt = S.r2off[ii + 1] - S.r2off[ii];
+      if (nt + nr > S.cap_nv) return szv::ST_WORKSPACE;
+      RegionSink s3 = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+      st = clip_fixed(S.ws, S.cap_nv, TX, TY, nt, RX, RY, nr, szv::OP_INTERSECTION, &s3);
+      if (st != szv::ST_OK) return st;
+      if (s3.nr > 0) {
+        double Anew = region_polyarea(TX, TY, nt);
+        if (Anew / Ar - 1 > 0) { fdx = -fdx; fdy = -fdy; }
+      }
+    }
+    double Fx = fdx * Ar * Force_factor, Fy = fdy * Ar * Force_factor;                 // :167
+    // :170-183
+    double v1x = f1.Ui + f1.ksi_ice * (pcx - f1.Xi), v1y = f1.Vi + f1.ksi_ice * (pcy - f1.Yi);
+    double v2x = f2.Ui + f2.ksi_ice * (pcx - f2.Xi), v2y = f2.Vi + f2.ksi_ice * (pcy - f2.Yi);
+    double vtx = v1x - v2x, vty = v1y - v2y;
+    double dtx, dty;
+    if (maxd(absd(vtx), absd(vty)) == 0) { dtx = 0; dty = 0; }
+    else { double nv = ::sqrt(vtx * vtx + vty * vty); dtx = vtx / nv; dty = vty / nv; }
+    double vn = ::sqrt(vtx * vtx + vty * vty);
+    double coef = -(dtx * vtx + dty * vty) * dl * G * vn;
+    double ftx = coef * dtx * dt, fty = coef * dty * dt;
+    double nF = ::sqrt(Fx * Fx + Fy * Fy);
+    if (::sqrt(ftx * ftx + fty * fty) > mu * nF) {
+      ftx = -mu * nF * dtx; fty = -mu * nF * dty;
+    }
+    if (out.nrows >= S.cap_rows) return szv::ST_OUT_CAPACITY;
+    double *row = S.rows + 5 * out.nrows;
+    row[0] = Fx + ftx; row[1] = Fy + fty; row[2] = pcx; row[3] = pcy; row[4] = Ar;
+    ++out.nrows;
+  }
+  return szv::ST_OK;
+}
+
+} // namespace szc

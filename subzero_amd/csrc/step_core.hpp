@@ -1,0 +1,694 @@
+// step_core.hpp -- the per-timestep pipeline of floe_interactions_all.m:16-285 as a sequence of kernel
+// bodies.  Each body is the work of ONE thread of its kernel; step.hip wraps every body in a __global__
+// launcher, and tests/hostsim runs the same bodies in plain loops on the CPU, so the whole GPU step can be
+// checked against the oracle without a GPU.
+//
+// Stages (reference lines) and their parallel shape:
+//   ext_init / ghost_flag_* / ghost_emit_*   :16-66    one thread per floe, stable compaction by prefix sum
+//   broad                                     :76-120   one thread per (extended) floe i, all j > i
+//   pair_count / pair_expand                  :123-133  per-floe pair counts -> prefix sum -> flat pair list
+//   narrow                                    :133,151  one thread per candidate pair (contact.hpp)
+//   incoming                                  :187-214  pairs register with their partner floe
+//   row_count / row_fill                      :136-145,167,198,221-263  per-floe contact rows (CSR), in the
+//                                             reference's row order; torques, sums, kill/transfer marks
+//   integrate                                 :242-245,249-285 + calc_trajectory.m
+// Summation order inside every floe follows the reference (own rows ascending partner, wall, mirrored rows
+// ascending partner), so forces do not depend on scheduling.
+#pragma once
+#include "contact.hpp"
+#include "detmath.hpp"
+
+namespace szs {
+
+using szv::i64;
+
+enum { WALL = -2 }; // partner id of the floe-vs-boundary candidate
+
+// device image of the Floe struct array (SoA).  Field names follow initialize_floe_values.m:12-52.
+struct Floes {
+  int n, nb, n_stress, n_mc;
+  double *Xi, *Yi, *alpha_i, *Ui, *Vi, *ksi_ice;
+  double *h, *area, *mass, *inertia_moment, *rmax;
+  double *dXi_p, *dYi_p, *dUi_p, *dVi_p, *dalpha_i_p, *dksi_ice_p;
+  double *FxOA, *FyOA, *torqueOA;
+  int *alive;
+  int *vert_off;
+  double *c0x, *c0y, *cax, *cay;
+  double *StressH;      // [floe][slot][4]
+  int *StressCount;
+  double *Stress, *strain;
+  double *mcX, *mcY;    // [floe][q]
+  unsigned char *mcA;
+  double *collision_force, *collision_torque, *OverlapArea;
+  int *kill, *transfer; // capacity 4 * n (extended list)
+  double *StressSum;    // [floe][4] running sum of the StressH slots (device only)
+};
+
+struct Params {
+  double dt, HFo, Modulus, mu, nu;
+  int doInt, COLLISION, PERIODIC, reserved;
+  double c2_boundary[10];
+  double fb_h, fb_area, fb_Xi, fb_Yi, fb_Ui, fb_Vi, fb_ksi_ice;
+  int nxo, nyo;
+  const double *Xo, *Yo, *Uocn, *Vocn, *Uwind, *Vwind;
+  double fCoriolis, turn_angle;
+  double Lx, Ly; // max of c2_boundary rows (:9-10), filled by the host wrapper
+};
+
+// counters living in device memory
+enum {
+  C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
+  C_ERR_MC, C_SCR_BUMP, C_COUNT
+};
+
+struct Work {
+  int cap_ext;   // 4 * n
+  int pot_cap;   // candidates per floe
+  i64 cap_pairs; // pairs the scratch arena is sized for
+  // extended list: real floes then ghosts
+  int *ext_src, *ext_num, *ext_parent, *xg_of, *yg_of;
+  double *ext_x, *ext_y;
+  int *flag, *scan;             // cap_ext
+  unsigned long long *counters; // C_COUNT
+  // broad-phase
+  int *pot_cnt, *pot_list;      // [cap_ext], [cap_ext * pot_cap] partner indices, 1-based, ascending
+  // flat pair list
+  int *pair_cnt;                // per ext floe (incl. wall candidate)
+  i64 *pair_nv;                 // per ext floe: sum of ring sizes of its pairs
+  i64 *pair_base, *nv_base;     // exclusive prefix sums of the two
+  int *pair_i, *pair_j;         // [cap_pairs]
+  i64 *pair_nvoff;              // [cap_pairs] vertices in pairs before p
+  // narrow-phase results
+  char *scratch; i64 scratch_bytes;
+  i64 *pair_scr;                // [cap_pairs] offset of the pair's scratch slice
+  int *pair_mult;               // [cap_pairs] capacity tier used
+  int *pair_nrows, *pair_status, *pair_flag; // flag: 1 sentinel +Inf, 2 sentinel -Inf, 4 contributes rows
+  int *retry_list;
+  // mirrored rows
+  int *inc_cnt, *inc_list;      // [cap_ext], [cap_ext * pot_cap] pair ids
+  // contact rows, CSR over the extended list
+  int *row_cnt; i64 *row_off;   // [cap_ext], [cap_ext + 1]
+  double *rows; i64 cap_rows;   // 7 doubles per row
+  double *cf_ext, *ct_ext, *ov_ext; // per ext floe: sum Fx,Fy (2), sum torque, OverlapArea
+  int *tmax;                    // cap_ext: transfer(kill(i)) = i resolution
+};
+
+// per-pair scratch slice: linear bound so that offsets follow from prefix sums (see carve())
+enum { SCR_PER_V = 704, SCR_PER_PAIR = 4096 };
+
+SZ_HD double sgn(double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); }
+SZ_HD double absd(double v) { return v < 0 ? -v : v; }
+SZ_HD int iabs(int v) { return v < 0 ? -v : v; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+__device__ inline int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+__device__ inline int atomic_max(int *p, int v) { return atomicMax(p, v); }
+#else
+inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+inline int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
+inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// ghosts (:16-66)
+// ---------------------------------------------------------------------------------------------
+SZ_HD void ext_init(int i, const Floes &F, Work &W) { // i < n
+  W.ext_src[i] = i; W.ext_x[i] = F.Xi[i]; W.ext_y[i] = F.Yi[i]; W.ext_num[i] = i + 1;
+}
+SZ_HD void ext_clear(int e, Work &W) { // e < cap_ext
+  W.xg_of[e] = -1; W.yg_of[e] = -1; W.pot_cnt[e] = 0; W.inc_cnt[e] = 0; W.tmax[e] = 0;
+  W.pair_cnt[e] = 0; W.pair_nv[e] = 0; W.row_cnt[e] = 0;
+  W.cf_ext[2 * e] = 0; W.cf_ext[2 * e + 1] = 0; W.ct_ext[e] = 0; W.ov_ext[e] = 0;
+}
+SZ_HD void marks_clear(int e, const Floes &F) { F.kill[e] = 0; F.transfer[e] = 0; } // e < 4 n (:123)
+// flag[e] = alive and the translated ring reaches beyond the box in dimension dim (:31,:52)
+SZ_HD void ghost_flag(int e, int dim, const Floes &F, const Params &P, Work &W) {
+  int s = W.ext_src[e], v0 = F.vert_off[s], nv = F.vert_off[s + 1] - v0;
+  double m = 0;
+  for (int k = 0; k < nv; ++k) {
+    double v = (dim == 0) ? F.cax[v0 + k] + W.ext_x[e] : F.cay[v0 + k] + W.ext_y[e];
+    m = szc::maxd(m, absd(v));
+  }
+  W.flag[e] = (F.alive[s] && m > (dim == 0 ? P.Lx : P.Ly)) ? 1 : 0;
+}
+// e's ghost goes to slot base + scan[e] (:33-37, :54-58)
+SZ_HD void ghost_emit(int e, int dim, int base, const Floes &F, const Params &P, Work &W) {
+  if (!W.flag[e]) return;
+  int g = base + W.scan[e];
+  if (g >= W.cap_ext) return; // cannot happen: cap_ext = 4 n
+  W.ext_src[g] = W.ext_src[e];
+  W.ext_x[g] = (dim == 0) ? W.ext_x[e] - 2 * P.Lx * sgn(W.ext_x[e]) : W.ext_x[e];
+  W.ext_y[g] = (dim == 1) ? W.ext_y[e] - 2 * P.Ly * sgn(W.ext_y[e]) : W.ext_y[e];
+  W.ext_num[g] = -iabs(W.ext_num[e]);
+  W.ext_parent[g] = e;
+  if (dim == 0) W.xg_of[e] = g; else W.yg_of[e] = g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// broad-phase (:76-120): candidates of extended floe i among j > i, in ascending j
+// ---------------------------------------------------------------------------------------------
+SZ_HD void broad(int i, int N, const Floes &F, const Params &P, Work &W) {
+  int cnt = 0;
+  int *mine = W.pot_list + (size_t)i * W.pot_cap;
+  const int si = W.ext_src[i];
+  // mems starts as the candidate list of the floe a ghost was copied from (:94-99)
+  const int *init = nullptr; int ninit = 0;
+  if (W.ext_num[i] < 0) {
+    int root = iabs(W.ext_num[i]) - 1;
+    init = W.pot_list + (size_t)root * W.pot_cap;
+    ninit = W.pot_cnt[root];
+  }
+  const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
+  const double lim = szc::mind(2 * P.Lx, 2 * P.Ly);
+  if (F.alive[si] && !(xi != xi) && P.COLLISION) {
+    for (int j = i + 1; j < N; ++j) {
+      const int sj = W.ext_src[j];
+      if (!F.alive[sj]) continue;
+      double dx = xi - W.ext_x[j], dy = yi - W.ext_y[j];
+      double R = ri + F.rmax[sj];
+      double d2 = dx * dx + dy * dy;
+      if (d2 > R * R * 1.000001) continue;      // cheap reject; the exact test follows
+      if (!(::sqrt(d2) < R)) continue;          // :103
+      int key = iabs(W.ext_num[j]);
+      bool member = false;
+      for (int q = 0; q < ninit && !member; ++q) member = (init[q] == key);
+      for (int q = 0; q < cnt && !member; ++q) member = (W.ext_num[mine[q] - 1] == key); // mems grows by FloeNums(j) (:113)
+      if (!(!member || 2 * R > lim)) continue;
+      if (cnt >= W.pot_cap) { atomic_add(&W.counters[C_ERR_POT], 1ULL); break; }
+      mine[cnt++] = j + 1;
+    }
+  }
+  W.pot_cnt[i] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat pair list
+// ---------------------------------------------------------------------------------------------
+SZ_HD bool has_wall_pair(int i, int N, const Floes &F, const Params &P) { return !P.PERIODIC && i >= F.nb && i < N; }
+
+SZ_HD void pair_count(int i, int N, const Floes &F, const Params &P, Work &W) { // i < N
+  int cnt = 0; i64 nv = 0;
+  if (i >= F.nb) {
+    const int si = W.ext_src[i], ni = F.vert_off[si + 1] - F.vert_off[si];
+    cnt = W.pot_cnt[i];
+    const int *mine = W.pot_list + (size_t)i * W.pot_cap;
+    for (int q = 0; q < cnt; ++q) {
+      int sj = W.ext_src[mine[q] - 1];
+      nv += ni + (F.vert_off[sj + 1] - F.vert_off[sj]);
+    }
+    if (has_wall_pair(i, N, F, P)) { ++cnt; nv += ni + 4; }
+  }
+  W.pair_cnt[i] = cnt; W.pair_nv[i] = nv;
+}
+SZ_HD void pair_expand(int i, int N, const Floes &F, const Params &P, Work &W) { // after scans
+  if (i < F.nb) return;
+  i64 p = W.pair_base[i], nvo = W.nv_base[i];
+  const int si = W.ext_src[i], ni = F.vert_off[si + 1] - F.vert_off[si];
+  const int *mine = W.pot_list + (size_t)i * W.pot_cap;
+  for (int q = 0; q < W.pot_cnt[i]; ++q, ++p) {
+    if (p >= W.cap_pairs) return;
+    int j = mine[q] - 1, sj = W.ext_src[j];
+    W.pair_i[p] = i; W.pair_j[p] = j; W.pair_nvoff[p] = nvo;
+    nvo += ni + (F.vert_off[sj + 1] - F.vert_off[sj]);
+  }
+  if (has_wall_pair(i, N, F, P) && p < W.cap_pairs) {
+    W.pair_i[p] = i; W.pair_j[p] = WALL; W.pair_nvoff[p] = nvo;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// narrow-phase: one candidate pair
+// ---------------------------------------------------------------------------------------------
+SZ_HD size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// Lays the PairScratch out inside [base, base + bytes).  Returns false when it does not fit.
+SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScratch &S) {
+  const int cap_nv = mult * (n1 + n2 + 2);
+  char *p = base, *end = base + bytes;
+  S.cap_nv = cap_nv;
+  S.ws = p; p += up16((size_t)szv::WS_PER_VERTEX * cap_nv + szv::WS_PER_CLIP);
+  S.f1x = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
+  S.f1y = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
+  S.f2x = (i64 *)p; p += up16(8 * (size_t)(n2 + 1));
+  S.f2y = (i64 *)p; p += up16(8 * (size_t)(n2 + 1));
+  S.fsx = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
+  S.fsy = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
+  S.cap_v = 2 * cap_nv + 8; S.cap_r = cap_nv / 2 + 4;
+  S.r1x = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
+  S.r1y = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
+  S.r2x = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
+  S.r2y = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
+  S.r1off = (int *)p; p += up16(4 * (size_t)(S.cap_r + 1));
+  S.r2off = (int *)p; p += up16(4 * (size_t)(S.cap_r + 1));
+  S.cap_p = cap_nv + 8;
+  S.px = (double *)p; p += up16(8 * (size_t)S.cap_p);
+  S.py = (double *)p; p += up16(8 * (size_t)S.cap_p);
+  S.cap_rows = S.cap_r;
+  S.rows = (double *)p; p += up16(40 * (size_t)S.cap_rows);
+  return p <= end;
+}
+SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
+
+// t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
+SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W) {
+  i64 p = list ? (i64)list[t] : t;
+  const int i = W.pair_i[p], j = W.pair_j[p];
+  const int si = W.ext_src[i];
+  const int v1 = F.vert_off[si], n1 = F.vert_off[si + 1] - v1;
+  szc::RingD ring1 = {F.cax + v1, F.cay + v1, W.ext_x[i], W.ext_y[i], n1, 0};
+  szc::Body b1 = {W.ext_x[i], W.ext_y[i], F.Ui[si], F.Vi[si], F.ksi_ice[si], F.h[si], F.area[si]};
+  szc::RingD ring2;
+  szc::Body b2;
+  double bx[4], by[4];
+  bool boundary = (j == WALL);
+  int n2;
+  if (boundary) {
+    for (int k = 0; k < 4; ++k) { bx[k] = P.c2_boundary[2 * k]; by[k] = P.c2_boundary[2 * k + 1]; }
+    n2 = 4;
+    szc::RingD r = {bx, by, 0.0, 0.0, 4, 0};
+    ring2 = r;
+    szc::Body b = {P.fb_Xi, P.fb_Yi, P.fb_Ui, P.fb_Vi, P.fb_ksi_ice, P.fb_h, P.fb_area};
+    b2 = b;
+  } else {
+    const int sj = W.ext_src[j];
+    const int v2 = F.vert_off[sj];
+    n2 = F.vert_off[sj + 1] - v2;
+    szc::RingD r = {F.cax + v2, F.cay + v2, W.ext_x[j], W.ext_y[j], n2, 0};
+    ring2 = r;
+    szc::Body b = {W.ext_x[j], W.ext_y[j], F.Ui[sj], F.Vi[sj], F.ksi_ice[sj], F.h[sj], F.area[sj]};
+    b2 = b;
+  }
+  // scratch slice: closed form in the first pass, bump-allocated behind it for retries
+  i64 off, bytes = scratch_bytes_for((i64)n1 + n2, mult);
+  if (!list) off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
+  else off = (i64)atomic_add(&W.counters[C_SCR_BUMP], (unsigned long long)bytes);
+  W.pair_scr[p] = off; W.pair_mult[p] = mult;
+  W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
+  szc::PairScratch S;
+  if (off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, n1, n2, mult, S)) {
+    W.pair_status[p] = szv::ST_WORKSPACE;
+    atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
+    return;
+  }
+  szc::PairOut out;
+  int st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
+                             P.mu, P.nu, S, out);
+  W.pair_status[p] = st;
+  if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
+    unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
+    W.retry_list[k] = (int)p;
+    return;
+  }
+  if (st != szv::ST_OK) { atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
+  int flag = 0;
+  double sabs = 0;
+  for (int r = 0; r < out.nrows; ++r) sabs += absd(S.rows[5 * r]) + absd(S.rows[5 * r + 1]);
+  if (sabs != 0) flag |= 4;                                       // :135 / :157
+  else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
+  W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
+  W.pair_flag[p] = flag;
+}
+SZ_HD const double *pair_rows(i64 p, const Floes &F, const Work &W) {
+  // the rows are the last member of the slice; recompute the layout
+  const int i = W.pair_i[p], j = W.pair_j[p];
+  const int si = W.ext_src[i];
+  const int n1 = F.vert_off[si + 1] - F.vert_off[si];
+  int n2 = 4;
+  if (j != WALL) { int sj = W.ext_src[j]; n2 = F.vert_off[sj + 1] - F.vert_off[sj]; }
+  szc::PairScratch S;
+  carve(W.scratch + W.pair_scr[p], scratch_bytes_for((i64)n1 + n2, W.pair_mult[p]), n1, n2, W.pair_mult[p], S);
+  return S.rows;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mirrored rows: pair p = (i, j) registers with j (:187-214)
+// ---------------------------------------------------------------------------------------------
+SZ_HD void incoming(i64 p, Work &W) {
+  if (!(W.pair_flag[p] & 4)) return;
+  int j = W.pair_j[p];
+  if (j == WALL) return;
+  int k = atomic_add(&W.inc_cnt[j], 1);
+  if (k >= W.pot_cap) { atomic_add(&W.counters[C_ERR_INC], 1ULL); return; }
+  W.inc_list[(size_t)j * W.pot_cap + k] = (int)p;
+}
+
+SZ_HD void row_count(int i, Work &W) { // i < N
+  int cnt = 0;
+  for (i64 p = W.pair_base[i]; p < W.pair_base[i] + W.pair_cnt[i]; ++p) cnt += W.pair_nrows[p];
+  int ninc = W.inc_cnt[i] < W.pot_cap ? W.inc_cnt[i] : W.pot_cap;
+  int *inc = W.inc_list + (size_t)i * W.pot_cap;
+  // ascending pair id == ascending source floe (pairs are laid out by source floe)
+  for (int a = 1; a < ninc; ++a) {
+    int v = inc[a], b = a;
+    while (b > 0 && inc[b - 1] > v) { inc[b] = inc[b - 1]; --b; }
+    inc[b] = v;
+  }
+  for (int a = 0; a < ninc; ++a) cnt += W.pair_nrows[inc[a]];
+  W.row_cnt[i] = cnt;
+}
+
+// rows of extended floe i in the reference's order, torques and sums; kill/transfer marks of its pairs
+SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
+  const int N0 = F.n;
+  i64 r = W.row_off[i];
+  double *rows = W.rows;
+  double ov = 0;
+  // own pairs, ascending partner, wall last (:129-172)
+  for (i64 p = W.pair_base[i]; p < W.pair_base[i] + W.pair_cnt[i]; ++p) {
+    const int j = W.pair_j[p];
+    const int fl = W.pair_flag[p];
+    if (fl & 4) {
+      const double *pr = pair_rows(p, F, W);
+      double so = 0;
+      for (int k = 0; k < W.pair_nrows[p]; ++k, ++r) {
+        if (r >= W.cap_rows) return;
+        double *w = rows + 7 * r;
+        double fx = pr[5 * k], fy = pr[5 * k + 1];
+        if (j == WALL) {
+          if (absd(pr[5 * k + 3]) == P.Ly) fx = 0;            // :160-162
+          if (absd(pr[5 * k + 2]) == P.Lx) fy = 0;            // :163-165
+          w[0] = SZC_INF;
+        } else w[0] = (double)(j + 1);
+        w[1] = fx; w[2] = fy; w[3] = pr[5 * k + 2]; w[4] = pr[5 * k + 3]; w[5] = 0; w[6] = pr[5 * k + 4];
+        so += pr[5 * k + 4];
+      }
+      ov = so + ov;                                           // :137 / :168
+    } else if ((fl & 3) && j != WALL && i + 1 > F.nb) {       // :138-145
+      if (i + 1 <= N0 && (fl & 1)) { F.kill[i] = i + 1; F.transfer[i] = j + 1; }
+      else if (j + 1 <= N0) F.kill[i] = j + 1;
+    }
+  }
+  // mirrored rows, ascending source floe (:187-214)
+  int ninc = W.inc_cnt[i] < W.pot_cap ? W.inc_cnt[i] : W.pot_cap;
+  const int *inc = W.inc_list + (size_t)i * W.pot_cap;
+  for (int a = 0; a < ninc; ++a) {
+    const i64 p = inc[a];
+    const double *pr = pair_rows(p, F, W);
+    const int src = W.pair_i[p];
+    for (int k = 0; k < W.pair_nrows[p]; ++k, ++r) {
+      if (r >= W.cap_rows) return;
+      double *w = rows + 7 * r;
+      w[0] = (double)(src + 1); w[1] = -pr[5 * k]; w[2] = -pr[5 * k + 1];
+      w[3] = pr[5 * k + 2]; w[4] = pr[5 * k + 3]; w[5] = 0; w[6] = pr[5 * k + 4];
+      ov = ov + pr[5 * k + 4];                                // :199
+    }
+  }
+  W.ov_ext[i] = ov;
+  // torque about the floe position of this (possibly ghost) entry, then the sums (:221-239, :251-263)
+  const i64 r0 = W.row_off[i];
+  const double x = W.ext_x[i], y = W.ext_y[i];
+  double sfx = 0, sfy = 0, stq = 0;
+  for (i64 q = r0; q < r; ++q) {
+    double *w = rows + 7 * q;
+    w[5] = (w[3] - x) * w[2] - (w[4] - y) * w[1];
+  }
+  for (i64 q = r0; q < r; ++q) { sfx += rows[7 * q + 1]; sfy += rows[7 * q + 2]; stq += rows[7 * q + 5]; }
+  W.cf_ext[2 * i] = sfx; W.cf_ext[2 * i + 1] = sfy; W.ct_ext[i] = stq;
+  // floe centre outside the box (:152-155)
+  if (!P.PERIODIC && i >= F.nb && i < N0) {
+    const double *c = P.c2_boundary;
+    // inpolygon of one point against the 5-point closed box, inpolygon.m:150-224
+    double mnx = c[0], mxx = c[0], mny = c[1], mxy = c[1];
+    for (int k = 1; k < 5; ++k) { mnx = szc::mind(mnx, c[2 * k]); mxx = szc::maxd(mxx, c[2 * k]); mny = szc::mind(mny, c[2 * k + 1]); mxy = szc::maxd(mxy, c[2 * k + 1]); }
+    bool in = false;
+    if (x >= mnx && x <= mxx && y >= mny && y <= mxy) {
+      double sumdq = 0; bool on = false;
+      for (int m = 0; m < 4; ++m) {
+        double xa = c[2 * m], ya = c[2 * m + 1], xb = c[2 * m + 2], yb = c[2 * m + 3];
+        double avx = absd(0.5 * (xa + xb)), avy = absd(0.5 * (ya + yb));
+        double sf = szc::maxd(avx, avy); sf = szc::maxd(sf, avx * avy);
+        double ax = xa - x, ay = ya - y, bx = xb - x, by = yb - y;
+        int qa, qb;
+        { bool px = ax > 0, py = ay > 0; qa = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+        { bool px = bx > 0, py = by > 0; qb = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+        double cp = ax * by - bx * ay;
+        double scp = (cp > 0) ? 1 : (cp < 0 ? -1 : 0);
+        if (absd(cp) < sf * SZC_EPS * 3) scp = 0;
+        double dp = ax * bx + ay * by;
+        double dq = qb - qa;
+        if (absd(dq) == 3) dq = -dq / 3;
+        if (absd(dq) == 2) dq = 2 * scp;
+        sumdq += dq;
+        if (scp == 0 && dp <= 0) on = true;
+      }
+      in = (sumdq != 0) || on;
+    }
+    if (!in) F.alive[i] = 0;
+  }
+}
+
+// transfer(kill(i)) = i for the largest such i (:175-179): first collect, then apply
+SZ_HD void transfer_collect(int i, const Floes &F, Work &W) { // i < N
+  int k = F.kill[i];
+  if (iabs(k - (i + 1)) > 0 && k > 0) atomic_max(&W.tmax[k - 1], i + 1);
+}
+SZ_HD void transfer_apply(int i, const Floes &F, Work &W) {
+  if (W.tmax[i] > 0) F.transfer[i] = W.tmax[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// calc_trajectory.m for real floe i (plus :242-245 ghost sums, :262-277 own sums and periodic wrap)
+// ---------------------------------------------------------------------------------------------
+SZ_HD double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, const double *V, double xq, double yq) {
+  if (!(xq >= Xo[0] && xq <= Xo[nx - 1] && yq >= Yo[0] && yq <= Yo[ny - 1])) return __builtin_nan("");
+  int ix = (int)::floor((xq - Xo[0]) / (Xo[1] - Xo[0]));
+  int iy = (int)::floor((yq - Yo[0]) / (Yo[1] - Yo[0]));
+  if (ix > nx - 2) ix = nx - 2;
+  if (iy > ny - 2) iy = ny - 2;
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  while (ix > 0 && xq < Xo[ix]) --ix;
+  while (ix < nx - 2 && xq > Xo[ix + 1]) ++ix;
+  while (iy > 0 && yq < Yo[iy]) --iy;
+  while (iy < ny - 2 && yq > Yo[iy + 1]) ++iy;
+  double tx = (xq - Xo[ix]) / (Xo[ix + 1] - Xo[ix]);
+  double ty = (yq - Yo[iy]) / (Yo[iy + 1] - Yo[iy]);
+  double v00 = V[iy + (size_t)ny * ix], v01 = V[iy + (size_t)ny * (ix + 1)];
+  double v10 = V[iy + 1 + (size_t)ny * ix], v11 = V[iy + 1 + (size_t)ny * (ix + 1)];
+  double a = v00 * (1 - tx) + v01 * tx;
+  double b = v10 * (1 - tx) + v11 * tx;
+  return a * (1 - ty) + b * ty;
+}
+
+SZ_HD void integrate(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
+  const int N0 = F.n;
+  (void)N0;
+  // ghost sums first (:242-245): the X ghost, then the Y ghost, of this floe; then the floe's own (:262-263)
+  double cfx = 0, cfy = 0, ctq = 0;
+  if (P.PERIODIC) {
+    int g = W.xg_of[i];
+    if (g >= 0) { cfx = cfx + W.cf_ext[2 * g]; cfy = cfy + W.cf_ext[2 * g + 1]; ctq = ctq + W.ct_ext[g]; }
+    g = W.yg_of[i];
+    if (g >= 0) { cfx = cfx + W.cf_ext[2 * g]; cfy = cfy + W.cf_ext[2 * g + 1]; ctq = ctq + W.ct_ext[g]; }
+  }
+  const i64 r0 = W.row_off[i], r1 = W.row_off[i + 1];
+  const int nrows = (int)(r1 - r0);
+  if (nrows > 0) { cfx = W.cf_ext[2 * i] + cfx; cfy = W.cf_ext[2 * i + 1] + cfy; ctq = W.ct_ext[i] + ctq; }
+  F.collision_force[2 * i] = cfx; F.collision_force[2 * i + 1] = cfy;
+  F.collision_torque[i] = ctq;
+  F.OverlapArea[i] = W.ov_ext[i];
+  const double x_before = W.ext_x[i];
+  if (P.PERIODIC) {                                              // :267-277
+    if (absd(F.Xi[i]) > P.Lx) F.Xi[i] = F.Xi[i] - 2 * P.Lx * sgn(F.Xi[i]);
+    if (absd(F.Yi[i]) > P.Ly) F.Yi[i] = F.Yi[i] - 2 * P.Ly * sgn(F.Yi[i]);
+  }
+  if (!F.alive[i]) return;                                       // :280
+
+  // ---- calc_trajectory.m ----
+  const double dt = P.dt;
+  double ext_fx = cfx, ext_fy = cfy, ext_torque = ctq;
+  const int Nz = F.n_stress;
+  double *SH = F.StressH + (size_t)i * Nz * 4;
+  double S[4] = {0, 0, 0, 0};
+  if (nrows > 0) {                                               // :9-13
+    double rx = F.Xi[i], ry = F.Yi[i];
+    double s11 = 0, s12 = 0, s21 = 0, s22 = 0, t11 = 0, t12 = 0, t21 = 0, t22 = 0;
+    for (i64 q = r0; q < r1; ++q) {
+      const double *a = W.rows + 7 * q;
+      s11 += (a[3] - rx) * a[1]; s12 += (a[4] - ry) * a[1];
+      s21 += (a[3] - rx) * a[2]; s22 += (a[4] - ry) * a[2];
+      t11 += a[1] * (a[3] - rx); t12 += a[2] * (a[3] - rx);
+      t21 += a[1] * (a[4] - ry); t22 += a[2] * (a[4] - ry);
+    }
+    double c = 1 / (2 * F.area[i] * F.h[i]);
+    S[0] = c * (s11 + t11); S[1] = c * (s21 + t21); S[2] = c * (s12 + t12); S[3] = c * (s22 + t22);
+  }
+  // everything calc_trajectory changes before it may return [] is staged here, so that a removed floe
+  // keeps its pre-call fields (floe_interactions_all.m:282)
+  int scount = F.StressCount[i];
+  if (scount > Nz) scount = 1;                                   // :15-17
+  double hh = F.h[i], mass = F.mass[i], inertia = F.inertia_moment[i];
+  int alive = F.alive[i];
+  if (hh > 10) hh = 10;                                          // :36-41
+  else if (mass < 100) { mass = 1e3; alive = 0; }
+  while (szc::maxd(absd(ext_fx), absd(ext_fy)) > mass / (5 * dt)) { // :42-46
+    ext_fx = ext_fx / 10; ext_fy = ext_fy / 10; ext_torque = ext_torque / 10;
+  }
+  const double rho0 = 1027, Cd = 3e-3, rho_air = 1.2, Cd_atm = 1e-3;
+  const double fc = P.fCoriolis;
+  const double floe_area = F.area[i];
+  double dh = P.HFo * dt / hh;                                   // :76-80
+  double floe_mass = (hh - dh) / hh * mass;
+  double floe_inertia = (hh - dh) / hh * inertia;
+  double h_new = hh - dh;
+  bool removed = false;
+  if (F.Xi[i] != F.Xi[i]) removed = true;                        // :89
+  const int v0 = F.vert_off[i], nvr = F.vert_off[i + 1] - v0;
+  const int nmc = F.n_mc;
+  const bool doforce = P.doInt || h_new < 0.1;                   // :94,:121
+  if (!removed) {                                                // :116
+    double mxx = F.cax[v0], mnx = F.cax[v0], mxy = F.cay[v0], mny = F.cay[v0];
+    for (int k = 1; k < nvr; ++k) {
+      mxx = szc::maxd(mxx, F.cax[v0 + k]); mnx = szc::mind(mnx, F.cax[v0 + k]);
+      mxy = szc::maxd(mxy, F.cay[v0 + k]); mny = szc::mind(mny, F.cay[v0 + k]);
+    }
+    double Xomax = P.Xo[0], Xomin = P.Xo[0], Yomax = P.Yo[0], Yomin = P.Yo[0];
+    for (int k = 1; k < P.nxo; ++k) { Xomax = szc::maxd(Xomax, P.Xo[k]); Xomin = szc::mind(Xomin, P.Xo[k]); }
+    for (int k = 1; k < P.nyo; ++k) { Yomax = szc::maxd(Yomax, P.Yo[k]); Yomin = szc::mind(Yomin, P.Yo[k]); }
+    if (mxx + F.Xi[i] > Xomax || mnx + F.Xi[i] < Xomin || mxy + F.Yi[i] > Yomax || mny + F.Yi[i] < Yomin)
+      removed = true;
+  }
+  if (!removed && doforce) {                                     // :100-110 needs rand(): not reproducible
+    int cnt = 0;
+    for (int q = 0; q < nmc; ++q) cnt += F.mcA[(size_t)i * nmc + q] ? 1 : 0;
+    if (cnt == 0) { atomic_add(&W.counters[C_ERR_MC], 1ULL); return; }
+  }
+  if (removed || x_before != x_before) { F.kill[i] = i + 1; }   // :282
+  if (removed) return;
+  // commit the staged fields
+  for (int q = 0; q < 4; ++q) {
+    double old = SH[(size_t)(scount - 1) * 4 + q];
+    SH[(size_t)(scount - 1) * 4 + q] = S[q];                     // :18 / :26
+    double sum = F.StressSum[4 * i + q] - old + S[q];
+    F.StressSum[4 * i + q] = sum;
+    F.Stress[4 * i + q] = sum / Nz;                              // :20 mean(StressH,3) as a running sum
+  }
+  F.StressCount[i] = scount + 1;
+  F.h[i] = h_new; F.mass[i] = floe_mass; F.inertia_moment[i] = floe_inertia; F.alive[i] = alive;
+  if (alive != 1) return;                                        // :118
+
+  if (doforce) {                                                 // :95-98, :121-166
+    double sa, ca;
+    szm::sincos(F.alpha_i[i], sa, ca);
+    const double *mx = F.mcX + (size_t)i * nmc, *my = F.mcY + (size_t)i * nmc;
+    const unsigned char *A = F.mcA + (size_t)i * nmc;
+    const double Xi = F.Xi[i], Yi = F.Yi[i];
+    double sta, cta;
+    szm::sincos(P.turn_angle, sta, cta);
+    double su = 0, sv = 0; int cnt = 0;
+    for (int q = 0; q < nmc; ++q) {
+      if (!A[q]) continue;
+      double xr1 = ca * mx[q] + (-sa) * my[q], xr2 = sa * mx[q] + ca * my[q];
+      double Xg = xr1 + Xi, Yg = xr2 + Yi;
+      su += interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uwind, Xg, Yg);
+      sv += interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vwind, Xg, Yg);
+      ++cnt;
+    }
+    double U10 = su / cnt, V10 = sv / cnt;
+    double w10 = ::sqrt(U10 * U10 + V10 * V10);
+    double Fx_atm = rho_air * Cd_atm * w10 * U10;
+    double Fy_atm = rho_air * Cd_atm * w10 * V10;
+    double sFx = 0, sFy = 0, sT = 0;
+    for (int q = 0; q < nmc; ++q) {
+      if (!A[q]) continue; // only the points inside the floe enter the means (:163-165)
+      double xr1 = ca * mx[q] + (-sa) * my[q], xr2 = sa * mx[q] + ca * my[q];
+      double Xg = xr1 + Xi, Yg = xr2 + Yi;
+      double th = szm::atan2(xr2, xr1), rho = szc::hyp(xr1, xr2);
+      double Uo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uocn, Xg, Yg);
+      double Vo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vocn, Xg, Yg);
+      double sth, cth;
+      szm::sincos(th, sth, cth);
+      double Uice = F.Ui[i] - rho * F.ksi_ice[i] * sth;
+      double Vice = F.Vi[i] + rho * F.ksi_ice[i] * cth;
+      double Fx_p = -(floe_mass / floe_area) * fc * Vo;
+      double Fy_p = +(floe_mass / floe_area) * fc * Uo;
+      double du = Uo - Uice, dv = Vo - Vice;
+      double sp = ::sqrt(du * du + dv * dv);
+      double tauX = rho0 * Cd * sp * (cta * du - sta * dv);
+      double tauY = rho0 * Cd * sp * (sta * du + cta * dv);
+      double Fx = tauX + Fx_atm + Fx_p;
+      double Fy = tauY + Fy_atm + Fy_p;
+      double tq = (-Fx * sth + Fy * cth) * rho;
+      Fx = Fx + (floe_mass / floe_area) * fc * F.Vi[i];
+      Fy = Fy - (floe_mass / floe_area) * fc * F.Ui[i];
+      sFx += Fx; sFy += Fy; sT += tq;
+    }
+    F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt;
+  }
+  // :174-177
+  double dx = 1.5 * dt * F.Ui[i] - 0.5 * dt * F.dXi_p[i];
+  double dy = 1.5 * dt * F.Vi[i] - 0.5 * dt * F.dYi_p[i];
+  F.Xi[i] = F.Xi[i] + dx; F.dXi_p[i] = F.Ui[i];
+  F.Yi[i] = F.Yi[i] + dy; F.dYi_p[i] = F.Vi[i];
+  F.alpha_i[i] = F.alpha_i[i] + 1.5 * dt * F.ksi_ice[i] - 0.5 * dt * F.dalpha_i_p[i];
+  F.dalpha_i_p[i] = F.ksi_ice[i];
+  // :181-208
+  double numU = F.FxOA[i] * floe_area + ext_fx, numV = F.FyOA[i] * floe_area + ext_fy;
+  double dUi_dt = numU / floe_mass, dVi_dt = numV / floe_mass;
+  bool have_frac = false;
+  double frac = 0;
+  bool bigU = absd(dt * dUi_dt) > 0.5 * h_new, bigV = absd(dt * dVi_dt) > 0.5 * h_new;
+  bool smallU = absd(dt * dUi_dt) < 0.5 * h_new, smallV = absd(dt * dVi_dt) < 0.5 * h_new;
+  if (bigU && bigV) {
+    double a = sgn(dUi_dt) * 0.5 * h_new / dt, b = sgn(dVi_dt) * 0.5 * h_new / dt;
+    double frac1 = a / numU * floe_mass, frac2 = b / numV * floe_mass;
+    frac = szc::mind(frac1, frac2); have_frac = true;
+  } else if (bigU && smallV) {
+    double a = sgn(dUi_dt) * 0.5 * h_new / dt;
+    frac = a / numU * floe_mass; have_frac = true;
+  } else if (smallU && bigV) {
+    double b = sgn(dVi_dt) * 0.5 * h_new / dt;
+    frac = b / numV * floe_mass; have_frac = true;
+  }
+  if (have_frac) { dUi_dt = frac * (numU / floe_mass); dVi_dt = frac * (numV / floe_mass); }
+  F.Ui[i] = F.Ui[i] + 1.5 * dt * dUi_dt - 0.5 * dt * F.dUi_p[i];
+  F.Vi[i] = F.Vi[i] + 1.5 * dt * dVi_dt - 0.5 * dt * F.dVi_p[i];
+  F.dUi_p[i] = dUi_dt; F.dVi_p[i] = dVi_dt;
+  // :210-219
+  double dksi = (F.torqueOA[i] * floe_area + ext_torque) / floe_inertia;
+  if (have_frac) dksi = frac * dksi;
+  double ksi = F.ksi_ice[i] + 1.5 * dt * dksi - 0.5 * dt * F.dksi_ice_p[i];
+  if (absd(ksi) > 1e-5) ksi = sgn(ksi) * 1e-5;
+  F.ksi_ice[i] = ksi;
+  F.dksi_ice_p[i] = dksi;
+  // :221-222
+  double sa, ca;
+  szm::sincos(F.alpha_i[i], sa, ca);
+  for (int k = 0; k < nvr; ++k) {
+    F.cax[v0 + k] = ca * F.c0x[v0 + k] + (-sa) * F.c0y[v0 + k];
+    F.cay[v0 + k] = sa * F.c0x[v0 + k] + ca * F.c0y[v0 + k];
+  }
+  if (P.doInt) {                                                 // :224-234
+    double sudy = 0, sudx = 0, svdy = 0, svdx = 0;
+    double U0 = 0, V0 = 0, Uprev = 0, Vprev = 0;
+    for (int k = 0; k <= nvr; ++k) {
+      int kk = (k == nvr) ? 0 : k;
+      double cxk = F.cax[v0 + kk], cyk = F.cay[v0 + kk];
+      double Uk, Vk;
+      if (k == nvr) { Uk = U0; Vk = V0; }
+      else {
+        double th = szm::atan2(cyk, cxk), rh = szc::hyp(cxk, cyk);
+        double sth, cth;
+        szm::sincos(th, sth, cth);
+        Uk = F.Ui[i] - rh * F.ksi_ice[i] * sth;
+        Vk = F.Vi[i] + rh * F.ksi_ice[i] * cth;
+        if (k == 0) { U0 = Uk; V0 = Vk; }
+      }
+      if (k > 0) {
+        double dU = Uk - Uprev, dV = Vk - Vprev;
+        double dcy = cyk - F.cay[v0 + k - 1], dcx = cxk - F.cax[v0 + k - 1];
+        sudy += dU * dcy; sudx += dU * dcx; svdy += dV * dcy; svdx += dV * dcx;
+      }
+      Uprev = Uk; Vprev = Vk;
+    }
+    double du_dx = 0.5 * sudy / floe_area, du_dy = 0.5 * sudx / floe_area;
+    double dv_dx = 0.5 * svdy / floe_area, dv_dy = 0.5 * svdx / floe_area;
+    F.strain[4 * i + 0] = 0.5 * (du_dx + du_dx);
+    F.strain[4 * i + 1] = 0.5 * (dv_dx + du_dy);
+    F.strain[4 * i + 2] = 0.5 * (du_dy + dv_dx);
+    F.strain[4 * i + 3] = 0.5 * (dv_dy + dv_dy);
+  }
+}
+
+} // namespace szs

@@ -1,0 +1,180 @@
+// TEST-ONLY: runs the kernel bodies of subzero_amd/csrc/step_core.hpp in plain loops on the CPU -- the
+// same source the GPU kernels execute -- so the CPU test-suite can compare the device pipeline with the
+// oracle without a GPU.  Not part of the product; nothing in subzero_amd/ loads this.
+#include "../../subzero_amd/csrc/step_core.hpp"
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace szs;
+
+template <class T> static T *alloc(std::vector<std::vector<char> > &pool, size_t n) {
+  pool.emplace_back(n * sizeof(T) + 64);
+  memset(pool.back().data(), 0, pool.back().size());
+  return (T *)(((uintptr_t)pool.back().data() + 15) & ~(uintptr_t)15);
+}
+
+extern "C" {
+
+// same field order as OrFloes / szFloeState
+struct HFloes {
+  int32_t n, nb, n_stress, n_mc;
+  double *Xi, *Yi, *alpha_i, *Ui, *Vi, *ksi_ice;
+  double *h, *area, *mass, *inertia_moment, *rmax;
+  double *dXi_p, *dYi_p, *dUi_p, *dVi_p, *dalpha_i_p, *dksi_ice_p;
+  double *FxOA, *FyOA, *torqueOA;
+  int32_t *alive;
+  int32_t *vert_off;
+  double *c0x, *c0y, *cax, *cay;
+  double *StressH;
+  int32_t *StressCount;
+  double *Stress, *strain;
+  double *mcX, *mcY;
+  uint8_t *mcA;
+  double *collision_force, *collision_torque, *OverlapArea;
+  int32_t *kill, *transfer;
+};
+struct HParams {
+  double dt, HFo, Modulus, mu, nu;
+  int32_t doInt, COLLISION, PERIODIC, reserved;
+  double c2_boundary[10];
+  double fb_h, fb_area, fb_Xi, fb_Yi, fb_Ui, fb_Vi, fb_ksi_ice;
+  int32_t nxo, nyo;
+  const double *Xo, *Yo, *Uocn, *Vocn, *Uwind, *Vwind;
+  double fCoriolis, turn_angle;
+};
+
+
+// returns 0, or: -1 output capacity, -5 workspace, -7 candidate-list overflow, -8 clip error, -9 MC regen
+int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, int64_t inter_cap,
+              int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext,
+              int32_t pot_cap, int64_t *retried) {
+  std::vector<std::vector<char> > pool;
+  Floes F;
+  F.n = hf->n; F.nb = hf->nb; F.n_stress = hf->n_stress; F.n_mc = hf->n_mc;
+  F.Xi = hf->Xi; F.Yi = hf->Yi; F.alpha_i = hf->alpha_i; F.Ui = hf->Ui; F.Vi = hf->Vi; F.ksi_ice = hf->ksi_ice;
+  F.h = hf->h; F.area = hf->area; F.mass = hf->mass; F.inertia_moment = hf->inertia_moment; F.rmax = hf->rmax;
+  F.dXi_p = hf->dXi_p; F.dYi_p = hf->dYi_p; F.dUi_p = hf->dUi_p; F.dVi_p = hf->dVi_p;
+  F.dalpha_i_p = hf->dalpha_i_p; F.dksi_ice_p = hf->dksi_ice_p;
+  F.FxOA = hf->FxOA; F.FyOA = hf->FyOA; F.torqueOA = hf->torqueOA;
+  F.alive = hf->alive; F.vert_off = hf->vert_off;
+  F.c0x = hf->c0x; F.c0y = hf->c0y; F.cax = hf->cax; F.cay = hf->cay;
+  F.StressH = hf->StressH; F.StressCount = hf->StressCount; F.Stress = hf->Stress; F.strain = hf->strain;
+  F.mcX = hf->mcX; F.mcY = hf->mcY; F.mcA = hf->mcA;
+  F.collision_force = hf->collision_force; F.collision_torque = hf->collision_torque; F.OverlapArea = hf->OverlapArea;
+  F.kill = hf->kill; F.transfer = hf->transfer;
+  const int n = F.n;
+  F.StressSum = alloc<double>(pool, (size_t)n * 4);
+  for (int i = 0; i < n; ++i)
+    for (int q = 0; q < 4; ++q) {
+      double s = 0;
+      for (int z = 0; z < F.n_stress; ++z) s += F.StressH[((size_t)i * F.n_stress + z) * 4 + q];
+      F.StressSum[4 * i + q] = s;
+    }
+  Params P;
+  P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
+  P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
+  memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
+  P.fb_h = hp->fb_h; P.fb_area = hp->fb_area; P.fb_Xi = hp->fb_Xi; P.fb_Yi = hp->fb_Yi; P.fb_Ui = hp->fb_Ui;
+  P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
+  P.nxo = hp->nxo; P.nyo = hp->nyo; P.Xo = hp->Xo; P.Yo = hp->Yo; P.Uocn = hp->Uocn; P.Vocn = hp->Vocn;
+  P.Uwind = hp->Uwind; P.Vwind = hp->Vwind; P.fCoriolis = hp->fCoriolis; P.turn_angle = hp->turn_angle;
+  P.Lx = P.c2_boundary[0]; P.Ly = P.c2_boundary[1];
+  for (int k = 1; k < 5; ++k) { P.Lx = szc::maxd(P.Lx, P.c2_boundary[2 * k]); P.Ly = szc::maxd(P.Ly, P.c2_boundary[2 * k + 1]); }
+
+  Work W;
+  memset(&W, 0, sizeof(W));
+  const int cap = 4 * n;
+  W.cap_ext = cap; W.pot_cap = pot_cap;
+  W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap);
+  W.xg_of = alloc<int>(pool, cap); W.yg_of = alloc<int>(pool, cap);
+  W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap);
+  W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
+  W.counters = alloc<unsigned long long>(pool, C_COUNT);
+  W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * pot_cap);
+  W.pair_cnt = alloc<int>(pool, cap); W.pair_nv = alloc<i64>(pool, cap);
+  W.pair_base = alloc<i64>(pool, cap + 1); W.nv_base = alloc<i64>(pool, cap + 1);
+  W.inc_cnt = alloc<int>(pool, cap); W.inc_list = alloc<int>(pool, (size_t)cap * pot_cap);
+  W.row_cnt = alloc<int>(pool, cap); W.row_off = alloc<i64>(pool, cap + 1);
+  W.cf_ext = alloc<double>(pool, 2 * (size_t)cap); W.ct_ext = alloc<double>(pool, cap); W.ov_ext = alloc<double>(pool, cap);
+  W.tmax = alloc<int>(pool, cap);
+
+  for (int e = 0; e < cap; ++e) { ext_clear(e, W); marks_clear(e, F); }
+  for (int i = 0; i < n; ++i) ext_init(i, F, W);
+  int N = n;
+  if (P.PERIODIC) {
+    for (int dim = 0; dim < 2; ++dim) {
+      int n1 = N, g = 0;
+      for (int e = 0; e < n1; ++e) ghost_flag(e, dim, F, P, W);
+      for (int e = 0; e < n1; ++e) { W.scan[e] = g; g += W.flag[e]; }
+      for (int e = 0; e < n1; ++e) ghost_emit(e, dim, n1, F, P, W);
+      N = n1 + g;
+    }
+  }
+  *n_ext = N;
+  for (int i = F.nb; i < n; ++i) broad(i, N, F, P, W);     // reals first: ghosts read their lists
+  for (int i = n; i < N; ++i) broad(i, N, F, P, W);
+  if (W.counters[C_ERR_POT]) return -7;
+  for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
+  i64 np = 0, nvt = 0;
+  for (int i = 0; i < N; ++i) { W.pair_base[i] = np; W.nv_base[i] = nvt; np += W.pair_cnt[i]; nvt += W.pair_nv[i]; }
+  W.pair_base[N] = np; W.nv_base[N] = nvt;
+  W.cap_pairs = np + 1;
+  W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
+  W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
+  W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
+  W.retry_list = alloc<int>(pool, np + 1);
+  for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
+  // candidate pairs as the oracle reports them (without wall candidates)
+  {
+    int64_t k = 0;
+    for (i64 p = 0; p < np; ++p) {
+      if (W.pair_j[p] == WALL) continue;
+      if (k < pair_cap) { pair_i[k] = W.pair_i[p] + 1; pair_j[k] = W.pair_j[p] + 1; }
+      ++k;
+    }
+    *npairs_out = k;
+    if (k > pair_cap) return -1;
+  }
+  i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
+  i64 reserve = main_bytes / 2 + (8 << 20);
+  W.scratch_bytes = main_bytes + reserve;
+  W.scratch = alloc<char>(pool, (size_t)W.scratch_bytes);
+  W.counters[C_SCR_BUMP] = (unsigned long long)main_bytes;
+  for (i64 p = 0; p < np; ++p) narrow(p, nullptr, 1, F, P, W);
+  *retried = (int64_t)W.counters[C_RETRY];
+  int mult = 1;
+  std::vector<int> list;
+  while (W.counters[C_RETRY] > 0) {
+    mult *= 8;
+    if (mult > 512) return -5;
+    list.assign(W.retry_list, W.retry_list + W.counters[C_RETRY]);
+    W.counters[C_RETRY] = 0;
+    for (size_t t = 0; t < list.size(); ++t) narrow((i64)t, list.data(), mult, F, P, W);
+  }
+  if (W.counters[C_ERR_ARENA]) return -5;
+  if (W.counters[C_ERR_CLIP]) return -8;
+  for (i64 p = np - 1; p >= 0; --p) incoming(p, W);        // reversed on purpose: order must not matter
+  if (W.counters[C_ERR_INC]) return -7;
+  for (int i = 0; i < N; ++i) row_count(i, W);
+  i64 nr = 0;
+  for (int i = 0; i < N; ++i) { W.row_off[i] = nr; nr += W.row_cnt[i]; }
+  W.row_off[N] = nr;
+  W.cap_rows = nr + 1;
+  W.rows = alloc<double>(pool, 7 * (size_t)(nr + 1));
+  for (int i = 0; i < N; ++i) row_fill(i, N, F, P, W);
+  for (int i = 0; i < N; ++i) transfer_collect(i, F, W);
+  for (int i = 0; i < cap; ++i) transfer_apply(i, F, W);
+  for (int i = F.nb; i < n; ++i) integrate(i, F, P, W);
+  if (W.counters[C_ERR_MC]) return -9;
+  for (int i = 0; i < F.nb; ++i) { F.collision_force[2 * i] = 0; F.collision_force[2 * i + 1] = 0; F.collision_torque[i] = 0; F.OverlapArea[i] = 0; }
+  // contact rows of the real floes
+  inter_off[0] = 0;
+  if (W.row_off[n] > inter_cap) return -1;
+  for (int i = 0; i < n; ++i) inter_off[i + 1] = (int32_t)W.row_off[i + 1];
+  memcpy(inter, W.rows, sizeof(double) * 7 * (size_t)W.row_off[n]);
+  return 0;
+}
+
+} // extern "C"

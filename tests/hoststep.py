@@ -1,0 +1,77 @@
+"""ctypes binding of tests/hostsim/libstep_host.so: the device step pipeline (subzero_amd/csrc/step_core.hpp)
+compiled for the host.  TEST INFRASTRUCTURE."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(ROOT, "tests", "hostsim", "libstep_host.so")
+    src = os.path.join(ROOT, "tests", "hostsim", "step_host.cpp")
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "detmath.hpp")]
+    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unused-function", src, "-o", path])
+    L = ctypes.CDLL(path)
+    L.host_step.argtypes = [ctypes.POINTER(orc.CFloes), ctypes.POINTER(orc.CParams), orc._ip, orc._dp,
+                            ctypes.c_int64, orc._ip, orc._ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
+                            orc._ip, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
+    _lib = L
+    return L
+
+
+def step(S, P, pot_cap=32):
+    L = lib()
+    cf, cp = orc.pack_floes(S), orc.pack_params(P)
+    cap_rows = 64 * S.n + 1024
+    cap_pairs = 64 * S.n + 1024
+    inter_off = np.zeros(S.n + 1, np.int32); inter = np.zeros((cap_rows, 7))
+    pi = np.zeros(cap_pairs, np.int32); pj = np.zeros(cap_pairs, np.int32)
+    npairs = ctypes.c_int64(); next_ = ctypes.c_int32(); retried = ctypes.c_int64()
+    rc = L.host_step(ctypes.byref(cf), ctypes.byref(cp), orc._p(inter_off, orc._ip), orc._p(inter), cap_rows,
+                     orc._p(pi, orc._ip), orc._p(pj, orc._ip), cap_pairs, ctypes.byref(npairs), ctypes.byref(next_),
+                     pot_cap, ctypes.byref(retried))
+    if rc != 0:
+        raise RuntimeError("host_step failed: %d" % rc)
+    r = orc.StepResult()
+    r.inter_off = inter_off
+    r.inter = inter[:inter_off[-1]].copy()
+    r.pairs = np.stack([pi[:npairs.value], pj[:npairs.value]], 1)
+    r.n_ext = next_.value
+    r.retried = retried.value
+    return r
+
+
+STATE_FIELDS = ["Xi", "Yi", "alpha_i", "Ui", "Vi", "ksi_ice", "h", "area", "mass", "inertia_moment", "rmax",
+                "dXi_p", "dYi_p", "dUi_p", "dVi_p", "dalpha_i_p", "dksi_ice_p", "FxOA", "FyOA", "torqueOA",
+                "alive", "cax", "cay", "StressCount", "strain", "collision_force", "collision_torque",
+                "OverlapArea", "kill", "transfer", "StressH"]
+
+
+def compare_states(A, B, exact=True, rtol=1e-10):
+    """Field-by-field comparison of two FloeStates; returns list of (field, max abs diff, max rel diff)."""
+    bad = []
+    for k in STATE_FIELDS:
+        a, b = np.asarray(getattr(A, k)), np.asarray(getattr(B, k))
+        if a.dtype.kind in "iu":
+            if not np.array_equal(a, b):
+                bad.append((k, int(np.abs(a.astype(np.int64) - b).max()), None))
+            continue
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        if same.all():
+            continue
+        d = np.abs(a - b)
+        scale = np.maximum(np.abs(a), np.abs(b))
+        rel = np.where(scale > 0, d / np.where(scale > 0, scale, 1), 0)
+        if exact or np.nanmax(rel) > rtol:
+            bad.append((k, float(np.nanmax(d)), float(np.nanmax(rel))))
+    return bad
