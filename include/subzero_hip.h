@@ -111,6 +111,85 @@ int szClipBatchDevice(szContext *ctx, int npairs,
                       const int64_t *d_bx, const int64_t *d_by, const int32_t *d_boff,
                       int total_a, int total_b, int method, szClipStats *stats);
 
+
+/* ---- B2: the Floe struct-array step ---------------------------------------------------------
+ * Replaces floe_interactions_all.m:16-285 (ghost floes, broad-phase, floe_interactions per candidate,
+ * contact mirror, torques and sums, periodic wrap, calc_trajectory).  Lines 288-507 (ridging, rafting,
+ * fuse / kill bookkeeping) stay with the caller and consume `kill` / `transfer`.
+ *
+ * szFloeState is the struct-of-arrays image of the Floe struct array; field names are those of
+ * Initialize_Model/initialize_floe_values.m:12-52.  All pointers are HOST pointers owned by the caller.
+ * Rings are CSR: floe i owns vertices vert_off[i]..vert_off[i+1] of c0 (unrotated) and c_alpha, closed
+ * (first vertex repeated, initialize_floe_values.m:17).  2x2 matrices are MATLAB column-major
+ * [xx, yx, xy, yy].  StressH is [floe][slot][4]; mcX/mcY/mcA are the Monte-Carlo fields X, Y, A as
+ * [floe][point].  kill / transfer have capacity 4*n: they are indexed over the extended list (real floes
+ * then ghost floes), exactly as the reference's arrays grow when a ghost row assigns into them. */
+typedef struct szFloeState {
+  int32_t n;        /* floes in the array (all alive ones the caller kept, floe_interactions_all.m:12-13) */
+  int32_t nb;       /* Nb: leading topography floes */
+  int32_t n_stress; /* slots of StressH (1000) */
+  int32_t n_mc;     /* Monte-Carlo points per floe (1000) */
+  double *Xi, *Yi, *alpha_i, *Ui, *Vi, *ksi_ice;
+  double *h, *area, *mass, *inertia_moment, *rmax;
+  double *dXi_p, *dYi_p, *dUi_p, *dVi_p, *dalpha_i_p, *dksi_ice_p;
+  double *FxOA, *FyOA, *torqueOA;
+  int32_t *alive;
+  int32_t *vert_off;
+  double *c0x, *c0y, *cax, *cay;
+  double *StressH;
+  int32_t *StressCount;
+  double *Stress, *strain;
+  double *mcX, *mcY;
+  uint8_t *mcA;
+  double *collision_force, *collision_torque, *OverlapArea;
+  int32_t *kill, *transfer;
+} szFloeState;
+
+/* the arguments of floe_interactions_all.m:1 the accelerated part reads (+ the Modulus global, :7) */
+typedef struct szStepParams {
+  double dt, HFo, Modulus;
+  double mu, nu;            /* floe_interactions.m:20-21 (0.2, 0.3 as shipped) */
+  int32_t doInt, COLLISION, PERIODIC, reserved;
+  double c2_boundary[10];   /* 2x5 column-major: x0,y0,x1,y1,... */
+  double fb_h, fb_area, fb_Xi, fb_Yi, fb_Ui, fb_Vi, fb_ksi_ice; /* floebound (Subzero.m:67-69) */
+  int32_t nxo, nyo;
+  const double *Xo, *Yo;       /* ocean.Xo, ocean.Yo */
+  const double *Uocn, *Vocn;   /* nyo x nxo column-major */
+  const double *Uwind, *Vwind; /* winds.u, winds.v, same shape */
+  double fCoriolis, turn_angle;
+} szStepParams;
+
+typedef struct szStepStats {
+  double step_ms;      /* HIP-event time of the whole step on the context's stream */
+  double broad_ms, narrow_ms, rows_ms, integrate_ms;
+  int64_t n_ext;       /* real + ghost floes */
+  int64_t n_pairs;     /* candidate pairs incl. floe-vs-wall candidates */
+  int64_t n_rows;      /* contact rows over the extended list */
+  int64_t pair_vertices; /* sum of ring sizes over the candidate pairs */
+  int64_t retried;     /* pairs re-run at a larger scratch tier */
+} szStepStats;
+
+/* which fields szFloesDownload copies back */
+enum {
+  SZ_SYNC_DYNAMIC = 1, /* everything calc_trajectory / the step writes except the two bulk histories */
+  SZ_SYNC_STRESSH = 2, /* StressH */
+  SZ_SYNC_ALL = 3
+};
+
+/* Copies the whole struct array to the GPU (replaces any previous one).  The state then lives on the
+ * device across szStep calls (dirty-field download only when MATLAB needs it). */
+int szFloesUpload(szContext *ctx, const szFloeState *host);
+/* One timestep on the device-resident floes. */
+int szStep(szContext *ctx, const szStepParams *params, szStepStats *stats);
+int szFloesDownload(szContext *ctx, szFloeState *host, int what);
+/* Floe(i).interactions of the last step for the n real floes, CSR: 7 doubles per row
+ * [partner (1-based; Inf = boundary), Fx, Fy, Px, Py, torque, overlap], row order of the reference. */
+int szInteractionsDownload(szContext *ctx, int32_t *inter_off, double *inter, int64_t cap_rows);
+/* candidate list of the last step's broad-phase (floe_interactions_all.m:103), 1-based (i, j) over the
+ * extended list, in the reference's order; wall candidates excluded. */
+int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t cap, int64_t *npairs,
+                    int32_t *n_ext);
+
 /* clipper(P) orientation mode (mexclipper.cpp:134-145): 1 if Area(P) >= 0 else 0.  Host arithmetic
  * on n vertices (an O(n) sum; there is nothing to accelerate). */
 int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation);

@@ -34,10 +34,84 @@ class ClipStats(ctypes.Structure):
                 ("failed", ctypes.c_int64)]
 
 
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_bp = ctypes.POINTER(ctypes.c_uint8)
+
+
+class FloeStateC(ctypes.Structure):
+    """szFloeState"""
+    _fields_ = (
+        [("n", ctypes.c_int32), ("nb", ctypes.c_int32), ("n_stress", ctypes.c_int32), ("n_mc", ctypes.c_int32)]
+        + [(k, _dp) for k in ["Xi", "Yi", "alpha_i", "Ui", "Vi", "ksi_ice", "h", "area", "mass",
+                              "inertia_moment", "rmax", "dXi_p", "dYi_p", "dUi_p", "dVi_p", "dalpha_i_p",
+                              "dksi_ice_p", "FxOA", "FyOA", "torqueOA"]]
+        + [("alive", _ip), ("vert_off", _ip), ("c0x", _dp), ("c0y", _dp), ("cax", _dp), ("cay", _dp),
+           ("StressH", _dp), ("StressCount", _ip), ("Stress", _dp), ("strain", _dp), ("mcX", _dp),
+           ("mcY", _dp), ("mcA", _bp), ("collision_force", _dp), ("collision_torque", _dp),
+           ("OverlapArea", _dp), ("kill", _ip), ("transfer", _ip)])
+
+
+class StepParamsC(ctypes.Structure):
+    """szStepParams"""
+    _fields_ = [("dt", ctypes.c_double), ("HFo", ctypes.c_double), ("Modulus", ctypes.c_double),
+                ("mu", ctypes.c_double), ("nu", ctypes.c_double),
+                ("doInt", ctypes.c_int32), ("COLLISION", ctypes.c_int32), ("PERIODIC", ctypes.c_int32),
+                ("reserved", ctypes.c_int32),
+                ("c2_boundary", ctypes.c_double * 10),
+                ("fb_h", ctypes.c_double), ("fb_area", ctypes.c_double), ("fb_Xi", ctypes.c_double),
+                ("fb_Yi", ctypes.c_double), ("fb_Ui", ctypes.c_double), ("fb_Vi", ctypes.c_double),
+                ("fb_ksi_ice", ctypes.c_double),
+                ("nxo", ctypes.c_int32), ("nyo", ctypes.c_int32),
+                ("Xo", _dp), ("Yo", _dp), ("Uocn", _dp), ("Vocn", _dp), ("Uwind", _dp), ("Vwind", _dp),
+                ("fCoriolis", ctypes.c_double), ("turn_angle", ctypes.c_double)]
+
+
+class StepStats(ctypes.Structure):
+    _fields_ = [("step_ms", ctypes.c_double), ("broad_ms", ctypes.c_double), ("narrow_ms", ctypes.c_double),
+                ("rows_ms", ctypes.c_double), ("integrate_ms", ctypes.c_double),
+                ("n_ext", ctypes.c_int64), ("n_pairs", ctypes.c_int64), ("n_rows", ctypes.c_int64),
+                ("pair_vertices", ctypes.c_int64), ("retried", ctypes.c_int64)]
+
+
+SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3
+
+
+def pack_floes(S):
+    """szFloeState over the arrays of a synth.FloeState-like object (which must outlive the struct)."""
+    c = FloeStateC()
+    c.n, c.nb, c.n_stress, c.n_mc = S.n, S.nb, S.n_stress, S.n_mc
+    for name, typ in FloeStateC._fields_[4:]:
+        arr = getattr(S, name)
+        if not arr.flags["C_CONTIGUOUS"]:
+            raise SubzeroError("field %s must be C-contiguous" % name)
+        setattr(c, name, arr.ctypes.data_as(typ))
+    return c
+
+
+def pack_params(P):
+    c = StepParamsC()
+    for k in ["dt", "HFo", "Modulus", "mu", "nu", "doInt", "COLLISION", "PERIODIC", "fb_h", "fb_area", "fb_Xi",
+              "fb_Yi", "fb_Ui", "fb_Vi", "fb_ksi_ice", "fCoriolis", "turn_angle"]:
+        setattr(c, k, getattr(P, k))
+    c.reserved = 0
+    cb = np.asarray(P.c2_boundary, np.float64)
+    for k in range(5):
+        c.c2_boundary[2 * k] = cb[0, k]; c.c2_boundary[2 * k + 1] = cb[1, k]
+    c.nxo, c.nyo = len(P.Xo), len(P.Yo)
+    # (ny, nx) numpy arrays -> MATLAB column-major storage
+    P._keep_c = [np.ascontiguousarray(P.Xo, np.float64), np.ascontiguousarray(P.Yo, np.float64)] + \
+                [np.ascontiguousarray(np.asarray(a, np.float64).T) for a in (P.Uocn, P.Vocn, P.Uwind, P.Vwind)]
+    for name, arr in zip(["Xo", "Yo", "Uocn", "Vocn", "Uwind", "Vwind"], P._keep_c):
+        setattr(c, name, arr.ctypes.data_as(_dp))
+    return c
+
+
 # every symbol include/subzero_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
     "szClipBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
+    "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize",
 ]
 
@@ -68,6 +142,11 @@ def load():
     L.szClipBatchDevice.argtypes = [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ClipStats)]
     L.szOrientation.argtypes = [_i64p, _i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.szFloesUpload.argtypes = [_vp, ctypes.POINTER(FloeStateC)]
+    L.szStep.argtypes = [_vp, ctypes.POINTER(StepParamsC), ctypes.POINTER(StepStats)]
+    L.szFloesDownload.argtypes = [_vp, ctypes.POINTER(FloeStateC), ctypes.c_int]
+    L.szInteractionsDownload.argtypes = [_vp, _ip, _dp, ctypes.c_int64]
+    L.szPairsDownload.argtypes = [_vp, _ip, _ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _ip]
     L.szDeviceAlloc.argtypes = [_vp, ctypes.POINTER(_vp), ctypes.c_int64]
     L.szDeviceFree.argtypes = [_vp, _vp]
     L.szCopyToDevice.argtypes = [_vp, _vp, _vp, ctypes.c_int64]
@@ -153,6 +232,62 @@ class Context:
         self.check(self.L.szClipBatchDevice(self.h, npairs, d_ax, d_ay, d_aoff, d_bx, d_by, d_boff,
                                             total_a, total_b, method, ctypes.byref(stats)), "szClipBatchDevice")
         return stats
+
+
+class FloeInteractions:
+    """Host mirror of the reference's step call (floe_interactions_all.m:1, lines 16-285): the Floe struct
+    array lives on the GPU between steps; `step` is one call of the accelerated part, `download` brings the
+    fields MATLAB-side code reads back into the host arrays."""
+
+    def __init__(self, ctx, floes):
+        self.ctx, self.floes = ctx, floes
+        self._c = pack_floes(floes)
+        ctx.check(ctx.L.szFloesUpload(ctx.h, ctypes.byref(self._c)), "szFloesUpload")
+
+    def step(self, params):
+        cp = pack_params(params)
+        st = StepStats()
+        self.ctx.check(self.ctx.L.szStep(self.ctx.h, ctypes.byref(cp), ctypes.byref(st)), "szStep")
+        return st
+
+    def download(self, what=SYNC_DYNAMIC):
+        self.ctx.check(self.ctx.L.szFloesDownload(self.ctx.h, ctypes.byref(self._c), what), "szFloesDownload")
+        return self.floes
+
+    def interactions(self):
+        """(inter_off[n+1], rows[K,7]) -- Floe(i).interactions of the last step."""
+        n = self.floes.n
+        off = np.zeros(n + 1, np.int32)
+        cap = 64 * n + 1024
+        while True:
+            rows = np.zeros((cap, 7))
+            rc = self.ctx.L.szInteractionsDownload(self.ctx.h, off.ctypes.data_as(_ip), rows.ctypes.data_as(_dp), cap)
+            if rc == SZ_ERR_CAPACITY:
+                cap *= 4
+                continue
+            self.ctx.check(rc, "szInteractionsDownload")
+            return off, rows[:off[-1]].copy()
+
+    def pairs(self):
+        """Candidate pairs (1-based, extended list) of the last step and N (real + ghost floes)."""
+        cap = 64 * self.floes.n + 1024
+        while True:
+            pi = np.zeros(cap, np.int32); pj = np.zeros(cap, np.int32)
+            npairs = ctypes.c_int64(); next_ = ctypes.c_int32()
+            rc = self.ctx.L.szPairsDownload(self.ctx.h, pi.ctypes.data_as(_ip), pj.ctypes.data_as(_ip), cap,
+                                            ctypes.byref(npairs), ctypes.byref(next_))
+            if rc == SZ_ERR_CAPACITY:
+                cap *= 4
+                continue
+            self.ctx.check(rc, "szPairsDownload")
+            return np.stack([pi[:npairs.value], pj[:npairs.value]], 1), next_.value
+
+
+def collision_count(rows):
+    """calc_collisionNum.m:6 -- finite-partner rows / 2 + boundary rows."""
+    if len(rows) == 0:
+        return 0.0
+    return float((rows[:, 0] < np.inf).sum()) / 2 + float((rows[:, 0] == np.inf).sum())
 
 
 def orientation(x, y):

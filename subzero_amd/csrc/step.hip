@@ -1,3 +1,474 @@
-// step.hip -- placeholder until the B2 surface lands
+// step.hip -- the B2 surface of include/subzero_hip.h on gfx950: device-resident Floe struct array and one
+// timestep of floe_interactions_all.m:16-285 as a chain of kernels over the bodies in step_core.hpp.
+//
+// Launch shapes (all 1-D, 256-thread workgroups unless noted; the work is irregular FP64/int64 geometry,
+// so the rules that matter are occupancy, coalesced SoA loads and short dependent chains -- no MFMA):
+//   k_ext_clear / k_ext_init / k_ghost_flag / k_ghost_emit   one thread per (extended) floe
+//   k_scan_*                                                  one 1024-thread workgroup, chunked scan
+//   k_broad                                                   one thread per extended floe i, j > i
+//   k_pair_count / k_pair_expand                              one thread per extended floe
+//   k_narrow                                                  one thread per candidate pair, 64-thread
+//                                                             workgroups (one wave) for fine-grained dispatch
+//   k_incoming / k_row_count / k_row_fill / k_transfer_*      per pair / per extended floe
+//   k_integrate                                               one thread per real floe
+// Two host read-backs per step size the pair scratch and the contact-row buffer (grow-only, owned by the
+// context).  No CPU fallback exists: every failure is an error code.
 #include "context.hpp"
-void sz_step_destroy(szContext *) {}
+#include "step_core.hpp"
+
+using namespace szs;
+
+struct StepState {
+  Floes F;            // device pointers
+  Work W;             // device pointers
+  std::vector<DevBuf> bufs;
+  int n = 0, nb = 0, n_stress = 0, n_mc = 0, nverts = 0;
+  int pot_cap = 32;
+  // ocean grids on the device
+  DevBuf oXo, oYo, oU, oV, oWu, oWv;
+  int nxo = 0, nyo = 0;
+  bool have_ocean = false;
+  // grow-only per-step buffers
+  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
+  DevBuf scratch, rows;
+  i64 last_npairs = 0, last_nrows_real = 0;
+  int last_next = 0;
+  bool stepped = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+__device__ inline int dev_next(const Work &W) { return (int)W.counters[C_NEXT]; }
+
+__global__ void k_ext_clear(Floes F, Work W) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < W.cap_ext) { ext_clear(e, W); marks_clear(e, F); }
+  if (e < F.n) ext_init(e, F, W);
+  if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
+}
+__global__ void k_ghost_flag(int dim, Floes F, Params P, Work W) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int n1 = (dim == 0) ? F.n : F.n + (int)W.counters[C_GX];
+  if (e < n1) ghost_flag(e, dim, F, P, W);
+}
+__global__ void k_ghost_emit(int dim, Floes F, Params P, Work W) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int n1 = (dim == 0) ? F.n : F.n + (int)W.counters[C_GX];
+  if (e < n1) ghost_emit(e, dim, n1, F, P, W);
+}
+
+// exclusive scan by one workgroup: thread t owns a contiguous chunk
+template <class TIn, class TOut>
+__device__ void block_scan(const TIn *in, TOut *out, int n, TOut *total) {
+  __shared__ long long part[1024];
+  const int T = blockDim.x, t = threadIdx.x;
+  int chunk = (n + T - 1) / T;
+  int lo = t * chunk, hi = lo + chunk;
+  if (lo > n) lo = n;
+  if (hi > n) hi = n;
+  long long s = 0;
+  for (int k = lo; k < hi; ++k) s += (long long)in[k];
+  part[t] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan of the partials
+  for (int d = 1; d < T; d <<= 1) {
+    long long v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  long long base = (t == 0) ? 0 : part[t - 1];
+  for (int k = lo; k < hi; ++k) { out[k] = (TOut)base; base += (long long)in[k]; }
+  if (t == T - 1 && total) *total = (TOut)part[T - 1];
+}
+__global__ void __launch_bounds__(1024) k_scan_ghost(int dim, Floes F, Work W) {
+  __shared__ int tot;
+  int n1 = (dim == 0) ? F.n : F.n + (int)W.counters[C_GX];
+  block_scan<int, int>(W.flag, W.scan, n1, &tot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    W.counters[dim == 0 ? C_GX : C_GY] = (unsigned long long)tot;
+    W.counters[C_NEXT] = (unsigned long long)(n1 + tot);
+  }
+}
+__global__ void __launch_bounds__(1024) k_scan_pairs(Work W) {
+  __shared__ i64 tot;
+  int N = dev_next(W);
+  block_scan<int, i64>(W.pair_cnt, W.pair_base, N, &tot);
+  __syncthreads();
+  if (threadIdx.x == 0) { W.counters[C_NPAIRS] = (unsigned long long)tot; W.pair_base[N] = tot; }
+  __syncthreads();
+  block_scan<i64, i64>(W.pair_nv, W.nv_base, N, &tot);
+  __syncthreads();
+  if (threadIdx.x == 0) { W.counters[C_NVTOT] = (unsigned long long)tot; W.nv_base[N] = tot; }
+}
+__global__ void __launch_bounds__(1024) k_scan_rows(Work W) {
+  __shared__ i64 tot;
+  int N = dev_next(W);
+  block_scan<int, i64>(W.row_cnt, W.row_off, N, &tot);
+  __syncthreads();
+  if (threadIdx.x == 0) { W.counters[C_NROWS] = (unsigned long long)tot; W.row_off[N] = tot; }
+}
+
+__global__ void k_broad(int lo_is_real, Floes F, Params P, Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
+  else { i += F.n; if (i >= N) return; }
+  broad(i, N, F, P, W);
+}
+__global__ void k_pair_count(Floes F, Params P, Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) pair_count(i, N, F, P, W);
+}
+__global__ void k_pair_expand(Floes F, Params P, Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) pair_expand(i, N, F, P, W);
+}
+__global__ void __launch_bounds__(64) k_narrow(i64 count, const int *list, int mult, Floes F, Params P, Work W) {
+  i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) narrow(t, list, mult, F, P, W);
+}
+__global__ void k_incoming(i64 np, Work W) {
+  i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < np) incoming(p, W);
+}
+__global__ void k_row_count(Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) row_count(i, W);
+}
+__global__ void k_row_fill(Floes F, Params P, Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) row_fill(i, N, F, P, W);
+}
+__global__ void k_transfer_collect(Floes F, Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) transfer_collect(i, F, W);
+}
+__global__ void k_transfer_apply(Floes F, Work W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < W.cap_ext) transfer_apply(i, F, W);
+}
+__global__ void k_integrate(Floes F, Params P, Work W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
+  if (i < F.n) integrate(i, F, P, W);
+  int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z < F.nb) { F.collision_force[2 * z] = 0; F.collision_force[2 * z + 1] = 0; F.collision_torque[z] = 0; F.OverlapArea[z] = 0; }
+}
+// running sums of the stress history, once after upload
+__global__ void k_stress_sum(Floes F) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  for (int q = 0; q < 4; ++q) {
+    double s = 0;
+    for (int z = 0; z < F.n_stress; ++z) s += F.StressH[((size_t)i * F.n_stress + z) * 4 + q];
+    F.StressSum[4 * i + q] = s;
+  }
+}
+
+inline dim3 grid_for(i64 n, int block) { return dim3((unsigned)((n + block - 1) / block > 0 ? (n + block - 1) / block : 1)); }
+
+template <class T>
+int dev_alloc(szContext *ctx, StepState *S, T *&ptr, size_t count) {
+  S->bufs.emplace_back();
+  DevBuf &b = S->bufs.back();
+  int rc = sz_reserve(ctx, b, count * sizeof(T) + 64);
+  if (rc) return rc;
+  ptr = (T *)b.p;
+  return SZ_OK;
+}
+template <class T>
+int dev_put(szContext *ctx, StepState *S, T *&ptr, const T *src, size_t count) {
+  int rc = dev_alloc(ctx, S, ptr, count);
+  if (rc) return rc;
+  if (count) SZ_HIP(ctx, hipMemcpy(ptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return SZ_OK;
+}
+
+} // namespace
+
+void sz_step_destroy(szContext *ctx) {
+  StepState *S = ctx->step;
+  if (!S) return;
+  for (DevBuf &b : S->bufs) sz_release(b);
+  DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
+                    &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
+                    &S->retry_copy, &S->scratch, &S->rows};
+  for (DevBuf *b : more) sz_release(*b);
+  for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
+  delete S;
+  ctx->step = nullptr;
+}
+
+extern "C" {
+
+int szFloesUpload(szContext *ctx, const szFloeState *h) {
+  if (!ctx || !h) return SZ_ERR_BAD_ARG;
+  if (h->n <= 0 || h->nb < 0 || h->nb > h->n || h->n_stress <= 0 || h->n_mc <= 0 || !h->vert_off)
+    return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFloesUpload: bad sizes");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sz_step_destroy(ctx);
+  StepState *S = new StepState();
+  ctx->step = S;
+  for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
+  const int n = h->n;
+  const int nv = h->vert_off[n];
+  S->n = n; S->nb = h->nb; S->n_stress = h->n_stress; S->n_mc = h->n_mc; S->nverts = nv;
+  S->bufs.reserve(128);
+  Floes &F = S->F;
+  F.n = n; F.nb = h->nb; F.n_stress = h->n_stress; F.n_mc = h->n_mc;
+  int rc;
+#define PUT(field, count) if ((rc = dev_put(ctx, S, F.field, h->field, (size_t)(count)))) return rc;
+  PUT(Xi, n) PUT(Yi, n) PUT(alpha_i, n) PUT(Ui, n) PUT(Vi, n) PUT(ksi_ice, n)
+  PUT(h, n) PUT(area, n) PUT(mass, n) PUT(inertia_moment, n) PUT(rmax, n)
+  PUT(dXi_p, n) PUT(dYi_p, n) PUT(dUi_p, n) PUT(dVi_p, n) PUT(dalpha_i_p, n) PUT(dksi_ice_p, n)
+  PUT(FxOA, n) PUT(FyOA, n) PUT(torqueOA, n)
+  PUT(alive, n) PUT(vert_off, n + 1)
+  PUT(c0x, nv) PUT(c0y, nv) PUT(cax, nv) PUT(cay, nv)
+  PUT(StressH, (size_t)n * h->n_stress * 4) PUT(StressCount, n) PUT(Stress, 4 * (size_t)n) PUT(strain, 4 * (size_t)n)
+  PUT(mcX, (size_t)n * h->n_mc) PUT(mcY, (size_t)n * h->n_mc) PUT(mcA, (size_t)n * h->n_mc)
+  PUT(collision_force, 2 * (size_t)n) PUT(collision_torque, n) PUT(OverlapArea, n)
+#undef PUT
+  if ((rc = dev_alloc(ctx, S, F.kill, 4 * (size_t)n))) return rc;
+  if ((rc = dev_alloc(ctx, S, F.transfer, 4 * (size_t)n))) return rc;
+  if ((rc = dev_alloc(ctx, S, F.StressSum, 4 * (size_t)n))) return rc;
+  Work &W = S->W;
+  memset(&W, 0, sizeof(W));
+  const size_t cap = 4 * (size_t)n;
+  W.cap_ext = (int)cap; W.pot_cap = S->pot_cap;
+#define NEW(field, count) if ((rc = dev_alloc(ctx, S, W.field, (size_t)(count)))) return rc;
+  NEW(ext_src, cap) NEW(ext_num, cap) NEW(ext_parent, cap) NEW(xg_of, cap) NEW(yg_of, cap)
+  NEW(ext_x, cap) NEW(ext_y, cap) NEW(flag, cap) NEW(scan, cap) NEW(counters, C_COUNT)
+  NEW(pot_cnt, cap) NEW(pot_list, cap * W.pot_cap)
+  NEW(pair_cnt, cap) NEW(pair_nv, cap) NEW(pair_base, cap + 1) NEW(nv_base, cap + 1)
+  NEW(inc_cnt, cap) NEW(inc_list, cap * W.pot_cap)
+  NEW(row_cnt, cap) NEW(row_off, cap + 1) NEW(cf_ext, 2 * cap) NEW(ct_ext, cap) NEW(ov_ext, cap) NEW(tmax, cap)
+#undef NEW
+  hipLaunchKernelGGL(k_stress_sum, grid_for(n, 256), dim3(256), 0, ctx->stream, F);
+  SZ_HIP(ctx, hipGetLastError());
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SZ_OK;
+}
+
+int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
+  if (!ctx || !hp) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStep: no floes uploaded");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  // ocean / wind grids: uploaded on the first step and whenever the forcing is refreshed
+  if (!S->have_ocean || hp->doInt) {
+    if (hp->nxo < 2 || hp->nyo < 2 || !hp->Xo || !hp->Yo || !hp->Uocn || !hp->Vocn || !hp->Uwind || !hp->Vwind)
+      return sz_fail(ctx, SZ_ERR_BAD_ARG, "szStep: ocean / wind grids missing");
+    size_t g = (size_t)hp->nxo * hp->nyo * 8;
+    if ((rc = sz_reserve(ctx, S->oXo, (size_t)hp->nxo * 8))) return rc;
+    if ((rc = sz_reserve(ctx, S->oYo, (size_t)hp->nyo * 8))) return rc;
+    if ((rc = sz_reserve(ctx, S->oU, g)) || (rc = sz_reserve(ctx, S->oV, g)) || (rc = sz_reserve(ctx, S->oWu, g)) ||
+        (rc = sz_reserve(ctx, S->oWv, g))) return rc;
+    SZ_HIP(ctx, hipMemcpyAsync(S->oXo.p, hp->Xo, (size_t)hp->nxo * 8, hipMemcpyHostToDevice, st));
+    SZ_HIP(ctx, hipMemcpyAsync(S->oYo.p, hp->Yo, (size_t)hp->nyo * 8, hipMemcpyHostToDevice, st));
+    SZ_HIP(ctx, hipMemcpyAsync(S->oU.p, hp->Uocn, g, hipMemcpyHostToDevice, st));
+    SZ_HIP(ctx, hipMemcpyAsync(S->oV.p, hp->Vocn, g, hipMemcpyHostToDevice, st));
+    SZ_HIP(ctx, hipMemcpyAsync(S->oWu.p, hp->Uwind, g, hipMemcpyHostToDevice, st));
+    SZ_HIP(ctx, hipMemcpyAsync(S->oWv.p, hp->Vwind, g, hipMemcpyHostToDevice, st));
+    S->nxo = hp->nxo; S->nyo = hp->nyo; S->have_ocean = true;
+  }
+  Params P;
+  P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
+  P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
+  memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
+  P.fb_h = hp->fb_h; P.fb_area = hp->fb_area; P.fb_Xi = hp->fb_Xi; P.fb_Yi = hp->fb_Yi; P.fb_Ui = hp->fb_Ui;
+  P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
+  P.nxo = S->nxo; P.nyo = S->nyo;
+  P.Xo = (const double *)S->oXo.p; P.Yo = (const double *)S->oYo.p;
+  P.Uocn = (const double *)S->oU.p; P.Vocn = (const double *)S->oV.p;
+  P.Uwind = (const double *)S->oWu.p; P.Vwind = (const double *)S->oWv.p;
+  P.fCoriolis = hp->fCoriolis; P.turn_angle = hp->turn_angle;
+  P.Lx = P.c2_boundary[0]; P.Ly = P.c2_boundary[1];
+  for (int k = 1; k < 5; ++k) {
+    if (P.c2_boundary[2 * k] > P.Lx) P.Lx = P.c2_boundary[2 * k];
+    if (P.c2_boundary[2 * k + 1] > P.Ly) P.Ly = P.c2_boundary[2 * k + 1];
+  }
+  Floes &F = S->F;
+  Work &W = S->W;
+  const int n = S->n;
+  const int cap = W.cap_ext;
+
+  SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
+  hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, W);
+  if (P.PERIODIC) {
+    for (int dim = 0; dim < 2; ++dim) {
+      int bound = (dim == 0) ? n : 2 * n;
+      hipLaunchKernelGGL(k_ghost_flag, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
+      hipLaunchKernelGGL(k_scan_ghost, dim3(1), dim3(1024), 0, st, dim, F, W);
+      hipLaunchKernelGGL(k_ghost_emit, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
+    }
+  }
+  hipLaunchKernelGGL(k_broad, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
+  if (P.PERIODIC) hipLaunchKernelGGL(k_broad, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
+  hipLaunchKernelGGL(k_pair_count, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, st, W);
+  SZ_HIP(ctx, hipGetLastError());
+  SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
+  unsigned long long c[C_COUNT];
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (c[C_ERR_POT]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "broad-phase: %llu floe(s) have more than %d candidates", c[C_ERR_POT], W.pot_cap);
+  const i64 np = (i64)c[C_NPAIRS], nvt = (i64)c[C_NVTOT];
+  const int N = (int)c[C_NEXT];
+
+  // per-pair buffers and scratch, sized for this step (grow-only)
+  const size_t npa = (size_t)np + 1;
+  if ((rc = sz_reserve(ctx, S->pair_i, npa * 4)) || (rc = sz_reserve(ctx, S->pair_j, npa * 4)) ||
+      (rc = sz_reserve(ctx, S->pair_nvoff, npa * 8)) || (rc = sz_reserve(ctx, S->pair_scr, npa * 8)) ||
+      (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
+      (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
+      (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4))) return rc;
+  const i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
+  const i64 reserve = main_bytes / 2 + (8 << 20);
+  if ((rc = sz_reserve(ctx, S->scratch, (size_t)(main_bytes + reserve)))) return rc;
+  W.cap_pairs = (i64)npa;
+  W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
+  W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
+  W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
+  W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
+  unsigned long long bump = (unsigned long long)main_bytes;
+  SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_SCR_BUMP], &bump, 8, hipMemcpyHostToDevice, st));
+
+  hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
+  SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
+  i64 retried = 0;
+  if (np > 0) {
+    hipLaunchKernelGGL(k_narrow, grid_for(np, 64), dim3(64), 0, st, np, (const int *)nullptr, 1, F, P, W);
+    SZ_HIP(ctx, hipGetLastError());
+  }
+  SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipStreamSynchronize(st));
+  int mult = 1;
+  while (c[C_RETRY] > 0) {
+    mult *= 8;
+    if (mult > 512) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) outgrew the 512x scratch tier", c[C_RETRY]);
+    i64 nl = (i64)c[C_RETRY];
+    if (mult == 8) retried = nl;
+    SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
+    unsigned long long zero = 0;
+    SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &zero, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_narrow, grid_for(nl, 64), dim3(64), 0, st, nl, (const int *)S->retry_copy.p, mult, F, P, W);
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+    SZ_HIP(ctx, hipStreamSynchronize(st));
+  }
+  if (c[C_ERR_ARENA]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) did not fit the scratch arena", c[C_ERR_ARENA]);
+  if (c[C_ERR_CLIP]) return sz_fail(ctx, SZ_ERR_HIP, "narrow-phase: %llu pair(s) hit the reference's \"Clipper Error.\" condition", c[C_ERR_CLIP]);
+
+  if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
+  hipLaunchKernelGGL(k_row_count, grid_for(cap, 256), dim3(256), 0, st, W);
+  hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, W);
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
+  const i64 nr = (i64)c[C_NROWS];
+  if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)(nr + 1)))) return rc;
+  W.rows = (double *)S->rows.p; W.cap_rows = nr + 1;
+  hipLaunchKernelGGL(k_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_transfer_collect, grid_for(cap, 256), dim3(256), 0, st, F, W);
+  hipLaunchKernelGGL(k_transfer_apply, grid_for(cap, 256), dim3(256), 0, st, F, W);
+  SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
+  hipLaunchKernelGGL(k_integrate, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  SZ_HIP(ctx, hipGetLastError());
+  SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (c[C_ERR_MC])
+    return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
+  S->last_npairs = np; S->last_next = N; S->stepped = true;
+  if (stats) {
+    float ms;
+    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;
+    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[1])); stats->broad_ms = ms;
+    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[2], S->ev[3])); stats->narrow_ms = ms;
+    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[3], S->ev[4])); stats->rows_ms = ms;
+    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[4], S->ev[5])); stats->integrate_ms = ms;
+    stats->n_ext = N; stats->n_pairs = np; stats->n_rows = nr; stats->pair_vertices = nvt; stats->retried = retried;
+  }
+  return SZ_OK;
+}
+
+int szFloesDownload(szContext *ctx, szFloeState *h, int what) {
+  if (!ctx || !h) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szFloesDownload: no floes uploaded");
+  if (h->n != S->n) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFloesDownload: n mismatch");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const Floes &F = S->F;
+  const size_t n = (size_t)S->n, nv = (size_t)S->nverts;
+#define GET(field, count) if (h->field) SZ_HIP(ctx, hipMemcpy(h->field, F.field, (size_t)(count) * sizeof(*h->field), hipMemcpyDeviceToHost));
+  if (what & SZ_SYNC_DYNAMIC) {
+    GET(Xi, n) GET(Yi, n) GET(alpha_i, n) GET(Ui, n) GET(Vi, n) GET(ksi_ice, n)
+    GET(h, n) GET(area, n) GET(mass, n) GET(inertia_moment, n) GET(rmax, n)
+    GET(dXi_p, n) GET(dYi_p, n) GET(dUi_p, n) GET(dVi_p, n) GET(dalpha_i_p, n) GET(dksi_ice_p, n)
+    GET(FxOA, n) GET(FyOA, n) GET(torqueOA, n) GET(alive, n)
+    GET(cax, nv) GET(cay, nv)
+    GET(StressCount, n) GET(Stress, 4 * n) GET(strain, 4 * n)
+    GET(collision_force, 2 * n) GET(collision_torque, n) GET(OverlapArea, n)
+    GET(kill, 4 * n) GET(transfer, 4 * n)
+  }
+  if (what & SZ_SYNC_STRESSH) { GET(StressH, n * S->n_stress * 4) }
+#undef GET
+  return SZ_OK;
+}
+
+int szInteractionsDownload(szContext *ctx, int32_t *inter_off, double *inter, int64_t cap_rows) {
+  if (!ctx || !inter_off) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S || !S->stepped) return sz_fail(ctx, SZ_ERR_STATE, "szInteractionsDownload: no step taken");
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = S->n;
+  std::vector<i64> off((size_t)n + 1);
+  SZ_HIP(ctx, hipMemcpy(off.data(), S->W.row_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i <= n; ++i) inter_off[i] = (int32_t)off[i];
+  if (off[n] > cap_rows) return sz_fail(ctx, SZ_ERR_CAPACITY, "szInteractionsDownload: %lld rows, capacity %lld", (long long)off[n], (long long)cap_rows);
+  if (off[n] > 0) {
+    if (!inter) return SZ_ERR_BAD_ARG;
+    SZ_HIP(ctx, hipMemcpy(inter, S->W.rows, (size_t)off[n] * 56, hipMemcpyDeviceToHost));
+  }
+  return SZ_OK;
+}
+
+int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t cap, int64_t *npairs, int32_t *n_ext) {
+  if (!ctx || !npairs || !n_ext) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S || !S->stepped) return sz_fail(ctx, SZ_ERR_STATE, "szPairsDownload: no step taken");
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const i64 np = S->last_npairs;
+  std::vector<int> pi((size_t)np + 1), pj((size_t)np + 1);
+  if (np) {
+    SZ_HIP(ctx, hipMemcpy(pi.data(), S->W.pair_i, (size_t)np * 4, hipMemcpyDeviceToHost));
+    SZ_HIP(ctx, hipMemcpy(pj.data(), S->W.pair_j, (size_t)np * 4, hipMemcpyDeviceToHost));
+  }
+  int64_t k = 0;
+  for (i64 p = 0; p < np; ++p) {
+    if (pj[p] == WALL) continue;
+    if (k < cap) { pair_i[k] = pi[p] + 1; pair_j[k] = pj[p] + 1; }
+    ++k;
+  }
+  *npairs = k;
+  *n_ext = S->last_next;
+  if (k > cap) return sz_fail(ctx, SZ_ERR_CAPACITY, "szPairsDownload: %lld pairs, capacity %lld", (long long)k, (long long)cap);
+  return SZ_OK;
+}
+
+} // extern "C"

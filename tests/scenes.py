@@ -1,0 +1,68 @@
+"""Seeded scenes for the step parity tests (shared by the CPU and GPU suites)."""
+import numpy as np
+from subzero_amd import synth
+import clipgen
+
+
+def pack(n=400, periodic=True, seed=4, vel_seed=2, sigma=0.1, n_stress=16, **kw):
+    S = synth.voronoi_field(n, 1.0, seed=seed, vel_seed=vel_seed, vel_sigma=sigma, n_stress=n_stress, **kw)
+    P = synth.StepParams(dt=10, periodic=periodic)
+    P.Modulus = synth.reference_modulus(S)
+    return S, P
+
+
+def concave(n=60, periodic=True, seed=11, n_stress=16):
+    """Real floe outlines (reference fixture FloeShapes.mat) laid out on a jittered lattice so that
+    neighbours overlap a little: exercises the non-convex branches of floe_interactions.m:117-137."""
+    rng = np.random.default_rng(seed)
+    shapes, _ = clipgen.load_shapes()
+    shapes = [s for s in shapes if len(s) <= 90]
+    side = int(np.ceil(np.sqrt(n)))
+    polys = []
+    pitch = 2e5 / side
+    for k in range(n):
+        s = shapes[rng.integers(len(shapes))]
+        c = s.mean(0)
+        r = np.sqrt(((s - c) ** 2).sum(1).max())
+        sc = 0.56 * pitch / r
+        th = rng.uniform(0, 2 * np.pi)
+        rot = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        gx, gy = k % side, k // side
+        ctr = np.array([-1e5 + (gx + 0.5) * pitch, -1e5 + (gy + 0.5) * pitch]) + rng.uniform(-0.05, 0.05, 2) * pitch
+        polys.append((s - c) @ rot.T * sc + ctr)
+    S = synth.build_state(polys, height=0.5, seed=seed, n_stress=n_stress)
+    vr = np.random.default_rng(seed + 1)
+    S.Ui[:] = vr.normal(0, 0.2, S.n); S.Vi[:] = vr.normal(0, 0.2, S.n)
+    S.ksi_ice[:] = vr.normal(0, 2e-6, S.n)
+    P = synth.StepParams(dt=10, periodic=periodic, height=0.5)
+    P.Modulus = synth.reference_modulus(S)
+    return S, P
+
+
+def two_boxes(offset=0.0):
+    """test/conservation_test.m:22-33: two 20 km boxes approaching head-on (optionally offset in y)."""
+    h = 1e4
+    b = np.array([[-h, -h], [-h, h], [h, h], [h, -h]], float)
+    polys = [b + [-1e4 - 5, 0.0], b + [1e4 + 5, offset]]
+    S = synth.build_state(polys, height=1.0, seed=5, n_stress=16)
+    S.Ui[:] = [0.1, -0.1]
+    P = synth.StepParams(dt=10, periodic=False, height=1.0)
+    P.Modulus = 9e7  # test/test_conservation/Modulus.mat
+    return S, P
+
+
+def boxes_and_triangle():
+    """test/conservation_test.m:36-41 geometry: two boxes and a triangle between them."""
+    h = 1e4
+    b = np.array([[-h, -h], [-h, h], [h, h], [h, -h]], float)
+    t = np.array([[-8e3, -1e4], [0.0, 1.2e4], [8e3, -1e4]])
+    polys = [b + [-1.8005e4, 0.0], t, b + [1.8005e4, 0.0]]
+    S = synth.build_state(polys, height=1.0, seed=6, n_stress=16)
+    S.Ui[:] = [0.15, 0.0, -0.15]
+    P = synth.StepParams(dt=10, periodic=False, height=1.0)
+    P.Modulus = 9e7
+    return S, P
+
+
+def kinetic_energy(S):
+    return 0.5 * (S.mass * (S.Ui ** 2 + S.Vi ** 2)).sum() + 0.5 * (S.inertia_moment * S.ksi_ice ** 2).sum()
