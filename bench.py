@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Benchmark of the floe-interaction hot path (BASELINE.json: floe-timesteps/s and contact-pairs/s).
+
+A "step" is one call of the accelerated part of floe_interactions_all (szStep) on the device-resident
+floe field; every 10th step refreshes the ocean/wind forcing, as the reference driver does
+(Subzero.m:153-166).  Workload at N = 1: BASELINE.json configs[3] geometry on one GPU -- 1e4 Voronoi floes,
+concentration 1.0, periodic box, dt = 10 s (the configuration the metric's target is quoted on).
+
+One JSON line on stdout (rank 0).  `value` is floe-timesteps/s with all inputs resident in HBM.
+  roofline     : the pair-interaction kernel (k_narrow) priced by the ALGORITHMIC bytes of SURVEY.md 8(d)
+                 (16 B per ring vertex of both rings + 2 x 56 B of body scalars + 56 B per contact row)
+                 over its HIP-event duration, against the 8 TB/s HBM3E peak.  The kernel is bound by
+                 divergent int64/FP64 ALU work, not by HBM: the fraction is reported as computed.
+  cpu_baseline : the CPU oracle (C++ restatement of the MATLAB path around the reference's own Clipper)
+                 on the host cores, a bounded sample of the same workload.  TEST INFRASTRUCTURE timed as a
+                 baseline only; the product path never calls it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(n_floes, seed=4):
+    from subzero_amd import synth
+    S = synth.voronoi_field(n_floes, 1.0, seed=seed, vel_seed=2, vel_sigma=0.1)
+    P = synth.StepParams(dt=10.0, periodic=True)
+    P.Modulus = synth.reference_modulus(S)
+    return S, P
+
+
+def cpu_baseline(S, P, budget_s=20.0):
+    """Oracle steps on the host cores from the same (already colliding) state; bounded sample."""
+    import oracle
+    threads = os.cpu_count() or 1
+    A = S.copy()
+    t0 = time.time()
+    steps = 0
+    it = 1
+    while True:
+        P.doInt = int(it % 10 == 0)
+        oracle.step(A, P, threads=threads)
+        steps += 1; it += 1
+        el = time.time() - t0
+        if el > budget_s or steps >= 12:
+            break
+    return {"value": S.n * steps / el, "unit": "floe-timesteps/s", "cores": threads,
+            "kind": "port", "clip": oracle.lib().clip_kind,
+            "sample": "%d oracle timesteps of the same %d-floe field (state after the GPU run), %d threads, %.1f s"
+                      % (steps, S.n, threads, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--floes", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    from subzero_amd import capi
+    if world > 1:
+        from subzero_amd import multigpu
+        return multigpu.bench_main(args, rank, local_rank, world)
+
+    S, P = build_workload(args.floes)
+    ctx = capi.Context(local_rank)
+    sim = capi.FloeInteractions(ctx, S)
+    it = 0
+    for _ in range(args.warmup):
+        P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+    ctx.check(ctx.L.szSynchronize(ctx.h), "sync")
+    narrow_ms = pair_bytes = 0.0
+    pairs = rows = 0
+    dev_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        P.doInt = int(it % 10 == 0)
+        st = sim.step(P); it += 1
+        narrow_ms += st.narrow_ms; dev_ms += st.step_ms
+        pairs += st.n_pairs; rows += st.n_rows
+        # B_pair = 16 (n_i+1 + n_j+1) + 2*56 + 56 K, summed over the candidate pairs
+        pair_bytes += 16.0 * st.pair_vertices + 112.0 * st.n_pairs + 56.0 * st.pair_rows
+    ctx.check(ctx.L.szSynchronize(ctx.h), "sync")
+    el = time.perf_counter() - t0
+
+    off, inter = sim.interactions()
+    collisions = capi.collision_count(inter)
+    sim.download(capi.SYNC_ALL)
+
+    k = args.steps
+    achieved = (pair_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_narrow.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "floe-timesteps/sec", "value": S.n * k / el, "unit": "floe-timesteps/s",
+        "n_gpus": 1, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64+int64", "data": "synthetic",
+        "config": {"workload": "pack%d: %d Voronoi floes, concentration 1.0, periodic +-1e5 m box, dt=10 s, "
+                               "collisions + ocean drag (forcing refreshed every 10th step)" % (S.n, S.n),
+                   "floes": int(S.n), "parallelism": "1 GPU"},
+        "timesteps_per_s": k / el,
+        "contact_pairs_per_s": collisions * k / el,
+        "candidate_pairs_per_s": pairs / el,
+        "contact_rows_last_step": int(len(inter)), "collisions_last_step": collisions,
+        "device_ms_per_step": dev_ms / k,
+        "roofline": {"bound": "hbm", "kernel": "k_narrow (pair interaction: clip + contact force)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(S, P)
+    ctx.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

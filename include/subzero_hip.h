@@ -167,6 +167,7 @@ typedef struct szStepStats {
   int64_t n_rows;      /* contact rows over the extended list */
   int64_t pair_vertices; /* sum of ring sizes over the candidate pairs */
   int64_t retried;     /* pairs re-run at a larger scratch tier */
+  int64_t pair_rows;   /* contact rows produced by the candidate pairs (before mirroring) */
 } szStepStats;
 
 /* which fields szFloesDownload copies back */

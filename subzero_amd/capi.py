@@ -71,7 +71,8 @@ class StepStats(ctypes.Structure):
     _fields_ = [("step_ms", ctypes.c_double), ("broad_ms", ctypes.c_double), ("narrow_ms", ctypes.c_double),
                 ("rows_ms", ctypes.c_double), ("integrate_ms", ctypes.c_double),
                 ("n_ext", ctypes.c_int64), ("n_pairs", ctypes.c_int64), ("n_rows", ctypes.c_int64),
-                ("pair_vertices", ctypes.c_int64), ("retried", ctypes.c_int64)]
+                ("pair_vertices", ctypes.c_int64), ("retried", ctypes.c_int64),
+                ("pair_rows", ctypes.c_int64)]
 
 
 SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3

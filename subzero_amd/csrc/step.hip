@@ -10,7 +10,8 @@
 //   k_narrow                                                  one thread per candidate pair, 64-thread
 //                                                             workgroups (one wave) for fine-grained dispatch
 //   k_incoming / k_row_count / k_row_fill / k_transfer_*      per pair / per extended floe
-//   k_integrate                                               one thread per real floe
+//   k_integrate_pre / k_integrate_post                        one thread per real floe
+//   k_forcing                                                 one wave per real floe (Monte-Carlo forcing)
 // Two host read-backs per step size the pair scratch and the contact-row buffer (grow-only, owned by the
 // context).  No CPU fallback exists: every failure is an error code.
 #include "context.hpp"
@@ -31,6 +32,8 @@ struct StepState {
   // grow-only per-step buffers
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
   DevBuf scratch, rows;
+  DevBuf cell_cnt, cell_off, cell_fill, cell_items;
+  double rmax_max = 0;
   i64 last_npairs = 0, last_nrows_real = 0;
   int last_next = 0;
   bool stepped = false;
@@ -121,6 +124,32 @@ __global__ void k_broad(int lo_is_real, Floes F, Params P, Work W) {
   else { i += F.n; if (i >= N) return; }
   broad(i, N, F, P, W);
 }
+__global__ void k_cell_clear(Work W) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c <= W.cells_x * W.cells_y) { W.cell_cnt[c] = 0; W.cell_fill[c] = 0; }
+}
+__global__ void k_cell_count(Work W) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < dev_next(W)) cell_count(e, W);
+}
+__global__ void __launch_bounds__(1024) k_scan_cells(Work W) {
+  __shared__ int tot;
+  const int nc = W.cells_x * W.cells_y;
+  block_scan<int, int>(W.cell_cnt, W.cell_off, nc, &tot);
+  __syncthreads();
+  if (threadIdx.x == 0) W.cell_off[nc] = tot;
+}
+__global__ void k_cell_fill(Work W) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < dev_next(W)) cell_fill(e, W);
+}
+__global__ void k_broad_binned(int lo_is_real, Floes F, Params P, Work W) {
+  int N = dev_next(W);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
+  else { i += F.n; if (i >= N) return; }
+  broad_binned(i, N, F, P, W);
+}
 __global__ void k_pair_count(Floes F, Params P, Work W) {
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,11 +187,71 @@ __global__ void k_transfer_apply(Floes F, Work W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < W.cap_ext) transfer_apply(i, F, W);
 }
-__global__ void k_integrate(Floes F, Params P, Work W) {
+__global__ void k_integrate_pre(Floes F, Params P, Work W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
-  if (i < F.n) integrate(i, F, P, W);
+  if (i < F.n) integrate_pre(i, F, P, W);
   int z = blockIdx.x * blockDim.x + threadIdx.x;
   if (z < F.nb) { F.collision_force[2 * z] = 0; F.collision_force[2 * z + 1] = 0; F.collision_torque[z] = 0; F.OverlapArea[z] = 0; }
+}
+__global__ void k_integrate_post(Floes F, Params P, Work W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
+  if (i < F.n) integrate_post(i, F, P, W);
+}
+// Ocean / wind forcing (calc_trajectory.m:95-98,121-166): one wave per floe.  The 64 lanes evaluate the
+// Monte-Carlo points 64 at a time (contiguous reads of the floe's [point] row) into LDS; then single
+// lanes add the per-point values up left to right over the
+// points inside the floe -- the summation order of the serial form, so the result is bit-identical to it.
+#define FORCE_MAX_MC 1024
+__global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
+  __shared__ double s0[FORCE_MAX_MC], s1[FORCE_MAX_MC], s2[FORCE_MAX_MC];
+  __shared__ double red[4];
+  __shared__ int scnt;
+  const int i = blockIdx.x + F.nb;
+  if (i >= F.n) return;
+  if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the wave
+  const int lane = threadIdx.x;
+  const int nmc = F.n_mc;
+  const double *mx = F.mcX + i * F.mc_si, *my = F.mcY + i * F.mc_si;
+  const unsigned char *A = F.mcA + i * F.mc_si;
+  const long long sq = F.mc_sq;
+  ForceCtx c;
+  force_ctx(i, F, P, c);
+  // pass 1: winds at the points inside the floe
+  for (int q = lane; q < nmc; q += 64) {
+    double uw = 0, vw = 0;
+    if (A[q * sq]) wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
+    s0[q] = uw; s1[q] = vw;
+  }
+  __syncthreads();
+  if (lane == 0) { double s = 0; int cnt = 0; for (int q = 0; q < nmc; ++q) if (A[q * sq]) { s += s0[q]; ++cnt; } red[0] = s; scnt = cnt; }
+  if (lane == 1) { double s = 0; for (int q = 0; q < nmc; ++q) if (A[q * sq]) s += s1[q]; red[1] = s; }
+  __syncthreads();
+  const int cnt = scnt;
+  if (cnt == 0) { // calc_trajectory.m:100-110 would regenerate the points with rand()
+    if (lane == 0) { atomicAdd(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; }
+    return;
+  }
+  wind_stress(c, red[0], red[1], cnt);
+  __syncthreads();
+  // pass 2: stresses and torque
+  for (int q = lane; q < nmc; q += 64) {
+    double Fx = 0, Fy = 0, tq = 0;
+    if (A[q * sq]) force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
+    s0[q] = Fx; s1[q] = Fy; s2[q] = tq;
+  }
+  __syncthreads();
+  if (lane < 3) {
+    const double *src = (lane == 0) ? s0 : (lane == 1) ? s1 : s2;
+    double s = 0;
+    for (int q = 0; q < nmc; ++q) if (A[q * sq]) s += src[q];
+    red[lane] = s;
+  }
+  __syncthreads();
+  if (lane == 0) { F.FxOA[i] = red[0] / cnt; F.FyOA[i] = red[1] / cnt; F.torqueOA[i] = red[2] / cnt; }
+}
+__global__ void k_forcing_serial(Floes F, Params P, Work W) { // n_mc beyond the LDS staging size
+  int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
+  if (i < F.n) forcing_serial(i, F, P, W);
 }
 // running sums of the stress history, once after upload
 __global__ void k_stress_sum(Floes F) {
@@ -202,7 +291,7 @@ void sz_step_destroy(szContext *ctx) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows};
+                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   delete S;
@@ -237,6 +326,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   PUT(c0x, nv) PUT(c0y, nv) PUT(cax, nv) PUT(cay, nv)
   PUT(StressH, (size_t)n * h->n_stress * 4) PUT(StressCount, n) PUT(Stress, 4 * (size_t)n) PUT(strain, 4 * (size_t)n)
   PUT(mcX, (size_t)n * h->n_mc) PUT(mcY, (size_t)n * h->n_mc) PUT(mcA, (size_t)n * h->n_mc)
+  F.mc_si = h->n_mc; F.mc_sq = 1; // [floe][point]: the forcing kernel reads one floe's points with one wave
   PUT(collision_force, 2 * (size_t)n) PUT(collision_torque, n) PUT(OverlapArea, n)
 #undef PUT
   if ((rc = dev_alloc(ctx, S, F.kill, 4 * (size_t)n))) return rc;
@@ -253,7 +343,9 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   NEW(pair_cnt, cap) NEW(pair_nv, cap) NEW(pair_base, cap + 1) NEW(nv_base, cap + 1)
   NEW(inc_cnt, cap) NEW(inc_list, cap * W.pot_cap)
   NEW(row_cnt, cap) NEW(row_off, cap + 1) NEW(cf_ext, 2 * cap) NEW(ct_ext, cap) NEW(ov_ext, cap) NEW(tmax, cap)
+  NEW(st_ext, 3 * (size_t)n) NEW(st_flag, n)
 #undef NEW
+  for (int i = 0; i < n; ++i) if (h->rmax[i] > S->rmax_max) S->rmax_max = h->rmax[i];
   hipLaunchKernelGGL(k_stress_sum, grid_for(n, 256), dim3(256), 0, ctx->stream, F);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -315,8 +407,26 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
       hipLaunchKernelGGL(k_ghost_emit, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
     }
   }
-  hipLaunchKernelGGL(k_broad, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
-  if (P.PERIODIC) hipLaunchKernelGGL(k_broad, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
+  // uniform grid over [-L - cs, L + cs]^2, cell edge cs = 2 max(rmax); positions outside clamp to the border
+  {
+    double cs = 2 * S->rmax_max;
+    if (!(cs > 0)) cs = 1;
+    W.cell_size = cs; W.cell_x0 = -P.Lx - cs; W.cell_y0 = -P.Ly - cs;
+    double nx = (2 * P.Lx + 2 * cs) / cs + 1, ny = (2 * P.Ly + 2 * cs) / cs + 1;
+    W.cells_x = (nx > 2048 || !(nx > 0)) ? 2048 : (int)nx;
+    W.cells_y = (ny > 2048 || !(ny > 0)) ? 2048 : (int)ny;
+    const size_t nc = (size_t)W.cells_x * W.cells_y + 1;
+    if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
+        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_items, (size_t)cap * 4))) return rc;
+    W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
+    W.cell_items = (int *)S->cell_items.p;
+    hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
+    hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, W);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, W);
+    hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, W);
+  }
+  hipLaunchKernelGGL(k_broad_binned, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
+  if (P.PERIODIC) hipLaunchKernelGGL(k_broad_binned, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
   hipLaunchKernelGGL(k_pair_count, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, st, W);
   SZ_HIP(ctx, hipGetLastError());
@@ -386,7 +496,10 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   hipLaunchKernelGGL(k_transfer_collect, grid_for(cap, 256), dim3(256), 0, st, F, W);
   hipLaunchKernelGGL(k_transfer_apply, grid_for(cap, 256), dim3(256), 0, st, F, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
-  hipLaunchKernelGGL(k_integrate, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_integrate_pre, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  if (S->n_mc <= FORCE_MAX_MC) hipLaunchKernelGGL(k_forcing, dim3(n - S->nb > 0 ? n - S->nb : 1), dim3(64), 0, st, F, P, W);
+  else hipLaunchKernelGGL(k_forcing_serial, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
   SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
@@ -401,7 +514,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[2], S->ev[3])); stats->narrow_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[3], S->ev[4])); stats->rows_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[4], S->ev[5])); stats->integrate_ms = ms;
-    stats->n_ext = N; stats->n_pairs = np; stats->n_rows = nr; stats->pair_vertices = nvt; stats->retried = retried;
+    stats->n_ext = N; stats->n_pairs = np; stats->n_rows = nr; stats->pair_vertices = nvt; stats->retried = retried; stats->pair_rows = (int64_t)c[C_PAIRROWS];
   }
   return SZ_OK;
 }

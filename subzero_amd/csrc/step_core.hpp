@@ -37,8 +37,9 @@ struct Floes {
   double *StressH;      // [floe][slot][4]
   int *StressCount;
   double *Stress, *strain;
-  double *mcX, *mcY;    // [floe][q]
-  unsigned char *mcA;
+  double *mcX, *mcY;    // point q of floe i at [i * mc_si + q * mc_sq]
+  unsigned char *mcA;   // ([floe][q] everywhere today: mc_si = n_mc, mc_sq = 1)
+  long long mc_si, mc_sq;
   double *collision_force, *collision_torque, *OverlapArea;
   int *kill, *transfer; // capacity 4 * n (extended list)
   double *StressSum;    // [floe][4] running sum of the StressH slots (device only)
@@ -58,7 +59,7 @@ struct Params {
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_SCR_BUMP, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_SCR_BUMP, C_COUNT
 };
 
 struct Work {
@@ -91,6 +92,13 @@ struct Work {
   double *rows; i64 cap_rows;   // 7 doubles per row
   double *cf_ext, *ct_ext, *ov_ext; // per ext floe: sum Fx,Fy (2), sum torque, OverlapArea
   int *tmax;                    // cap_ext: transfer(kill(i)) = i resolution
+  // uniform grid over the extended list for the broad-phase (cell edge >= 2 * max rmax)
+  double cell_size, cell_x0, cell_y0;
+  int cells_x, cells_y;
+  int *cell_cnt, *cell_off, *cell_fill, *cell_items; // [cells_x * cells_y (+1)], items: cap_ext
+  // calc_trajectory values handed from integrate_pre to forcing / integrate_post (per real floe)
+  double *st_ext; // [3 n] external force x, y and torque after the limiter (:42-46)
+  int *st_flag;   // ST_GO | ST_FORCE
 };
 
 // per-pair scratch slice: linear bound so that offsets follow from prefix sums (see carve())
@@ -178,6 +186,83 @@ SZ_HD void broad(int i, int N, const Floes &F, const Params &P, Work &W) {
       if (cnt >= W.pot_cap) { atomic_add(&W.counters[C_ERR_POT], 1ULL); break; }
       mine[cnt++] = j + 1;
     }
+  }
+  W.pot_cnt[i] = cnt;
+}
+
+// Same candidates through a uniform grid: every partner of i lies in the 3 x 3 cells around i because the
+// cell edge is at least 2 * max(rmax) >= rmax(i) + rmax(j).  Out-of-range positions clamp to the border
+// cells, which only adds tests.  Candidates are gathered unordered, sorted by j, then filtered in order.
+SZ_HD int cell_coord(double v, double v0, double cs, int ncell) {
+  double t = (v - v0) / cs;
+  if (!(t > 0)) return 0;            // also NaN
+  if (t >= (double)(ncell - 1)) return ncell - 1;
+  return (int)t;
+}
+SZ_HD int cell_of(int e, const Work &W) {
+  return cell_coord(W.ext_y[e], W.cell_y0, W.cell_size, W.cells_y) * W.cells_x +
+         cell_coord(W.ext_x[e], W.cell_x0, W.cell_size, W.cells_x);
+}
+SZ_HD void cell_count(int e, Work &W) { atomic_add(&W.cell_cnt[cell_of(e, W)], 1); }
+SZ_HD void cell_fill(int e, Work &W) {
+  int c = cell_of(e, W);
+  int k = atomic_add(&W.cell_fill[c], 1);
+  W.cell_items[W.cell_off[c] + k] = e;
+}
+SZ_HD void broad_binned(int i, int N, const Floes &F, const Params &P, Work &W) {
+  int cnt = 0;
+  int *mine = W.pot_list + (size_t)i * W.pot_cap;
+  const int si = W.ext_src[i];
+  const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
+  if (F.alive[si] && !(xi != xi) && P.COLLISION) {
+    const int cx = cell_coord(xi, W.cell_x0, W.cell_size, W.cells_x);
+    const int cy = cell_coord(yi, W.cell_y0, W.cell_size, W.cells_y);
+    bool overflow = false;
+    for (int gy = cy - 1; gy <= cy + 1 && !overflow; ++gy) {
+      if (gy < 0 || gy >= W.cells_y) continue;
+      for (int gx = cx - 1; gx <= cx + 1 && !overflow; ++gx) {
+        if (gx < 0 || gx >= W.cells_x) continue;
+        const int c = gy * W.cells_x + gx;
+        for (int q = W.cell_off[c]; q < W.cell_off[c + 1]; ++q) {
+          const int j = W.cell_items[q];
+          if (j <= i) continue;
+          const int sj = W.ext_src[j];
+          if (!F.alive[sj]) continue;
+          double dx = xi - W.ext_x[j], dy = yi - W.ext_y[j];
+          double R = ri + F.rmax[sj];
+          double d2 = dx * dx + dy * dy;
+          if (d2 > R * R * 1.000001) continue;
+          if (!(::sqrt(d2) < R)) continue;      // :103
+          if (cnt >= W.pot_cap) { overflow = true; break; }
+          // insert keeping ascending j
+          int k = cnt;
+          while (k > 0 && mine[k - 1] > j + 1) { mine[k] = mine[k - 1]; --k; }
+          mine[k] = j + 1;
+          ++cnt;
+        }
+      }
+    }
+    if (overflow) atomic_add(&W.counters[C_ERR_POT], 1ULL);
+    // the mems filter, in ascending j (:93-99, :103, :113)
+    const int *init = nullptr; int ninit = 0;
+    if (W.ext_num[i] < 0) {
+      int root = iabs(W.ext_num[i]) - 1;
+      init = W.pot_list + (size_t)root * W.pot_cap;
+      ninit = W.pot_cnt[root];
+    }
+    const double lim = szc::mind(2 * P.Lx, 2 * P.Ly);
+    int kept = 0;
+    for (int a = 0; a < cnt; ++a) {
+      const int j = mine[a] - 1;
+      const int key = iabs(W.ext_num[j]);
+      bool member = false;
+      for (int q = 0; q < ninit && !member; ++q) member = (init[q] == key);
+      for (int q = 0; q < kept && !member; ++q) member = (W.ext_num[mine[q] - 1] == key);
+      const double R = ri + F.rmax[W.ext_src[j]];
+      if (!(!member || 2 * R > lim)) continue;
+      mine[kept++] = j + 1;
+    }
+    cnt = kept;
   }
   W.pot_cnt[i] = cnt;
 }
@@ -308,6 +393,7 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
+  if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
 }
 SZ_HD const double *pair_rows(i64 p, const Floes &F, const Work &W) {
   // the rows are the last member of the slice; recompute the layout
@@ -471,9 +557,13 @@ SZ_HD double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, 
   return a * (1 - ty) + b * ty;
 }
 
-SZ_HD void integrate(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
-  const int N0 = F.n;
-  (void)N0;
+// calc_trajectory is split in three kernels so that the Monte-Carlo forcing (1000 points per floe, every
+// 10th step) can run with one wave per floe:  integrate_pre  ->  forcing  ->  integrate_post.
+// Values handed from one to the next live in Work::st_* (per real floe).
+enum { ST_GO = 1, ST_FORCE = 2 };
+
+SZ_HD void integrate_pre(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
+  W.st_flag[i] = 0;
   // ghost sums first (:242-245): the X ghost, then the Y ghost, of this floe; then the floe's own (:262-263)
   double cfx = 0, cfy = 0, ctq = 0;
   if (P.PERIODIC) {
@@ -525,9 +615,6 @@ SZ_HD void integrate(int i, const Floes &F, const Params &P, Work &W) { // nb <=
   while (szc::maxd(absd(ext_fx), absd(ext_fy)) > mass / (5 * dt)) { // :42-46
     ext_fx = ext_fx / 10; ext_fy = ext_fy / 10; ext_torque = ext_torque / 10;
   }
-  const double rho0 = 1027, Cd = 3e-3, rho_air = 1.2, Cd_atm = 1e-3;
-  const double fc = P.fCoriolis;
-  const double floe_area = F.area[i];
   double dh = P.HFo * dt / hh;                                   // :76-80
   double floe_mass = (hh - dh) / hh * mass;
   double floe_inertia = (hh - dh) / hh * inertia;
@@ -535,7 +622,6 @@ SZ_HD void integrate(int i, const Floes &F, const Params &P, Work &W) { // nb <=
   bool removed = false;
   if (F.Xi[i] != F.Xi[i]) removed = true;                        // :89
   const int v0 = F.vert_off[i], nvr = F.vert_off[i + 1] - v0;
-  const int nmc = F.n_mc;
   const bool doforce = P.doInt || h_new < 0.1;                   // :94,:121
   if (!removed) {                                                // :116
     double mxx = F.cax[v0], mnx = F.cax[v0], mxy = F.cay[v0], mny = F.cay[v0];
@@ -548,11 +634,6 @@ SZ_HD void integrate(int i, const Floes &F, const Params &P, Work &W) { // nb <=
     for (int k = 1; k < P.nyo; ++k) { Yomax = szc::maxd(Yomax, P.Yo[k]); Yomin = szc::mind(Yomin, P.Yo[k]); }
     if (mxx + F.Xi[i] > Xomax || mnx + F.Xi[i] < Xomin || mxy + F.Yi[i] > Yomax || mny + F.Yi[i] < Yomin)
       removed = true;
-  }
-  if (!removed && doforce) {                                     // :100-110 needs rand(): not reproducible
-    int cnt = 0;
-    for (int q = 0; q < nmc; ++q) cnt += F.mcA[(size_t)i * nmc + q] ? 1 : 0;
-    if (cnt == 0) { atomic_add(&W.counters[C_ERR_MC], 1ULL); return; }
   }
   if (removed || x_before != x_before) { F.kill[i] = i + 1; }   // :282
   if (removed) return;
@@ -567,55 +648,94 @@ SZ_HD void integrate(int i, const Floes &F, const Params &P, Work &W) { // nb <=
   F.StressCount[i] = scount + 1;
   F.h[i] = h_new; F.mass[i] = floe_mass; F.inertia_moment[i] = floe_inertia; F.alive[i] = alive;
   if (alive != 1) return;                                        // :118
+  W.st_ext[3 * i] = ext_fx; W.st_ext[3 * i + 1] = ext_fy; W.st_ext[3 * i + 2] = ext_torque;
+  W.st_flag[i] = ST_GO | (doforce ? ST_FORCE : 0);
+}
 
-  if (doforce) {                                                 // :95-98, :121-166
-    double sa, ca;
-    szm::sincos(F.alpha_i[i], sa, ca);
-    const double *mx = F.mcX + (size_t)i * nmc, *my = F.mcY + (size_t)i * nmc;
-    const unsigned char *A = F.mcA + (size_t)i * nmc;
-    const double Xi = F.Xi[i], Yi = F.Yi[i];
-    double sta, cta;
-    szm::sincos(P.turn_angle, sta, cta);
-    double su = 0, sv = 0; int cnt = 0;
-    for (int q = 0; q < nmc; ++q) {
-      if (!A[q]) continue;
-      double xr1 = ca * mx[q] + (-sa) * my[q], xr2 = sa * mx[q] + ca * my[q];
-      double Xg = xr1 + Xi, Yg = xr2 + Yi;
-      su += interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uwind, Xg, Yg);
-      sv += interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vwind, Xg, Yg);
-      ++cnt;
-    }
-    double U10 = su / cnt, V10 = sv / cnt;
-    double w10 = ::sqrt(U10 * U10 + V10 * V10);
-    double Fx_atm = rho_air * Cd_atm * w10 * U10;
-    double Fy_atm = rho_air * Cd_atm * w10 * V10;
-    double sFx = 0, sFy = 0, sT = 0;
-    for (int q = 0; q < nmc; ++q) {
-      if (!A[q]) continue; // only the points inside the floe enter the means (:163-165)
-      double xr1 = ca * mx[q] + (-sa) * my[q], xr2 = sa * mx[q] + ca * my[q];
-      double Xg = xr1 + Xi, Yg = xr2 + Yi;
-      double th = szm::atan2(xr2, xr1), rho = szc::hyp(xr1, xr2);
-      double Uo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uocn, Xg, Yg);
-      double Vo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vocn, Xg, Yg);
-      double sth, cth;
-      szm::sincos(th, sth, cth);
-      double Uice = F.Ui[i] - rho * F.ksi_ice[i] * sth;
-      double Vice = F.Vi[i] + rho * F.ksi_ice[i] * cth;
-      double Fx_p = -(floe_mass / floe_area) * fc * Vo;
-      double Fy_p = +(floe_mass / floe_area) * fc * Uo;
-      double du = Uo - Uice, dv = Vo - Vice;
-      double sp = ::sqrt(du * du + dv * dv);
-      double tauX = rho0 * Cd * sp * (cta * du - sta * dv);
-      double tauY = rho0 * Cd * sp * (sta * du + cta * dv);
-      double Fx = tauX + Fx_atm + Fx_p;
-      double Fy = tauY + Fy_atm + Fy_p;
-      double tq = (-Fx * sth + Fy * cth) * rho;
-      Fx = Fx + (floe_mass / floe_area) * fc * F.Vi[i];
-      Fy = Fy - (floe_mass / floe_area) * fc * F.Ui[i];
-      sFx += Fx; sFy += Fy; sT += tq;
-    }
-    F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt;
+// ---- forcing (:95-98, :121-166): per-point pieces, summed left to right over the points inside the floe ----
+struct ForceCtx {
+  double sa, ca, sta, cta, Xi, Yi, Ui, Vi, ksi, mass_per_area, fc, Fx_atm, Fy_atm;
+};
+SZ_HD void force_ctx(int i, const Floes &F, const Params &P, ForceCtx &c) {
+  szm::sincos(F.alpha_i[i], c.sa, c.ca);
+  szm::sincos(P.turn_angle, c.sta, c.cta);
+  c.Xi = F.Xi[i]; c.Yi = F.Yi[i]; c.Ui = F.Ui[i]; c.Vi = F.Vi[i]; c.ksi = F.ksi_ice[i];
+  c.mass_per_area = F.mass[i] / F.area[i]; c.fc = P.fCoriolis;
+  c.Fx_atm = 0; c.Fy_atm = 0;
+}
+SZ_HD void wind_point(const ForceCtx &c, const Params &P, double mx, double my, double &uw, double &vw) {
+  double xr1 = c.ca * mx + (-c.sa) * my, xr2 = c.sa * mx + c.ca * my;
+  double Xg = xr1 + c.Xi, Yg = xr2 + c.Yi;
+  uw = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uwind, Xg, Yg);
+  vw = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vwind, Xg, Yg);
+}
+SZ_HD void wind_stress(ForceCtx &c, double su, double sv, int cnt) {            // :139-141
+  const double rho_air = 1.2, Cd_atm = 1e-3;
+  double U10 = su / cnt, V10 = sv / cnt;
+  double w10 = ::sqrt(U10 * U10 + V10 * V10);
+  c.Fx_atm = rho_air * Cd_atm * w10 * U10;
+  c.Fy_atm = rho_air * Cd_atm * w10 * V10;
+}
+SZ_HD void force_point(const ForceCtx &c, const Params &P, double mx, double my, double &Fx, double &Fy, double &tq) {
+  const double rho0 = 1027, Cd = 3e-3;
+  double xr1 = c.ca * mx + (-c.sa) * my, xr2 = c.sa * mx + c.ca * my;
+  double Xg = xr1 + c.Xi, Yg = xr2 + c.Yi;
+  double th = szm::atan2(xr2, xr1), rho = szc::hyp(xr1, xr2);
+  double Uo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uocn, Xg, Yg);
+  double Vo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vocn, Xg, Yg);
+  double sth, cth;
+  szm::sincos(th, sth, cth);
+  double Uice = c.Ui - rho * c.ksi * sth;
+  double Vice = c.Vi + rho * c.ksi * cth;
+  double Fx_p = -(c.mass_per_area) * c.fc * Vo;
+  double Fy_p = +(c.mass_per_area) * c.fc * Uo;
+  double du = Uo - Uice, dv = Vo - Vice;
+  double sp = ::sqrt(du * du + dv * dv);
+  double tauX = rho0 * Cd * sp * (c.cta * du - c.sta * dv);
+  double tauY = rho0 * Cd * sp * (c.sta * du + c.cta * dv);
+  Fx = tauX + c.Fx_atm + Fx_p;
+  Fy = tauY + c.Fy_atm + Fy_p;
+  tq = (-Fx * sth + Fy * cth) * rho;
+  Fx = Fx + (c.mass_per_area) * c.fc * c.Vi;
+  Fy = Fy - (c.mass_per_area) * c.fc * c.Ui;
+}
+// whole forcing of one floe by one thread (host emulation; the GPU uses the wave-per-floe kernel in step.hip,
+// which evaluates the same per-point functions and adds them up in the same order)
+SZ_HD void forcing_serial(int i, const Floes &F, const Params &P, Work &W) {
+  if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return;
+  const int nmc = F.n_mc;
+  const double *mx = F.mcX + i * F.mc_si, *my = F.mcY + i * F.mc_si;
+  const unsigned char *A = F.mcA + i * F.mc_si;
+  const long long sq = F.mc_sq;
+  int cnt = 0;
+  for (int q = 0; q < nmc; ++q) cnt += A[q * sq] ? 1 : 0;
+  if (cnt == 0) { atomic_add(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; return; } // :100-110 needs rand()
+  ForceCtx c;
+  force_ctx(i, F, P, c);
+  double su = 0, sv = 0;
+  for (int q = 0; q < nmc; ++q) {
+    if (!A[q * sq]) continue;
+    double uw, vw;
+    wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
+    su += uw; sv += vw;
   }
+  wind_stress(c, su, sv, cnt);
+  double sFx = 0, sFy = 0, sT = 0;
+  for (int q = 0; q < nmc; ++q) {
+    if (!A[q * sq]) continue; // only the points inside the floe enter the means (:163-165)
+    double Fx, Fy, tq;
+    force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
+    sFx += Fx; sFy += Fy; sT += tq;
+  }
+  F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt;
+}
+
+SZ_HD void integrate_post(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
+  if (!(W.st_flag[i] & ST_GO)) return;
+  const double dt = P.dt;
+  const double ext_fx = W.st_ext[3 * i], ext_fy = W.st_ext[3 * i + 1], ext_torque = W.st_ext[3 * i + 2];
+  const double floe_area = F.area[i], floe_mass = F.mass[i], floe_inertia = F.inertia_moment[i], h_new = F.h[i];
+  const int v0 = F.vert_off[i], nvr = F.vert_off[i + 1] - v0;
   // :174-177
   double dx = 1.5 * dt * F.Ui[i] - 0.5 * dt * F.dXi_p[i];
   double dy = 1.5 * dt * F.Vi[i] - 0.5 * dt * F.dYi_p[i];

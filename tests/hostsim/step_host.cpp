@@ -61,7 +61,7 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
   F.alive = hf->alive; F.vert_off = hf->vert_off;
   F.c0x = hf->c0x; F.c0y = hf->c0y; F.cax = hf->cax; F.cay = hf->cay;
   F.StressH = hf->StressH; F.StressCount = hf->StressCount; F.Stress = hf->Stress; F.strain = hf->strain;
-  F.mcX = hf->mcX; F.mcY = hf->mcY; F.mcA = hf->mcA;
+  F.mcX = hf->mcX; F.mcY = hf->mcY; F.mcA = hf->mcA; F.mc_si = hf->n_mc; F.mc_sq = 1;
   F.collision_force = hf->collision_force; F.collision_torque = hf->collision_torque; F.OverlapArea = hf->OverlapArea;
   F.kill = hf->kill; F.transfer = hf->transfer;
   const int n = F.n;
@@ -86,16 +86,16 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
   Work W;
   memset(&W, 0, sizeof(W));
   const int cap = 4 * n;
-  W.cap_ext = cap; W.pot_cap = pot_cap;
+  W.cap_ext = cap; W.pot_cap = pot_cap < 0 ? -pot_cap : pot_cap;
   W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap);
   W.xg_of = alloc<int>(pool, cap); W.yg_of = alloc<int>(pool, cap);
   W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap);
   W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
   W.counters = alloc<unsigned long long>(pool, C_COUNT);
-  W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * pot_cap);
+  W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
   W.pair_cnt = alloc<int>(pool, cap); W.pair_nv = alloc<i64>(pool, cap);
   W.pair_base = alloc<i64>(pool, cap + 1); W.nv_base = alloc<i64>(pool, cap + 1);
-  W.inc_cnt = alloc<int>(pool, cap); W.inc_list = alloc<int>(pool, (size_t)cap * pot_cap);
+  W.inc_cnt = alloc<int>(pool, cap); W.inc_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
   W.row_cnt = alloc<int>(pool, cap); W.row_off = alloc<i64>(pool, cap + 1);
   W.cf_ext = alloc<double>(pool, 2 * (size_t)cap); W.ct_ext = alloc<double>(pool, cap); W.ov_ext = alloc<double>(pool, cap);
   W.tmax = alloc<int>(pool, cap);
@@ -113,8 +113,30 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
     }
   }
   *n_ext = N;
-  for (int i = F.nb; i < n; ++i) broad(i, N, F, P, W);     // reals first: ghosts read their lists
-  for (int i = n; i < N; ++i) broad(i, N, F, P, W);
+  if (pot_cap < 0) {                                         // all-pairs form (negative pot_cap selects it)
+    W.pot_cap = pot_cap = -pot_cap;
+    for (int i = F.nb; i < n; ++i) broad(i, N, F, P, W);     // reals first: ghosts read their lists
+    for (int i = n; i < N; ++i) broad(i, N, F, P, W);
+  } else {
+    double rm = 0;
+    for (int i = 0; i < n; ++i) rm = szc::maxd(rm, F.rmax[i]);
+    W.cell_size = 2 * rm;
+    W.cell_x0 = -P.Lx - W.cell_size; W.cell_y0 = -P.Ly - W.cell_size;
+    W.cells_x = (int)((2 * P.Lx + 2 * W.cell_size) / W.cell_size) + 1;
+    W.cells_y = (int)((2 * P.Ly + 2 * W.cell_size) / W.cell_size) + 1;
+    if (W.cells_x > 2048) W.cells_x = 2048;
+    if (W.cells_y > 2048) W.cells_y = 2048;
+    const int nc = W.cells_x * W.cells_y;
+    W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
+    W.cell_items = alloc<int>(pool, cap);
+    for (int e = 0; e < N; ++e) cell_count(e, W);
+    int acc = 0;
+    for (int c = 0; c < nc; ++c) { W.cell_off[c] = acc; acc += W.cell_cnt[c]; }
+    W.cell_off[nc] = acc;
+    for (int e = N - 1; e >= 0; --e) cell_fill(e, W);        // reversed on purpose: order must not matter
+    for (int i = F.nb; i < n; ++i) broad_binned(i, N, F, P, W);
+    for (int i = n; i < N; ++i) broad_binned(i, N, F, P, W);
+  }
   if (W.counters[C_ERR_POT]) return -7;
   for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
   i64 np = 0, nvt = 0;
@@ -166,7 +188,10 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
   for (int i = 0; i < N; ++i) row_fill(i, N, F, P, W);
   for (int i = 0; i < N; ++i) transfer_collect(i, F, W);
   for (int i = 0; i < cap; ++i) transfer_apply(i, F, W);
-  for (int i = F.nb; i < n; ++i) integrate(i, F, P, W);
+  W.st_ext = alloc<double>(pool, 3 * (size_t)n); W.st_flag = alloc<int>(pool, n);
+  for (int i = F.nb; i < n; ++i) integrate_pre(i, F, P, W);
+  for (int i = F.nb; i < n; ++i) forcing_serial(i, F, P, W);
+  for (int i = F.nb; i < n; ++i) integrate_post(i, F, P, W);
   if (W.counters[C_ERR_MC]) return -9;
   for (int i = 0; i < F.nb; ++i) { F.collision_force[2 * i] = 0; F.collision_force[2 * i + 1] = 0; F.collision_torque[i] = 0; F.OverlapArea[i] = 0; }
   // contact rows of the real floes
