@@ -205,6 +205,7 @@ __global__ void k_integrate_post(Floes F, Params P, Work W) {
 __global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
   __shared__ double s0[FORCE_MAX_MC], s1[FORCE_MAX_MC], s2[FORCE_MAX_MC];
   __shared__ double red[4];
+  __shared__ unsigned char sA[FORCE_MAX_MC];
   __shared__ int scnt;
   const int i = blockIdx.x + F.nb;
   if (i >= F.n) return;
@@ -219,12 +220,13 @@ __global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
   // pass 1: winds at the points inside the floe
   for (int q = lane; q < nmc; q += 64) {
     double uw = 0, vw = 0;
-    if (A[q * sq]) wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
-    s0[q] = uw; s1[q] = vw;
+    const unsigned char in = A[q * sq];
+    if (in) wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
+    s0[q] = uw; s1[q] = vw; sA[q] = in;
   }
   __syncthreads();
-  if (lane == 0) { double s = 0; int cnt = 0; for (int q = 0; q < nmc; ++q) if (A[q * sq]) { s += s0[q]; ++cnt; } red[0] = s; scnt = cnt; }
-  if (lane == 1) { double s = 0; for (int q = 0; q < nmc; ++q) if (A[q * sq]) s += s1[q]; red[1] = s; }
+  if (lane == 0) { double s = 0; int cnt = 0; for (int q = 0; q < nmc; ++q) if (sA[q]) { s += s0[q]; ++cnt; } red[0] = s; scnt = cnt; }
+  if (lane == 1) { double s = 0; for (int q = 0; q < nmc; ++q) if (sA[q]) s += s1[q]; red[1] = s; }
   __syncthreads();
   const int cnt = scnt;
   if (cnt == 0) { // calc_trajectory.m:100-110 would regenerate the points with rand()
@@ -236,14 +238,14 @@ __global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
   // pass 2: stresses and torque
   for (int q = lane; q < nmc; q += 64) {
     double Fx = 0, Fy = 0, tq = 0;
-    if (A[q * sq]) force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
+    if (sA[q]) force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
     s0[q] = Fx; s1[q] = Fy; s2[q] = tq;
   }
   __syncthreads();
   if (lane < 3) {
     const double *src = (lane == 0) ? s0 : (lane == 1) ? s1 : s2;
     double s = 0;
-    for (int q = 0; q < nmc; ++q) if (A[q * sq]) s += src[q];
+    for (int q = 0; q < nmc; ++q) if (sA[q]) s += src[q];
     red[lane] = s;
   }
   __syncthreads();
