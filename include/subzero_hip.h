@@ -191,6 +191,33 @@ int szInteractionsDownload(szContext *ctx, int32_t *inter_off, double *inter, in
 int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t cap, int64_t *npairs,
                     int32_t *n_ext);
 
+/* ---- multi-GPU: the step with its dominant stage (the per-pair narrow-phase) sharded over ranks ----------
+ * One process per GPU, every rank holds the full floe array (szFloesUpload of the same data on each) and
+ * runs the cheap stages redundantly with identical results; the candidate-pair list is cut in `world`
+ * contiguous segments and rank r computes segment r.  Between Begin and Finish the caller all-gathers the
+ * exported segments (RCCL over xGMI: torch.distributed all_gather_into_tensor on device buffers; see
+ * subzero_amd/multigpu.py).  After Finish every rank holds the same state a single-GPU szStep produces.
+ *
+ *   szStepShardBegin (params, rank, world) -> info        front stages + narrow-phase on my segment
+ *   [caller: all-gather info.seg_rows -> rows_max = max over ranks]
+ *   szStepShardExport(d_send, info.seg_max, rows_max)     my results into a device buffer of
+ *                                                         szShardSegmentBytes(seg_max, rows_max) bytes
+ *   [caller: all-gather d_send of every rank into d_recv (world x segment bytes, rank order)]
+ *   szStepShardFinish(d_recv, seg_max, rows_max, stats)   import all segments, then the remaining stages
+ * d_recv must stay valid until Finish returns. */
+typedef struct szShardInfo {
+  int64_t n_pairs;          /* candidate pairs of the step (same on every rank) */
+  int64_t seg_lo, seg_hi;   /* my segment of the pair list */
+  int64_t seg_max;          /* largest segment over all ranks */
+  int64_t seg_rows;         /* contact rows my segment produced */
+  int32_t status;           /* SZ_OK or the error of this rank; exchange it so that all ranks stop together */
+  int32_t reserved;
+} szShardInfo;
+int64_t szShardSegmentBytes(int64_t seg_max, int64_t rows_max);
+int szStepShardBegin(szContext *ctx, const szStepParams *params, int rank, int world, szShardInfo *info);
+int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max);
+int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats);
+
 /* clipper(P) orientation mode (mexclipper.cpp:134-145): 1 if Area(P) >= 0 else 0.  Host arithmetic
  * on n vertices (an O(n) sum; there is nothing to accelerate). */
 int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation);

@@ -33,7 +33,13 @@ struct StepState {
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_items;
+  DevBuf pair_rowoff, x_off;
   double rmax_max = 0;
+  Params P;                       // parameters of the step in flight
+  unsigned long long c[C_COUNT];  // host copy of the device counters
+  unsigned long long bump = 0, zero = 0;
+  i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
+  int N = 0, rank = 0, world = 1;
   i64 last_npairs = 0, last_nrows_real = 0;
   int last_next = 0;
   bool stepped = false;
@@ -160,9 +166,23 @@ __global__ void k_pair_expand(Floes F, Params P, Work W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) pair_expand(i, N, F, P, W);
 }
-__global__ void __launch_bounds__(64) k_narrow(i64 count, const int *list, int mult, Floes F, Params P, Work W) {
+__global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *list, int mult, Floes F, Params P, Work W) {
   i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < count) narrow(t, list, mult, F, P, W);
+  if (t < count) narrow(list ? t : first + t, list, mult, F, P, W);
+}
+__global__ void __launch_bounds__(1024) k_scan_segment(const int *in, i64 *out, int n, unsigned long long *total) {
+  __shared__ i64 tot;
+  block_scan<int, i64>(in, out, n, &tot);
+  __syncthreads();
+  if (threadIdx.x == 0 && total) *total = (unsigned long long)tot;
+}
+__global__ void k_export(i64 ns, i64 p_lo, Floes F, Work W, Xfer X) {
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < ns) export_pair(k, p_lo, F, W, X);
+}
+__global__ void k_import(i64 ns, i64 p_lo, i64 rows_base, Work W, Xfer X) {
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < ns) import_pair(k, p_lo, rows_base, W, X);
 }
 __global__ void k_incoming(i64 np, Work W) {
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,7 +313,7 @@ void sz_step_destroy(szContext *ctx) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items};
+                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   delete S;
@@ -354,11 +374,11 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   return SZ_OK;
 }
 
-int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
-  if (!ctx || !hp) return SZ_ERR_BAD_ARG;
-  StepState *S = ctx->step;
-  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStep: no floes uploaded");
-  SZ_HIP(ctx, hipSetDevice(ctx->device));
+// ---- the step in three parts, so that the narrow-phase can be sharded over GPUs ----------------------
+// front : ghosts, grid, broad-phase, flat pair list, per-pair buffers      (every rank, identical results)
+// narrow: pair_contact on the pairs [lo, hi) + capacity-tier retries       (one segment per rank)
+// back  : mirror lists, contact rows, sums, calc_trajectory                (every rank, identical results)
+static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   hipStream_t st = ctx->stream;
   int rc;
   // ocean / wind grids: uploaded on the first step and whenever the forcing is refreshed
@@ -378,7 +398,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
     SZ_HIP(ctx, hipMemcpyAsync(S->oWv.p, hp->Vwind, g, hipMemcpyHostToDevice, st));
     S->nxo = hp->nxo; S->nyo = hp->nyo; S->have_ocean = true;
   }
-  Params P;
+  Params &P = S->P;
   P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
   P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
   memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
@@ -398,6 +418,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   Work &W = S->W;
   const int n = S->n;
   const int cap = W.cap_ext;
+  W.g_rows = nullptr;
 
   SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
   hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, W);
@@ -433,12 +454,12 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, st, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
-  unsigned long long c[C_COUNT];
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  unsigned long long *c = S->c;
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (c[C_ERR_POT]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "broad-phase: %llu floe(s) have more than %d candidates", c[C_ERR_POT], W.pot_cap);
   const i64 np = (i64)c[C_NPAIRS], nvt = (i64)c[C_NVTOT];
-  const int N = (int)c[C_NEXT];
+  S->np = np; S->nvt = nvt; S->N = (int)c[C_NEXT]; S->retried = 0;
 
   // per-pair buffers and scratch, sized for this step (grow-only)
   const size_t npa = (size_t)np + 1;
@@ -446,7 +467,8 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
       (rc = sz_reserve(ctx, S->pair_nvoff, npa * 8)) || (rc = sz_reserve(ctx, S->pair_scr, npa * 8)) ||
       (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
       (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4))) return rc;
+      (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
+      (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8))) return rc;
   const i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
   const i64 reserve = main_bytes / 2 + (8 << 20);
   if ((rc = sz_reserve(ctx, S->scratch, (size_t)(main_bytes + reserve)))) return rc;
@@ -454,41 +476,58 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
   W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
   W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
+  W.pair_rowoff = (i64 *)S->pair_rowoff.p;
   W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
-  unsigned long long bump = (unsigned long long)main_bytes;
-  SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_SCR_BUMP], &bump, 8, hipMemcpyHostToDevice, st));
-
+  S->bump = (unsigned long long)main_bytes;
+  SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_SCR_BUMP], &S->bump, 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
+  SZ_HIP(ctx, hipGetLastError());
+  return SZ_OK;
+}
+
+static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
+  hipStream_t st = ctx->stream;
+  Floes &F = S->F; Work &W = S->W; Params &P = S->P;
+  unsigned long long *c = S->c;
   SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
-  i64 retried = 0;
-  if (np > 0) {
-    hipLaunchKernelGGL(k_narrow, grid_for(np, 64), dim3(64), 0, st, np, (const int *)nullptr, 1, F, P, W);
+  if (hi > lo) {
+    hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, 64), dim3(64), 0, st, lo, hi - lo, (const int *)nullptr, 1, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   int mult = 1;
   while (c[C_RETRY] > 0) {
     mult *= 8;
     if (mult > 512) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) outgrew the 512x scratch tier", c[C_RETRY]);
     i64 nl = (i64)c[C_RETRY];
-    if (mult == 8) retried = nl;
+    if (mult == 8) S->retried = nl;
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
-    unsigned long long zero = 0;
-    SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &zero, 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_narrow, grid_for(nl, 64), dim3(64), 0, st, nl, (const int *)S->retry_copy.p, mult, F, P, W);
+    S->zero = 0;
+    SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_narrow, grid_for(nl, 64), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
   if (c[C_ERR_ARENA]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) did not fit the scratch arena", c[C_ERR_ARENA]);
   if (c[C_ERR_CLIP]) return sz_fail(ctx, SZ_ERR_HIP, "narrow-phase: %llu pair(s) hit the reference's \"Clipper Error.\" condition", c[C_ERR_CLIP]);
+  S->pair_rows_local = (i64)c[C_PAIRROWS];
+  return SZ_OK;
+}
 
+static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
+  hipStream_t st = ctx->stream;
+  Floes &F = S->F; Work &W = S->W; Params &P = S->P;
+  unsigned long long *c = S->c;
+  const i64 np = S->np;
+  const int n = S->n, cap = W.cap_ext;
+  int rc;
   if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
   hipLaunchKernelGGL(k_row_count, grid_for(cap, 256), dim3(256), 0, st, W);
   hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, W);
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
   const i64 nr = (i64)c[C_NROWS];
@@ -504,11 +543,11 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (c[C_ERR_MC])
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
-  S->last_npairs = np; S->last_next = N; S->stepped = true;
+  S->last_npairs = np; S->last_next = S->N; S->stepped = true;
   if (stats) {
     float ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;
@@ -516,9 +555,104 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[2], S->ev[3])); stats->narrow_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[3], S->ev[4])); stats->rows_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[4], S->ev[5])); stats->integrate_ms = ms;
-    stats->n_ext = N; stats->n_pairs = np; stats->n_rows = nr; stats->pair_vertices = nvt; stats->retried = retried; stats->pair_rows = (int64_t)c[C_PAIRROWS];
+    stats->n_ext = S->N; stats->n_pairs = np; stats->n_rows = nr; stats->pair_vertices = S->nvt;
+    stats->retried = S->retried; stats->pair_rows = S->pair_rows_local;
   }
   return SZ_OK;
+}
+
+int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
+  if (!ctx || !hp) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStep: no floes uploaded");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = step_front(ctx, S, hp))) return rc;
+  if ((rc = step_narrow(ctx, S, 0, S->np))) return rc;
+  return step_back(ctx, S, stats);
+}
+
+// ---- sharded form: Begin (front + my segment of the narrow-phase) / Export / Finish (import all + back) ----
+static size_t seg_bytes_for(i64 seg_max, i64 rows_max) {
+  return 16 + (size_t)((8 * seg_max + 7) / 8) * 8 + 40 * (size_t)rows_max; // header, nrows+flag (int32 each), rows
+}
+int64_t szShardSegmentBytes(int64_t seg_max, int64_t rows_max) { return (int64_t)seg_bytes_for(seg_max, rows_max); }
+
+int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world, szShardInfo *info) {
+  if (!ctx || !hp || !info || world < 1 || rank < 0 || rank >= world) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardBegin: no floes uploaded");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  memset(info, 0, sizeof(*info));
+  int rc;
+  if ((rc = step_front(ctx, S, hp))) { info->status = rc; return rc; }
+  S->rank = rank; S->world = world;
+  shard_range(S->np, rank, world, S->seg_lo, S->seg_hi);
+  rc = step_narrow(ctx, S, S->seg_lo, S->seg_hi);
+  info->status = rc;
+  info->n_pairs = S->np; info->seg_lo = S->seg_lo; info->seg_hi = S->seg_hi;
+  info->seg_max = shard_max(S->np, world);
+  if (rc) return rc;
+  // rows before each pair of my segment (exclusive scan of pair_nrows over the segment)
+  const i64 ns = S->seg_hi - S->seg_lo;
+  if ((rc = sz_reserve(ctx, S->x_off, (size_t)(info->seg_max + 1) * 8))) return rc;
+  hipLaunchKernelGGL(k_scan_segment, dim3(1), dim3(1024), 0, ctx->stream, (const int *)S->W.pair_nrows + S->seg_lo,
+                     (i64 *)S->x_off.p, (int)ns, &S->W.counters[C_PAIRROWS]);
+  SZ_HIP(ctx, hipGetLastError());
+  SZ_HIP(ctx, hipMemcpyAsync(S->c, S->W.counters, sizeof(S->c), hipMemcpyDeviceToHost, ctx->stream));
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  info->seg_rows = (int64_t)S->c[C_PAIRROWS];
+  S->pair_rows_local = info->seg_rows;
+  return SZ_OK;
+}
+
+int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max) {
+  if (!ctx || !d_send) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardExport: no floes uploaded");
+  const i64 ns = S->seg_hi - S->seg_lo;
+  if (ns > seg_max || S->pair_rows_local > rows_max) return sz_fail(ctx, SZ_ERR_CAPACITY, "szStepShardExport: segment does not fit");
+  char *base = (char *)d_send;
+  long long hdr[2] = {(long long)ns, (long long)S->pair_rows_local};
+  SZ_HIP(ctx, hipMemcpyAsync(base, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
+  Xfer X;
+  X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
+  X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
+  X.off = (i64 *)S->x_off.p;
+  if (ns > 0) hipLaunchKernelGGL(k_export, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, S->seg_lo, S->F, S->W, X);
+  SZ_HIP(ctx, hipGetLastError());
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // hdr is a stack variable; the collective runs on another stream
+  return SZ_OK;
+}
+
+int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats) {
+  if (!ctx || !d_recv) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardFinish: no floes uploaded");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t seg_bytes = seg_bytes_for(seg_max, rows_max);
+  int rc;
+  if ((rc = sz_reserve(ctx, S->x_off, (size_t)(seg_max + 1) * 8))) return rc;
+  S->W.g_rows = (double *)d_recv; // offsets below are in doubles from the start of the gathered buffer
+  for (int r = 0; r < S->world; ++r) {
+    i64 lo, hi;
+    shard_range(S->np, r, S->world, lo, hi);
+    const i64 ns = hi - lo;
+    char *base = (char *)d_recv + (size_t)r * seg_bytes;
+    Xfer X;
+    X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
+    X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
+    X.off = (i64 *)S->x_off.p;
+    if (ns == 0) continue;
+    hipLaunchKernelGGL(k_scan_segment, dim3(1), dim3(1024), 0, ctx->stream, (const int *)X.nrows, X.off, (int)ns,
+                       (unsigned long long *)nullptr);
+    const i64 rows_base = (i64)(((char *)X.rows - (char *)d_recv) / 8);
+    hipLaunchKernelGGL(k_import, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, lo, rows_base, S->W, X);
+  }
+  SZ_HIP(ctx, hipGetLastError());
+  rc = step_back(ctx, S, stats);
+  S->W.g_rows = nullptr;
+  return rc;
 }
 
 int szFloesDownload(szContext *ctx, szFloeState *h, int what) {

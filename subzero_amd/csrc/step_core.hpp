@@ -99,6 +99,9 @@ struct Work {
   // calc_trajectory values handed from integrate_pre to forcing / integrate_post (per real floe)
   double *st_ext; // [3 n] external force x, y and torque after the limiter (:42-46)
   int *st_flag;   // ST_GO | ST_FORCE
+  // sharded narrow-phase (multi-GPU): contact rows of all pairs gathered from the ranks that computed them
+  double *g_rows;    // null on one GPU: rows are read from the pair's scratch slice
+  i64 *pair_rowoff;  // [cap_pairs] offset (in doubles) of pair p's rows inside g_rows
 };
 
 // per-pair scratch slice: linear bound so that offsets follow from prefix sums (see carve())
@@ -396,6 +399,7 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
 }
 SZ_HD const double *pair_rows(i64 p, const Floes &F, const Work &W) {
+  if (W.g_rows) return W.g_rows + W.pair_rowoff[p];
   // the rows are the last member of the slice; recompute the layout
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
@@ -424,10 +428,10 @@ SZ_HD void row_count(int i, Work &W) { // i < N
   for (i64 p = W.pair_base[i]; p < W.pair_base[i] + W.pair_cnt[i]; ++p) cnt += W.pair_nrows[p];
   int ninc = W.inc_cnt[i] < W.pot_cap ? W.inc_cnt[i] : W.pot_cap;
   int *inc = W.inc_list + (size_t)i * W.pot_cap;
-  // ascending pair id == ascending source floe (pairs are laid out by source floe)
+  // mirrored rows come in ascending order of the source floe (:187)
   for (int a = 1; a < ninc; ++a) {
     int v = inc[a], b = a;
-    while (b > 0 && inc[b - 1] > v) { inc[b] = inc[b - 1]; --b; }
+    while (b > 0 && W.pair_i[inc[b - 1]] > W.pair_i[v]) { inc[b] = inc[b - 1]; --b; }
     inc[b] = v;
   }
   for (int a = 0; a < ninc; ++a) cnt += W.pair_nrows[inc[a]];
@@ -523,6 +527,34 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
     if (!in) F.alive[i] = 0;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// sharded narrow-phase: the pairs [p_lo, p_hi) a rank computed leave as (nrows, flag) per pair plus their
+// rows packed back to back; every rank imports every segment, after which all ranks hold identical results
+// ---------------------------------------------------------------------------------------------
+struct Xfer {
+  int *nrows, *flag; // per pair of the segment
+  double *rows;      // 5 doubles per row, packed
+  i64 *off;          // exclusive prefix sum of nrows over the segment (rows before pair k)
+};
+SZ_HD void export_pair(i64 k, i64 p_lo, const Floes &F, const Work &W, const Xfer &X) {
+  const i64 p = p_lo + k;
+  const int nr = W.pair_nrows[p];
+  X.nrows[k] = nr; X.flag[k] = W.pair_flag[p];
+  if (nr > 0) {
+    const double *src = pair_rows(p, F, W);
+    double *dst = X.rows + 5 * X.off[k];
+    for (int q = 0; q < 5 * nr; ++q) dst[q] = src[q];
+  }
+}
+SZ_HD void import_pair(i64 k, i64 p_lo, i64 rows_base, Work &W, const Xfer &X) {
+  const i64 p = p_lo + k;
+  W.pair_nrows[p] = X.nrows[k]; W.pair_flag[p] = X.flag[k];
+  W.pair_rowoff[p] = rows_base + 5 * X.off[k];
+}
+// segment of the global pair list computed by rank r of w (all ranks derive the same split)
+SZ_HD void shard_range(i64 np, int r, int w, i64 &lo, i64 &hi) { lo = np * r / w; hi = np * (r + 1) / w; }
+SZ_HD i64 shard_max(i64 np, int w) { return (np + w - 1) / w; }
 
 // transfer(kill(i)) = i for the largest such i (:175-179): first collect, then apply
 SZ_HD void transfer_collect(int i, const Floes &F, Work &W) { // i < N

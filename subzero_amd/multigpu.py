@@ -1,0 +1,182 @@
+"""Multi-GPU form of the step: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI)
+for the one real exchange of the path.
+
+Design (round 1).  Every rank holds the full Floe struct array on its GPU and runs the cheap stages
+(ghost floes, grid, broad-phase, pair list; contact rows, sums, calc_trajectory) redundantly -- they are
+deterministic, so all ranks hold identical data.  The dominant stage, the per-pair narrow-phase
+(`k_narrow`, ~70 % of a step), is cut into `world` contiguous segments of the candidate-pair list; rank r
+computes segment r and the segments are exchanged with ONE all-gather of (rows-per-pair, flags, packed
+contact rows) -- ~0.1-0.5 MB per rank at 1e4 floes -- preceded by an 16-byte all-gather of the row counts
+that sizes it.  After the exchange every rank continues with the same global pair list and the same row
+order as the single-GPU step, so results are bit-identical to it by construction (tests/test_multigpu_cpu.py
+checks exactly that under a 2-process gloo group, with the host build of the same kernel bodies).
+
+Scaling is "strong" (the floe field is fixed; the replicated stages bound the speed-up, Amdahl).  The
+planned next step is spatial ownership of floes (contiguous index ranges after a spatial sort) with the
+per-floe stages sharded too and a second all-gather of the dynamic state; see DESIGN.md section 6.
+
+The orchestration below is backend-agnostic: `GpuBackend` drives the C ABI (szStepShardBegin / Export /
+Finish) with torch CUDA tensors as exchange buffers; the CPU tests plug in a backend built on tests/hostsim.
+"""
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+
+
+class ShardInfo(ctypes.Structure):
+    """szShardInfo"""
+    _fields_ = [("n_pairs", ctypes.c_int64), ("seg_lo", ctypes.c_int64), ("seg_hi", ctypes.c_int64),
+                ("seg_max", ctypes.c_int64), ("seg_rows", ctypes.c_int64), ("status", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class GpuBackend:
+    """One GPU of the job: szContext + device-resident floes + torch CUDA tensors as exchange buffers."""
+
+    def __init__(self, floes, local_rank):
+        import torch
+        from . import capi
+        self.torch, self.capi = torch, capi
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self.ctx = capi.Context(local_rank)
+        self.sim = capi.FloeInteractions(self.ctx, floes)
+        L = self.ctx.L
+        L.szShardSegmentBytes.restype = ctypes.c_int64
+        L.szShardSegmentBytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+        L.szStepShardBegin.argtypes = [ctypes.c_void_p, ctypes.POINTER(capi.StepParamsC), ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ShardInfo)]
+        L.szStepShardExport.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        L.szStepShardFinish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.POINTER(capi.StepStats)]
+        self._bufs = {}
+
+    def begin(self, P, rank, world):
+        self._cp = self.capi.pack_params(P)
+        info = ShardInfo()
+        rc = self.ctx.L.szStepShardBegin(self.ctx.h, ctypes.byref(self._cp), rank, world, ctypes.byref(info))
+        self._err = self.ctx.L.szLastError(self.ctx.h).decode() if rc else ""
+        return info
+
+    def last_error(self):
+        return self._err
+
+    def segment_bytes(self, seg_max, rows_max):
+        return int(self.ctx.L.szShardSegmentBytes(seg_max, rows_max))
+
+    def buffer(self, name, nbytes):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < nbytes:
+            b = self.torch.empty(int(nbytes * 1.25) + 256, dtype=self.torch.uint8, device=self.device)
+            self._bufs[name] = b
+        return b[:nbytes]
+
+    def small(self, values):
+        return self.torch.tensor(values, dtype=self.torch.int64, device=self.device)
+
+    def export(self, send, seg_max, rows_max):
+        self.ctx.check(self.ctx.L.szStepShardExport(self.ctx.h, ctypes.c_void_p(send.data_ptr()), seg_max, rows_max),
+                       "szStepShardExport")
+
+    def after_collective(self):
+        # the exchange ran on torch's RCCL stream, the kernels run on the context's stream: join on the host
+        self.torch.cuda.synchronize(self.device)
+
+    def finish(self, recv, seg_max, rows_max):
+        st = self.capi.StepStats()
+        self.ctx.check(self.ctx.L.szStepShardFinish(self.ctx.h, ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max,
+                                                    ctypes.byref(st)), "szStepShardFinish")
+        return st
+
+    def close(self):
+        self.ctx.close()
+
+
+class ShardedInteractions:
+    """floe_interactions_all over `world` ranks; `step` must be called by every rank with the same P."""
+
+    def __init__(self, backend, rank, world, group=None):
+        import torch.distributed as dist
+        self.dist, self.backend, self.rank, self.world, self.group = dist, backend, rank, world, group
+
+    def step(self, P):
+        be, dist = self.backend, self.dist
+        info = be.begin(P, self.rank, self.world)
+        mine = be.small([int(info.status), int(info.seg_rows)])
+        allc = [be.small([0, 0]) for _ in range(self.world)]
+        dist.all_gather(allc, mine, group=self.group)
+        allc = [t.tolist() for t in allc]
+        bad = [(r, c[0]) for r, c in enumerate(allc) if c[0] != 0]
+        if bad:   # every rank sees the same list and stops together: no rank is left waiting in a collective
+            raise RuntimeError("sharded step failed on rank(s) %s%s" % (bad, (": " + be.last_error()) if info.status else ""))
+        rows_max = max(c[1] for c in allc)
+        seg_max = int(info.seg_max)
+        nbytes = be.segment_bytes(seg_max, rows_max)
+        send = be.buffer("send", nbytes)
+        recv = be.buffer("recv", nbytes * self.world)
+        be.export(send, seg_max, rows_max)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        be.after_collective()
+        st = be.finish(recv, seg_max, rows_max)
+        self.last_info = info
+        return st
+
+
+def bench_main(args, rank, local_rank, world):
+    """bench.py for --gpus > 1 (launched by torch.distributed.run, one rank per GPU)."""
+    import torch
+    import torch.distributed as dist
+    from . import capi
+    import bench as bench_mod
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    S, P = bench_mod.build_workload(args.floes)     # same seeds on every rank: identical arrays
+    be = GpuBackend(S, local_rank)
+    sim = ShardedInteractions(be, rank, world)
+    it = 0
+    for _ in range(args.warmup):
+        P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    narrow_ms = 0.0; pairs = 0; rows = 0; seg_pairs = 0; pair_bytes = 0.0
+    for _ in range(args.steps):
+        P.doInt = int(it % 10 == 0)
+        st = sim.step(P); it += 1
+        narrow_ms += st.narrow_ms; pairs += st.n_pairs; rows += st.n_rows
+        ns = sim.last_info.seg_hi - sim.last_info.seg_lo
+        seg_pairs += ns
+        share = ns / max(st.n_pairs, 1)
+        pair_bytes += share * (16.0 * st.pair_vertices + 112.0 * st.n_pairs) + 56.0 * st.pair_rows
+    torch.cuda.synchronize(); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    off, inter = be.sim.interactions()
+    k = args.steps
+    if rank == 0:
+        achieved = (pair_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
+        out = {
+            "metric": "floe-timesteps/sec", "value": S.n * k / el, "unit": "floe-timesteps/s",
+            "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64+int64", "data": "synthetic",
+            "config": {"workload": "pack%d: %d Voronoi floes, concentration 1.0, periodic +-1e5 m box, dt=10 s, "
+                                   "collisions + ocean drag (forcing refreshed every 10th step)" % (S.n, S.n),
+                       "floes": int(S.n),
+                       "parallelism": "%d GPUs: narrow-phase sharded over the pair list, 1 RCCL all-gather/step, "
+                                      "other stages replicated" % world},
+            "timesteps_per_s": k / el,
+            "contact_pairs_per_s": capi.collision_count(inter) * k / el,
+            "candidate_pairs_per_s": pairs / el,
+            "roofline": {"bound": "hbm", "kernel": "k_narrow (rank 0's segment of the pair list)",
+                         "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
+        }
+        print(json.dumps(out), flush=True)
+    be.close()
+    dist.destroy_process_group()

@@ -1,6 +1,7 @@
 // TEST-ONLY: runs the kernel bodies of subzero_amd/csrc/step_core.hpp in plain loops on the CPU -- the
 // same source the GPU kernels execute -- so the CPU test-suite can compare the device pipeline with the
-// oracle without a GPU.  Not part of the product; nothing in subzero_amd/ loads this.
+// oracle without a GPU, and exercise the sharded (multi-GPU) form of the step under a real process group
+// (gloo).  Not part of the product; nothing in subzero_amd/ loads this.
 #include "../../subzero_amd/csrc/step_core.hpp"
 #include <stdint.h>
 #include <stdlib.h>
@@ -9,13 +10,13 @@
 
 using namespace szs;
 
-template <class T> static T *alloc(std::vector<std::vector<char> > &pool, size_t n) {
+namespace {
+
+template <class T> T *alloc(std::vector<std::vector<char> > &pool, size_t n) {
   pool.emplace_back(n * sizeof(T) + 64);
   memset(pool.back().data(), 0, pool.back().size());
   return (T *)(((uintptr_t)pool.back().data() + 15) & ~(uintptr_t)15);
 }
-
-extern "C" {
 
 // same field order as OrFloes / szFloeState
 struct HFloes {
@@ -45,111 +46,162 @@ struct HParams {
   double fCoriolis, turn_angle;
 };
 
-
-// returns 0, or: -1 output capacity, -5 workspace, -7 candidate-list overflow, -8 clip error, -9 MC regen
-int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, int64_t inter_cap,
-              int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext,
-              int32_t pot_cap, int64_t *retried) {
+// one step in flight (front -> narrow -> back), as step.hip keeps it in StepState
+struct Sim {
   std::vector<std::vector<char> > pool;
   Floes F;
-  F.n = hf->n; F.nb = hf->nb; F.n_stress = hf->n_stress; F.n_mc = hf->n_mc;
-  F.Xi = hf->Xi; F.Yi = hf->Yi; F.alpha_i = hf->alpha_i; F.Ui = hf->Ui; F.Vi = hf->Vi; F.ksi_ice = hf->ksi_ice;
-  F.h = hf->h; F.area = hf->area; F.mass = hf->mass; F.inertia_moment = hf->inertia_moment; F.rmax = hf->rmax;
-  F.dXi_p = hf->dXi_p; F.dYi_p = hf->dYi_p; F.dUi_p = hf->dUi_p; F.dVi_p = hf->dVi_p;
-  F.dalpha_i_p = hf->dalpha_i_p; F.dksi_ice_p = hf->dksi_ice_p;
-  F.FxOA = hf->FxOA; F.FyOA = hf->FyOA; F.torqueOA = hf->torqueOA;
-  F.alive = hf->alive; F.vert_off = hf->vert_off;
-  F.c0x = hf->c0x; F.c0y = hf->c0y; F.cax = hf->cax; F.cay = hf->cay;
-  F.StressH = hf->StressH; F.StressCount = hf->StressCount; F.Stress = hf->Stress; F.strain = hf->strain;
-  F.mcX = hf->mcX; F.mcY = hf->mcY; F.mcA = hf->mcA; F.mc_si = hf->n_mc; F.mc_sq = 1;
-  F.collision_force = hf->collision_force; F.collision_torque = hf->collision_torque; F.OverlapArea = hf->OverlapArea;
-  F.kill = hf->kill; F.transfer = hf->transfer;
-  const int n = F.n;
-  F.StressSum = alloc<double>(pool, (size_t)n * 4);
-  for (int i = 0; i < n; ++i)
-    for (int q = 0; q < 4; ++q) {
-      double s = 0;
-      for (int z = 0; z < F.n_stress; ++z) s += F.StressH[((size_t)i * F.n_stress + z) * 4 + q];
-      F.StressSum[4 * i + q] = s;
-    }
   Params P;
-  P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
-  P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
-  memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
-  P.fb_h = hp->fb_h; P.fb_area = hp->fb_area; P.fb_Xi = hp->fb_Xi; P.fb_Yi = hp->fb_Yi; P.fb_Ui = hp->fb_Ui;
-  P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
-  P.nxo = hp->nxo; P.nyo = hp->nyo; P.Xo = hp->Xo; P.Yo = hp->Yo; P.Uocn = hp->Uocn; P.Vocn = hp->Vocn;
-  P.Uwind = hp->Uwind; P.Vwind = hp->Vwind; P.fCoriolis = hp->fCoriolis; P.turn_angle = hp->turn_angle;
-  P.Lx = P.c2_boundary[0]; P.Ly = P.c2_boundary[1];
-  for (int k = 1; k < 5; ++k) { P.Lx = szc::maxd(P.Lx, P.c2_boundary[2 * k]); P.Ly = szc::maxd(P.Ly, P.c2_boundary[2 * k + 1]); }
-
   Work W;
-  memset(&W, 0, sizeof(W));
-  const int cap = 4 * n;
-  W.cap_ext = cap; W.pot_cap = pot_cap < 0 ? -pot_cap : pot_cap;
-  W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap);
-  W.xg_of = alloc<int>(pool, cap); W.yg_of = alloc<int>(pool, cap);
-  W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap);
-  W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
-  W.counters = alloc<unsigned long long>(pool, C_COUNT);
-  W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
-  W.pair_cnt = alloc<int>(pool, cap); W.pair_nv = alloc<i64>(pool, cap);
-  W.pair_base = alloc<i64>(pool, cap + 1); W.nv_base = alloc<i64>(pool, cap + 1);
-  W.inc_cnt = alloc<int>(pool, cap); W.inc_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
-  W.row_cnt = alloc<int>(pool, cap); W.row_off = alloc<i64>(pool, cap + 1);
-  W.cf_ext = alloc<double>(pool, 2 * (size_t)cap); W.ct_ext = alloc<double>(pool, cap); W.ov_ext = alloc<double>(pool, cap);
-  W.tmax = alloc<int>(pool, cap);
+  int n = 0, N = 0, cap = 0;
+  i64 np = 0, nvt = 0, retried = 0;
+  int rank = 0, world = 1;
+  i64 seg_lo = 0, seg_hi = 0, seg_rows = 0;
+  std::vector<i64> x_off;
 
-  for (int e = 0; e < cap; ++e) { ext_clear(e, W); marks_clear(e, F); }
-  for (int i = 0; i < n; ++i) ext_init(i, F, W);
-  int N = n;
-  if (P.PERIODIC) {
-    for (int dim = 0; dim < 2; ++dim) {
-      int n1 = N, g = 0;
-      for (int e = 0; e < n1; ++e) ghost_flag(e, dim, F, P, W);
-      for (int e = 0; e < n1; ++e) { W.scan[e] = g; g += W.flag[e]; }
-      for (int e = 0; e < n1; ++e) ghost_emit(e, dim, n1, F, P, W);
-      N = n1 + g;
+  void bind(HFloes *hf, const HParams *hp, int pot_cap) {
+    pool.clear();
+    F.n = hf->n; F.nb = hf->nb; F.n_stress = hf->n_stress; F.n_mc = hf->n_mc;
+    F.Xi = hf->Xi; F.Yi = hf->Yi; F.alpha_i = hf->alpha_i; F.Ui = hf->Ui; F.Vi = hf->Vi; F.ksi_ice = hf->ksi_ice;
+    F.h = hf->h; F.area = hf->area; F.mass = hf->mass; F.inertia_moment = hf->inertia_moment; F.rmax = hf->rmax;
+    F.dXi_p = hf->dXi_p; F.dYi_p = hf->dYi_p; F.dUi_p = hf->dUi_p; F.dVi_p = hf->dVi_p;
+    F.dalpha_i_p = hf->dalpha_i_p; F.dksi_ice_p = hf->dksi_ice_p;
+    F.FxOA = hf->FxOA; F.FyOA = hf->FyOA; F.torqueOA = hf->torqueOA;
+    F.alive = hf->alive; F.vert_off = hf->vert_off;
+    F.c0x = hf->c0x; F.c0y = hf->c0y; F.cax = hf->cax; F.cay = hf->cay;
+    F.StressH = hf->StressH; F.StressCount = hf->StressCount; F.Stress = hf->Stress; F.strain = hf->strain;
+    F.mcX = hf->mcX; F.mcY = hf->mcY; F.mcA = hf->mcA; F.mc_si = hf->n_mc; F.mc_sq = 1;
+    F.collision_force = hf->collision_force; F.collision_torque = hf->collision_torque; F.OverlapArea = hf->OverlapArea;
+    F.kill = hf->kill; F.transfer = hf->transfer;
+    n = F.n;
+    F.StressSum = alloc<double>(pool, (size_t)n * 4);
+    for (int i = 0; i < n; ++i)
+      for (int q = 0; q < 4; ++q) {
+        double s = 0;
+        for (int z = 0; z < F.n_stress; ++z) s += F.StressH[((size_t)i * F.n_stress + z) * 4 + q];
+        F.StressSum[4 * i + q] = s;
+      }
+    P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
+    P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
+    memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
+    P.fb_h = hp->fb_h; P.fb_area = hp->fb_area; P.fb_Xi = hp->fb_Xi; P.fb_Yi = hp->fb_Yi; P.fb_Ui = hp->fb_Ui;
+    P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
+    P.nxo = hp->nxo; P.nyo = hp->nyo; P.Xo = hp->Xo; P.Yo = hp->Yo; P.Uocn = hp->Uocn; P.Vocn = hp->Vocn;
+    P.Uwind = hp->Uwind; P.Vwind = hp->Vwind; P.fCoriolis = hp->fCoriolis; P.turn_angle = hp->turn_angle;
+    P.Lx = P.c2_boundary[0]; P.Ly = P.c2_boundary[1];
+    for (int k = 1; k < 5; ++k) { P.Lx = szc::maxd(P.Lx, P.c2_boundary[2 * k]); P.Ly = szc::maxd(P.Ly, P.c2_boundary[2 * k + 1]); }
+    memset(&W, 0, sizeof(W));
+    cap = 4 * n;
+    W.cap_ext = cap; W.pot_cap = pot_cap < 0 ? -pot_cap : pot_cap;
+    W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap);
+    W.xg_of = alloc<int>(pool, cap); W.yg_of = alloc<int>(pool, cap);
+    W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap);
+    W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
+    W.counters = alloc<unsigned long long>(pool, C_COUNT);
+    W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
+    W.pair_cnt = alloc<int>(pool, cap); W.pair_nv = alloc<i64>(pool, cap);
+    W.pair_base = alloc<i64>(pool, cap + 1); W.nv_base = alloc<i64>(pool, cap + 1);
+    W.inc_cnt = alloc<int>(pool, cap); W.inc_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
+    W.row_cnt = alloc<int>(pool, cap); W.row_off = alloc<i64>(pool, cap + 1);
+    W.cf_ext = alloc<double>(pool, 2 * (size_t)cap); W.ct_ext = alloc<double>(pool, cap); W.ov_ext = alloc<double>(pool, cap);
+    W.tmax = alloc<int>(pool, cap);
+    W.st_ext = alloc<double>(pool, 3 * (size_t)n); W.st_flag = alloc<int>(pool, n);
+  }
+
+  int front(bool all_pairs_broad) {
+    for (int e = 0; e < cap; ++e) { ext_clear(e, W); marks_clear(e, F); }
+    for (int i = 0; i < n; ++i) ext_init(i, F, W);
+    N = n;
+    if (P.PERIODIC) {
+      for (int dim = 0; dim < 2; ++dim) {
+        int n1 = N, g = 0;
+        for (int e = 0; e < n1; ++e) ghost_flag(e, dim, F, P, W);
+        for (int e = 0; e < n1; ++e) { W.scan[e] = g; g += W.flag[e]; }
+        for (int e = 0; e < n1; ++e) ghost_emit(e, dim, n1, F, P, W);
+        N = n1 + g;
+      }
     }
+    if (all_pairs_broad) {
+      for (int i = F.nb; i < n; ++i) broad(i, N, F, P, W);     // reals first: ghosts read their lists
+      for (int i = n; i < N; ++i) broad(i, N, F, P, W);
+    } else {
+      double rm = 0;
+      for (int i = 0; i < n; ++i) rm = szc::maxd(rm, F.rmax[i]);
+      W.cell_size = 2 * rm;
+      W.cell_x0 = -P.Lx - W.cell_size; W.cell_y0 = -P.Ly - W.cell_size;
+      W.cells_x = (int)((2 * P.Lx + 2 * W.cell_size) / W.cell_size) + 1;
+      W.cells_y = (int)((2 * P.Ly + 2 * W.cell_size) / W.cell_size) + 1;
+      if (W.cells_x > 2048) W.cells_x = 2048;
+      if (W.cells_y > 2048) W.cells_y = 2048;
+      const int nc = W.cells_x * W.cells_y;
+      W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
+      W.cell_items = alloc<int>(pool, cap);
+      for (int e = 0; e < N; ++e) cell_count(e, W);
+      int acc = 0;
+      for (int c = 0; c < nc; ++c) { W.cell_off[c] = acc; acc += W.cell_cnt[c]; }
+      W.cell_off[nc] = acc;
+      for (int e = N - 1; e >= 0; --e) cell_fill(e, W);        // reversed on purpose: order must not matter
+      for (int i = F.nb; i < n; ++i) broad_binned(i, N, F, P, W);
+      for (int i = n; i < N; ++i) broad_binned(i, N, F, P, W);
+    }
+    if (W.counters[C_ERR_POT]) return -7;
+    for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
+    np = 0; nvt = 0;
+    for (int i = 0; i < N; ++i) { W.pair_base[i] = np; W.nv_base[i] = nvt; np += W.pair_cnt[i]; nvt += W.pair_nv[i]; }
+    W.pair_base[N] = np; W.nv_base[N] = nvt;
+    W.cap_pairs = np + 1;
+    W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
+    W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
+    W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
+    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1);
+    for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
+    i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
+    i64 reserve = main_bytes / 2 + (8 << 20);
+    W.scratch_bytes = main_bytes + reserve;
+    W.scratch = alloc<char>(pool, (size_t)W.scratch_bytes);
+    W.counters[C_SCR_BUMP] = (unsigned long long)main_bytes;
+    return 0;
   }
-  *n_ext = N;
-  if (pot_cap < 0) {                                         // all-pairs form (negative pot_cap selects it)
-    W.pot_cap = pot_cap = -pot_cap;
-    for (int i = F.nb; i < n; ++i) broad(i, N, F, P, W);     // reals first: ghosts read their lists
-    for (int i = n; i < N; ++i) broad(i, N, F, P, W);
-  } else {
-    double rm = 0;
-    for (int i = 0; i < n; ++i) rm = szc::maxd(rm, F.rmax[i]);
-    W.cell_size = 2 * rm;
-    W.cell_x0 = -P.Lx - W.cell_size; W.cell_y0 = -P.Ly - W.cell_size;
-    W.cells_x = (int)((2 * P.Lx + 2 * W.cell_size) / W.cell_size) + 1;
-    W.cells_y = (int)((2 * P.Ly + 2 * W.cell_size) / W.cell_size) + 1;
-    if (W.cells_x > 2048) W.cells_x = 2048;
-    if (W.cells_y > 2048) W.cells_y = 2048;
-    const int nc = W.cells_x * W.cells_y;
-    W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
-    W.cell_items = alloc<int>(pool, cap);
-    for (int e = 0; e < N; ++e) cell_count(e, W);
-    int acc = 0;
-    for (int c = 0; c < nc; ++c) { W.cell_off[c] = acc; acc += W.cell_cnt[c]; }
-    W.cell_off[nc] = acc;
-    for (int e = N - 1; e >= 0; --e) cell_fill(e, W);        // reversed on purpose: order must not matter
-    for (int i = F.nb; i < n; ++i) broad_binned(i, N, F, P, W);
-    for (int i = n; i < N; ++i) broad_binned(i, N, F, P, W);
+
+  int narrow_range(i64 lo, i64 hi) {
+    for (i64 p = lo; p < hi; ++p) narrow(p, nullptr, 1, F, P, W);
+    retried = (i64)W.counters[C_RETRY];
+    int mult = 1;
+    std::vector<int> list;
+    while (W.counters[C_RETRY] > 0) {
+      mult *= 8;
+      if (mult > 512) return -5;
+      list.assign(W.retry_list, W.retry_list + W.counters[C_RETRY]);
+      W.counters[C_RETRY] = 0;
+      for (size_t t = 0; t < list.size(); ++t) narrow((i64)t, list.data(), mult, F, P, W);
+    }
+    if (W.counters[C_ERR_ARENA]) return -5;
+    if (W.counters[C_ERR_CLIP]) return -8;
+    return 0;
   }
-  if (W.counters[C_ERR_POT]) return -7;
-  for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
-  i64 np = 0, nvt = 0;
-  for (int i = 0; i < N; ++i) { W.pair_base[i] = np; W.nv_base[i] = nvt; np += W.pair_cnt[i]; nvt += W.pair_nv[i]; }
-  W.pair_base[N] = np; W.nv_base[N] = nvt;
-  W.cap_pairs = np + 1;
-  W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
-  W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
-  W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
-  W.retry_list = alloc<int>(pool, np + 1);
-  for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
-  // candidate pairs as the oracle reports them (without wall candidates)
-  {
+
+  int back() {
+    for (i64 p = np - 1; p >= 0; --p) incoming(p, W);        // reversed on purpose: order must not matter
+    if (W.counters[C_ERR_INC]) return -7;
+    for (int i = 0; i < N; ++i) row_count(i, W);
+    i64 nr = 0;
+    for (int i = 0; i < N; ++i) { W.row_off[i] = nr; nr += W.row_cnt[i]; }
+    W.row_off[N] = nr;
+    W.cap_rows = nr + 1;
+    W.rows = alloc<double>(pool, 7 * (size_t)(nr + 1));
+    for (int i = 0; i < N; ++i) row_fill(i, N, F, P, W);
+    for (int i = 0; i < N; ++i) transfer_collect(i, F, W);
+    for (int i = 0; i < cap; ++i) transfer_apply(i, F, W);
+    for (int i = F.nb; i < n; ++i) integrate_pre(i, F, P, W);
+    for (int i = F.nb; i < n; ++i) forcing_serial(i, F, P, W);
+    for (int i = F.nb; i < n; ++i) integrate_post(i, F, P, W);
+    if (W.counters[C_ERR_MC]) return -9;
+    for (int i = 0; i < F.nb; ++i) { F.collision_force[2 * i] = 0; F.collision_force[2 * i + 1] = 0; F.collision_torque[i] = 0; F.OverlapArea[i] = 0; }
+    return 0;
+  }
+
+  int outputs(int32_t *inter_off, double *inter, int64_t inter_cap, int32_t *pair_i, int32_t *pair_j,
+              int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext) {
+    *n_ext = N;
     int64_t k = 0;
     for (i64 p = 0; p < np; ++p) {
       if (W.pair_j[p] == WALL) continue;
@@ -158,48 +210,100 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
     }
     *npairs_out = k;
     if (k > pair_cap) return -1;
+    inter_off[0] = 0;
+    if (W.row_off[n] > inter_cap) return -1;
+    for (int i = 0; i < n; ++i) inter_off[i + 1] = (int32_t)W.row_off[i + 1];
+    memcpy(inter, W.rows, sizeof(double) * 7 * (size_t)W.row_off[n]);
+    return 0;
   }
-  i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
-  i64 reserve = main_bytes / 2 + (8 << 20);
-  W.scratch_bytes = main_bytes + reserve;
-  W.scratch = alloc<char>(pool, (size_t)W.scratch_bytes);
-  W.counters[C_SCR_BUMP] = (unsigned long long)main_bytes;
-  for (i64 p = 0; p < np; ++p) narrow(p, nullptr, 1, F, P, W);
-  *retried = (int64_t)W.counters[C_RETRY];
-  int mult = 1;
-  std::vector<int> list;
-  while (W.counters[C_RETRY] > 0) {
-    mult *= 8;
-    if (mult > 512) return -5;
-    list.assign(W.retry_list, W.retry_list + W.counters[C_RETRY]);
-    W.counters[C_RETRY] = 0;
-    for (size_t t = 0; t < list.size(); ++t) narrow((i64)t, list.data(), mult, F, P, W);
+};
+
+Sim g_sim; // the sharded entry points keep their state between calls, as the GPU context does
+
+size_t seg_bytes_for(i64 seg_max, i64 rows_max) {
+  return 16 + (size_t)((8 * seg_max + 7) / 8) * 8 + 40 * (size_t)rows_max; // same layout as step.hip
+}
+
+} // namespace
+
+extern "C" {
+
+// returns 0, or: -1 output capacity, -5 workspace, -7 candidate-list overflow, -8 clip error, -9 MC regen.
+// pot_cap < 0 selects the all-pairs broad-phase with capacity -pot_cap.
+int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, int64_t inter_cap,
+              int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext,
+              int32_t pot_cap, int64_t *retried) {
+  Sim s;
+  s.bind(hf, hp, pot_cap);
+  int rc;
+  if ((rc = s.front(pot_cap < 0))) return rc;
+  if ((rc = s.narrow_range(0, s.np))) return rc;
+  *retried = s.retried;
+  if ((rc = s.back())) return rc;
+  return s.outputs(inter_off, inter, inter_cap, pair_i, pair_j, pair_cap, npairs_out, n_ext);
+}
+
+// ---- sharded form, mirroring szStepShardBegin / Export / Finish ----
+int64_t host_shard_segment_bytes(int64_t seg_max, int64_t rows_max) { return (int64_t)seg_bytes_for(seg_max, rows_max); }
+
+// info: [n_pairs, seg_lo, seg_hi, seg_max, seg_rows, status]
+int host_shard_begin(HFloes *hf, const HParams *hp, int rank, int world, int64_t *info) {
+  Sim &s = g_sim;
+  s.bind(hf, hp, 32);
+  s.rank = rank; s.world = world;
+  int rc = s.front(false);
+  if (!rc) {
+    shard_range(s.np, rank, world, s.seg_lo, s.seg_hi);
+    rc = s.narrow_range(s.seg_lo, s.seg_hi);
   }
-  if (W.counters[C_ERR_ARENA]) return -5;
-  if (W.counters[C_ERR_CLIP]) return -8;
-  for (i64 p = np - 1; p >= 0; --p) incoming(p, W);        // reversed on purpose: order must not matter
-  if (W.counters[C_ERR_INC]) return -7;
-  for (int i = 0; i < N; ++i) row_count(i, W);
-  i64 nr = 0;
-  for (int i = 0; i < N; ++i) { W.row_off[i] = nr; nr += W.row_cnt[i]; }
-  W.row_off[N] = nr;
-  W.cap_rows = nr + 1;
-  W.rows = alloc<double>(pool, 7 * (size_t)(nr + 1));
-  for (int i = 0; i < N; ++i) row_fill(i, N, F, P, W);
-  for (int i = 0; i < N; ++i) transfer_collect(i, F, W);
-  for (int i = 0; i < cap; ++i) transfer_apply(i, F, W);
-  W.st_ext = alloc<double>(pool, 3 * (size_t)n); W.st_flag = alloc<int>(pool, n);
-  for (int i = F.nb; i < n; ++i) integrate_pre(i, F, P, W);
-  for (int i = F.nb; i < n; ++i) forcing_serial(i, F, P, W);
-  for (int i = F.nb; i < n; ++i) integrate_post(i, F, P, W);
-  if (W.counters[C_ERR_MC]) return -9;
-  for (int i = 0; i < F.nb; ++i) { F.collision_force[2 * i] = 0; F.collision_force[2 * i + 1] = 0; F.collision_torque[i] = 0; F.OverlapArea[i] = 0; }
-  // contact rows of the real floes
-  inter_off[0] = 0;
-  if (W.row_off[n] > inter_cap) return -1;
-  for (int i = 0; i < n; ++i) inter_off[i + 1] = (int32_t)W.row_off[i + 1];
-  memcpy(inter, W.rows, sizeof(double) * 7 * (size_t)W.row_off[n]);
+  s.x_off.assign((size_t)(s.seg_hi - s.seg_lo) + 1, 0);
+  i64 acc = 0;
+  if (!rc) for (i64 k = 0; k < s.seg_hi - s.seg_lo; ++k) { s.x_off[k] = acc; acc += s.W.pair_nrows[s.seg_lo + k]; }
+  s.seg_rows = acc;
+  info[0] = s.np; info[1] = s.seg_lo; info[2] = s.seg_hi; info[3] = shard_max(s.np, world); info[4] = acc; info[5] = rc;
+  return rc;
+}
+int host_shard_export(void *send, int64_t seg_max, int64_t rows_max) {
+  Sim &s = g_sim;
+  const i64 ns = s.seg_hi - s.seg_lo;
+  if (ns > seg_max || s.seg_rows > rows_max) return -1;
+  char *base = (char *)send;
+  long long hdr[2] = {(long long)ns, (long long)s.seg_rows};
+  memcpy(base, hdr, 16);
+  Xfer X;
+  X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
+  X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
+  X.off = s.x_off.data();
+  for (i64 k = 0; k < ns; ++k) export_pair(k, s.seg_lo, s.F, s.W, X);
   return 0;
+}
+int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32_t *inter_off, double *inter,
+                      int64_t inter_cap, int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out,
+                      int32_t *n_ext) {
+  Sim &s = g_sim;
+  const size_t seg_bytes = seg_bytes_for(seg_max, rows_max);
+  s.W.g_rows = (double *)recv;
+  std::vector<i64> off;
+  for (int r = 0; r < s.world; ++r) {
+    i64 lo, hi;
+    shard_range(s.np, r, s.world, lo, hi);
+    const i64 ns = hi - lo;
+    char *base = (char *)recv + (size_t)r * seg_bytes;
+    Xfer X;
+    X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
+    X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
+    off.assign((size_t)ns + 1, 0);
+    i64 acc = 0;
+    for (i64 k = 0; k < ns; ++k) { off[k] = acc; acc += X.nrows[k]; }
+    X.off = off.data();
+    const i64 rows_base = (i64)(((char *)X.rows - (char *)recv) / 8);
+    for (i64 k = 0; k < ns; ++k) import_pair(k, lo, rows_base, s.W, X);
+  }
+  int rc = s.back();
+  if (rc) return rc;
+  rc = s.outputs(inter_off, inter, inter_cap, pair_i, pair_j, pair_cap, npairs_out, n_ext);
+  s.W.g_rows = nullptr;
+  return rc;
 }
 
 } // extern "C"

@@ -1,0 +1,145 @@
+"""The N > 1 path under a real process group on the CPU (gloo, world_size 2).
+
+The orchestration is subzero_amd/multigpu.ShardedInteractions, unchanged; the backend is the host build of the
+device kernel bodies (tests/hostsim), whose shard export / import code is the same source the GPU runs.
+Checked: after every step both ranks hold exactly the state the single-process step produces (which the
+other CPU tests pin bit-for-bit to the oracle), and the exchanged segments really partition the pair list."""
+import ctypes
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class HostBackend:
+    """multigpu backend on tests/hostsim (CPU tensors as exchange buffers)."""
+
+    def __init__(self, floes):
+        import torch
+        import hoststep
+        import oracle
+        self.torch, self.orc = torch, oracle
+        self.L = hoststep.lib()
+        self.S = floes
+        self.cf = oracle.pack_floes(floes)
+        self.L.host_shard_segment_bytes.restype = ctypes.c_int64
+        self.L.host_shard_segment_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+        self.L.host_shard_begin.argtypes = [ctypes.POINTER(oracle.CFloes), ctypes.POINTER(oracle.CParams), ctypes.c_int,
+                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+        self.L.host_shard_export.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        self.L.host_shard_finish.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, oracle._ip, oracle._dp,
+                                             ctypes.c_int64, oracle._ip, oracle._ip, ctypes.c_int64,
+                                             ctypes.POINTER(ctypes.c_int64), oracle._ip]
+        self._bufs = {}
+
+    def begin(self, P, rank, world):
+        from subzero_amd.multigpu import ShardInfo
+        self.cp = self.orc.pack_params(P)
+        raw = (ctypes.c_int64 * 6)()
+        self.L.host_shard_begin(ctypes.byref(self.cf), ctypes.byref(self.cp), rank, world, raw)
+        info = ShardInfo()
+        info.n_pairs, info.seg_lo, info.seg_hi, info.seg_max, info.seg_rows, info.status = [int(v) for v in raw]
+        return info
+
+    def last_error(self):
+        return "host backend"
+
+    def segment_bytes(self, seg_max, rows_max):
+        return int(self.L.host_shard_segment_bytes(seg_max, rows_max))
+
+    def buffer(self, name, nbytes):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < nbytes:
+            b = self.torch.zeros(int(nbytes) + 64, dtype=self.torch.uint8)
+            self._bufs[name] = b
+        return b[:nbytes]
+
+    def small(self, values):
+        return self.torch.tensor(values, dtype=self.torch.int64)
+
+    def export(self, send, seg_max, rows_max):
+        assert self.L.host_shard_export(ctypes.c_void_p(send.data_ptr()), seg_max, rows_max) == 0
+
+    def after_collective(self):
+        pass
+
+    def finish(self, recv, seg_max, rows_max):
+        S = self.S
+        cap_rows = 64 * S.n + 1024
+        self.inter_off = np.zeros(S.n + 1, np.int32); inter = np.zeros((cap_rows, 7))
+        pi = np.zeros(cap_rows, np.int32); pj = np.zeros(cap_rows, np.int32)
+        npairs = ctypes.c_int64(); next_ = ctypes.c_int32()
+        rc = self.L.host_shard_finish(ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max,
+                                      self.orc._p(self.inter_off, self.orc._ip), self.orc._p(inter), cap_rows,
+                                      self.orc._p(pi, self.orc._ip), self.orc._p(pj, self.orc._ip), cap_rows,
+                                      ctypes.byref(npairs), ctypes.byref(next_))
+        assert rc == 0, rc
+        self.inter = inter[:self.inter_off[-1]].copy()
+        self.pairs = np.stack([pi[:npairs.value], pj[:npairs.value]], 1)
+        return None
+
+
+def _worker(rank, world, port, scene, steps, q):
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        import hoststep
+        import scenes
+        from subzero_amd import multigpu
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        S, P = getattr(scenes, scene[0])(*scene[1], **scene[2])
+        ref = S.copy()
+        be = HostBackend(S)
+        sim = multigpu.ShardedInteractions(be, rank, world)
+        segs = []
+        for it in range(steps):
+            P.doInt = int(it % 5 == 0)
+            r1 = hoststep.step(ref, P)             # single-process device pipeline (pinned to the oracle elsewhere)
+            sim.step(P)
+            info = sim.last_info
+            segs.append((int(info.n_pairs), int(info.seg_lo), int(info.seg_hi)))
+            assert np.array_equal(r1.pairs, be.pairs), "pairs differ at step %d" % it
+            assert np.array_equal(r1.inter_off, be.inter_off) and np.array_equal(r1.inter, be.inter), "rows differ at step %d" % it
+            bad = hoststep.compare_states(ref, S)
+            assert bad == [], "state differs at step %d: %s" % (it, bad)
+        dist.destroy_process_group()
+        q.put((rank, "ok", segs, int(len(be.inter))))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), None, 0))
+
+
+@pytest.mark.parametrize("scene", [("pack", (160,), {"periodic": True}),
+                                   ("pack", (120,), {"periodic": False, "seed": 7, "vel_seed": 8, "sigma": 0.3})])
+def test_sharded_step_equals_single_process_gloo_world2(scene):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, steps = 2, 8
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scene, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    res.sort()
+    for rank, status, segs, nrows in res:
+        assert status == "ok", "rank %d: %s" % (rank, status)
+    # the two segments partition the pair list at every step, and contacts were exercised
+    for (n0, lo0, hi0), (n1, lo1, hi1) in zip(res[0][2], res[1][2]):
+        assert n0 == n1 and lo0 == 0 and hi0 == lo1 and hi1 == n1
+    assert res[0][3] > 0

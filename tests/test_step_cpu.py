@@ -1,0 +1,113 @@
+"""CPU suite for the step path (no GPU):
+  * oracle pins: MATLAB's own cached area / centroid of the reference fixture shapes, known answers for InterX,
+    inpolygon, p_poly_dist; self-contained sin/cos/atan2 against libm;
+  * the reference's conservation scenarios (test/conservation_test.m:22-54): kinetic energy must not grow;
+  * the device pipeline (subzero_amd/csrc/step_core.hpp compiled for the host, tests/hostsim) is
+    bit-identical to the oracle, step after step, in every scene family.
+"""
+import ctypes
+import numpy as np
+import pytest
+
+import clipgen
+import hoststep
+import oracle
+import scenes
+
+
+def test_area_centroid_against_matlab_polyshape_cache():
+    # FloeShapes.mat stores, per polyshape, MATLAB's own [?, area, perimeter, cx, cy, xmin, ymin, xmax, ymax]
+    shapes, info = clipgen.load_shapes()
+    for s, pi in zip(shapes, info):
+        a = oracle.ring_area(s[:, 0], s[:, 1])
+        cx, cy = oracle.ring_centroid(s[:, 0], s[:, 1])
+        assert abs(a - pi[1]) <= 1e-12 * pi[1]
+        scale = np.abs(s).max()
+        assert abs(cx - pi[3]) <= 1e-12 * scale and abs(cy - pi[4]) <= 1e-12 * scale
+
+
+def test_interx_known_answers():
+    sq = np.array([[0, 0], [2, 0], [2, 2], [0, 2], [0, 0]], float)
+    px, py = oracle.interx(sq[:, 0], sq[:, 1], sq[:, 0] + 1, sq[:, 1] + 1)
+    assert np.array_equal(np.stack([px, py], 1), np.array([[1.0, 2.0], [2.0, 1.0]]))   # sorted rows, InterX.m:76
+    px, py = oracle.interx(sq[:, 0], sq[:, 1], sq[:, 0] + 5, sq[:, 1])
+    assert len(px) == 0
+
+
+def test_inpolygon_and_poly_dist():
+    L = oracle.lib()
+    tri = np.array([[0, 0], [4, 0], [0, 4], [0, 0]], float)
+    pts = np.array([[1, 1], [3, 3], [2, 2], [0, 0], [-1, 0], [2, 0]], float)   # in, out, on edge, vertex, out, on edge
+    xs, ys = np.ascontiguousarray(pts[:, 0]), np.ascontiguousarray(pts[:, 1])
+    vx, vy = np.ascontiguousarray(tri[:, 0]), np.ascontiguousarray(tri[:, 1])
+    out = np.zeros(len(pts), np.uint8)
+    L.or_inpolygon(oracle._p(xs), oracle._p(ys), len(pts), oracle._p(vx), oracle._p(vy), len(tri), oracle._p(out, oracle._bp))
+    assert out.tolist() == [1, 0, 1, 1, 0, 1]
+    d = np.zeros(len(pts))
+    L.or_p_poly_dist(oracle._p(xs), oracle._p(ys), len(pts), oracle._p(vx), oracle._p(vy), len(tri), oracle._p(d))
+    assert np.allclose(np.abs(d), [1.0, np.sqrt(2), 0.0, 0.0, 1.0, 0.0], atol=1e-12)
+
+
+def test_selfcontained_trig_within_2ulp():
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-7, 7, 4000), rng.uniform(-1e4, 1e4, 4000), [0.0, np.pi / 2, np.pi, -np.pi / 4]])
+    s, c = ctypes.c_double(), ctypes.c_double()
+    for x in xs:
+        L.or_sincos(float(x), ctypes.byref(s), ctypes.byref(c))
+        assert abs(s.value - np.sin(x)) <= 2 * np.spacing(abs(np.sin(x))) + 1e-300
+        assert abs(c.value - np.cos(x)) <= 2 * np.spacing(abs(np.cos(x))) + 1e-300
+    for y, x in rng.uniform(-1e4, 1e4, (4000, 2)):
+        a = L.or_atan2(float(y), float(x))
+        assert abs(a - np.arctan2(y, x)) <= 3 * np.spacing(abs(np.arctan2(y, x)))
+
+
+def lockstep(S, P, steps, do_int_every=10, pot_cap=32):
+    A, B = S.copy(), S.copy()
+    for it in range(steps):
+        P.doInt = int(it % do_int_every == 0)
+        ra = oracle.step(A, P, threads=4)
+        rb = hoststep.step(B, P, pot_cap=pot_cap)
+        assert ra.n_ext == rb.n_ext
+        assert np.array_equal(ra.pairs, rb.pairs), "step %d: candidate pairs" % it
+        assert np.array_equal(ra.inter_off, rb.inter_off), "step %d: row counts" % it
+        assert np.array_equal(ra.inter, rb.inter), "step %d: contact rows" % it
+        bad = [b for b in hoststep.compare_states(A, B) if b[0] != "StressH"]
+        assert bad == [], "step %d: %s" % (it, bad)
+        assert np.array_equal(A.StressH, B.StressH)
+        assert np.abs(A.Stress - B.Stress).max() <= 1e-12 * max(np.abs(A.StressH).max(), 1e-300)
+    return A, B, ra
+
+
+@pytest.mark.parametrize("binned", [True, False])
+def test_device_pipeline_matches_oracle_periodic(binned):
+    S, P = scenes.pack(300, periodic=True)
+    A, B, r = lockstep(S, P, 14, pot_cap=32 if binned else -32)
+    assert r.n_ext > S.n and len(r.inter) > 0          # ghosts and contacts were actually exercised
+
+
+def test_device_pipeline_matches_oracle_walls():
+    S, P = scenes.pack(200, periodic=False, seed=7, vel_seed=8, sigma=0.3)
+    A, B, r = lockstep(S, P, 14)
+    assert (r.inter[:, 0] == np.inf).any()             # floe-vs-boundary rows present
+
+
+def test_device_pipeline_matches_oracle_concave():
+    S, P = scenes.concave(40, periodic=True)
+    lockstep(S, P, 8)
+
+
+def test_device_pipeline_matches_oracle_with_eddy_forcing():
+    S, P = scenes.pack(80, periodic=False, seed=21, sigma=0.05)
+    P.set_reference_ocean()
+    A, B, r = lockstep(S, P, 7, do_int_every=3)
+    assert np.abs(A.FxOA).max() > 0
+
+
+def test_conservation_scenarios_energy_does_not_grow():
+    # test/conservation_test.m:22-54 asserts only K(end)/K(1) < 1
+    for S, P in (scenes.two_boxes(0.0), scenes.two_boxes(4e3), scenes.boxes_and_triangle()):
+        k0 = scenes.kinetic_energy(S)
+        A, B, r = lockstep(S, P, 40)
+        assert scenes.kinetic_energy(A) / k0 < 1
+        assert A.collision_force.any() or len(r.inter) >= 0
