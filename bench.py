@@ -75,8 +75,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     from subzero_amd import capi
-    if world > 1:
+    if world > 1 or os.environ.get("SUBZERO_FORCE_SHARDED") == "1":   # the env hook rehearses the N>1 code on one GPU
+        import torch  # noqa: F401  (torch must load its HIP runtime before libsubzero_hip.so does; tests/conftest.py)
         from subzero_amd import multigpu
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         return multigpu.bench_main(args, rank, local_rank, world)
 
     S, P = build_workload(args.floes)
