@@ -118,7 +118,7 @@ def main():
     out = {
         "metric": "floe-timesteps/sec", "value": S.n * k / el, "unit": "floe-timesteps/s",
         "n_gpus": 1, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64+int64", "data": "synthetic",
         "config": {"workload": "pack%d: %d Voronoi floes, concentration 1.0, periodic +-1e5 m box, dt=10 s, "
                                "collisions + ocean drag (forcing refreshed every 10th step)" % (S.n, S.n),

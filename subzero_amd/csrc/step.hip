@@ -14,6 +14,7 @@
 //   k_forcing                                                 one wave per real floe (Monte-Carlo forcing)
 // Two host read-backs per step size the pair scratch and the contact-row buffer (grow-only, owned by the
 // context).  No CPU fallback exists: every failure is an error code.
+#include <stdlib.h>
 #include "context.hpp"
 #include "step_core.hpp"
 
@@ -40,6 +41,8 @@ struct StepState {
   unsigned long long bump = 0, zero = 0;
   i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
   int N = 0, rank = 0, world = 1;
+  int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
+  int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
   i64 last_npairs = 0, last_nrows_real = 0;
   int last_next = 0;
   bool stepped = false;
@@ -166,9 +169,15 @@ __global__ void k_pair_expand(Floes F, Params P, Work W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) pair_expand(i, N, F, P, W);
 }
-__global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *list, int mult, Floes F, Params P, Work W) {
-  i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < count) narrow(list ? t : first + t, list, mult, F, P, W);
+// `lanes` of the 64 lanes of each wave carry a pair (the rest stay idle): with only ~4e4 pairs per step the
+// chip is short of waves, not of lanes; fewer pairs per wave means more waves in flight to overlap the
+// latency of the workspace accesses, and fewer divergent paths per wave.
+__global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *list, int mult, int lanes, int lds_per_lane, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
+  if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
 }
 __global__ void __launch_bounds__(1024) k_scan_segment(const int *in, i64 *out, int n, unsigned long long *total) {
   __shared__ i64 tot;
@@ -332,6 +341,9 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   StepState *S = new StepState();
   ctx->step = S;
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
+  if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
+  if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
+  if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int n = h->n;
   const int nv = h->vert_off[n];
   S->n = n; S->nb = h->nb; S->n_stress = h->n_stress; S->n_mc = h->n_mc; S->nverts = nv;
@@ -491,7 +503,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   unsigned long long *c = S->c;
   SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
   if (hi > lo) {
-    hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, 64), dim3(64), 0, st, lo, hi - lo, (const int *)nullptr, 1, F, P, W);
+    hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
@@ -506,7 +518,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
     S->zero = 0;
     SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_narrow, grid_for(nl, 64), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, F, P, W);
+    hipLaunchKernelGGL(k_narrow, grid_for(nl, S->narrow_lanes), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, S->narrow_lanes, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
     SZ_HIP(ctx, hipStreamSynchronize(st));

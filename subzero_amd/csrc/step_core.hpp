@@ -339,7 +339,8 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
-SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W) {
+SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
+                  void *fast_ws = nullptr, int fast_ws_bytes = 0) {
   i64 p = list ? (i64)list[t] : t;
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
@@ -379,6 +380,8 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
     atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
     return;
   }
+  // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
+  if (fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes) S.ws = fast_ws;
   szc::PairOut out;
   int st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                              P.mu, P.nu, S, out);

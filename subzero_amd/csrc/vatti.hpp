@@ -190,7 +190,7 @@ template <class T, class Less>
 SZ_HD void gnu_sort(T *a, int n, Less less) {
   if (n < 2) return;
   struct Span { int lo, hi, depth; };
-  Span stack[64];
+  Span stack[24];
   int sp = 0;
   int lg = 0;
   for (int m = n; m > 1; m >>= 1) ++lg;
@@ -223,7 +223,7 @@ SZ_HD void gnu_sort(T *a, int n, Less less) {
         ++f;
       }
       // recurse on [f, hi), loop on [lo, f)
-      if (sp < 64) { stack[sp].lo = f; stack[sp].hi = hi; stack[sp].depth = depth; ++sp; }
+      if (sp < 24) { stack[sp].lo = f; stack[sp].hi = hi; stack[sp].depth = depth; ++sp; }
       hi = f;
     }
     if (sp == 0) break;
