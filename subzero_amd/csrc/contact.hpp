@@ -77,6 +77,30 @@ SZ_HD_NOINLINE int clip_fixed(void *ws, int cap_nv, const i64 *ax, const i64 *ay
   return szv::clip_rings(ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
 }
 
+// compact-record form (inlined: the workspace pointer then stays provably in LDS for the GPU compiler)
+SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb,
+                             int op, RegionSink *sink) {
+  FixedRing a = {ax, ay}, b = {bx, by};
+  sink->nv = 0; sink->nr = 0;
+  if (sink->ox != nullptr) sink->roff[0] = 0;
+  return szv::clip_rings_compact(ws, a, na, b, nb, op, *sink);
+}
+// which sweep a pair uses: Wide records in the pair's HBM slice, or Compact records in a block of LDS
+struct ClipWide {
+  void *ws; int cap_nv;
+  SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
+    return clip_fixed(ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
+  }
+  SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
+};
+struct ClipCompact {
+  void *ws;
+  SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
+    return clip_fixed_compact(ws, ax, ay, na, bx, by, nb, op, sink);
+  }
+  SZ_HD bool fits(int nv) const { return nv <= szv::COMPACT_MAX_NV; }
+};
+
 // ---- rings in metres: c_alpha + (Xi, Yi), optionally closed by one more vertex (:62-67) ----
 struct RingD {
   const double *x, *y; // c_alpha of the floe (or the box)
@@ -180,6 +204,28 @@ SZ_HD bool in_region(double x, double y, const i64 *rx, const i64 *ry, int nr) {
   return (sumdq != 0) || on;
 }
 
+// Is (x, y) inside the region with a clearance of more than `margin` metres from its boundary?  Used to
+// certify, without running the sweep, that two regions overlap: if one point keeps a 1e-6 m clearance inside
+// both, their intersection contains a disc of ~4300 grid units radius, which no rounding of the sweep (<= 1
+// unit per vertex) can make vanish -- the reference's third clip (floe_interactions.m:158-159) is then
+// certainly non-empty.  A `false` only means "not certified": the caller runs the clip.
+SZ_HD bool clearly_inside(double x, double y, const i64 *rx, const i64 *ry, int nr, double margin) {
+  if (nr < 3 || !in_region(x, y, rx, ry, nr)) return false;
+  for (int m = 0; m < nr; ++m) {
+    int m1 = (m + 1 == nr) ? 0 : m + 1;
+    double xa = from_fixed(rx[m]), ya = from_fixed(ry[m]), xb = from_fixed(rx[m1]), yb = from_fixed(ry[m1]);
+    double ex = xb - xa, ey = yb - ya;
+    double px = x - xa, py = y - ya;
+    double ee = ex * ex + ey * ey;
+    double t = (ee > 0) ? (px * ex + py * ey) / ee : 0;
+    if (t < 0) t = 0;
+    if (t > 1) t = 1;
+    double dx = px - t * ex, dy = py - t * ey;
+    if (!(dx * dx + dy * dy > margin * margin)) return false;
+  }
+  return true;
+}
+
 // |p_poly_dist| of one point against the closed ring c (p_poly_dist.m:143-281)
 SZ_HD double dist_to_ring(double xp, double yp, const RingD &c) {
   int nv = c.len();
@@ -243,11 +289,26 @@ SZ_HD int crossings(const RingD &c1, const RingD &c2, double *px, double *py, in
   return np;
 }
 
-// The contact model for one pair.  Returns a szv::Status (ST_WORKSPACE / ST_OUT_CAPACITY ask for a
-// larger scratch tier; ST_CLIP_ERROR is the reference's "Clipper Error.").
-SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
-                       const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out) {
+// The contact model for one pair, in two parts so that candidates whose rings do not overlap stop after the
+// first clip (and free their lane): pair_clip1 -> regions in S.r1*, pair_finish -> contact rows.
+// Both return a szv::Status (ST_WORKSPACE / ST_OUT_CAPACITY ask for a larger tier; ST_CLIP_ERROR is the
+// reference's "Clipper Error.").
+template <class Clip>
+SZ_HD int pair_clip1(const RingD &ring1, const RingD &ring2, bool boundary, PairScratch &S, const Clip &clip, int &nreg) {
+  const int n1 = ring1.n, n2 = ring2.n;
+  for (int k = 0; k < n1; ++k) { S.f1x[k] = to_fixed(ring1.X(k)); S.f1y[k] = to_fixed(ring1.Y(k)); }
+  for (int k = 0; k < n2; ++k) { S.f2x[k] = to_fixed(ring2.X(k)); S.f2y[k] = to_fixed(ring2.Y(k)); }
+  const int op = boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION;
+  RegionSink s1 = {S.r1x, S.r1y, S.r1off, S.cap_v, S.cap_r, 0, 0};
+  int st = clip(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, op, &s1);                          // :29 / :34
+  nreg = (st == szv::ST_OK) ? s1.nr : 0;
+  return st;
+}
+
+template <class Clip>
+SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+                      const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
+                      PairScratch &S, int nreg, const Clip &clip, PairOut &out) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   // :10-21
   double h1 = f1.h, h2 = f2.h;
@@ -261,15 +322,9 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
     Force_factor = Modulus * h1 / r1;
   }
   double G = Modulus / (2 * (1 + nu));
-
   const int n1 = ring1.n, n2 = ring2.n;
-  for (int k = 0; k < n1; ++k) { S.f1x[k] = to_fixed(ring1.X(k)); S.f1y[k] = to_fixed(ring1.Y(k)); }
-  for (int k = 0; k < n2; ++k) { S.f2x[k] = to_fixed(ring2.X(k)); S.f2y[k] = to_fixed(ring2.Y(k)); }
   const int op = boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION;
-  RegionSink s1 = {S.r1x, S.r1y, S.r1off, S.cap_v, S.cap_r, 0, 0};
-  int st = clip_fixed(S.ws, S.cap_nv, S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, op, &s1);   // :29 / :34
-  if (st != szv::ST_OK) return st;
-  int nreg = s1.nr;
+  int st;
   if (boundary && nreg > 0) {                                                          // :35-40
     if (region_polyarea(S.r1x, S.r1y, S.r1off[1]) / f1.area > 0.75) overlap0 = SZC_INF;
   }
@@ -389,16 +444,20 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
     const int nc2 = c2.len();
     if (c2.extra) { S.f2x[n2] = S.f2x[0]; S.f2y[n2] = S.f2y[0]; }
     RegionSink s2 = {S.r2x, S.r2y, S.r2off, S.cap_v, S.cap_r, 0, 0};
-    st = clip_fixed(S.ws, S.cap_nv, S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, &s2);
+    st = clip(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, &s2);
     if (st != szv::ST_OK) return st;
     for (int ii = 0; ii < s2.nr; ++ii) {                                               // :156-165
       const i64 *TX = S.r2x + S.r2off[ii], *TY = S.r2y + S.r2off[ii];
       const int nt = S.r2off[ii + 1] - S.r2off[ii];
-      if (nt + nr > S.cap_nv) return szv::ST_WORKSPACE;
-      RegionSink s3 = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
-      st = clip_fixed(S.ws, S.cap_nv, TX, TY, nt, RX, RY, nr, szv::OP_INTERSECTION, &s3);
-      if (st != szv::ST_OK) return st;
-      if (s3.nr > 0) {
+      bool overlaps = clearly_inside(cx, cy, RX, RY, nr, 1e-6) && clearly_inside(cx, cy, TX, TY, nt, 1e-6);
+      if (!overlaps) {                                                                 // :158-159
+        if (!clip.fits(nt + nr)) return szv::ST_WORKSPACE;
+        RegionSink s3 = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+        st = clip(TX, TY, nt, RX, RY, nr, szv::OP_INTERSECTION, &s3);
+        if (st != szv::ST_OK) return st;
+        overlaps = s3.nr > 0;
+      }
+      if (overlaps) {
         double Anew = region_polyarea(TX, TY, nt);
         if (Anew / Ar - 1 > 0) { fdx = -fdx; fdy = -fdy; }
       }
@@ -424,6 +483,18 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
     ++out.nrows;
   }
   return szv::ST_OK;
+}
+
+// Both parts with Wide records in the pair's HBM slice (the general path).
+SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+                       const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
+                       PairScratch &S, PairOut &out) {
+  out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
+  ClipWide clip = {S.ws, S.cap_nv};
+  int nreg = 0;
+  int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
+  if (st != szv::ST_OK) return st;
+  return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
 }
 
 } // namespace szc

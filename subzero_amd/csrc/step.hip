@@ -34,7 +34,9 @@ struct StepState {
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_items;
-  DevBuf pair_rowoff, x_off;
+  DevBuf pair_rowoff, x_off, touch_list, pair_nreg;
+  int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
+  int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
   double rmax_max = 0;
   Params P;                       // parameters of the step in flight
   unsigned long long c[C_COUNT];  // host copy of the device counters
@@ -179,6 +181,25 @@ __global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *
   void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
   if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
 }
+// Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
+// 64-lane workgroup per CU (64 x 2344 B = 146.5 KB of the 160 KB); the lane stride is 8 x odd bytes so that
+// the same field of neighbouring lanes falls into different banks.  k_narrow_a: first clip of every pair;
+// k_narrow_b: contact model of the pairs that overlap (compacted by one atomic append per pair).
+#define FAST_WS_STRIDE 2344
+static_assert(FAST_WS_STRIDE % 16 == 8, "lane stride must be 8 x odd");
+__global__ void __launch_bounds__(64) k_narrow_a(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (t < count) narrow_a(first + t, F, P, W, smem + (size_t)threadIdx.x * FAST_WS_STRIDE);
+}
+__global__ void __launch_bounds__(64) k_narrow_b(int lanes, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  const i64 count = (i64)W.counters[C_TOUCH];
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (t < count) narrow_b(t, F, P, W, smem + (size_t)threadIdx.x * FAST_WS_STRIDE);
+}
 __global__ void __launch_bounds__(1024) k_scan_segment(const int *in, i64 *out, int n, unsigned long long *total) {
   __shared__ i64 tot;
   block_scan<int, i64>(in, out, n, &tot);
@@ -322,7 +343,7 @@ void sz_step_destroy(szContext *ctx) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off};
+                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   delete S;
@@ -343,6 +364,10 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
+  if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
+  SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
+  SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int n = h->n;
   const int nv = h->vert_off[n];
@@ -480,7 +505,8 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
       (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
       (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
       (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8))) return rc;
+      (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
+      (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
   const i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
   const i64 reserve = main_bytes / 2 + (8 << 20);
   if ((rc = sz_reserve(ctx, S->scratch, (size_t)(main_bytes + reserve)))) return rc;
@@ -489,6 +515,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
   W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
   W.pair_rowoff = (i64 *)S->pair_rowoff.p;
+  W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
   W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
   S->bump = (unsigned long long)main_bytes;
   SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_SCR_BUMP], &S->bump, 8, hipMemcpyHostToDevice, st));
@@ -502,19 +529,27 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   unsigned long long *c = S->c;
   SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
+  const bool fast = S->fast_path != 0;
   if (hi > lo) {
-    hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
+    if (fast) {
+      const int L = S->fast_lanes;
+      const size_t lds = (size_t)L * FAST_WS_STRIDE;
+      hipLaunchKernelGGL(k_narrow_a, grid_for(hi - lo, L), dim3(64), lds, st, lo, hi - lo, L, F, P, W);
+      hipLaunchKernelGGL(k_narrow_b, grid_for(hi - lo, L), dim3(64), lds, st, L, F, P, W);
+    } else {
+      hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
+    }
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
   SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
-  int mult = 1;
+  int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
   while (c[C_RETRY] > 0) {
-    mult *= 8;
+    mult = mult ? mult * 8 : 1;
     if (mult > 512) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) outgrew the 512x scratch tier", c[C_RETRY]);
     i64 nl = (i64)c[C_RETRY];
-    if (mult == 8) S->retried = nl;
+    if (mult == (fast ? 1 : 8)) S->retried = nl;
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
     S->zero = 0;
     SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));

@@ -59,7 +59,7 @@ struct Params {
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_SCR_BUMP, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_COUNT
 };
 
 struct Work {
@@ -85,6 +85,8 @@ struct Work {
   int *pair_mult;               // [cap_pairs] capacity tier used
   int *pair_nrows, *pair_status, *pair_flag; // flag: 1 sentinel +Inf, 2 sentinel -Inf, 4 contributes rows
   int *retry_list;
+  int *touch_list;              // pairs whose first clip found overlap regions (two-stage fast path)
+  int *pair_nreg;               // regions of the first clip
   // mirrored rows
   int *inc_cnt, *inc_list;      // [cap_ext], [cap_ext * pot_cap] pair ids
   // contact rows, CSR over the extended list
@@ -401,6 +403,95 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   W.pair_flag[p] = flag;
   if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
 }
+// ---- two-stage fast path: compact sweep records in a block of LDS (`fast_ws`), first clip for every pair
+// (narrow_a), the rest only for the pairs that overlap (narrow_b).  Pairs that do not fit the compact tier,
+// or whose lists overflow it, go to the retry list and take the general path (narrow) from scratch.
+struct PairSetup {
+  szc::RingD ring1, ring2;
+  szc::Body b1, b2;
+  double bx[4], by[4];
+  bool boundary;
+  int n1, n2;
+};
+SZ_HD void pair_setup(i64 p, const Floes &F, const Params &P, const Work &W, PairSetup &u) {
+  const int i = W.pair_i[p], j = W.pair_j[p];
+  const int si = W.ext_src[i];
+  const int v1 = F.vert_off[si];
+  u.n1 = F.vert_off[si + 1] - v1;
+  szc::RingD r1 = {F.cax + v1, F.cay + v1, W.ext_x[i], W.ext_y[i], u.n1, 0};
+  u.ring1 = r1;
+  szc::Body b1 = {W.ext_x[i], W.ext_y[i], F.Ui[si], F.Vi[si], F.ksi_ice[si], F.h[si], F.area[si]};
+  u.b1 = b1;
+  u.boundary = (j == WALL);
+  if (u.boundary) {
+    for (int k = 0; k < 4; ++k) { u.bx[k] = P.c2_boundary[2 * k]; u.by[k] = P.c2_boundary[2 * k + 1]; }
+    u.n2 = 4;
+    szc::RingD r = {u.bx, u.by, 0.0, 0.0, 4, 0};
+    u.ring2 = r;
+    szc::Body b = {P.fb_Xi, P.fb_Yi, P.fb_Ui, P.fb_Vi, P.fb_ksi_ice, P.fb_h, P.fb_area};
+    u.b2 = b;
+  } else {
+    const int sj = W.ext_src[j];
+    const int v2 = F.vert_off[sj];
+    u.n2 = F.vert_off[sj + 1] - v2;
+    szc::RingD r = {F.cax + v2, F.cay + v2, W.ext_x[j], W.ext_y[j], u.n2, 0};
+    u.ring2 = r;
+    szc::Body b = {W.ext_x[j], W.ext_y[j], F.Ui[sj], F.Vi[sj], F.ksi_ice[sj], F.h[sj], F.area[sj]};
+    u.b2 = b;
+  }
+}
+SZ_HD void to_general_path(i64 p, Work &W) {
+  unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
+  W.retry_list[k] = (int)p;
+  W.pair_status[p] = szv::ST_WORKSPACE;
+}
+SZ_HD bool pair_slice(i64 p, const PairSetup &u, Work &W, szc::PairScratch &S) {
+  i64 bytes = scratch_bytes_for((i64)u.n1 + u.n2, 1);
+  i64 off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
+  W.pair_scr[p] = off; W.pair_mult[p] = 1;
+  return !(off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, u.n1, u.n2, 1, S));
+}
+SZ_HD void narrow_a(i64 p, const Floes &F, const Params &P, Work &W, void *fast_ws) {
+  PairSetup u;
+  pair_setup(p, F, P, W, u);
+  W.pair_nrows[p] = 0; W.pair_flag[p] = 0; W.pair_nreg[p] = 0;
+  szc::PairScratch S;
+  if (!pair_slice(p, u, W, S)) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); return; }
+  if (u.n1 + u.n2 > szv::COMPACT_MAX_NV) { to_general_path(p, W); return; }
+  szc::ClipCompact clip = {fast_ws};
+  int nreg = 0;
+  int st = szc::pair_clip1(u.ring1, u.ring2, u.boundary, S, clip, nreg);
+  if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) { to_general_path(p, W); return; }
+  W.pair_status[p] = st;
+  if (st != szv::ST_OK) { atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
+  W.pair_nreg[p] = nreg;
+  if (nreg == 0) return; // no overlap region: floe_interactions.m:71-74 returns the zero sentinel
+  unsigned long long k = atomic_add(&W.counters[C_TOUCH], 1ULL);
+  W.touch_list[k] = (int)p;
+}
+SZ_HD void narrow_b(i64 t, const Floes &F, const Params &P, Work &W, void *fast_ws) {
+  const i64 p = W.touch_list[t];
+  PairSetup u;
+  pair_setup(p, F, P, W, u);
+  szc::PairScratch S;
+  pair_slice(p, u, W, S); // same slice as in narrow_a: regions of the first clip are in S.r1*
+  szc::ClipCompact clip = {fast_ws};
+  szc::PairOut out;
+  int st = szc::pair_finish(u.ring1, u.b1, u.ring2, u.b2, u.boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
+                            P.mu, P.nu, S, W.pair_nreg[p], clip, out);
+  if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) { to_general_path(p, W); return; }
+  W.pair_status[p] = st;
+  if (st != szv::ST_OK) { atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
+  int flag = 0;
+  double sabs = 0;
+  for (int r = 0; r < out.nrows; ++r) sabs += absd(S.rows[5 * r]) + absd(S.rows[5 * r + 1]);
+  if (sabs != 0) flag |= 4;
+  else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
+  W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
+  W.pair_flag[p] = flag;
+  if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+}
+
 SZ_HD const double *pair_rows(i64 p, const Floes &F, const Work &W) {
   if (W.g_rows) return W.g_rows + W.pair_rowoff[p];
   // the rows are the last member of the slice; recompute the layout

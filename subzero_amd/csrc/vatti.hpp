@@ -63,45 +63,49 @@ enum Status {
 enum { SIDE_NONE = 0, SIDE_LEFT = 1, SIDE_RIGHT = 2 };
 enum { KIND_SUBJECT = 0, KIND_CLIP = 1 };
 
-struct Edge {
-  Pt bot, cur, top;
-  double slope; // dx/dy, SZV_HORIZONTAL for dy == 0
-  int nxt, prv; // neighbours in the input ring
-  int up;       // next edge of the same bound (towards the local maximum)
-  int anext, aprev; // active-edge list
-  int snext, sprev; // sorted-edge list (also used as the pending-horizontals stack)
-  int wind, wind2;  // winding count of own kind / of the other kind
-  int ring;         // output ring index, or -1
-  signed char kind, side, wdelta, pad;
+// The records of the sweep's lists, parameterised by the integer type of list links (Ix) and of winding
+// counts (Wn): `Wide` (int) for rings of any size in an HBM workspace, `Compact` (int8) for the small
+// rings of Voronoi-like floes, so that a lane's whole workspace is ~2.3 KB and fits in LDS
+// (64 lanes x 2.3 KB < 160 KB per CU).  The algorithm is written once against the field names.
+template <class Ix, class Wn>
+struct Records {
+  struct Edge {
+    Pt bot, cur, top;
+    double slope; // dx/dy, SZV_HORIZONTAL for dy == 0
+    Ix nxt, prv;  // neighbours in the input ring
+    Ix up;        // next edge of the same bound (towards the local maximum)
+    Ix anext, aprev; // active-edge list
+    Ix snext, sprev; // sorted-edge list (also used as the pending-horizontals stack)
+    Wn wind, wind2;  // winding count of own kind / of the other kind
+    Ix ring;         // output ring index, or -1
+    signed char kind, side, wdelta, pad;
+  };
+  struct LocMin {
+    i64 y;
+    Ix left, right;
+  };
+  struct OutRing {
+    Ix idx;       // may be redirected to the ring this one was merged into
+    Ix first_left;
+    Ix pts;       // "left-most" point; pts.prev is the "right-most"
+    Ix bottom;
+    Ix hole;
+  };
+  struct OutPt {
+    Pt pt;
+    Ix idx, next, prev, pad;
+  };
+  struct Join {
+    Ix a, b;
+    Pt off;
+  };
+  struct Cross {
+    Ix e1, e2;
+    Pt pt;
+  };
 };
-
-struct LocMin {
-  i64 y;
-  int left, right;
-};
-
-struct OutRing {
-  int idx;       // may be redirected to the ring this one was merged into
-  int first_left;
-  int pts;       // "left-most" point; pts.prev is the "right-most"
-  int bottom;
-  int hole;
-};
-
-struct OutPt {
-  Pt pt;
-  int idx, next, prev, pad;
-};
-
-struct Join {
-  int a, b;
-  Pt off;
-};
-
-struct Cross {
-  int e1, e2;
-  Pt pt;
-};
+typedef Records<int, int> Wide;
+typedef Records<signed char, signed char> Compact; // at most 127 entries per list, even-odd fill only
 
 // ---- numeric kernels ----------------------------------------------------------------------
 
@@ -251,10 +255,10 @@ SZ_HD void gnu_sort(T *a, int n, Less less) {
   }
 }
 
-struct LocMinLess {
+template <class LocMin> struct LocMinLess {
   SZ_HD bool operator()(const LocMin &a, const LocMin &b) const { return b.y < a.y; }
 };
-struct CrossLess {
+template <class Cross> struct CrossLess {
   SZ_HD bool operator()(const Cross &a, const Cross &b) const { return b.pt.y < a.pt.y; }
 };
 
@@ -278,19 +282,37 @@ SZ_HD Caps caps_for(int nv) {
   c.crosses = 4 * nv + 8;
   return c;
 }
-SZ_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
-SZ_HD size_t workspace_bytes(int nv) {
-  Caps c = caps_for(nv);
-  return align16(sizeof(Edge) * c.edges) + align16(sizeof(LocMin) * c.minima) +
-         align16(sizeof(i64) * c.beams) + align16(sizeof(OutRing) * c.rings) +
-         align16(sizeof(OutPt) * c.pts) + align16(sizeof(Join) * c.joins) +
-         align16(sizeof(Join) * c.ghosts) + align16(sizeof(Cross) * c.crosses);
+// Fixed capacities of the compact tier: two closed rings of at most 18 points in total, i.e. 16 edges (what two Voronoi-like
+// floes, closed rings of 6-9 points, need).  Anything that does not fit reports ST_WORKSPACE and is re-run
+// with Wide records in HBM.
+enum { COMPACT_MAX_NV = 18 }; // closed rings: the closing duplicates are stripped, leaving <= 16 edges
+SZ_HD Caps caps_compact() {
+  Caps c;
+  c.edges = 16; c.minima = 4; c.beams = 16; c.rings = 6; c.pts = 24; c.joins = 4; c.ghosts = 4; c.crosses = 8;
+  return c;
 }
+SZ_HD size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+template <class Rec>
+SZ_HD size_t workspace_bytes_caps(const Caps &c) {
+  return align16(sizeof(typename Rec::Edge) * c.edges) + align16(sizeof(typename Rec::LocMin) * c.minima) +
+         align16(sizeof(i64) * c.beams) + align16(sizeof(typename Rec::OutRing) * c.rings) +
+         align16(sizeof(typename Rec::OutPt) * c.pts) + align16(sizeof(typename Rec::Join) * c.joins) +
+         align16(sizeof(typename Rec::Join) * c.ghosts) + align16(sizeof(typename Rec::Cross) * c.crosses);
+}
+SZ_HD size_t workspace_bytes(int nv) { return workspace_bytes_caps<Wide>(caps_for(nv)); }
+SZ_HD size_t workspace_bytes_compact() { return workspace_bytes_caps<Compact>(caps_compact()); }
 // Linear upper bound of workspace_bytes(nv), so that per-pair workspace offsets follow in closed form
 // from the CSR offsets of the inputs: offset(p) = WS_PER_VERTEX * (verts before p) + WS_PER_CLIP * p.
 enum { WS_PER_VERTEX = 528, WS_PER_CLIP = 1024 };
 
-struct Sweep {
+template <class Rec>
+struct SweepT {
+  typedef typename Rec::Edge Edge;
+  typedef typename Rec::LocMin LocMin;
+  typedef typename Rec::OutRing OutRing;
+  typedef typename Rec::OutPt OutPt;
+  typedef typename Rec::Join Join;
+  typedef typename Rec::Cross Cross;
   // storage
   Edge *E;
   LocMin *M;
@@ -309,8 +331,9 @@ struct Sweep {
   int op, fill_s, fill_c;
   int err;
 
-  SZ_HD void bind(void *buf, int nv) {
-    cap = caps_for(nv);
+  SZ_HD void bind(void *buf, int nv) { bind_caps(buf, caps_for(nv)); }
+  SZ_HD void bind_caps(void *buf, const Caps &c) {
+    cap = c;
     char *p = (char *)buf;
     E = (Edge *)p; p += align16(sizeof(Edge) * cap.edges);
     M = (LocMin *)p; p += align16(sizeof(LocMin) * cap.minima);
@@ -1290,7 +1313,7 @@ struct Sweep {
   SZ_HD bool order_crossings() {
     // crossings must be applied between edges that are adjacent at that moment
     sel_from_ael();
-    gnu_sort(X, nX, CrossLess());
+    gnu_sort(X, nX, CrossLess<Cross>());
     for (int i = 0; i < nX; ++i) {
       if (!adjacent_in_sel(X[i])) {
         int j = i + 1;
@@ -1652,7 +1675,7 @@ struct Sweep {
   // ---- driver ----
   SZ_HD bool run() {
     if (nM == 0) return false;
-    gnu_sort(M, nM, LocMinLess());
+    gnu_sort(M, nM, LocMinLess<LocMin>());
     nB = 0;
     for (int i = 0; i < nM; ++i) {
       push_beam(M[i].y);
@@ -1722,18 +1745,19 @@ struct Sweep {
   }
 };
 
+typedef SweepT<Wide> Sweep;
+
 // One boolean operation between a single subject ring and a single clip ring, evaluated as the mex
 // does (mexclipper.cpp:291-304).  RingA/RingB: callable (int) -> Pt.  Returns a Status.
 // workspace must hold workspace_bytes(cap_nv) bytes, cap_nv >= na + nb; simple polygons never need
 // more than cap_nv = na + nb, heavily self-intersecting input may (ST_WORKSPACE -> retry larger).
-template <class RingA, class RingB, class Sink>
-SZ_HD int clip_rings(void *workspace, int cap_nv, const RingA &a, int na, const RingB &b, int nb, int op,
-                     int fill_subject, int fill_clip, Sink &sink) {
+template <class Rec, class RingA, class RingB, class Sink>
+SZ_HD int clip_rings_t(void *workspace, const Caps &caps, const RingA &a, int na, const RingB &b, int nb,
+                       int op, int fill_subject, int fill_clip, Sink &sink) {
   if (op < 0 || op > 3 || fill_subject < 0 || fill_subject > 3 || fill_clip < 0 || fill_clip > 3)
     return ST_BAD_ARG;
-  if (cap_nv < na + nb) return ST_WORKSPACE;
-  Sweep s;
-  s.bind(workspace, cap_nv);
+  SweepT<Rec> s;
+  s.bind_caps(workspace, caps);
   s.op = op;
   s.fill_s = fill_subject;
   s.fill_c = fill_clip;
@@ -1744,6 +1768,18 @@ SZ_HD int clip_rings(void *workspace, int cap_nv, const RingA &a, int na, const 
   if (!s.run()) return s.err ? s.err : ST_CLIP_ERROR;
   if (!s.write(sink)) return ST_OUT_CAPACITY;
   return ST_OK;
+}
+template <class RingA, class RingB, class Sink>
+SZ_HD int clip_rings(void *workspace, int cap_nv, const RingA &a, int na, const RingB &b, int nb, int op,
+                     int fill_subject, int fill_clip, Sink &sink) {
+  if (cap_nv < na + nb) return ST_WORKSPACE;
+  return clip_rings_t<Wide>(workspace, caps_for(cap_nv), a, na, b, nb, op, fill_subject, fill_clip, sink);
+}
+// The compact tier: even-odd fill, at most COMPACT_MAX_NV input vertices, workspace_bytes_compact() bytes.
+template <class RingA, class RingB, class Sink>
+SZ_HD int clip_rings_compact(void *workspace, const RingA &a, int na, const RingB &b, int nb, int op, Sink &sink) {
+  if (na + nb > COMPACT_MAX_NV) return ST_WORKSPACE;
+  return clip_rings_t<Compact>(workspace, caps_compact(), a, na, b, nb, op, FILL_EVENODD, FILL_EVENODD, sink);
 }
 
 } // namespace szv

@@ -153,6 +153,7 @@ struct Sim {
     W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
     W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
     W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1);
+    W.touch_list = alloc<int>(pool, np + 1); W.pair_nreg = alloc<int>(pool, np + 1);
     for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
     i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
     i64 reserve = main_bytes / 2 + (8 << 20);
@@ -162,13 +163,23 @@ struct Sim {
     return 0;
   }
 
+  bool two_stage = true; // compact-record fast path first (as the GPU does), general path for the rest
   int narrow_range(i64 lo, i64 hi) {
-    for (i64 p = lo; p < hi; ++p) narrow(p, nullptr, 1, F, P, W);
+    std::vector<char> fast(szv::workspace_bytes_compact() + 64);
+    void *fw = (void *)(((uintptr_t)fast.data() + 15) & ~(uintptr_t)15);
+    W.counters[C_TOUCH] = 0;
+    if (two_stage) {
+      for (i64 p = hi - 1; p >= lo; --p) narrow_a(p, F, P, W, fw);           // any order
+      const i64 nt = (i64)W.counters[C_TOUCH];
+      for (i64 t = 0; t < nt; ++t) narrow_b(t, F, P, W, fw);
+    } else {
+      for (i64 p = lo; p < hi; ++p) narrow(p, nullptr, 1, F, P, W);
+    }
     retried = (i64)W.counters[C_RETRY];
-    int mult = 1;
+    int mult = two_stage ? 0 : 1;   // the fast path's leftovers start at the 1x general tier
     std::vector<int> list;
     while (W.counters[C_RETRY] > 0) {
-      mult *= 8;
+      mult = mult ? mult * 8 : 1;
       if (mult > 512) return -5;
       list.assign(W.retry_list, W.retry_list + W.counters[C_RETRY]);
       W.counters[C_RETRY] = 0;

@@ -19,6 +19,11 @@ struct Sink {
 };
 }
 
+static int g_try_compact = 0;
+static long long g_compact_done = 0;
+extern "C" void host_clip_set_compact(int on) { g_try_compact = on; g_compact_done = 0; }
+extern "C" long long host_clip_compact_count(void) { return g_compact_done; }
+
 extern "C" int host_clip_batch(int npairs,
                    const int64_t *ax, const int64_t *ay, const int32_t *aoff,
                    const int64_t *bx, const int64_t *by, const int32_t *boff,
@@ -33,9 +38,16 @@ extern "C" int host_clip_batch(int npairs,
     int na = aoff[p + 1] - aoff[p], nb = boff[p + 1] - boff[p];
     RingView a = {ax + aoff[p], ay + aoff[p]}, b = {bx + boff[p], by + boff[p]};
     int64_t nv0 = s.nv, nr0 = s.nr;
-    int st = 0;
+    int st = szv::ST_WORKSPACE;
+    // compact tier first (even-odd only), as the GPU's LDS path does; anything it cannot hold falls through
+    if (g_try_compact && fill_s == 0 && fill_c == 0) {
+      ws.resize(szv::workspace_bytes_compact() + 16);
+      void *w = (void *)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
+      st = szv::clip_rings_compact(w, a, na, b, nb, method, s);
+      if (st != szv::ST_WORKSPACE && st != szv::ST_OUT_CAPACITY) ++g_compact_done;
+    }
     // capacity tiers, as the GPU path retries overflowing pairs with a larger workspace
-    for (int cap = na + nb, tier = 0; tier < 4; ++tier, cap *= 8) {
+    for (int cap = na + nb, tier = 0; (st == szv::ST_WORKSPACE) && tier < 4; ++tier, cap *= 8) {
       ws.resize(szv::workspace_bytes(cap) + 16);
       void *w = (void *)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
       s.nv = nv0; s.nr = nr0;

@@ -89,3 +89,14 @@ def test_thousand_floes_collisions_count(ctx):
     S, P = scenes.pack(1000, periodic=True, n_stress=4)
     A, G, exact = lockstep(ctx, S, P, 6)
     assert exact
+
+
+def test_two_stage_lds_path_matches_oracle(ctx, monkeypatch):
+    # opt-in path: compact sweep records in LDS, first clip / contact stage as two kernels (SUBZERO_FAST_PATH=1)
+    monkeypatch.setenv("SUBZERO_FAST_PATH", "1")
+    S, P = scenes.pack(400, periodic=True)
+    A, G, exact = lockstep(ctx, S, P, 12)
+    assert exact
+    S, P = scenes.concave(40, periodic=True)      # rings too large for the compact tier: general path
+    A, G, exact = lockstep(ctx, S, P, 6)
+    assert exact
