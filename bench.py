@@ -30,10 +30,11 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_workload(n_floes, seed=4):
+def build_workload(n_floes, seed=4, box_scale=1.0):
     from subzero_amd import synth
-    S = synth.voronoi_field(n_floes, 1.0, seed=seed, vel_seed=2, vel_sigma=0.1)
-    P = synth.StepParams(dt=10.0, periodic=True)
+    L = 1e5 * box_scale
+    S = synth.voronoi_field(n_floes, 1.0, Lx=L, Ly=L, seed=seed, vel_seed=2, vel_sigma=0.1)
+    P = synth.StepParams(dt=10.0, Lx=L, Ly=L, periodic=True)
     P.Modulus = synth.reference_modulus(S)
     return S, P
 
@@ -118,11 +119,11 @@ def main():
     out = {
         "metric": "floe-timesteps/sec", "value": S.n * k / el, "unit": "floe-timesteps/s",
         "n_gpus": 1, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64+int64", "data": "synthetic",
         "config": {"workload": "pack%d: %d Voronoi floes, concentration 1.0, periodic +-1e5 m box, dt=10 s, "
                                "collisions + ocean drag (forcing refreshed every 10th step)" % (S.n, S.n),
-                   "floes": int(S.n), "parallelism": "1 GPU"},
+                   "floes": int(S.n), "floes_per_gpu": int(S.n), "parallelism": "1 GPU"},
         "timesteps_per_s": k / el,
         "contact_pairs_per_s": collisions * k / el,
         "candidate_pairs_per_s": pairs / el,

@@ -5,7 +5,7 @@
 // so the rules that matter are occupancy, coalesced SoA loads and short dependent chains -- no MFMA):
 //   k_ext_clear / k_ext_init / k_ghost_flag / k_ghost_emit   one thread per (extended) floe
 //   k_scan_*                                                  one 1024-thread workgroup, chunked scan
-//   k_broad                                                   one thread per extended floe i, j > i
+//   k_cell_* / k_broad_scan / k_broad_filter                  uniform grid; thread per (floe, neighbour cell); thread per floe
 //   k_pair_count / k_pair_expand                              one thread per extended floe
 //   k_narrow                                                  one thread per candidate pair, 64-thread
 //                                                             workgroups (one wave) for fine-grained dispatch
@@ -33,7 +33,7 @@ struct StepState {
   // grow-only per-step buffers
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
   DevBuf scratch, rows;
-  DevBuf cell_cnt, cell_off, cell_fill, cell_items;
+  DevBuf cell_cnt, cell_off, cell_fill, cell_items, cell_x, cell_y, cell_r;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg;
   int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
@@ -139,9 +139,9 @@ __global__ void k_cell_clear(Work W) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c <= W.cells_x * W.cells_y) { W.cell_cnt[c] = 0; W.cell_fill[c] = 0; }
 }
-__global__ void k_cell_count(Work W) {
+__global__ void k_cell_count(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < dev_next(W)) cell_count(e, W);
+  if (e < dev_next(W)) cell_count(e, F, W);
 }
 __global__ void __launch_bounds__(1024) k_scan_cells(Work W) {
   __shared__ int tot;
@@ -150,16 +150,22 @@ __global__ void __launch_bounds__(1024) k_scan_cells(Work W) {
   __syncthreads();
   if (threadIdx.x == 0) W.cell_off[nc] = tot;
 }
-__global__ void k_cell_fill(Work W) {
+__global__ void k_cell_fill(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < dev_next(W)) cell_fill(e, W);
+  if (e < dev_next(W)) cell_fill(e, F, W);
 }
-__global__ void k_broad_binned(int lo_is_real, Floes F, Params P, Work W) {
+__global__ void k_broad_scan(Floes F, Params P, Work W) { // thread (i, c9): 9 consecutive threads share floe i
+  int N = dev_next(W);
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int i = (int)(t / 9) + F.nb, c9 = (int)(t % 9);
+  if (i < N) broad_scan(i, c9, N, F, P, W);
+}
+__global__ void k_broad_filter(int lo_is_real, Floes F, Params P, Work W) {
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
   else { i += F.n; if (i >= N) return; }
-  broad_binned(i, N, F, P, W);
+  broad_filter(i, F, P, W);
 }
 __global__ void k_pair_count(Floes F, Params P, Work W) {
   int N = dev_next(W);
@@ -247,12 +253,12 @@ __global__ void k_integrate_post(Floes F, Params P, Work W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
   if (i < F.n) integrate_post(i, F, P, W);
 }
-// Ocean / wind forcing (calc_trajectory.m:95-98,121-166): one wave per floe.  The 64 lanes evaluate the
+// Ocean / wind forcing (calc_trajectory.m:95-98,121-166): one 256-thread workgroup per floe.  The threads evaluate the
 // Monte-Carlo points 64 at a time (contiguous reads of the floe's [point] row) into LDS; then single
 // lanes add the per-point values up left to right over the
 // points inside the floe -- the summation order of the serial form, so the result is bit-identical to it.
 #define FORCE_MAX_MC 1024
-__global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
+__global__ void __launch_bounds__(256) k_forcing(Floes F, Params P, Work W) {
   __shared__ double s0[FORCE_MAX_MC], s1[FORCE_MAX_MC], s2[FORCE_MAX_MC];
   __shared__ double red[4];
   __shared__ unsigned char sA[FORCE_MAX_MC];
@@ -268,7 +274,8 @@ __global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
   ForceCtx c;
   force_ctx(i, F, P, c);
   // pass 1: winds at the points inside the floe
-  for (int q = lane; q < nmc; q += 64) {
+  const int nthr = blockDim.x;
+  for (int q = lane; q < nmc; q += nthr) {
     double uw = 0, vw = 0;
     const unsigned char in = A[q * sq];
     if (in) wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
@@ -286,7 +293,7 @@ __global__ void __launch_bounds__(64) k_forcing(Floes F, Params P, Work W) {
   wind_stress(c, red[0], red[1], cnt);
   __syncthreads();
   // pass 2: stresses and torque
-  for (int q = lane; q < nmc; q += 64) {
+  for (int q = lane; q < nmc; q += nthr) {
     double Fx = 0, Fy = 0, tq = 0;
     if (sA[q]) force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
     s0[q] = Fx; s1[q] = Fy; s2[q] = tq;
@@ -343,7 +350,7 @@ void sz_step_destroy(szContext *ctx) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg};
+                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->cell_x, &S->cell_y, &S->cell_r};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   delete S;
@@ -477,16 +484,20 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     W.cells_y = (ny > 2048 || !(ny > 0)) ? 2048 : (int)ny;
     const size_t nc = (size_t)W.cells_x * W.cells_y + 1;
     if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
-        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_items, (size_t)cap * 4))) return rc;
+        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_items, (size_t)cap * 4)) ||
+        (rc = sz_reserve(ctx, S->cell_x, (size_t)cap * 8)) || (rc = sz_reserve(ctx, S->cell_y, (size_t)cap * 8)) ||
+        (rc = sz_reserve(ctx, S->cell_r, (size_t)cap * 8))) return rc;
+    W.cell_x = (double *)S->cell_x.p; W.cell_y = (double *)S->cell_y.p; W.cell_r = (double *)S->cell_r.p;
     W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
     W.cell_items = (int *)S->cell_items.p;
     hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
-    hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, W);
+    hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, W);
-    hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, W);
+    hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
   }
-  hipLaunchKernelGGL(k_broad_binned, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
-  if (P.PERIODIC) hipLaunchKernelGGL(k_broad_binned, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
+  hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_broad_filter, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
+  if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
   hipLaunchKernelGGL(k_pair_count, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
   hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, st, W);
   SZ_HIP(ctx, hipGetLastError());
@@ -585,7 +596,7 @@ static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
   hipLaunchKernelGGL(k_transfer_apply, grid_for(cap, 256), dim3(256), 0, st, F, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
   hipLaunchKernelGGL(k_integrate_pre, grid_for(n, 64), dim3(64), 0, st, F, P, W);
-  if (S->n_mc <= FORCE_MAX_MC) hipLaunchKernelGGL(k_forcing, dim3(n - S->nb > 0 ? n - S->nb : 1), dim3(64), 0, st, F, P, W);
+  if (S->n_mc <= FORCE_MAX_MC) hipLaunchKernelGGL(k_forcing, dim3(n - S->nb > 0 ? n - S->nb : 1), dim3(256), 0, st, F, P, W);
   else hipLaunchKernelGGL(k_forcing_serial, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());

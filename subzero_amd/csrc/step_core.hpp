@@ -98,6 +98,7 @@ struct Work {
   double cell_size, cell_x0, cell_y0;
   int cells_x, cells_y;
   int *cell_cnt, *cell_off, *cell_fill, *cell_items; // [cells_x * cells_y (+1)], items: cap_ext
+  double *cell_x, *cell_y, *cell_r;                  // position and rmax of the items, in cell order (cap_ext)
   // calc_trajectory values handed from integrate_pre to forcing / integrate_post (per real floe)
   double *st_ext; // [3 n] external force x, y and torque after the limiter (:42-46)
   int *st_flag;   // ST_GO | ST_FORCE
@@ -208,68 +209,73 @@ SZ_HD int cell_of(int e, const Work &W) {
   return cell_coord(W.ext_y[e], W.cell_y0, W.cell_size, W.cells_y) * W.cells_x +
          cell_coord(W.ext_x[e], W.cell_x0, W.cell_size, W.cells_x);
 }
-SZ_HD void cell_count(int e, Work &W) { atomic_add(&W.cell_cnt[cell_of(e, W)], 1); }
-SZ_HD void cell_fill(int e, Work &W) {
-  int c = cell_of(e, W);
-  int k = atomic_add(&W.cell_fill[c], 1);
-  W.cell_items[W.cell_off[c] + k] = e;
+// only live floes enter the grid (a dead floe is never a candidate, :101,:103); each item carries its
+// position and radius so that a cell is one contiguous stream of independent loads
+SZ_HD void cell_count(int e, const Floes &F, Work &W) {
+  if (F.alive[W.ext_src[e]]) atomic_add(&W.cell_cnt[cell_of(e, W)], 1);
 }
-SZ_HD void broad_binned(int i, int N, const Floes &F, const Params &P, Work &W) {
-  int cnt = 0;
-  int *mine = W.pot_list + (size_t)i * W.pot_cap;
+SZ_HD void cell_fill(int e, const Floes &F, Work &W) {
+  const int s = W.ext_src[e];
+  if (!F.alive[s]) return;
+  int c = cell_of(e, W);
+  int k = W.cell_off[c] + atomic_add(&W.cell_fill[c], 1);
+  W.cell_items[k] = e; W.cell_x[k] = W.ext_x[e]; W.cell_y[k] = W.ext_y[e]; W.cell_r[k] = F.rmax[s];
+}
+// broad_scan: thread (i, c9) tests floe i against the items of ONE of its 3 x 3 cells and appends the hits to
+// i's list (unordered, one atomic per hit).  broad_filter: thread i sorts its list by j and applies the `mems`
+// filter in order (:93-99, :103, :113); real floes first, ghosts afterwards (they read their root's list).
+SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Work &W) {
+  (void)N;
   const int si = W.ext_src[i];
   const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
-  if (F.alive[si] && !(xi != xi) && P.COLLISION) {
-    const int cx = cell_coord(xi, W.cell_x0, W.cell_size, W.cells_x);
-    const int cy = cell_coord(yi, W.cell_y0, W.cell_size, W.cells_y);
-    bool overflow = false;
-    for (int gy = cy - 1; gy <= cy + 1 && !overflow; ++gy) {
-      if (gy < 0 || gy >= W.cells_y) continue;
-      for (int gx = cx - 1; gx <= cx + 1 && !overflow; ++gx) {
-        if (gx < 0 || gx >= W.cells_x) continue;
-        const int c = gy * W.cells_x + gx;
-        for (int q = W.cell_off[c]; q < W.cell_off[c + 1]; ++q) {
-          const int j = W.cell_items[q];
-          if (j <= i) continue;
-          const int sj = W.ext_src[j];
-          if (!F.alive[sj]) continue;
-          double dx = xi - W.ext_x[j], dy = yi - W.ext_y[j];
-          double R = ri + F.rmax[sj];
-          double d2 = dx * dx + dy * dy;
-          if (d2 > R * R * 1.000001) continue;
-          if (!(::sqrt(d2) < R)) continue;      // :103
-          if (cnt >= W.pot_cap) { overflow = true; break; }
-          // insert keeping ascending j
-          int k = cnt;
-          while (k > 0 && mine[k - 1] > j + 1) { mine[k] = mine[k - 1]; --k; }
-          mine[k] = j + 1;
-          ++cnt;
-        }
-      }
-    }
-    if (overflow) atomic_add(&W.counters[C_ERR_POT], 1ULL);
-    // the mems filter, in ascending j (:93-99, :103, :113)
-    const int *init = nullptr; int ninit = 0;
-    if (W.ext_num[i] < 0) {
-      int root = iabs(W.ext_num[i]) - 1;
-      init = W.pot_list + (size_t)root * W.pot_cap;
-      ninit = W.pot_cnt[root];
-    }
-    const double lim = szc::mind(2 * P.Lx, 2 * P.Ly);
-    int kept = 0;
-    for (int a = 0; a < cnt; ++a) {
-      const int j = mine[a] - 1;
-      const int key = iabs(W.ext_num[j]);
-      bool member = false;
-      for (int q = 0; q < ninit && !member; ++q) member = (init[q] == key);
-      for (int q = 0; q < kept && !member; ++q) member = (W.ext_num[mine[q] - 1] == key);
-      const double R = ri + F.rmax[W.ext_src[j]];
-      if (!(!member || 2 * R > lim)) continue;
-      mine[kept++] = j + 1;
-    }
-    cnt = kept;
+  if (!(F.alive[si] && !(xi != xi) && P.COLLISION)) return;
+  const int gx = cell_coord(xi, W.cell_x0, W.cell_size, W.cells_x) + (c9 % 3) - 1;
+  const int gy = cell_coord(yi, W.cell_y0, W.cell_size, W.cells_y) + (c9 / 3) - 1;
+  if (gx < 0 || gx >= W.cells_x || gy < 0 || gy >= W.cells_y) return;
+  const int c = gy * W.cells_x + gx;
+  int *mine = W.pot_list + (size_t)i * W.pot_cap;
+  for (int q = W.cell_off[c]; q < W.cell_off[c + 1]; ++q) {
+    const int j = W.cell_items[q];
+    if (j <= i) continue;
+    double dx = xi - W.cell_x[q], dy = yi - W.cell_y[q];
+    double R = ri + W.cell_r[q];
+    double d2 = dx * dx + dy * dy;
+    if (d2 > R * R * 1.000001) continue;
+    if (!(::sqrt(d2) < R)) continue;      // :103
+    int k = atomic_add(&W.pot_cnt[i], 1);
+    if (k >= W.pot_cap) { atomic_add(&W.counters[C_ERR_POT], 1ULL); return; }
+    mine[k] = j + 1;
   }
-  W.pot_cnt[i] = cnt;
+}
+SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W) {
+  int *mine = W.pot_list + (size_t)i * W.pot_cap;
+  int cnt = W.pot_cnt[i];
+  if (cnt > W.pot_cap) cnt = W.pot_cap;
+  for (int a = 1; a < cnt; ++a) {          // ascending j
+    int v = mine[a], b = a;
+    while (b > 0 && mine[b - 1] > v) { mine[b] = mine[b - 1]; --b; }
+    mine[b] = v;
+  }
+  const int *init = nullptr; int ninit = 0;
+  if (W.ext_num[i] < 0) {
+    int root = iabs(W.ext_num[i]) - 1;
+    init = W.pot_list + (size_t)root * W.pot_cap;
+    ninit = W.pot_cnt[root];
+  }
+  const double ri = F.rmax[W.ext_src[i]];
+  const double lim = szc::mind(2 * P.Lx, 2 * P.Ly);
+  int kept = 0;
+  for (int a = 0; a < cnt; ++a) {
+    const int j = mine[a] - 1;
+    const int key = iabs(W.ext_num[j]);
+    bool member = false;
+    for (int q = 0; q < ninit && !member; ++q) member = (init[q] == key);
+    for (int q = 0; q < kept && !member; ++q) member = (W.ext_num[mine[q] - 1] == key);
+    const double R = ri + F.rmax[W.ext_src[j]];
+    if (!(!member || 2 * R > lim)) continue;
+    mine[kept++] = j + 1;
+  }
+  W.pot_cnt[i] = kept;
 }
 
 // ---------------------------------------------------------------------------------------------

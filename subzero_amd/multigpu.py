@@ -11,9 +11,12 @@ that sizes it.  After the exchange every rank continues with the same global pai
 order as the single-GPU step, so results are bit-identical to it by construction (tests/test_multigpu_cpu.py
 checks exactly that under a 2-process gloo group, with the host build of the same kernel bodies).
 
-Scaling is "strong" (the floe field is fixed; the replicated stages bound the speed-up, Amdahl).  The
-planned next step is spatial ownership of floes (contiguous index ranges after a spatial sort) with the
-per-floe stages sharded too and a second all-gather of the dynamic state; see DESIGN.md section 6.
+bench.py reports WEAK scaling (1e4 floes per GPU, box area grows with the GPU count): the narrow-phase is a
+latency chain of ~1.6 ms per pair whatever the number of pairs, so cutting a fixed 4.4e4-pair list in 8 would
+not shorten it; more floes per step is the axis along which this design scales.  The replicated stages grow
+with the total floe count and bound the efficiency.  The planned next step is spatial ownership of floes
+(contiguous index ranges after a spatial sort) with the per-floe stages sharded too and a second all-gather of
+the dynamic state; see DESIGN.md section 6.
 
 The orchestration below is backend-agnostic: `GpuBackend` drives the C ABI (szStepShardBegin / Export /
 Finish) with torch CUDA tensors as exchange buffers; the CPU tests plug in a backend built on tests/hostsim.
@@ -134,7 +137,9 @@ def bench_main(args, rank, local_rank, world):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    S, P = bench_mod.build_workload(args.floes)     # same seeds on every rank: identical arrays
+    # weak scaling: `floes` per GPU; the box grows with sqrt(world) so that the floe density (and the work per
+    # candidate pair) stays that of the one-GPU workload.  Same seeds on every rank: identical arrays.
+    S, P = bench_mod.build_workload(args.floes * world, box_scale=float(np.sqrt(world)))
     be = GpuBackend(S, local_rank)
     sim = ShardedInteractions(be, rank, world)
     it = 0
@@ -162,11 +167,12 @@ def bench_main(args, rank, local_rank, world):
         out = {
             "metric": "floe-timesteps/sec", "value": S.n * k / el, "unit": "floe-timesteps/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64+int64", "data": "synthetic",
-            "config": {"workload": "pack%d: %d Voronoi floes, concentration 1.0, periodic +-1e5 m box, dt=10 s, "
-                                   "collisions + ocean drag (forcing refreshed every 10th step)" % (S.n, S.n),
-                       "floes": int(S.n),
+            "config": {"workload": "pack%d: %d Voronoi floes (%d per GPU), concentration 1.0, periodic +-%.3g m box, "
+                                   "dt=10 s, collisions + ocean drag (forcing refreshed every 10th step)"
+                                   % (S.n, S.n, args.floes, 1e5 * np.sqrt(world)),
+                       "floes": int(S.n), "floes_per_gpu": int(args.floes),
                        "parallelism": "%d GPUs: narrow-phase sharded over the pair list, 1 RCCL all-gather/step, "
                                       "other stages replicated" % world},
             "timesteps_per_s": k / el,

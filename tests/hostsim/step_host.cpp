@@ -135,13 +135,16 @@ struct Sim {
       const int nc = W.cells_x * W.cells_y;
       W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
       W.cell_items = alloc<int>(pool, cap);
-      for (int e = 0; e < N; ++e) cell_count(e, W);
+      W.cell_x = alloc<double>(pool, cap); W.cell_y = alloc<double>(pool, cap); W.cell_r = alloc<double>(pool, cap);
+      for (int e = 0; e < N; ++e) cell_count(e, F, W);
       int acc = 0;
       for (int c = 0; c < nc; ++c) { W.cell_off[c] = acc; acc += W.cell_cnt[c]; }
       W.cell_off[nc] = acc;
-      for (int e = N - 1; e >= 0; --e) cell_fill(e, W);        // reversed on purpose: order must not matter
-      for (int i = F.nb; i < n; ++i) broad_binned(i, N, F, P, W);
-      for (int i = n; i < N; ++i) broad_binned(i, N, F, P, W);
+      for (int e = N - 1; e >= 0; --e) cell_fill(e, F, W);        // reversed on purpose: order must not matter
+      for (int i = N - 1; i >= F.nb; --i)
+        for (int c9 = 8; c9 >= 0; --c9) broad_scan(i, c9, N, F, P, W);   // any order
+      for (int i = F.nb; i < n; ++i) broad_filter(i, F, P, W);           // reals first: ghosts read their lists
+      for (int i = n; i < N; ++i) broad_filter(i, F, P, W);
     }
     if (W.counters[C_ERR_POT]) return -7;
     for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
