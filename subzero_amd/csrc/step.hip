@@ -45,6 +45,7 @@ struct StepState {
   int N = 0, rank = 0, world = 1;
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
+  int narrow_occ4 = -1;           // -1: choose per launch; 0 / 1 force the 1- / 4-waves-per-SIMD build (SUBZERO_NARROW_OCC4)
   i64 last_npairs = 0, last_nrows_real = 0;
   int last_next = 0;
   bool stepped = false;
@@ -187,6 +188,17 @@ __global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *
   void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
   if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
 }
+// The same kernel compiled for 4 waves per SIMD (128 VGPRs, more spilling): slower per wave, but when a step
+// has more waves than the chip has SIMDs (> ~6e4 pairs) the extra resident waves overlap each other's
+// memory waits -- the choice is made per launch from the pair count.
+__global__ void __launch_bounds__(64, 4) k_narrow_occ4(i64 first, i64 count, const int *list, int mult, int lanes, int lds_per_lane, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
+  if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
+}
+
 // Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
 // 64-lane workgroup per CU (64 x 2344 B = 146.5 KB of the 160 KB); the lane stride is 8 x odd bytes so that
 // the same field of neighbouring lanes falls into different banks.  k_narrow_a: first clip of every pair;
@@ -371,6 +383,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
+  if (const char *v = getenv("SUBZERO_NARROW_OCC4")) S->narrow_occ4 = atoi(v);
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -548,7 +561,12 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
       hipLaunchKernelGGL(k_narrow_a, grid_for(hi - lo, L), dim3(64), lds, st, lo, hi - lo, L, F, P, W);
       hipLaunchKernelGGL(k_narrow_b, grid_for(hi - lo, L), dim3(64), lds, st, L, F, P, W);
     } else {
-      hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
+      const i64 waves = (hi - lo + S->narrow_lanes - 1) / S->narrow_lanes;
+      const bool occ4 = S->narrow_occ4 == 1 || (S->narrow_occ4 < 0 && waves > 1536); // 1024 SIMDs on the chip
+      if (occ4)
+        hipLaunchKernelGGL(k_narrow_occ4, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
+      else
+        hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
     }
     SZ_HIP(ctx, hipGetLastError());
   }
