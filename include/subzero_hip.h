@@ -203,8 +203,13 @@ int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t ca
  *   szStepShardExport(d_send, info.seg_max, rows_max)     my results into a device buffer of
  *                                                         szShardSegmentBytes(seg_max, rows_max) bytes
  *   [caller: all-gather d_send of every rank into d_recv (world x segment bytes, rank order)]
- *   szStepShardFinish(d_recv, seg_max, rows_max, stats)   import all segments, then the remaining stages
- * d_recv must stay valid until Finish returns. */
+ *   szStepShardFinish(d_recv, seg_max, rows_max, stats, &fx)  import all segments, contact rows, sums
+ * d_recv must stay valid until Finish returns.  On steps that refresh the ocean/wind forcing (doInt) that
+ * stage is sharded too: Finish evaluates the forcing of this rank's floe range only and sets fx = 1; then
+ *   szStepShardForcing(d_send)    my FxOA / FyOA / torqueOA (szShardForcingBytes(ctx, world) bytes)
+ *   [caller: all-gather]
+ *   szStepShardEnd(d_recv, stats) import the other ranks' values, finish the step (calc_trajectory.m:174-234)
+ * When fx = 0 the step is complete after Finish (szStepShardEnd is then a no-op). */
 typedef struct szShardInfo {
   int64_t n_pairs;          /* candidate pairs of the step (same on every rank) */
   int64_t seg_lo, seg_hi;   /* my segment of the pair list */
@@ -216,7 +221,11 @@ typedef struct szShardInfo {
 int64_t szShardSegmentBytes(int64_t seg_max, int64_t rows_max);
 int szStepShardBegin(szContext *ctx, const szStepParams *params, int rank, int world, szShardInfo *info);
 int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max);
-int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats);
+int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats,
+                      int32_t *forcing_exchange);
+int64_t szShardForcingBytes(szContext *ctx, int world);
+int szStepShardForcing(szContext *ctx, void *d_send);
+int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats);
 
 /* clipper(P) orientation mode (mexclipper.cpp:134-145): 1 if Area(P) >= 0 else 0.  Host arithmetic
  * on n vertices (an O(n) sum; there is nothing to accelerate). */

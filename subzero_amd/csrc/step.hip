@@ -43,6 +43,8 @@ struct StepState {
   unsigned long long bump = 0, zero = 0;
   i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
   int N = 0, rank = 0, world = 1;
+  i64 nr = 0;
+  int force_exchange = 0;
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
   int narrow_occ4 = -1;           // -1: choose per launch; 0 / 1 force the 1- / 4-waves-per-SIMD build (SUBZERO_NARROW_OCC4)
@@ -270,14 +272,14 @@ __global__ void k_integrate_post(Floes F, Params P, Work W) {
 // lanes add the per-point values up left to right over the
 // points inside the floe -- the summation order of the serial form, so the result is bit-identical to it.
 #define FORCE_MAX_MC 1024
-__global__ void __launch_bounds__(256) k_forcing(Floes F, Params P, Work W) {
+__global__ void __launch_bounds__(256) k_forcing(int first, int last, Floes F, Params P, Work W) {
   __shared__ double s0[FORCE_MAX_MC], s1[FORCE_MAX_MC], s2[FORCE_MAX_MC];
   __shared__ double red[4];
   __shared__ unsigned char sA[FORCE_MAX_MC];
   __shared__ int scnt;
-  const int i = blockIdx.x + F.nb;
-  if (i >= F.n) return;
-  if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the wave
+  const int i = blockIdx.x + first;
+  if (i >= last) return;
+  if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
   const int lane = threadIdx.x;
   const int nmc = F.n_mc;
   const double *mx = F.mcX + i * F.mc_si, *my = F.mcY + i * F.mc_si;
@@ -320,9 +322,20 @@ __global__ void __launch_bounds__(256) k_forcing(Floes F, Params P, Work W) {
   __syncthreads();
   if (lane == 0) { F.FxOA[i] = red[0] / cnt; F.FyOA[i] = red[1] / cnt; F.torqueOA[i] = red[2] / cnt; }
 }
-__global__ void k_forcing_serial(Floes F, Params P, Work W) { // n_mc beyond the LDS staging size
-  int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
-  if (i < F.n) forcing_serial(i, F, P, W);
+__global__ void k_forcing_serial(int first, int last, Floes F, Params P, Work W) { // n_mc beyond the LDS staging size
+  int i = blockIdx.x * blockDim.x + threadIdx.x + first;
+  if (i < last) forcing_serial(i, F, P, W);
+}
+// sharded forcing: FxOA, FyOA, torqueOA of a floe range leave / arrive as three packed arrays of `cnt_max`
+__global__ void k_force_export(int first, int count, int cnt_max, Floes F, double *dst) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  dst[k] = F.FxOA[first + k]; dst[cnt_max + k] = F.FyOA[first + k]; dst[2 * (size_t)cnt_max + k] = F.torqueOA[first + k];
+}
+__global__ void k_force_import(int first, int count, int cnt_max, Floes F, const double *src) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  F.FxOA[first + k] = src[k]; F.FyOA[first + k] = src[cnt_max + k]; F.torqueOA[first + k] = src[2 * (size_t)cnt_max + k];
 }
 // running sums of the stress history, once after upload
 __global__ void k_stress_sum(Floes F) {
@@ -593,7 +606,21 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   return SZ_OK;
 }
 
-static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
+static int step_forcing(szContext *ctx, StepState *S, int first, int last) {
+  if (last <= first) return SZ_OK;
+  if (S->n_mc <= FORCE_MAX_MC) hipLaunchKernelGGL(k_forcing, dim3(last - first), dim3(256), 0, ctx->stream, first, last, S->F, S->P, S->W);
+  else hipLaunchKernelGGL(k_forcing_serial, grid_for(last - first, 64), dim3(64), 0, ctx->stream, first, last, S->F, S->P, S->W);
+  SZ_HIP(ctx, hipGetLastError());
+  return SZ_OK;
+}
+// floes [first, last) whose forcing rank r of w evaluates on a forcing step
+static void force_range(const StepState *S, int r, int w, int &first, int &last) {
+  const long long m = S->n - S->nb;
+  first = S->nb + (int)(m * r / w); last = S->nb + (int)(m * (r + 1) / w);
+}
+static int force_cnt_max(const StepState *S, int w) { return (S->n - S->nb + w - 1) / w; }
+
+static int step_back_a(szContext *ctx, StepState *S) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   unsigned long long *c = S->c;
@@ -614,8 +641,17 @@ static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
   hipLaunchKernelGGL(k_transfer_apply, grid_for(cap, 256), dim3(256), 0, st, F, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
   hipLaunchKernelGGL(k_integrate_pre, grid_for(n, 64), dim3(64), 0, st, F, P, W);
-  if (S->n_mc <= FORCE_MAX_MC) hipLaunchKernelGGL(k_forcing, dim3(n - S->nb > 0 ? n - S->nb : 1), dim3(256), 0, st, F, P, W);
-  else hipLaunchKernelGGL(k_forcing_serial, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  SZ_HIP(ctx, hipGetLastError());
+  S->nr = nr;
+  return SZ_OK;
+}
+
+static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
+  hipStream_t st = ctx->stream;
+  Floes &F = S->F; Work &W = S->W; Params &P = S->P;
+  unsigned long long *c = S->c;
+  const i64 np = S->np, nr = S->nr;
+  const int n = S->n;
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
@@ -635,6 +671,13 @@ static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
     stats->retried = S->retried; stats->pair_rows = S->pair_rows_local;
   }
   return SZ_OK;
+}
+
+static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
+  int rc;
+  if ((rc = step_back_a(ctx, S))) return rc;
+  if ((rc = step_forcing(ctx, S, S->nb, S->n))) return rc;
+  return step_back_b(ctx, S, stats);
 }
 
 int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
@@ -701,7 +744,8 @@ int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t row
   return SZ_OK;
 }
 
-int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats) {
+int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats,
+                      int32_t *forcing_exchange) {
   if (!ctx || !d_recv) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardFinish: no floes uploaded");
@@ -726,9 +770,58 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
     hipLaunchKernelGGL(k_import, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, lo, rows_base, S->W, X);
   }
   SZ_HIP(ctx, hipGetLastError());
-  rc = step_back(ctx, S, stats);
-  S->W.g_rows = nullptr;
-  return rc;
+  rc = step_back_a(ctx, S);
+  S->W.g_rows = nullptr; // the rows have been copied into the CSR; d_recv may be reused by the caller
+  if (rc) return rc;
+  // forcing: on a forcing step every rank evaluates its own floe range and the results are exchanged
+  // (szStepShardForcing / szStepShardEnd); otherwise the few thin floes (h < 0.1) are done redundantly
+  S->force_exchange = (S->P.doInt && S->world > 1) ? 1 : 0;
+  if (forcing_exchange) *forcing_exchange = S->force_exchange;
+  if (S->force_exchange) {
+    int f0, f1;
+    force_range(S, S->rank, S->world, f0, f1);
+    return step_forcing(ctx, S, f0, f1);
+  }
+  if ((rc = step_forcing(ctx, S, S->nb, S->n))) return rc;
+  return step_back_b(ctx, S, stats);
+}
+
+int64_t szShardForcingBytes(szContext *ctx, int world) {
+  if (!ctx || !ctx->step || world < 1) return 0;
+  return 24 * (int64_t)force_cnt_max(ctx->step, world);
+}
+
+int szStepShardForcing(szContext *ctx, void *d_send) {
+  if (!ctx || !d_send) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S || !S->force_exchange) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardForcing: no forcing exchange pending");
+  int f0, f1;
+  force_range(S, S->rank, S->world, f0, f1);
+  const int cm = force_cnt_max(S, S->world);
+  if (f1 > f0) hipLaunchKernelGGL(k_force_export, grid_for(f1 - f0, 256), dim3(256), 0, ctx->stream, f0, f1 - f0, cm, S->F, (double *)d_send);
+  SZ_HIP(ctx, hipGetLastError());
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SZ_OK;
+}
+
+int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardEnd: no floes uploaded");
+  if (!S->force_exchange) return SZ_OK; // Finish already completed the step
+  if (!d_recv) return SZ_ERR_BAD_ARG;
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  const int cm = force_cnt_max(S, S->world);
+  for (int r = 0; r < S->world; ++r) {
+    if (r == S->rank) continue;
+    int f0, f1;
+    force_range(S, r, S->world, f0, f1);
+    if (f1 > f0) hipLaunchKernelGGL(k_force_import, grid_for(f1 - f0, 256), dim3(256), 0, ctx->stream, f0, f1 - f0, cm, S->F,
+                                    (const double *)d_recv + 3 * (size_t)cm * r);
+  }
+  SZ_HIP(ctx, hipGetLastError());
+  S->force_exchange = 0;
+  return step_back_b(ctx, S, stats);
 }
 
 int szFloesDownload(szContext *ctx, szFloeState *h, int what) {

@@ -7,7 +7,9 @@ deterministic, so all ranks hold identical data.  The dominant stage, the per-pa
 (`k_narrow`, ~70 % of a step), is cut into `world` contiguous segments of the candidate-pair list; rank r
 computes segment r and the segments are exchanged with ONE all-gather of (rows-per-pair, flags, packed
 contact rows) -- ~0.1-0.5 MB per rank at 1e4 floes -- preceded by an 16-byte all-gather of the row counts
-that sizes it.  After the exchange every rank continues with the same global pair list and the same row
+that sizes it.  On the steps that refresh the ocean / wind forcing (every 10th) that stage -- the largest of
+the replicated ones, 1000 Monte-Carlo points per floe -- is sharded by floe range as well, with one more
+all-gather of 24 bytes per floe.  After the exchange every rank continues with the same global pair list and the same row
 order as the single-GPU step, so results are bit-identical to it by construction (tests/test_multigpu_cpu.py
 checks exactly that under a 2-process gloo group, with the host build of the same kernel bodies).
 
@@ -54,7 +56,11 @@ class GpuBackend:
                                        ctypes.POINTER(ShardInfo)]
         L.szStepShardExport.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
         L.szStepShardFinish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                        ctypes.POINTER(capi.StepStats)]
+                                        ctypes.POINTER(capi.StepStats), ctypes.POINTER(ctypes.c_int32)]
+        L.szShardForcingBytes.restype = ctypes.c_int64
+        L.szShardForcingBytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.szStepShardForcing.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.szStepShardEnd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(capi.StepStats)]
         self._bufs = {}
 
     def begin(self, P, rank, world):
@@ -89,10 +95,23 @@ class GpuBackend:
         self.torch.cuda.synchronize(self.device)
 
     def finish(self, recv, seg_max, rows_max):
-        st = self.capi.StepStats()
+        """-> (stats, forcing_exchange_pending)"""
+        self._st = self.capi.StepStats()
+        fx = ctypes.c_int32(0)
         self.ctx.check(self.ctx.L.szStepShardFinish(self.ctx.h, ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max,
-                                                    ctypes.byref(st)), "szStepShardFinish")
-        return st
+                                                    ctypes.byref(self._st), ctypes.byref(fx)), "szStepShardFinish")
+        return self._st, bool(fx.value)
+
+    def forcing_bytes(self, world):
+        return int(self.ctx.L.szShardForcingBytes(self.ctx.h, world))
+
+    def forcing_export(self, send):
+        self.ctx.check(self.ctx.L.szStepShardForcing(self.ctx.h, ctypes.c_void_p(send.data_ptr())), "szStepShardForcing")
+
+    def end(self, recv):
+        self.ctx.check(self.ctx.L.szStepShardEnd(self.ctx.h, ctypes.c_void_p(recv.data_ptr()), ctypes.byref(self._st)),
+                       "szStepShardEnd")
+        return self._st
 
     def close(self):
         self.ctx.close()
@@ -123,7 +142,16 @@ class ShardedInteractions:
         be.export(send, seg_max, rows_max)
         dist.all_gather_into_tensor(recv, send, group=self.group)
         be.after_collective()
-        st = be.finish(recv, seg_max, rows_max)
+        st, forcing_pending = be.finish(recv, seg_max, rows_max)
+        if forcing_pending:
+            # forcing step: every rank evaluated the ocean / wind forcing of its own floe range
+            fb = be.forcing_bytes(self.world)
+            fsend = be.buffer("fsend", fb)
+            frecv = be.buffer("frecv", fb * self.world)
+            be.forcing_export(fsend)
+            dist.all_gather_into_tensor(frecv, fsend, group=self.group)
+            be.after_collective()
+            st = be.end(frecv)
         self.last_info = info
         return st
 

@@ -193,7 +193,7 @@ struct Sim {
     return 0;
   }
 
-  int back() {
+  int back_a() {
     for (i64 p = np - 1; p >= 0; --p) incoming(p, W);        // reversed on purpose: order must not matter
     if (W.counters[C_ERR_INC]) return -7;
     for (int i = 0; i < N; ++i) row_count(i, W);
@@ -206,12 +206,27 @@ struct Sim {
     for (int i = 0; i < N; ++i) transfer_collect(i, F, W);
     for (int i = 0; i < cap; ++i) transfer_apply(i, F, W);
     for (int i = F.nb; i < n; ++i) integrate_pre(i, F, P, W);
-    for (int i = F.nb; i < n; ++i) forcing_serial(i, F, P, W);
+    return 0;
+  }
+  void forcing(int first, int last) { for (int i = first; i < last; ++i) forcing_serial(i, F, P, W); }
+  int back_b() {
     for (int i = F.nb; i < n; ++i) integrate_post(i, F, P, W);
     if (W.counters[C_ERR_MC]) return -9;
     for (int i = 0; i < F.nb; ++i) { F.collision_force[2 * i] = 0; F.collision_force[2 * i + 1] = 0; F.collision_torque[i] = 0; F.OverlapArea[i] = 0; }
     return 0;
   }
+  int back() {
+    int rc = back_a();
+    if (rc) return rc;
+    forcing(F.nb, n);
+    return back_b();
+  }
+  void force_range(int r, int w, int &first, int &last) const {
+    const long long m = n - F.nb;
+    first = F.nb + (int)(m * r / w); last = F.nb + (int)(m * (r + 1) / w);
+  }
+  int force_cnt_max(int w) const { return (n - F.nb + w - 1) / w; }
+  int force_exchange = 0;
 
   int outputs(int32_t *inter_off, double *inter, int64_t inter_cap, int32_t *pair_i, int32_t *pair_j,
               int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext) {
@@ -291,9 +306,9 @@ int host_shard_export(void *send, int64_t seg_max, int64_t rows_max) {
   for (i64 k = 0; k < ns; ++k) export_pair(k, s.seg_lo, s.F, s.W, X);
   return 0;
 }
-int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32_t *inter_off, double *inter,
-                      int64_t inter_cap, int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out,
-                      int32_t *n_ext) {
+// Finish: import + contact rows + sums; on a forcing step with world > 1 only this rank's floe range is
+// forced and *fx = 1 (then host_shard_forcing / host_shard_end complete the step)
+int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32_t *fx) {
   Sim &s = g_sim;
   const size_t seg_bytes = seg_bytes_for(seg_max, rows_max);
   s.W.g_rows = (double *)recv;
@@ -313,11 +328,47 @@ int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32
     const i64 rows_base = (i64)(((char *)X.rows - (char *)recv) / 8);
     for (i64 k = 0; k < ns; ++k) import_pair(k, lo, rows_base, s.W, X);
   }
-  int rc = s.back();
-  if (rc) return rc;
-  rc = s.outputs(inter_off, inter, inter_cap, pair_i, pair_j, pair_cap, npairs_out, n_ext);
+  int rc = s.back_a();
   s.W.g_rows = nullptr;
-  return rc;
+  if (rc) return rc;
+  s.force_exchange = (s.P.doInt && s.world > 1) ? 1 : 0;
+  *fx = s.force_exchange;
+  if (s.force_exchange) {
+    int f0, f1;
+    s.force_range(s.rank, s.world, f0, f1);
+    s.forcing(f0, f1);
+    return 0;
+  }
+  s.forcing(s.F.nb, s.n);
+  return s.back_b();
+}
+int64_t host_shard_forcing_bytes(int world) { return 24 * (int64_t)g_sim.force_cnt_max(world); }
+int host_shard_forcing(void *send) {
+  Sim &s = g_sim;
+  int f0, f1;
+  s.force_range(s.rank, s.world, f0, f1);
+  const int cm = s.force_cnt_max(s.world);
+  double *d = (double *)send;
+  for (int k = 0; k < f1 - f0; ++k) { d[k] = s.F.FxOA[f0 + k]; d[cm + k] = s.F.FyOA[f0 + k]; d[2 * (size_t)cm + k] = s.F.torqueOA[f0 + k]; }
+  return 0;
+}
+int host_shard_end(const void *recv) {
+  Sim &s = g_sim;
+  if (!s.force_exchange) return 0;
+  const int cm = s.force_cnt_max(s.world);
+  for (int r = 0; r < s.world; ++r) {
+    if (r == s.rank) continue;
+    int f0, f1;
+    s.force_range(r, s.world, f0, f1);
+    const double *d = (const double *)recv + 3 * (size_t)cm * r;
+    for (int k = 0; k < f1 - f0; ++k) { s.F.FxOA[f0 + k] = d[k]; s.F.FyOA[f0 + k] = d[cm + k]; s.F.torqueOA[f0 + k] = d[2 * (size_t)cm + k]; }
+  }
+  s.force_exchange = 0;
+  return s.back_b();
+}
+int host_shard_outputs(int32_t *inter_off, double *inter, int64_t inter_cap, int32_t *pair_i, int32_t *pair_j,
+                       int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext) {
+  return g_sim.outputs(inter_off, inter, inter_cap, pair_i, pair_j, pair_cap, npairs_out, n_ext);
 }
 
 } // extern "C"

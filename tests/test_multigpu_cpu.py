@@ -40,9 +40,14 @@ class HostBackend:
         self.L.host_shard_begin.argtypes = [ctypes.POINTER(oracle.CFloes), ctypes.POINTER(oracle.CParams), ctypes.c_int,
                                             ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
         self.L.host_shard_export.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
-        self.L.host_shard_finish.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, oracle._ip, oracle._dp,
-                                             ctypes.c_int64, oracle._ip, oracle._ip, ctypes.c_int64,
-                                             ctypes.POINTER(ctypes.c_int64), oracle._ip]
+        self.L.host_shard_finish.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, oracle._ip]
+        self.L.host_shard_forcing_bytes.restype = ctypes.c_int64
+        self.L.host_shard_forcing_bytes.argtypes = [ctypes.c_int]
+        self.L.host_shard_forcing.argtypes = [ctypes.c_void_p]
+        self.L.host_shard_end.argtypes = [ctypes.c_void_p]
+        self.L.host_shard_outputs.argtypes = [oracle._ip, oracle._dp, ctypes.c_int64, oracle._ip, oracle._ip,
+                                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), oracle._ip]
+        self.exchanges = 0
         self._bufs = {}
 
     def begin(self, P, rank, world):
@@ -76,19 +81,37 @@ class HostBackend:
     def after_collective(self):
         pass
 
-    def finish(self, recv, seg_max, rows_max):
+    def _outputs(self):
         S = self.S
         cap_rows = 64 * S.n + 1024
         self.inter_off = np.zeros(S.n + 1, np.int32); inter = np.zeros((cap_rows, 7))
         pi = np.zeros(cap_rows, np.int32); pj = np.zeros(cap_rows, np.int32)
         npairs = ctypes.c_int64(); next_ = ctypes.c_int32()
-        rc = self.L.host_shard_finish(ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max,
-                                      self.orc._p(self.inter_off, self.orc._ip), self.orc._p(inter), cap_rows,
-                                      self.orc._p(pi, self.orc._ip), self.orc._p(pj, self.orc._ip), cap_rows,
-                                      ctypes.byref(npairs), ctypes.byref(next_))
+        rc = self.L.host_shard_outputs(self.orc._p(self.inter_off, self.orc._ip), self.orc._p(inter), cap_rows,
+                                       self.orc._p(pi, self.orc._ip), self.orc._p(pj, self.orc._ip), cap_rows,
+                                       ctypes.byref(npairs), ctypes.byref(next_))
         assert rc == 0, rc
         self.inter = inter[:self.inter_off[-1]].copy()
         self.pairs = np.stack([pi[:npairs.value], pj[:npairs.value]], 1)
+
+    def finish(self, recv, seg_max, rows_max):
+        fx = ctypes.c_int32(0)
+        rc = self.L.host_shard_finish(ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max, ctypes.byref(fx))
+        assert rc == 0, rc
+        if not fx.value:
+            self._outputs()
+        return None, bool(fx.value)
+
+    def forcing_bytes(self, world):
+        return int(self.L.host_shard_forcing_bytes(world))
+
+    def forcing_export(self, send):
+        assert self.L.host_shard_forcing(ctypes.c_void_p(send.data_ptr())) == 0
+
+    def end(self, recv):
+        self.exchanges += 1
+        assert self.L.host_shard_end(ctypes.c_void_p(recv.data_ptr())) == 0
+        self._outputs()
         return None
 
 
@@ -102,6 +125,7 @@ def _worker(rank, world, port, scene, steps, q):
         from subzero_amd import multigpu
         dist.init_process_group("gloo", rank=rank, world_size=world)
         S, P = getattr(scenes, scene[0])(*scene[1], **scene[2])
+        P.set_reference_ocean()                       # non-trivial forcing, so that its exchange matters
         ref = S.copy()
         be = HostBackend(S)
         sim = multigpu.ShardedInteractions(be, rank, world)
@@ -117,6 +141,8 @@ def _worker(rank, world, port, scene, steps, q):
             bad = hoststep.compare_states(ref, S)
             assert bad == [], "state differs at step %d: %s" % (it, bad)
         dist.destroy_process_group()
+        assert be.exchanges == 2, be.exchanges        # forcing steps 0 and 5 went through the second all-gather
+        assert np.abs(S.FxOA).max() > 0
         q.put((rank, "ok", segs, int(len(be.inter))))
     except Exception as e:  # pragma: no cover
         import traceback

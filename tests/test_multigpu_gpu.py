@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 def test_two_emulated_ranks_equal_single_gpu_step():
     import torch
     S, P = scenes.pack(300, periodic=True)
+    P.set_reference_ocean()
     ref = S.copy()
     c0 = capi.Context(0)
     ref_sim = capi.FloeInteractions(c0, ref)
@@ -40,8 +41,19 @@ def test_two_emulated_ranks_equal_single_gpu_step():
             sends.append(s)
         recv = torch.cat(sends)             # what all_gather_into_tensor delivers, rank order
         torch.cuda.synchronize()
-        for r in range(world):
-            bes[r].finish(recv, seg_max, rows_max)
+        pend = [bes[r].finish(recv, seg_max, rows_max)[1] for r in range(world)]
+        assert pend == [bool(P.doInt)] * world
+        if pend[0]:                          # forcing step: the second exchange, again concatenated by hand
+            fb = bes[0].forcing_bytes(world)
+            fs = []
+            for r in range(world):
+                t = torch.empty(fb, dtype=torch.uint8, device="cuda:0")
+                bes[r].forcing_export(t)
+                fs.append(t)
+            frecv = torch.cat(fs)
+            torch.cuda.synchronize()
+            for r in range(world):
+                bes[r].end(frecv)
         ref_sim.download(capi.SYNC_ALL)
         off0, rows0 = ref_sim.interactions()
         for r in range(world):
