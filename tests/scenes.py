@@ -66,3 +66,31 @@ def boxes_and_triangle():
 
 def kinetic_energy(S):
     return 0.5 * (S.mass * (S.Ui ** 2 + S.Vi ** 2)).sum() + 0.5 * (S.inertia_moment * S.ksi_ice ** 2).sum()
+
+
+def edge_cases(periodic=False):
+    """A handful of floes arranged to hit the rarely taken branches of floe_interactions_all.m /
+    floe_interactions.m: a small floe swallowed by a big one (overlap > 55 % -> kill / transfer marks, :138-145),
+    a floe hanging mostly outside the wall ('dif' area > 75 % -> Inf, floe_interactions.m:35-40), its centre
+    outside the box (alive = 0, :152-155), a dead floe, a floe with NaN position, plus ordinary neighbours."""
+    def box(cx, cy, hx, hy):
+        return np.array([[cx - hx, cy - hy], [cx - hx, cy + hy], [cx + hx, cy + hy], [cx + hx, cy - hy]], float)
+    polys = [
+        box(-5e4, 0.0, 8e3, 8e3),            # 0 big
+        box(-5e4 + 2e3, 1e3, 2.5e3, 2.5e3),  # 1 small, fully inside 0
+        box(9.8e4, 3e4, 6e3, 6e3),           # 2 mostly inside the box, touching the east wall
+        box(1.04e5, -3e4, 5e3, 5e3),         # 3 centre outside the east wall
+        box(0.0, 5e4, 5e3, 5e3),             # 4 dead
+        box(2e4, -5e4, 5e3, 5e3),            # 5 NaN position
+        box(0.0, 0.0, 6e3, 6e3),             # 6 ordinary pair ...
+        box(1.15e4, 1e3, 6e3, 6e3),          # 7 ... overlapping by 500 m
+        box(3e4, 3e4, 4e3, 7e3),             # 8
+        box(3.75e4, 3.2e4, 4e3, 4e3),        # 9
+    ]
+    S = synth.build_state(polys, height=0.8, seed=9, n_stress=8)
+    S.Ui[:] = [0.0, 0.05, 0.1, 0.0, 0.0, 0.0, 0.1, -0.1, 0.05, -0.05]
+    S.alive[4] = 0
+    S.Xi[5] = np.nan
+    P = synth.StepParams(dt=10, periodic=periodic, height=0.8)
+    P.Modulus = 5e7
+    return S, P

@@ -111,3 +111,18 @@ def test_conservation_scenarios_energy_does_not_grow():
         A, B, r = lockstep(S, P, 40)
         assert scenes.kinetic_energy(A) / k0 < 1
         assert A.collision_force.any() or len(r.inter) >= 0
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+@pytest.mark.parametrize("nb,collision", [(0, 1), (2, 1), (0, 0)])
+def test_edge_cases_match_oracle(periodic, nb, collision):
+    # swallowed floe (kill / transfer marks), floe outside the wall, dead floe, NaN floe, Nb > 0, COLLISION off
+    S, P = scenes.edge_cases(periodic)
+    S.nb = nb; P.COLLISION = collision
+    A, B, r = lockstep(S, P, 4)
+    if nb == 0 and collision:
+        assert A.kill[0] == 2 and A.transfer[1] == 1        # floe 2 merges into floe 1 (floe_interactions_all.m:138-145,175-179)
+    if periodic:
+        assert A.kill[5] == 6                                # NaN position: removed by calc_trajectory (:282)
+    else:
+        assert A.alive[3] == 0 and A.alive[5] == 0           # centre outside the box (:152-155)

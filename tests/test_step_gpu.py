@@ -100,3 +100,16 @@ def test_two_stage_lds_path_matches_oracle(ctx, monkeypatch):
     S, P = scenes.concave(40, periodic=True)      # rings too large for the compact tier: general path
     A, G, exact = lockstep(ctx, S, P, 6)
     assert exact
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+@pytest.mark.parametrize("nb,collision", [(0, 1), (2, 1), (0, 0)])
+def test_edge_cases(ctx, periodic, nb, collision):
+    # swallowed floe (kill / transfer marks), floe outside the wall, dead floe, NaN floe, Nb > 0, COLLISION off
+    S, P = scenes.edge_cases(periodic)
+    S.nb = nb; P.COLLISION = collision
+    A, G, exact = lockstep(ctx, S, P, 4)
+    assert exact
+    assert np.array_equal(A.kill, G.kill) and np.array_equal(A.transfer, G.transfer)
+    if nb == 0 and collision:
+        assert G.kill[0] == 2 and G.transfer[1] == 1
