@@ -17,6 +17,7 @@
 #pragma once
 #include <math.h>
 #include "vatti.hpp"
+#include "convex.hpp"
 
 #if defined(__HIPCC__)
 #define SZ_HD_NOINLINE static __host__ __device__ __attribute__((noinline))
@@ -85,6 +86,18 @@ SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, con
   if (sink->ox != nullptr) sink->roff[0] = 0;
   return szv::clip_rings_compact(ws, a, na, b, nb, op, *sink);
 }
+#ifndef SZC_FAST_PROBE
+#define SZC_FAST_PROBE(st) ((void)0)   // the host test build counts fast-path hits and bail-outs here
+#endif
+// single-minimum fast path (convex.hpp); ST_BAIL = not the plain case, nothing written
+SZ_HD_NOINLINE int clip_fixed_fast(szx::FastBlock *blk, void *deque_mem, const i64 *ax, const i64 *ay, int na,
+                                   const i64 *bx, const i64 *by, int nb, RegionSink *sink) {
+  FixedRing a = {ax, ay}, b = {bx, by};
+  sink->nv = 0; sink->nr = 0;
+  if (sink->ox != nullptr) sink->roff[0] = 0;
+  szx::FastWs fw = {blk, (Pt *)deque_mem, 24};
+  return szx::clip_monotone(fw, a, na, b, nb, *sink);
+}
 // which sweep a pair uses: Wide records in the pair's HBM slice, or Compact records in a block of LDS
 struct ClipWide {
   void *ws; int cap_nv;
@@ -92,6 +105,22 @@ struct ClipWide {
     return clip_fixed(ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
   }
   SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
+};
+// The fast path alone: anything it does not cover (a bail-out, or the difference with the domain box) comes
+// back as ST_DEFER and the whole pair is redone by the general kernel.  A wave therefore never mixes the short
+// fast path with the long general sweep.  The 768-byte output deque borrows the start of the (idle) Wide
+// workspace of the pair's slice.
+enum { ST_DEFER = 101 };
+struct ClipFastOnly {
+  szx::FastBlock *blk;
+  void *deque_mem;
+  SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
+    if (op != szv::OP_INTERSECTION) return ST_DEFER;
+    int st = clip_fixed_fast(blk, deque_mem, ax, ay, na, bx, by, nb, sink);
+    SZC_FAST_PROBE(st);
+    return st == szx::ST_BAIL ? (int)ST_DEFER : st;
+  }
+  SZ_HD bool fits(int) const { return true; }
 };
 struct ClipCompact {
   void *ws;
@@ -449,7 +478,16 @@ SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, co
     for (int ii = 0; ii < s2.nr; ++ii) {                                               // :156-165
       const i64 *TX = S.r2x + S.r2off[ii], *TY = S.r2y + S.r2off[ii];
       const int nt = S.r2off[ii + 1] - S.r2off[ii];
+      // A point with a 1e-6 m disc inside both regions certifies that the third clip is not empty (a disc of
+      // 4295 fixed-point units cannot vanish in a sweep that rounds by one unit).  Try the centroid of the
+      // original overlap (the shifted one contains it when the shift deepens the overlap) and the centroid of
+      // the shifted overlap (when the shift makes it shallower); only if neither certifies run the clip.
       bool overlaps = clearly_inside(cx, cy, RX, RY, nr, 1e-6) && clearly_inside(cx, cy, TX, TY, nt, 1e-6);
+      if (!overlaps && nt >= 3) {
+        double tx, ty;
+        region_centroid(TX, TY, nt, tx, ty);
+        overlaps = clearly_inside(tx, ty, RX, RY, nr, 1e-6) && clearly_inside(tx, ty, TX, TY, nt, 1e-6);
+      }
       if (!overlaps) {                                                                 // :158-159
         if (!clip.fits(nt + nr)) return szv::ST_WORKSPACE;
         RegionSink s3 = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
@@ -488,13 +526,20 @@ SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, co
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out) {
+                       PairScratch &S, PairOut &out, szx::FastBlock *fast = nullptr) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
-  ClipWide clip = {S.ws, S.cap_nv};
+  ClipWide wide = {S.ws, S.cap_nv};
   int nreg = 0;
-  int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
+  if (fast != nullptr) {
+    if (boundary) return ST_DEFER;
+    ClipFastOnly clip = {fast, S.ws};
+    int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
+    if (st != szv::ST_OK) return st;
+    return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
+  }
+  int st = pair_clip1(ring1, ring2, boundary, S, wide, nreg);
   if (st != szv::ST_OK) return st;
-  return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
+  return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, wide, out);
 }
 
 } // namespace szc

@@ -45,6 +45,9 @@ struct StepState {
   int N = 0, rank = 0, world = 1;
   i64 nr = 0;
   int force_exchange = 0;
+  int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
+  int convex_lanes = 64;          // pairs per wave of that pass (SUBZERO_CONVEX_LANES)
+  int retry_lanes = 8;            // pairs per wave when the general kernel redoes what the first pass deferred (SUBZERO_RETRY_LANES)
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
   int narrow_occ4 = -1;           // -1: choose per launch; 0 / 1 force the 1- / 4-waves-per-SIMD build (SUBZERO_NARROW_OCC4)
@@ -199,6 +202,18 @@ __global__ void __launch_bounds__(64, 4) k_narrow_occ4(i64 first, i64 count, con
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
   if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
+}
+
+// First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
+// state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
+// Pairs it does not cover are appended to the retry list and redone by k_narrow.
+#define CONVEX_STRIDE 776
+static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE >= sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
+__global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (t < count) narrow(first + t, nullptr, 1, F, P, W, nullptr, 0, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
 }
 
 // Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
@@ -397,6 +412,9 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_NARROW_OCC4")) S->narrow_occ4 = atoi(v);
+  if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->convex_lanes = l; }
+  if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -566,9 +584,13 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   unsigned long long *c = S->c;
   SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
-  const bool fast = S->fast_path != 0;
+  const bool convex = S->convex_fast != 0 && S->fast_path == 0;
+  const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
   if (hi > lo) {
-    if (fast) {
+    if (convex) {
+      const int L = S->convex_lanes;
+      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo, L, F, P, W);
+    } else if (fast) {
       const int L = S->fast_lanes;
       const size_t lds = (size_t)L * FAST_WS_STRIDE;
       hipLaunchKernelGGL(k_narrow_a, grid_for(hi - lo, L), dim3(64), lds, st, lo, hi - lo, L, F, P, W);
@@ -595,7 +617,8 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
     S->zero = 0;
     SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_narrow, grid_for(nl, S->narrow_lanes), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, S->narrow_lanes, 0, F, P, W);
+    const int RL = fast ? S->retry_lanes : S->narrow_lanes;
+    hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
     SZ_HIP(ctx, hipStreamSynchronize(st));

@@ -348,7 +348,7 @@ SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
 SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
-                  void *fast_ws = nullptr, int fast_ws_bytes = 0) {
+                  void *fast_ws = nullptr, int fast_ws_bytes = 0, szx::FastBlock *fast_blk = nullptr) {
   i64 p = list ? (i64)list[t] : t;
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
@@ -378,7 +378,7 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   }
   // scratch slice: closed form in the first pass, bump-allocated behind it for retries
   i64 off, bytes = scratch_bytes_for((i64)n1 + n2, mult);
-  if (!list) off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
+  if (!list || mult == 1) off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;  // (a deferred pair redone at 1x keeps its slice)
   else off = (i64)atomic_add(&W.counters[C_SCR_BUMP], (unsigned long long)bytes);
   W.pair_scr[p] = off; W.pair_mult[p] = mult;
   W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
@@ -392,9 +392,9 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   if (fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes) S.ws = fast_ws;
   szc::PairOut out;
   int st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
-                             P.mu, P.nu, S, out);
+                             P.mu, P.nu, S, out, fast_blk);
   W.pair_status[p] = st;
-  if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
+  if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY || st == szc::ST_DEFER) {
     unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
     W.retry_list[k] = (int)p;
     return;

@@ -112,6 +112,100 @@ def convex_pairs(n, seed=0):
     return ps
 
 
+def _hull(pts):
+    """Convex hull (Andrew monotone chain) of integer points, strictly convex, counter-clockwise."""
+    pts = sorted(set(map(tuple, pts)))
+    if len(pts) < 3:
+        return None
+    def half(seq):
+        h = []
+        for p in seq:
+            while len(h) >= 2 and (h[-1][0] - h[-2][0]) * (p[1] - h[-2][1]) - (h[-1][1] - h[-2][1]) * (p[0] - h[-2][0]) <= 0:
+                h.pop()
+            h.append(p)
+        return h
+    lo, up = half(pts), half(pts[::-1])
+    h = lo[:-1] + up[:-1]
+    return np.array(h, np.int64) if len(h) >= 3 else None
+
+
+def hull_pairs(n, seed=0, grid=24, unit=1 << 32):
+    """Convex hulls of a few random lattice points: convex rings with many exact ties (vertices on one
+    scanline, vertices on edges, parallel and shared edges) -- the bail-out conditions of convex.hpp."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+    while len(ps) < n:
+        hs = []
+        for _k in range(2):
+            h = _hull(rng.integers(0, grid + 1, (rng.integers(3, 9), 2)))
+            if h is not None and rng.random() < 0.5:
+                h = h[::-1]
+            hs.append(h)
+        if hs[0] is None or hs[1] is None:
+            continue
+        k0, k1 = rng.integers(len(hs[0])), rng.integers(len(hs[1]))
+        a, b = np.roll(hs[0], k0, 0) * unit, np.roll(hs[1], k1, 0) * unit
+        if rng.random() < 0.5:
+            a = np.vstack([a, a[:1]]); b = np.vstack([b, b[:1]])
+        ps.add(a, b, fixed=True)
+    return ps
+
+
+def neighbour_pairs(n, seed=0):
+    """Convex floes that share an edge exactly (Voronoi neighbours at concentration 1), the second one
+    then nudged by a rigid motion between 1e-12 and 1e-1 of its size: from coincident to plainly crossing."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+    while len(ps) < n:
+        c = rng.uniform(-9e4, 9e4, 2)
+        m = rng.integers(8, 14)
+        pts = rng.uniform(-1500, 1500, (m, 2))
+        h = _hull(np.round(pts * 1e3).astype(np.int64))
+        if h is None or len(h) < 4 or len(h) > 9:
+            continue
+        a = h / 1e3
+        i = rng.integers(len(a))
+        p0, p1 = a[i], a[(i + 1) % len(a)]
+        e = (p1 - p0) / np.linalg.norm(p1 - p0)
+        nrm = np.array([e[1], -e[0]])                  # outward for a counter-clockwise ring
+        # mirror image of a across the shared edge, so the two rings share p0-p1
+        rel = a - p0
+        b = p0 + rel - 2 * np.outer(rel @ nrm, nrm)
+        eps = 10.0 ** rng.uniform(-12, -1) * 1500
+        th = rng.normal() * eps / 1500
+        b = _rot(b - b.mean(0), th) + b.mean(0) + rng.normal(size=2) * eps
+        if rng.random() < 0.5:
+            b = b[::-1]
+        ps.add(np.vstack([a + c, a[:1] + c]), np.vstack([b + c, b[:1] + c]))
+    return ps
+
+
+def monotone_pairs(n, seed=0):
+    """Rings with one local minimum and one maximum in y but concave sides (two zig-zag chains):
+    the sweep holds four active edges, yet the overlap may have several rings -- the fast path must bail."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+
+    def mono():
+        nl, nr = rng.integers(1, 4), rng.integers(1, 4)
+        ys = np.sort(rng.uniform(-1000, 1000, nl + nr + 2))
+        inner = rng.permutation(np.arange(1, nl + nr + 1))
+        yl, yr = np.sort(ys[inner[:nl]]), np.sort(ys[inner[nl:]])
+        xl, xr = rng.uniform(-1200, -100, nl), rng.uniform(100, 1200, nr)
+        bot, top = [rng.uniform(-300, 300), ys[0]], [rng.uniform(-300, 300), ys[-1]]
+        ring = [bot] + [[x, y] for x, y in zip(xr, yr)] + [top] + [[x, y] for x, y in zip(xl[::-1], yl[::-1])]
+        r = np.array(ring)
+        return r[::-1] if rng.random() < 0.5 else r
+
+    for _ in range(n):
+        a, b = mono(), mono()
+        c = rng.uniform(-9e4, 9e4, 2)
+        d = rng.uniform(0, 1800); ang = rng.uniform(0, 2 * np.pi)
+        b = _rot(b, rng.uniform(-0.6, 0.6)) + d * np.array([np.cos(ang), np.sin(ang)])
+        ps.add(np.vstack([a, a[:1]]) + c, np.vstack([b, b[:1]]) + c)
+    return ps
+
+
 def lattice_pairs(n, seed=0, grid=6, max_verts=9):
     """Small polygons on a coarse integer lattice: shared edges, horizontal edges, touching vertices,
     collinear runs, self-intersections -- the degenerate paths of the sweep (joins, horizontals)."""
@@ -171,14 +265,16 @@ def ref_lib():
 def host_lib():
     path = os.path.join(ROOT, "tests", "hostsim", "libvatti_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "vatti_host.cpp")
-    hdr = os.path.join(ROOT, "subzero_amd", "csrc", "vatti.hpp")
-    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("vatti.hpp", "convex.hpp")]
+    if (not os.path.exists(path)) or os.path.getmtime(path) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
                                src, "-o", path])
     L = ctypes.CDLL(path)
     L.host_clip_batch.argtypes = [ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_int,
                                   _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
+    L.host_clip_fast_count.restype = ctypes.c_longlong
+    L.host_clip_compact_count.restype = ctypes.c_longlong
     return L
 
 

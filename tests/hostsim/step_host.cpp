@@ -2,6 +2,9 @@
 // same source the GPU kernels execute -- so the CPU test-suite can compare the device pipeline with the
 // oracle without a GPU, and exercise the sharded (multi-GPU) form of the step under a real process group
 // (gloo).  Not part of the product; nothing in subzero_amd/ loads this.
+static long long g_fast_hits = 0, g_fast_bails = 0, g_bail_sites[64];
+#define SZX_BAIL_PROBE(site) (++g_bail_sites[(site) & 63])
+#define SZC_FAST_PROBE(st) ((st) == 100 ? ++g_fast_bails : ++g_fast_hits)
 #include "../../subzero_amd/csrc/step_core.hpp"
 #include <stdint.h>
 #include <stdlib.h>
@@ -9,6 +12,11 @@
 #include <vector>
 
 using namespace szs;
+
+static int g_narrow_mode = 2;
+extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
+extern "C" void host_bail_sites(long long *out) { for (int i = 0; i < 64; ++i) out[i] = g_bail_sites[i]; }
+extern "C" void host_fast_counts(long long *hits, long long *bails) { *hits = g_fast_hits; *bails = g_fast_bails; }
 
 namespace {
 
@@ -166,8 +174,10 @@ struct Sim {
     return 0;
   }
 
-  bool two_stage = true; // compact-record fast path first (as the GPU does), general path for the rest
+  // 0: general sweep only; 1: two-stage compact-record path first (the GPU's SUBZERO_FAST_PATH=1);
+  // 2: single-minimum fast path inside the general kernel (the GPU default)
   int narrow_range(i64 lo, i64 hi) {
+    const bool two_stage = (g_narrow_mode == 1);
     std::vector<char> fast(szv::workspace_bytes_compact() + 64);
     void *fw = (void *)(((uintptr_t)fast.data() + 15) & ~(uintptr_t)15);
     W.counters[C_TOUCH] = 0;
@@ -176,10 +186,11 @@ struct Sim {
       const i64 nt = (i64)W.counters[C_TOUCH];
       for (i64 t = 0; t < nt; ++t) narrow_b(t, F, P, W, fw);
     } else {
-      for (i64 p = lo; p < hi; ++p) narrow(p, nullptr, 1, F, P, W);
+      szx::FastBlock blk;
+      for (i64 p = lo; p < hi; ++p) narrow(p, nullptr, 1, F, P, W, nullptr, 0, g_narrow_mode == 2 ? &blk : nullptr);
     }
     retried = (i64)W.counters[C_RETRY];
-    int mult = two_stage ? 0 : 1;   // the fast path's leftovers start at the 1x general tier
+    int mult = (g_narrow_mode != 0) ? 0 : 1;   // the fast path's leftovers start at the 1x general tier
     std::vector<int> list;
     while (W.counters[C_RETRY] > 0) {
       mult = mult ? mult * 8 : 1;

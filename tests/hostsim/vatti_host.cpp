@@ -2,6 +2,7 @@
 // so the CPU test-suite can check the algorithm the GPU kernels run against the reference Clipper
 // (oracle/_ref) without a GPU.  Not part of the product; nothing in subzero_amd/ loads this.
 #include "../../subzero_amd/csrc/vatti.hpp"
+#include "../../subzero_amd/csrc/convex.hpp"
 #include <stdint.h>
 #include <stdlib.h>
 #include <vector>
@@ -23,6 +24,10 @@ static int g_try_compact = 0;
 static long long g_compact_done = 0;
 extern "C" void host_clip_set_compact(int on) { g_try_compact = on; g_compact_done = 0; }
 extern "C" long long host_clip_compact_count(void) { return g_compact_done; }
+static int g_try_fast = 0;
+static long long g_fast_done = 0;
+extern "C" void host_clip_set_fast(int on) { g_try_fast = on; g_fast_done = 0; }
+extern "C" long long host_clip_fast_count(void) { return g_fast_done; }
 
 extern "C" int host_clip_batch(int npairs,
                    const int64_t *ax, const int64_t *ay, const int32_t *aoff,
@@ -39,8 +44,16 @@ extern "C" int host_clip_batch(int npairs,
     RingView a = {ax + aoff[p], ay + aoff[p]}, b = {bx + boff[p], by + boff[p]};
     int64_t nv0 = s.nv, nr0 = s.nr;
     int st = szv::ST_WORKSPACE;
+    // single-minimum fast path first (intersection, even-odd), as k_narrow does; ST_BAIL falls through
+    if (g_try_fast && method == szv::OP_INTERSECTION && fill_s == 0 && fill_c == 0) {
+      szx::FastBlock blk; szv::Pt deq[64];
+      szx::FastWs fw = {&blk, deq, 32};
+      int fs = szx::clip_monotone(fw, a, na, b, nb, s);
+      if (fs == szx::ST_BAIL) { s.nv = nv0; s.nr = nr0; }
+      else { st = fs; ++g_fast_done; }
+    }
     // compact tier first (even-odd only), as the GPU's LDS path does; anything it cannot hold falls through
-    if (g_try_compact && fill_s == 0 && fill_c == 0) {
+    if (st == szv::ST_WORKSPACE && g_try_compact && fill_s == 0 && fill_c == 0) {
       ws.resize(szv::workspace_bytes_compact() + 16);
       void *w = (void *)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
       st = szv::clip_rings_compact(w, a, na, b, nb, method, s);

@@ -17,7 +17,7 @@ def lib():
         return _lib
     path = os.path.join(ROOT, "tests", "hostsim", "libstep_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "step_host.cpp")
-    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "detmath.hpp")]
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "convex.hpp", "detmath.hpp")]
     if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unused-function", src, "-o", path])
@@ -75,3 +75,15 @@ def compare_states(A, B, exact=True, rtol=1e-10):
         if exact or np.nanmax(rel) > rtol:
             bad.append((k, float(np.nanmax(d)), float(np.nanmax(rel))))
     return bad
+
+
+def set_narrow_mode(mode):
+    """0: general sweep only; 1: two-stage compact-record path; 2: single-minimum fast path (GPU default)."""
+    lib().host_set_narrow_mode(int(mode))
+
+
+def fast_counts():
+    """(clips the single-minimum fast path completed, clips it handed to the general sweep) so far."""
+    h, b = ctypes.c_longlong(), ctypes.c_longlong()
+    lib().host_fast_counts(ctypes.byref(h), ctypes.byref(b))
+    return h.value, b.value

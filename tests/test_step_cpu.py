@@ -86,6 +86,23 @@ def test_device_pipeline_matches_oracle_periodic(binned):
     assert r.n_ext > S.n and len(r.inter) > 0          # ghosts and contacts were actually exercised
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_every_narrow_phase_variant_matches_oracle(mode):
+    """General sweep only / two-stage compact path / single-minimum fast path (convex.hpp, the GPU default)."""
+    hoststep.set_narrow_mode(mode)
+    try:
+        h0, b0 = hoststep.fast_counts()
+        S, P = scenes.pack(250, periodic=True, seed=11, vel_seed=12, sigma=0.25)
+        lockstep(S, P, 8)
+        h1, b1 = hoststep.fast_counts()
+        if mode == 2:   # step 0 has every neighbour pair sharing an edge exactly (all bail); later steps do not
+            assert h1 - h0 > 1000 and b1 - b0 > 0, (h1 - h0, b1 - b0)
+        else:
+            assert h1 == h0 and b1 == b0
+    finally:
+        hoststep.set_narrow_mode(2)
+
+
 def test_device_pipeline_matches_oracle_walls():
     S, P = scenes.pack(200, periodic=False, seed=7, vel_seed=8, sigma=0.3)
     A, B, r = lockstep(S, P, 14)
