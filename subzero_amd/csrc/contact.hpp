@@ -92,7 +92,7 @@ SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, con
 // single-minimum fast path (convex.hpp); ST_BAIL = not the plain case, nothing written
 SZ_HD_NOINLINE int clip_fixed_fast(szx::FastBlock *blk, void *deque_mem, const i64 *ax, const i64 *ay, int na,
                                    const i64 *bx, const i64 *by, int nb, RegionSink *sink) {
-  FixedRing a = {ax, ay}, b = {bx, by};
+  szx::RingPtr a = {ax, ay}, b = {bx, by};
   sink->nv = 0; sink->nr = 0;
   if (sink->ox != nullptr) sink->roff[0] = 0;
   szx::FastWs fw = {blk, (Pt *)deque_mem, 24};
@@ -526,20 +526,25 @@ SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, co
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out, szx::FastBlock *fast = nullptr) {
+                       PairScratch &S, PairOut &out) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   ClipWide wide = {S.ws, S.cap_nv};
   int nreg = 0;
-  if (fast != nullptr) {
-    if (boundary) return ST_DEFER;
-    ClipFastOnly clip = {fast, S.ws};
-    int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
-    if (st != szv::ST_OK) return st;
-    return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
-  }
   int st = pair_clip1(ring1, ring2, boundary, S, wide, nreg);
   if (st != szv::ST_OK) return st;
   return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, wide, out);
+}
+// Both parts through the single-minimum fast path only; ST_DEFER = redo this pair with pair_contact.
+SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+                            const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
+                            PairScratch &S, PairOut &out, szx::FastBlock *fast) {
+  out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
+  if (boundary) return ST_DEFER;
+  ClipFastOnly clip = {fast, S.ws};
+  int nreg = 0;
+  int st = pair_clip1(ring1, ring2, false, S, clip, nreg);
+  if (st != szv::ST_OK) return st;
+  return pair_finish(ring1, f1, ring2, f2, false, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
 }
 
 } // namespace szc

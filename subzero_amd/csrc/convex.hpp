@@ -6,7 +6,7 @@
 // and the right bound of each ring -- and produces at most one output ring.  This file walks exactly the same
 // events in the same order and emits exactly the same points (same cross_point arithmetic, same front/back
 // insertion, same orientation fix-up, same first vertex), but its whole state is four edge records, the <= 12
-// vertices of each ring and six crossing slots (768 B, LDS-sized), and the output ring is a write-only deque.
+// vertices of each ring and six crossing slots (776 B, LDS-sized), and the output ring is a write-only deque.
 // There are no linked lists to chase.
 //
 // It NEVER guesses.  Anything outside the plain case makes it return ST_BAIL before anything is written to the
@@ -49,17 +49,22 @@ struct CCross {
   signed char e1, e2; // edge ids (poly * 2 + bound)
   short pad0; int pad1;
 };
+struct Mono {         // one cleaned ring: vertex count, bottom / top vertex, direction of the left bound
+  short n, bot, top, dir_left;
+};
 
-// per-lane state block; 768 bytes
+// per-lane state block; 776 bytes
 struct FastBlock {
-  Pt va[MAX_RING], vb[MAX_RING];
+  Pt v[2][MAX_RING];
   CEdge ed[4];
   CCross X[MAX_CROSS];
+  Mono m[2];
   signed char ord[4];  // edge ids in active-edge-list order
   signed char sel[4];
 };
 static_assert(sizeof(FastBlock) <= 776, "FastBlock grew: adjust the LDS lane stride");
 
+struct RingPtr { const i64 *x, *y; };
 struct FastWs {
   FastBlock *blk; // LDS on the GPU
   Pt *deq;        // output deque, capacity 2 * cap_half, middle at cap_half (HBM: written, read once at the end)
@@ -76,72 +81,68 @@ SZ_HD void cset_slope(CEdge &e) {
 // clipper.cpp:622-689 with Curr.Y = cur_y for both edges (every active edge sits on the current scanline)
 SZ_HD Pt ccross_point(const CEdge &a, const CEdge &b, i64 cur_y) {
   Pt ip;
-  if (a.slope == 0) {
-    ip.x = a.bot.x;
-    double k = (double)b.bot.y - ((double)b.bot.x / b.slope);
-    ip.y = szv::rnd((double)ip.x / b.slope + k);
-  } else if (b.slope == 0) {
-    ip.x = b.bot.x;
-    double k = (double)a.bot.y - ((double)a.bot.x / a.slope);
-    ip.y = szv::rnd((double)ip.x / a.slope + k);
+  const double fa = szv::dabs(a.slope), fb = szv::dabs(b.slope);
+  if (a.slope == 0 || b.slope == 0) {
+    const CEdge &vert = (a.slope == 0) ? a : b, &other = (a.slope == 0) ? b : a;
+    ip.x = vert.bot.x;
+    double k = (double)other.bot.y - ((double)other.bot.x / other.slope);
+    ip.y = szv::rnd((double)ip.x / other.slope + k);
   } else {
     double ka = (double)a.bot.x - (double)a.bot.y * a.slope;
     double kb = (double)b.bot.x - (double)b.bot.y * b.slope;
     double q = (kb - ka) / (a.slope - b.slope);
     ip.y = szv::rnd(q);
-    if (szv::dabs(a.slope) < szv::dabs(b.slope)) ip.x = szv::rnd(a.slope * q + ka);
-    else ip.x = szv::rnd(b.slope * q + kb);
+    ip.x = (fa < fb) ? szv::rnd(a.slope * q + ka) : szv::rnd(b.slope * q + kb);
   }
   if (ip.y < a.top.y || ip.y < b.top.y) {
     ip.y = (a.top.y > b.top.y) ? a.top.y : b.top.y;
-    if (szv::dabs(a.slope) < szv::dabs(b.slope)) ip.x = cx_at(a, ip.y);
-    else ip.x = cx_at(b, ip.y);
+    ip.x = cx_at((fa < fb) ? a : b, ip.y);
   }
   if (ip.y > cur_y) {
     ip.y = cur_y;
-    if (szv::dabs(a.slope) > szv::dabs(b.slope)) ip.x = cx_at(b, ip.y);
-    else ip.x = cx_at(a, ip.y);
+    ip.x = cx_at((fa > fb) ? b : a, ip.y);
   }
   return ip;
 }
 
-struct Mono { // one cleaned ring
-  const Pt *v;
-  int n, bot, top, dir_left;
-};
-
-// Copies the ring (closing duplicates stripped as clipper.cpp:1055-1058) and checks that the general code
-// would keep every vertex (0, else the reason for the bail-out); finds the single bottom / top vertex and which way the left bound runs.
-template <class Ring>
-SZ_HD int load_mono(const Ring &ring, int n_in, Pt *dst, Mono &m) {
-  int hi = n_in - 1;
-  while (hi > 0 && same(ring(hi), ring(0))) --hi;
-  while (hi > 0 && same(ring(hi), ring(hi - 1))) --hi;
-  if (hi < 2) return 1;
-  if (hi + 1 > MAX_RING) return 2;
-  const int n = hi + 1;
-  for (int i = 0; i < n; ++i) {
-    Pt p = ring(i);
-    const i64 lim = 0x3FFFFFFFFFFFFFFFLL;
-    if (p.x > lim || p.y > lim || -p.x > lim || -p.y > lim) return 3;
-    dst[i] = p;
+// Copies both rings into the block (closing duplicates stripped as clipper.cpp:1055-1058) and checks that the
+// general code would keep every vertex; finds each ring's single bottom / top vertex and which way its left
+// bound runs.  0, or the reason for the bail-out.
+SZ_HD int load_rings(FastBlock &K, const RingPtr &ra, int na, const RingPtr &rb, int nb) {
+  for (int poly = 0; poly < 2; ++poly) {
+    const i64 *xs = poly ? rb.x : ra.x, *ys = poly ? rb.y : ra.y;
+    int hi = (poly ? nb : na) - 1;
+    while (hi > 0 && xs[hi] == xs[0] && ys[hi] == ys[0]) --hi;
+    while (hi > 0 && xs[hi] == xs[hi - 1] && ys[hi] == ys[hi - 1]) --hi;
+    if (hi < 2) return 1;
+    if (hi + 1 > MAX_RING) return 2;
+    const int n = hi + 1;
+    Pt *dst = K.v[poly];
+    for (int i = 0; i < n; ++i) {
+      Pt p; p.x = xs[i]; p.y = ys[i];
+      const i64 lim = 0x3FFFFFFFFFFFFFFFLL;
+      if (p.x > lim || p.y > lim || -p.x > lim || -p.y > lim) return 3;
+      dst[i] = p;
+    }
+    int nmin = 0, nmax = 0, bot = 0, top = 0;
+    Pt p = dst[n - 1], c = dst[0];
+    for (int i = 0; i < n; ++i) {
+      const Pt q = dst[i + 1 == n ? 0 : i + 1];
+      if (same(c, q) || szv::collinear3(p, c, q)) return 4;   // the general code would drop this vertex
+      if (c.y == q.y) return 5;                               // horizontal edge
+      if (c.y > p.y && c.y > q.y) { ++nmin; bot = i; }
+      if (c.y < p.y && c.y < q.y) { ++nmax; top = i; }
+      p = c; c = q;
+    }
+    if (nmin != 1 || nmax != 1) return 6;
+    // the left bound starts with the edge of larger slope (clipper.cpp:1194-1204)
+    const Pt b = dst[bot], fn = dst[bot + 1 == n ? 0 : bot + 1], fp = dst[bot == 0 ? n - 1 : bot - 1];
+    double s_next = (double)(fn.x - b.x) / (double)(fn.y - b.y);
+    double s_prev = (double)(fp.x - b.x) / (double)(fp.y - b.y);
+    if (s_next == s_prev) return 7;
+    Mono m; m.n = (short)n; m.bot = (short)bot; m.top = (short)top; m.dir_left = (short)((s_next < s_prev) ? -1 : +1);
+    K.m[poly] = m;
   }
-  int nmin = 0, nmax = 0, bot = 0, top = 0;
-  for (int i = 0; i < n; ++i) {
-    const Pt &p = dst[i == 0 ? n - 1 : i - 1], &c = dst[i], &q = dst[i + 1 == n ? 0 : i + 1];
-    if (same(c, q) || szv::collinear3(p, c, q)) return 4;   // the general code would drop this vertex
-    if (c.y == q.y) return 5;                               // horizontal edge
-    if (c.y > p.y && c.y > q.y) { ++nmin; bot = i; }
-    if (c.y < p.y && c.y < q.y) { ++nmax; top = i; }
-  }
-  if (nmin != 1 || nmax != 1) return 6;
-  m.v = dst; m.n = n; m.bot = bot; m.top = top;
-  // the left bound starts with the edge of larger slope (clipper.cpp:1194-1204)
-  const Pt &b = dst[bot], &fn = dst[bot + 1 == n ? 0 : bot + 1], &fp = dst[bot == 0 ? n - 1 : bot - 1];
-  double s_next = (double)(fn.x - b.x) / (double)(fn.y - b.y);
-  double s_prev = (double)(fp.x - b.x) / (double)(fp.y - b.y);
-  if (s_next == s_prev) return 7;
-  m.dir_left = (s_next < s_prev) ? -1 : +1;
   return 0;
 }
 
@@ -151,83 +152,34 @@ struct Deque {
   bool open, used, overflow;
 };
 
-SZ_HD void dq_emit(Deque &q, CEdge &e, const Pt &pt) {
+SZ_HD void dq_start(Deque &q, const Pt &pt) {
+  q.used = true; q.open = true;
+  q.lo = q.cap_half; q.hi = q.cap_half + 1;
+  q.d[q.cap_half] = pt; q.front = q.back = pt;
+}
+SZ_HD void dq_emit(Deque &q, int side, const Pt &pt) {
   // Clipper::AddOutPt for the single output ring: front insertion for the left side, back for the right
   if (!q.open) return;
-  const bool to_front = (e.side == szv::SIDE_LEFT);
-  if (to_front && same(pt, q.front)) return;
-  if (!to_front && same(pt, q.back)) return;
-  if (to_front) {
-    if (q.lo == 0) { q.overflow = true; return; }
-    q.d[--q.lo] = pt; q.front = pt;
-  } else {
-    if (q.hi == 2 * q.cap_half) { q.overflow = true; return; }
-    q.d[q.hi++] = pt; q.back = pt;
-  }
+  const bool to_front = (side == szv::SIDE_LEFT);
+  if (same(pt, to_front ? q.front : q.back)) return;
+  if (to_front ? (q.lo == 0) : (q.hi == 2 * q.cap_half)) { q.overflow = true; return; }
+  const int at = to_front ? --q.lo : q.hi++;
+  q.d[at] = pt;
+  if (to_front) q.front = pt; else q.back = pt;
 }
 
-template <class RingA, class RingB, class Sink>
-SZ_HD int clip_monotone(const FastWs &w, const RingA &ra, int na, const RingB &rb, int nb, Sink &sink) {
+template <class Sink>
+SZ_HD int clip_monotone(const FastWs &w, const RingPtr &ra, int na, const RingPtr &rb, int nb, Sink &sink) {
   FastBlock &K = *w.blk;
-  Mono P[2];
-  if (int why = load_mono(ra, na, K.va, P[0])) SZX_BAIL(30 + why);
-  if (int why = load_mono(rb, nb, K.vb, P[1])) SZX_BAIL(40 + why);
+  if (int why = load_rings(K, ra, na, rb, nb)) SZX_BAIL(30 + why);
   CEdge *ed = K.ed;
   signed char *ord = K.ord;
   int k = 0;                   // active edges
-  bool pending[2] = {true, true};
+  int pending = 3;             // bit p: ring p not yet inserted
   Deque q;
   q.d = w.deq; q.cap_half = w.cap_half; q.lo = q.hi = w.cap_half; q.open = false; q.used = false; q.overflow = false;
   q.front.x = q.front.y = q.back.x = q.back.y = 0;
-
-  auto start_edge = [&](int id, int poly, int bound) {
-    const Mono &m = P[poly];
-    CEdge &e = ed[id];
-    e.poly = (signed char)poly;
-    e.dir = (signed char)(bound == 0 ? m.dir_left : -m.dir_left);
-    int vt = m.bot + e.dir;
-    if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-    e.bot = m.v[m.bot]; e.top = m.v[vt]; e.vtop = (short)vt;
-    e.last = (vt == m.top);
-    cset_slope(e);
-    e.curx = e.bot.x;
-    e.ring = -1; e.side = szv::SIDE_NONE; e.wind2 = 0;
-  };
-
-  i64 y = (P[0].v[P[0].bot].y > P[1].v[P[1].bot].y) ? P[0].v[P[0].bot].y : P[1].v[P[1].bot].y;
-  if (P[0].v[P[0].bot].y == P[1].v[P[1].bot].y) SZX_BAIL(2);
-
-  // ---- insertion of a ring's local minimum at scanline y (clipper.cpp:1978-2077) ----
-  auto insert_min = [&](int poly) -> bool {
-    const int idl = poly * 2, idr = poly * 2 + 1;
-    start_edge(idl, poly, 0);
-    start_edge(idr, poly, 1);
-    const i64 x = ed[idl].curx;
-    int pos = 0;
-    while (pos < k) {
-      const CEdge &o = ed[ord[pos]];
-      if (o.curx == x) return false;          // a tie: vertex on an edge or coincident vertices
-      if (x < o.curx) break;
-      ++pos;
-    }
-    for (int i = k - 1; i >= pos; --i) ord[i + 2] = ord[i];
-    ord[pos] = (signed char)idl; ord[pos + 1] = (signed char)idr;
-    k += 2;
-    // even-odd winding against the other ring: edges of the other ring to the left (clipper.cpp:1624-1729)
-    int w2 = pos & 1;                          // every edge to the left belongs to the other ring
-    ed[idl].wind2 = ed[idr].wind2 = (signed char)w2;
-    if (w2) {                                  // contributing -> AddLocalMinPoly (clipper.cpp:1841-1882)
-      if (q.used) return false;                // a second output ring: not the plain case
-      q.used = true; q.open = true;
-      q.lo = q.hi = q.cap_half;
-      q.d[q.hi++] = ed[idl].bot; q.front = q.back = ed[idl].bot;
-      ed[idl].ring = ed[idr].ring = 0;
-      ed[idl].side = szv::SIDE_LEFT; ed[idr].side = szv::SIDE_RIGHT;
-    }
-    pending[poly] = false;
-    return true;
-  };
-  if (!insert_min(P[0].v[P[0].bot].y == y ? 0 : 1)) SZX_BAIL(3);
+  i64 y = 0;                   // current scanline (unused until the first ring is inserted)
 
   for (int guard = 0; guard < 64; ++guard) {
     // next scanline: the highest y still below the current one
@@ -239,10 +191,11 @@ SZ_HD int clip_monotone(const FastWs &w, const RingA &ra, int na, const RingB &r
       if (!have || e.top.y > top_y) { have = true; top_y = e.top.y; sources = 1; src_poly = e.poly; }
       else if (e.top.y == top_y) { if (e.poly != src_poly) SZX_BAIL(4); ++sources; }
     }
+    int insert = -1;            // ring whose local minimum lies on the next scanline
     for (int p = 0; p < 2; ++p) {
-      if (!pending[p]) continue;
-      i64 by = P[p].v[P[p].bot].y;
-      if (!have || by > top_y) { have = true; top_y = by; sources = 1; src_poly = p + 2; }
+      if (!(pending >> p & 1)) continue;
+      i64 by = K.v[p][K.m[p].bot].y;
+      if (!have || by > top_y) { have = true; top_y = by; sources = 1; insert = p; }
       else if (by == top_y) SZX_BAIL(5);
     }
     if (!have) break;
@@ -271,15 +224,12 @@ SZ_HD int clip_monotone(const FastWs &w, const RingA &ra, int na, const RingB &r
             if (e.slope == en.slope) SZX_BAIL(8);
             if (nX >= MAX_CROSS) SZX_BAIL(9);
             Pt pt = ccross_point(e, en, y);
-            if (pt.y < top_y) { pt.x = cx_at(e, top_y); pt.y = top_y; }
+            if (pt.y < top_y) { pt.x = e.curx; pt.y = top_y; }
             K.X[nX].e1 = sl[i]; K.X[nX].e2 = sl[i + 1]; K.X[nX].pt = pt; ++nX;
             signed char t = sl[i]; sl[i] = sl[i + 1]; sl[i + 1] = t;
             modified = true;
-            ++i;                                               // the same edge keeps moving right
-          } else {
-            if (e.curx == en.curx && e.poly != en.poly) SZX_BAIL(10); // tie between the two rings
-            ++i;
-          }
+          } else if (e.curx == en.curx && e.poly != en.poly) SZX_BAIL(10); // tie between the two rings
+          ++i;                                               // (after a swap the same edge keeps moving right)
         }
         if (ns > 1) --ns; else break;
       } while (modified);
@@ -308,24 +258,18 @@ SZ_HD int clip_monotone(const FastWs &w, const RingA &ra, int na, const RingB &r
       e1.wind2 = (signed char)(e1.wind2 == 0 ? 1 : 0);
       e2.wind2 = (signed char)(e2.wind2 == 0 ? 1 : 0);
       const bool c1 = e1.ring >= 0, c2 = e2.ring >= 0;
-      if (c1 && c2) {                       // AddLocalMaxPoly: the ring closes here
-        dq_emit(q, e1, pt);
-        e1.ring = e2.ring = -1;
-        q.open = false;
-      } else if (c1) {
-        dq_emit(q, e1, pt);
-        signed char s = e1.side; e1.side = e2.side; e2.side = s;
-        e2.ring = e1.ring; e1.ring = -1;
-      } else if (c2) {
-        dq_emit(q, e2, pt);
-        signed char s = e1.side; e1.side = e2.side; e2.side = s;
-        e1.ring = e2.ring; e2.ring = -1;
+      if (c1 || c2) {
+        // both: AddLocalMaxPoly, the ring closes here; one: that edge emits and hands ring and side over
+        dq_emit(q, c1 ? e1.side : e2.side, pt);
+        if (c1 && c2) { e1.ring = e2.ring = -1; q.open = false; }
+        else {
+          signed char s = e1.side; e1.side = e2.side; e2.side = s;
+          signed char r = e1.ring; e1.ring = e2.ring; e2.ring = r;
+        }
       } else {                              // AddLocalMinPoly(e1, e2): a ring starts at a crossing
         if (q.used) SZX_BAIL(12);
         if (!(e1.slope < e2.slope)) SZX_BAIL(13);   // e1 crosses from left to right: its slope is the smaller
-        q.used = true; q.open = true;
-        q.lo = q.hi = q.cap_half;
-        q.d[q.hi++] = pt; q.front = q.back = pt;
+        dq_start(q, pt);
         e1.ring = e2.ring = 0;
         e1.side = szv::SIDE_RIGHT; e2.side = szv::SIDE_LEFT;
       }
@@ -334,71 +278,102 @@ SZ_HD int clip_monotone(const FastWs &w, const RingA &ra, int na, const RingB &r
       signed char t = ord[p1]; ord[p1] = ord[p2]; ord[p2] = t;
     }
 
-    // ---- top of the scanbeam (clipper.cpp:3009-3113) ----
-    {
-      int i = 0;
-      while (i < k) {
-        CEdge &e = ed[ord[i]];
-        if (e.top.y == top_y && e.last) {
-          // DoMaxima: the other top edge of the ring must be the next active edge
-          if (i + 1 >= k) SZX_BAIL(14);
-          CEdge &mp = ed[ord[i + 1]];
-          if (mp.poly != e.poly || !(mp.top.y == top_y && mp.last)) SZX_BAIL(15);
-          if (e.ring < 0 && mp.ring < 0) { /* nothing to emit */ }
-          else if (e.ring >= 0 && mp.ring >= 0) { dq_emit(q, e, e.top); e.ring = mp.ring = -1; q.open = false; }
-          else SZX_BAIL(16);               // the general code reports an error here
-          for (int j = i + 2; j < k; ++j) ord[j - 2] = ord[j];
-          k -= 2;
-          continue;                          // the edge that slid into slot i is looked at next
-        }
-        e.curx = cx_at(e, top_y);
-        ++i;
+    // ---- top of the scanbeam (clipper.cpp:3009-3113); curx of every edge is already x(top_y) ----
+    for (int i = 0; i < k; ++i) {
+      CEdge &e = ed[ord[i]];
+      if (e.top.y != top_y) continue;
+      if (e.last) {
+        // DoMaxima: the other top edge of the ring must be the next active edge
+        if (i + 1 >= k) SZX_BAIL(14);
+        CEdge &mp = ed[ord[i + 1]];
+        if (mp.poly != e.poly || !(mp.top.y == top_y && mp.last)) SZX_BAIL(15);
+        if (e.ring >= 0 && mp.ring >= 0) { dq_emit(q, e.side, e.top); e.ring = mp.ring = -1; q.open = false; }
+        else if (e.ring >= 0 || mp.ring >= 0) SZX_BAIL(16);   // the general code reports an error here
+        for (int j = i + 2; j < k; ++j) ord[j - 2] = ord[j];
+        k -= 2;
+        --i;                                 // the edge that slid into slot i is looked at next
+        continue;
       }
-      for (i = 0; i < k; ++i) {
-        CEdge &e = ed[ord[i]];
-        if (e.top.y != top_y) continue;      // an intermediate vertex of a bound
-        if (e.ring >= 0) dq_emit(q, e, e.top);
-        const Mono &m = P[e.poly];
-        int vt = e.vtop + e.dir;
-        if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-        e.bot = e.top; e.top = m.v[vt]; e.vtop = (short)vt;
-        e.last = (vt == m.top);
-        cset_slope(e);
-        e.curx = e.bot.x;
-        // a neighbour of the other ring passing through this vertex is the join case of the general code
-        if (i > 0 && ed[ord[i - 1]].curx == e.curx) SZX_BAIL(17);
-        if (i + 1 < k && ed[ord[i + 1]].curx == e.curx) SZX_BAIL(18);
-      }
+      // an intermediate vertex of a bound: emit it and step to the next edge of the bound.  (The general
+      // code does this in a second pass over the list; with one vertex per scanline the order is the same.)
+      if (e.ring >= 0) dq_emit(q, e.side, e.top);
+      const Mono m = K.m[e.poly];
+      int vt = e.vtop + e.dir;
+      if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
+      e.bot = e.top; e.top = K.v[e.poly][vt]; e.vtop = (short)vt;
+      e.last = (vt == m.top);
+      cset_slope(e);
+      e.curx = e.bot.x;
+      // a neighbour of the other ring passing through this vertex is the join case of the general code
+      if (i > 0 && ed[ord[i - 1]].curx == e.curx) SZX_BAIL(17);
+      if (i + 1 < k && ed[ord[i + 1]].curx == e.curx) SZX_BAIL(18);
     }
     y = top_y;
-    for (int p = 0; p < 2; ++p)
-      if (pending[p] && P[p].v[P[p].bot].y == y) { if (!insert_min(p)) SZX_BAIL(19); }
+
+    // ---- insertion of a ring's local minimum on this scanline (clipper.cpp:1978-2077) ----
+    if (insert >= 0) {
+      const Mono m = K.m[insert];
+      const Pt bot = K.v[insert][m.bot];
+      int pos = 0;
+      while (pos < k) {
+        const i64 ox = ed[ord[pos]].curx;
+        if (ox == bot.x) SZX_BAIL(19);        // a tie: vertex on an edge or coincident vertices
+        if (bot.x < ox) break;
+        ++pos;
+      }
+      for (int i = k - 1; i >= pos; --i) ord[i + 2] = ord[i];
+      // even-odd winding against the other ring = parity of its edges to the left (clipper.cpp:1624-1729);
+      // inside the other ring -> contributing -> AddLocalMinPoly (clipper.cpp:1841-1882)
+      const int w2 = pos & 1;
+      if (w2) {
+        if (q.used) SZX_BAIL(3);              // a second output ring: not the plain case
+        dq_start(q, bot);
+      }
+      for (int bound = 0; bound < 2; ++bound) {
+        const int id = insert * 2 + bound;
+        ord[pos + bound] = (signed char)id;
+        CEdge e;
+        e.poly = (signed char)insert;
+        e.dir = (signed char)(bound == 0 ? m.dir_left : -m.dir_left);
+        int vt = m.bot + e.dir;
+        if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
+        e.bot = bot; e.top = K.v[insert][vt]; e.vtop = (short)vt;
+        e.last = (vt == m.top);
+        cset_slope(e);
+        e.curx = bot.x;
+        e.wind2 = (signed char)w2;
+        e.ring = (signed char)(w2 ? 0 : -1);
+        e.side = (signed char)(w2 ? (bound == 0 ? szv::SIDE_LEFT : szv::SIDE_RIGHT) : szv::SIDE_NONE);
+        ed[id] = e;
+      }
+      k += 2;
+      pending &= ~(1 << insert);
+    }
     if (q.overflow) SZX_BAIL(20);
   }
-  if (k != 0 || pending[0] || pending[1] || q.open || q.overflow) SZX_BAIL(21);
+  if (k != 0 || pending != 0 || q.open || q.overflow) SZX_BAIL(21);
   if (!q.used) return szv::ST_OK;            // no overlap: empty result
   const int cnt = q.hi - q.lo;
   if (cnt < 3) SZX_BAIL(22);               // the general code disposes of such rings in FixupOutPolygon
   const Pt *d = q.d + q.lo;
-  // Area(outRec) from the head, following next (clipper.cpp:405-416); an outer ring must come out positive
+  // Area(outRec) from the head, following next (clipper.cpp:405-416); an outer ring must come out positive.
+  // FixupOutPolygon would drop duplicate / collinear points and move the start: leave those to the general code.
   double a = 0;
-  for (int i = 0; i < cnt; ++i) {
-    const Pt &pv = d[i == 0 ? cnt - 1 : i - 1], &cu = d[i];
-    a += (double)(pv.x + cu.x) * (double)(pv.y - cu.y);
+  {
+    Pt pv = d[cnt - 1], cu = d[0];
+    for (int i = 0; i < cnt; ++i) {
+      const Pt nx = d[i + 1 == cnt ? 0 : i + 1];
+      a += (double)(pv.x + cu.x) * (double)(pv.y - cu.y);
+      if (same(cu, nx) || szv::collinear3(pv, cu, nx)) SZX_BAIL(23);
+      pv = cu; cu = nx;
+    }
   }
   const bool reverse = !(a * 0.5 > 0);
-  // FixupOutPolygon would drop duplicate / collinear points and move the start: leave those to the general code
-  for (int i = 0; i < cnt; ++i) {
-    const Pt &pv = d[i == 0 ? cnt - 1 : i - 1], &cu = d[i], &nx = d[i + 1 == cnt ? 0 : i + 1];
-    if (same(cu, nx) || szv::collinear3(pv, cu, nx)) SZX_BAIL(23);
-  }
   // BuildResult: start at pts.prev and walk backwards (clipper.cpp:3199-3217)
   if (!sink.ring_begin()) return szv::ST_OUT_CAPACITY;
-  if (!reverse) {
-    for (int i = cnt - 1; i >= 0; --i) if (!sink.vertex(d[i])) return szv::ST_OUT_CAPACITY;
-  } else {
-    for (int i = 1; i < cnt; ++i) if (!sink.vertex(d[i])) return szv::ST_OUT_CAPACITY;
-    if (!sink.vertex(d[0])) return szv::ST_OUT_CAPACITY;
+  for (int i = 0; i < cnt; ++i) {
+    const int at = reverse ? (i + 1 == cnt ? 0 : i + 1) : cnt - 1 - i;
+    if (!sink.vertex(d[at])) return szv::ST_OUT_CAPACITY;
   }
   if (!sink.ring_end()) return szv::ST_OUT_CAPACITY;
   return szv::ST_OK;

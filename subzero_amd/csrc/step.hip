@@ -35,6 +35,7 @@ struct StepState {
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_items, cell_x, cell_y, cell_r;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg;
+  long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
   int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
   double rmax_max = 0;
@@ -81,58 +82,112 @@ __global__ void k_ghost_emit(int dim, Floes F, Params P, Work W) {
   if (e < n1) ghost_emit(e, dim, n1, F, P, W);
 }
 
-// exclusive scan by one workgroup: thread t owns a contiguous chunk
-template <class TIn, class TOut>
-__device__ void block_scan(const TIn *in, TOut *out, int n, TOut *total) {
-  __shared__ long long part[1024];
-  const int T = blockDim.x, t = threadIdx.x;
-  int chunk = (n + T - 1) / T;
-  int lo = t * chunk, hi = lo + chunk;
-  if (lo > n) lo = n;
-  if (hi > n) hi = n;
-  long long s = 0;
-  for (int k = lo; k < hi; ++k) s += (long long)in[k];
-  part[t] = s;
-  __syncthreads();
-  // Hillis-Steele inclusive scan of the partials
-  for (int d = 1; d < T; d <<= 1) {
-    long long v = (t >= d) ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+// ---- exclusive scans: two launches of <= 256 workgroups (one per CU), no spinning --------------------------
+// k_scan_reduce: workgroup b sums its tile of the input -> agg[b]; k_scan_write: workgroup b adds up the
+// aggregates before it, scans its tile (coalesced 1024-element slabs, wave shuffles + 16 LDS words) and writes;
+// the last workgroup stores the total.  A Job names the arrays: n(), load(ch, k), store(ch, k, v),
+// finish(totals), CH channels scanned side by side.
+__device__ inline long long wave_scan_incl(long long v) {
+  const int lane = threadIdx.x & 63;
+  for (int d = 1; d < 64; d <<= 1) {
+    long long u = __shfl_up(v, d);
+    if (lane >= d) v += u;
   }
-  long long base = (t == 0) ? 0 : part[t - 1];
-  for (int k = lo; k < hi; ++k) { out[k] = (TOut)base; base += (long long)in[k]; }
-  if (t == T - 1 && total) *total = (TOut)part[T - 1];
+  return v;
 }
-__global__ void __launch_bounds__(1024) k_scan_ghost(int dim, Floes F, Work W) {
-  __shared__ int tot;
-  int n1 = (dim == 0) ? F.n : F.n + (int)W.counters[C_GX];
-  block_scan<int, int>(W.flag, W.scan, n1, &tot);
+// inclusive scan over the 1024 threads of the workgroup; *total = sum over the workgroup
+__device__ inline long long block_scan_incl(long long v, long long *lds16, long long *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long inc = wave_scan_incl(v);
+  __syncthreads();                       // lds16 may still be read from the previous slab
+  if (lane == 63) lds16[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    W.counters[dim == 0 ? C_GX : C_GY] = (unsigned long long)tot;
-    W.counters[C_NEXT] = (unsigned long long)(n1 + tot);
+  long long before = 0, all = 0;
+  for (int w = 0; w < 16; ++w) { long long x = lds16[w]; if (w < wave) before += x; all += x; }
+  *total = all;
+  return inc + before;
+}
+template <class Job>
+__global__ void __launch_bounds__(1024) k_scan_reduce(Job job, int tile, long long *agg) {
+  __shared__ long long lds16[16];
+  const int n = job.n();
+  const long long lo = (long long)blockIdx.x * tile;
+  for (int ch = 0; ch < Job::CH; ++ch) {
+    long long s = 0;
+    for (long long k = lo + threadIdx.x; k < lo + tile && k < n; k += 1024) s += job.load(ch, (int)k);
+    long long tot;
+    (void)block_scan_incl(s, lds16, &tot);
+    if (threadIdx.x == 0) agg[ch * 256 + blockIdx.x] = tot;
   }
 }
-__global__ void __launch_bounds__(1024) k_scan_pairs(Work W) {
-  __shared__ i64 tot;
-  int N = dev_next(W);
-  block_scan<int, i64>(W.pair_cnt, W.pair_base, N, &tot);
-  __syncthreads();
-  if (threadIdx.x == 0) { W.counters[C_NPAIRS] = (unsigned long long)tot; W.pair_base[N] = tot; }
-  __syncthreads();
-  block_scan<i64, i64>(W.pair_nv, W.nv_base, N, &tot);
-  __syncthreads();
-  if (threadIdx.x == 0) { W.counters[C_NVTOT] = (unsigned long long)tot; W.nv_base[N] = tot; }
+template <class Job>
+__global__ void __launch_bounds__(1024) k_scan_write(Job job, int tile, const long long *agg) {
+  __shared__ long long lds16[16];
+  const int n = job.n();
+  const long long lo = (long long)blockIdx.x * tile;
+  long long totals[Job::CH];
+  for (int ch = 0; ch < Job::CH; ++ch) {
+    long long mine = ((int)threadIdx.x < (int)blockIdx.x) ? agg[ch * 256 + threadIdx.x] : 0, carry;
+    (void)block_scan_incl(mine, lds16, &carry);
+    for (long long s0 = lo; s0 < lo + tile && s0 < n; s0 += 1024) {
+      const long long k = s0 + threadIdx.x;
+      const long long v = (k < n) ? job.load(ch, (int)k) : 0;
+      long long tot;
+      const long long inc = block_scan_incl(v, lds16, &tot);
+      if (k < n) job.store(ch, (int)k, carry + inc - v);
+      carry += tot;
+    }
+    totals[ch] = carry;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) job.finish(totals);
 }
-__global__ void __launch_bounds__(1024) k_scan_rows(Work W) {
-  __shared__ i64 tot;
-  int N = dev_next(W);
-  block_scan<int, i64>(W.row_cnt, W.row_off, N, &tot);
-  __syncthreads();
-  if (threadIdx.x == 0) { W.counters[C_NROWS] = (unsigned long long)tot; W.row_off[N] = tot; }
-}
+struct ScanGhost {
+  enum { CH = 1 };
+  int dim; Floes F; Work W;
+  __device__ int n() const { return (dim == 0) ? F.n : F.n + (int)W.counters[C_GX]; }
+  __device__ long long load(int, int k) const { return W.flag[k]; }
+  __device__ void store(int, int k, long long v) const { W.scan[k] = (int)v; }
+  __device__ void finish(const long long *t) const {
+    W.counters[dim == 0 ? C_GX : C_GY] = (unsigned long long)t[0];
+    W.counters[C_NEXT] = (unsigned long long)(n() + t[0]);
+  }
+};
+struct ScanPairs { // pair counts -> pair_base, pair vertex counts -> nv_base
+  enum { CH = 2 };
+  Work W;
+  __device__ int n() const { return dev_next(W); }
+  __device__ long long load(int ch, int k) const { return ch == 0 ? (long long)W.pair_cnt[k] : (long long)W.pair_nv[k]; }
+  __device__ void store(int ch, int k, long long v) const { if (ch == 0) W.pair_base[k] = v; else W.nv_base[k] = v; }
+  __device__ void finish(const long long *t) const {
+    const int N = n();
+    W.counters[C_NPAIRS] = (unsigned long long)t[0]; W.pair_base[N] = t[0];
+    W.counters[C_NVTOT] = (unsigned long long)t[1]; W.nv_base[N] = t[1];
+  }
+};
+struct ScanRows {
+  enum { CH = 1 };
+  Work W;
+  __device__ int n() const { return dev_next(W); }
+  __device__ long long load(int, int k) const { return W.row_cnt[k]; }
+  __device__ void store(int, int k, long long v) const { W.row_off[k] = v; }
+  __device__ void finish(const long long *t) const { W.counters[C_NROWS] = (unsigned long long)t[0]; W.row_off[n()] = t[0]; }
+};
+struct ScanCells {
+  enum { CH = 1 };
+  Work W;
+  __device__ int n() const { return W.cells_x * W.cells_y; }
+  __device__ long long load(int, int k) const { return W.cell_cnt[k]; }
+  __device__ void store(int, int k, long long v) const { W.cell_off[k] = (int)v; }
+  __device__ void finish(const long long *t) const { W.cell_off[n()] = (int)t[0]; }
+};
+struct ScanSegment {
+  enum { CH = 1 };
+  const int *in; i64 *out; int count; unsigned long long *total;
+  __device__ int n() const { return count; }
+  __device__ long long load(int, int k) const { return in[k]; }
+  __device__ void store(int, int k, long long v) const { out[k] = v; }
+  __device__ void finish(const long long *t) const { if (total) *total = (unsigned long long)t[0]; }
+};
 
 __global__ void k_broad(int lo_is_real, Floes F, Params P, Work W) {
   int N = dev_next(W);
@@ -148,13 +203,6 @@ __global__ void k_cell_clear(Work W) {
 __global__ void k_cell_count(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < dev_next(W)) cell_count(e, F, W);
-}
-__global__ void __launch_bounds__(1024) k_scan_cells(Work W) {
-  __shared__ int tot;
-  const int nc = W.cells_x * W.cells_y;
-  block_scan<int, int>(W.cell_cnt, W.cell_off, nc, &tot);
-  __syncthreads();
-  if (threadIdx.x == 0) W.cell_off[nc] = tot;
 }
 __global__ void k_cell_fill(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +261,7 @@ __global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)threadIdx.x >= lanes) return;
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow(first + t, nullptr, 1, F, P, W, nullptr, 0, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
+  if (t < count) narrow_convex(first + t, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
 }
 
 // Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
@@ -234,12 +282,6 @@ __global__ void __launch_bounds__(64) k_narrow_b(int lanes, Floes F, Params P, W
   const i64 count = (i64)W.counters[C_TOUCH];
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   if (t < count) narrow_b(t, F, P, W, smem + (size_t)threadIdx.x * FAST_WS_STRIDE);
-}
-__global__ void __launch_bounds__(1024) k_scan_segment(const int *in, i64 *out, int n, unsigned long long *total) {
-  __shared__ i64 tot;
-  block_scan<int, i64>(in, out, n, &tot);
-  __syncthreads();
-  if (threadIdx.x == 0 && total) *total = (unsigned long long)tot;
 }
 __global__ void k_export(i64 ns, i64 p_lo, Floes F, Work W, Xfer X) {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,6 +405,17 @@ __global__ void k_stress_sum(Floes F) {
   }
 }
 
+// both launches of a scan over at most `bound` elements (the device-side count may be smaller)
+template <class Job>
+static void launch_scan(hipStream_t st, long long *agg, i64 bound, const Job &job) {
+  i64 per = (bound + 255) / 256;
+  int tile = (int)((per + 1023) / 1024) * 1024;
+  if (tile < 1024) tile = 1024;
+  int blocks = (int)((bound + tile - 1) / tile);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_scan_reduce<Job>, dim3(blocks), dim3(1024), 0, st, job, tile, agg);
+  hipLaunchKernelGGL(k_scan_write<Job>, dim3(blocks), dim3(1024), 0, st, job, tile, (const long long *)agg);
+}
 inline dim3 grid_for(i64 n, int block) { return dim3((unsigned)((n + block - 1) / block > 0 ? (n + block - 1) / block : 1)); }
 
 template <class T>
@@ -409,6 +462,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   StepState *S = new StepState();
   ctx->step = S;
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
+  { int rc0 = dev_alloc(ctx, S, S->scan_agg, 512); if (rc0) return rc0; }
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_NARROW_OCC4")) S->narrow_occ4 = atoi(v);
@@ -514,7 +568,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     for (int dim = 0; dim < 2; ++dim) {
       int bound = (dim == 0) ? n : 2 * n;
       hipLaunchKernelGGL(k_ghost_flag, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
-      hipLaunchKernelGGL(k_scan_ghost, dim3(1), dim3(1024), 0, st, dim, F, W);
+      launch_scan(st, S->scan_agg, cap, ScanGhost{dim, F, W});
       hipLaunchKernelGGL(k_ghost_emit, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
     }
   }
@@ -536,14 +590,14 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     W.cell_items = (int *)S->cell_items.p;
     hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
     hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, W);
+    launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
     hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
   }
   hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, F, P, W);
   hipLaunchKernelGGL(k_broad_filter, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
   if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
   hipLaunchKernelGGL(k_pair_count, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
-  hipLaunchKernelGGL(k_scan_pairs, dim3(1), dim3(1024), 0, st, W);
+  launch_scan(st, S->scan_agg, cap, ScanPairs{W});
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
   unsigned long long *c = S->c;
@@ -652,7 +706,7 @@ static int step_back_a(szContext *ctx, StepState *S) {
   int rc;
   if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
   hipLaunchKernelGGL(k_row_count, grid_for(cap, 256), dim3(256), 0, st, W);
-  hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, W);
+  launch_scan(st, S->scan_agg, cap, ScanRows{W});
   SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
@@ -738,8 +792,8 @@ int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world
   // rows before each pair of my segment (exclusive scan of pair_nrows over the segment)
   const i64 ns = S->seg_hi - S->seg_lo;
   if ((rc = sz_reserve(ctx, S->x_off, (size_t)(info->seg_max + 1) * 8))) return rc;
-  hipLaunchKernelGGL(k_scan_segment, dim3(1), dim3(1024), 0, ctx->stream, (const int *)S->W.pair_nrows + S->seg_lo,
-                     (i64 *)S->x_off.p, (int)ns, &S->W.counters[C_PAIRROWS]);
+  launch_scan(ctx->stream, S->scan_agg, ns, ScanSegment{(const int *)S->W.pair_nrows + S->seg_lo, (i64 *)S->x_off.p, (int)ns,
+                                                       &S->W.counters[C_PAIRROWS]});
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipMemcpyAsync(S->c, S->W.counters, sizeof(S->c), hipMemcpyDeviceToHost, ctx->stream));
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -787,8 +841,7 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
     X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
     X.off = (i64 *)S->x_off.p;
     if (ns == 0) continue;
-    hipLaunchKernelGGL(k_scan_segment, dim3(1), dim3(1024), 0, ctx->stream, (const int *)X.nrows, X.off, (int)ns,
-                       (unsigned long long *)nullptr);
+    launch_scan(ctx->stream, S->scan_agg, ns, ScanSegment{(const int *)X.nrows, X.off, (int)ns, (unsigned long long *)nullptr});
     const i64 rows_base = (i64)(((char *)X.rows - (char *)d_recv) / 8);
     hipLaunchKernelGGL(k_import, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, lo, rows_base, S->W, X);
   }

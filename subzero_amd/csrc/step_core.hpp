@@ -347,8 +347,9 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
-SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
-                  void *fast_ws = nullptr, int fast_ws_bytes = 0, szx::FastBlock *fast_blk = nullptr) {
+template <bool CONVEX_ONLY>
+SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
+                    void *fast_ws, int fast_ws_bytes, szx::FastBlock *fast_blk) {
   i64 p = list ? (i64)list[t] : t;
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
@@ -391,8 +392,13 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
   if (fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes) S.ws = fast_ws;
   szc::PairOut out;
-  int st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
-                             P.mu, P.nu, S, out, fast_blk);
+  int st;
+  if (CONVEX_ONLY)
+    st = szc::pair_contact_fast(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
+                                P.mu, P.nu, S, out, fast_blk);
+  else
+    st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
+                           P.mu, P.nu, S, out);
   W.pair_status[p] = st;
   if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY || st == szc::ST_DEFER) {
     unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
@@ -408,6 +414,15 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
   if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+}
+// the general sweep for every clip of the pair
+SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
+                  void *fast_ws = nullptr, int fast_ws_bytes = 0) {
+  narrow_t<false>(t, list, mult, F, P, W, fast_ws, fast_ws_bytes, nullptr);
+}
+// the single-minimum fast path only (convex.hpp); pairs it does not cover go to the retry list for narrow()
+SZ_HD void narrow_convex(i64 p, const Floes &F, const Params &P, Work &W, szx::FastBlock *blk) {
+  narrow_t<true>(p, nullptr, 1, F, P, W, nullptr, 0, blk);
 }
 // ---- two-stage fast path: compact sweep records in a block of LDS (`fast_ws`), first clip for every pair
 // (narrow_a), the rest only for the pairs that overlap (narrow_b).  Pairs that do not fit the compact tier,

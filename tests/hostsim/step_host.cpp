@@ -187,7 +187,10 @@ struct Sim {
       for (i64 t = 0; t < nt; ++t) narrow_b(t, F, P, W, fw);
     } else {
       szx::FastBlock blk;
-      for (i64 p = lo; p < hi; ++p) narrow(p, nullptr, 1, F, P, W, nullptr, 0, g_narrow_mode == 2 ? &blk : nullptr);
+      for (i64 p = lo; p < hi; ++p) {
+        if (g_narrow_mode == 2) narrow_convex(p, F, P, W, &blk);
+        else narrow(p, nullptr, 1, F, P, W);
+      }
     }
     retried = (i64)W.counters[C_RETRY];
     int mult = (g_narrow_mode != 0) ? 0 : 1;   // the fast path's leftovers start at the 1x general tier

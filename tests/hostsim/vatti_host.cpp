@@ -48,7 +48,8 @@ extern "C" int host_clip_batch(int npairs,
     if (g_try_fast && method == szv::OP_INTERSECTION && fill_s == 0 && fill_c == 0) {
       szx::FastBlock blk; szv::Pt deq[64];
       szx::FastWs fw = {&blk, deq, 32};
-      int fs = szx::clip_monotone(fw, a, na, b, nb, s);
+      szx::RingPtr pa = {(const szv::i64 *)a.x, (const szv::i64 *)a.y}, pb = {(const szv::i64 *)b.x, (const szv::i64 *)b.y};
+      int fs = szx::clip_monotone(fw, pa, na, pb, nb, s);
       if (fs == szx::ST_BAIL) { s.nv = nv0; s.nr = nr0; }
       else { st = fs; ++g_fast_done; }
     }
