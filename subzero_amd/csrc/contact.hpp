@@ -90,12 +90,13 @@ SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, con
 #define SZC_FAST_PROBE(st) ((void)0)   // the host test build counts fast-path hits and bail-outs here
 #endif
 // single-minimum fast path (convex.hpp); ST_BAIL = not the plain case, nothing written
-SZ_HD_NOINLINE int clip_fixed_fast(szx::FastBlock *blk, void *deque_mem, const i64 *ax, const i64 *ay, int na,
+template <class Blk>
+SZ_HD_NOINLINE int clip_fixed_fast(Blk *blk, void *deque_mem, const i64 *ax, const i64 *ay, int na,
                                    const i64 *bx, const i64 *by, int nb, RegionSink *sink) {
   szx::RingPtr a = {ax, ay}, b = {bx, by};
   sink->nv = 0; sink->nr = 0;
   if (sink->ox != nullptr) sink->roff[0] = 0;
-  szx::FastWs fw = {blk, (Pt *)deque_mem, 24};
+  szx::FastWsT<Blk> fw = {blk, (Pt *)deque_mem, 24};
   return szx::clip_monotone(fw, a, na, b, nb, *sink);
 }
 // which sweep a pair uses: Wide records in the pair's HBM slice, or Compact records in a block of LDS
@@ -111,8 +112,9 @@ struct ClipWide {
 // fast path with the long general sweep.  The 768-byte output deque borrows the start of the (idle) Wide
 // workspace of the pair's slice.
 enum { ST_DEFER = 101 };
+template <class Blk>
 struct ClipFastOnly {
-  szx::FastBlock *blk;
+  Blk *blk;
   void *deque_mem;
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
     if (op != szv::OP_INTERSECTION) return ST_DEFER;
@@ -535,12 +537,13 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
   return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, wide, out);
 }
 // Both parts through the single-minimum fast path only; ST_DEFER = redo this pair with pair_contact.
+template <class Blk>
 SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                             const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                            PairScratch &S, PairOut &out, szx::FastBlock *fast) {
+                            PairScratch &S, PairOut &out, Blk *fast) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   if (boundary) return ST_DEFER;
-  ClipFastOnly clip = {fast, S.ws};
+  ClipFastOnly<Blk> clip = {fast, S.ws};
   int nreg = 0;
   int st = pair_clip1(ring1, ring2, false, S, clip, nreg);
   if (st != szv::ST_OK) return st;

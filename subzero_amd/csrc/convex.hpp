@@ -11,7 +11,7 @@
 //
 // It NEVER guesses.  Anything outside the plain case makes it return ST_BAIL before anything is written to the
 // sink, and the caller runs the general sweep instead:
-//   more than 12 vertices, duplicate or collinear input vertices (the general code would drop them),
+//   more vertices than the block holds (12 in the first pass, 32 in the second), duplicate or collinear input vertices (the general code would drop them),
 //   more than one local minimum, a horizontal edge, two vertices on one scanline, parallel crossing edges,
 //   any tie in x between edges of the two rings (a vertex on an edge, coincident vertices, shared edges),
 //   a second output ring, an edge between the two top edges of a ring, collinear or duplicate output points,
@@ -26,7 +26,7 @@ using szv::i64;
 using szv::Pt;
 using szv::same;
 
-enum { ST_BAIL = 100, MAX_RING = 12, MAX_CROSS = 6 };
+enum { ST_BAIL = 100, MAX_CROSS = 6 };
 #ifndef SZX_BAIL_PROBE
 #define SZX_BAIL_PROBE(site) ((void)(site))  // the host test build histograms the bail-out sites
 #endif
@@ -53,20 +53,25 @@ struct Mono {         // one cleaned ring: vertex count, bottom / top vertex, di
   short n, bot, top, dir_left;
 };
 
-// per-lane state block; 776 bytes
-struct FastBlock {
-  Pt v[2][MAX_RING];
+// per-lane state block: 392 + 32 NV bytes (776 for the 12-vertex block of the first pass)
+template <int NV_>
+struct FastBlockT {
+  enum { NV = NV_ };   // most vertices a ring may have
+  Pt v[2][NV_];
   CEdge ed[4];
   CCross X[MAX_CROSS];
   Mono m[2];
   signed char ord[4];  // edge ids in active-edge-list order
   signed char sel[4];
 };
-static_assert(sizeof(FastBlock) <= 776, "FastBlock grew: adjust the LDS lane stride");
+typedef FastBlockT<12> FastBlock;      // first pass over all pairs: 64 lanes x 776 B of LDS per wave
+typedef FastBlockT<32> FastBlockBig;   // second pass over the few pairs with longer rings: 1416 B per lane
+static_assert(sizeof(FastBlock) == 776 && sizeof(FastBlockBig) == 1416, "FastBlock layout changed: adjust the LDS lane strides");
 
 struct RingPtr { const i64 *x, *y; };
-struct FastWs {
-  FastBlock *blk; // LDS on the GPU
+template <class Blk>
+struct FastWsT {
+  Blk *blk;       // LDS on the GPU
   Pt *deq;        // output deque, capacity 2 * cap_half, middle at cap_half (HBM: written, read once at the end)
   int cap_half;
 };
@@ -108,14 +113,15 @@ SZ_HD Pt ccross_point(const CEdge &a, const CEdge &b, i64 cur_y) {
 // Copies both rings into the block (closing duplicates stripped as clipper.cpp:1055-1058) and checks that the
 // general code would keep every vertex; finds each ring's single bottom / top vertex and which way its left
 // bound runs.  0, or the reason for the bail-out.
-SZ_HD int load_rings(FastBlock &K, const RingPtr &ra, int na, const RingPtr &rb, int nb) {
+template <class Blk>
+SZ_HD int load_rings(Blk &K, const RingPtr &ra, int na, const RingPtr &rb, int nb) {
   for (int poly = 0; poly < 2; ++poly) {
     const i64 *xs = poly ? rb.x : ra.x, *ys = poly ? rb.y : ra.y;
     int hi = (poly ? nb : na) - 1;
     while (hi > 0 && xs[hi] == xs[0] && ys[hi] == ys[0]) --hi;
     while (hi > 0 && xs[hi] == xs[hi - 1] && ys[hi] == ys[hi - 1]) --hi;
     if (hi < 2) return 1;
-    if (hi + 1 > MAX_RING) return 2;
+    if (hi + 1 > (int)Blk::NV) return 2;
     const int n = hi + 1;
     Pt *dst = K.v[poly];
     for (int i = 0; i < n; ++i) {
@@ -168,9 +174,9 @@ SZ_HD void dq_emit(Deque &q, int side, const Pt &pt) {
   if (to_front) q.front = pt; else q.back = pt;
 }
 
-template <class Sink>
-SZ_HD int clip_monotone(const FastWs &w, const RingPtr &ra, int na, const RingPtr &rb, int nb, Sink &sink) {
-  FastBlock &K = *w.blk;
+template <class Blk, class Sink>
+SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const RingPtr &rb, int nb, Sink &sink) {
+  Blk &K = *w.blk;
   if (int why = load_rings(K, ra, na, rb, nb)) SZX_BAIL(30 + why);
   CEdge *ed = K.ed;
   signed char *ord = K.ord;

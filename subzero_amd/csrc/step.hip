@@ -255,13 +255,22 @@ __global__ void __launch_bounds__(64, 4) k_narrow_occ4(i64 first, i64 count, con
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
+// k_narrow_convex_big: the same for the pairs that pass deferred, with room for 32-vertex rings, a few lanes per wave.
 #define CONVEX_STRIDE 776
+#define CONVEX_BIG_STRIDE 1416
 static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE >= sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
+static_assert(CONVEX_BIG_STRIDE % 16 == 8 && CONVEX_BIG_STRIDE >= sizeof(szx::FastBlockBig), "lane stride must be 8 x odd and hold a FastBlockBig");
 __global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)threadIdx.x >= lanes) return;
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow_convex(first + t, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
+  if (t < count) narrow_convex(first + t, (const int *)nullptr, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
+}
+__global__ void __launch_bounds__(64) k_narrow_convex_big(i64 count, const int *list, int lanes, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (t < count) narrow_convex(t, list, F, P, W, (szx::FastBlockBig *)(smem + (size_t)threadIdx.x * CONVEX_BIG_STRIDE));
 }
 
 // Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
@@ -473,6 +482,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
+  SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_convex_big, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CONVEX_BIG_STRIDE));
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int n = h->n;
   const int nv = h->vert_off[n];
@@ -662,12 +672,25 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
   SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (convex && c[C_RETRY] > 0) {
+    // second pass: what the 12-vertex blocks deferred, through the same fast path with 32-vertex blocks
+    const i64 nl = (i64)c[C_RETRY];
+    S->retried = nl;
+    SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
+    S->zero = 0;
+    SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
+    const int L = S->retry_lanes;
+    hipLaunchKernelGGL(k_narrow_convex_big, grid_for(nl, L), dim3(64), (size_t)L * CONVEX_BIG_STRIDE, st, nl, (const int *)S->retry_copy.p, L, F, P, W);
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
+    SZ_HIP(ctx, hipStreamSynchronize(st));
+  }
   int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
   while (c[C_RETRY] > 0) {
     mult = mult ? mult * 8 : 1;
     if (mult > 512) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) outgrew the 512x scratch tier", c[C_RETRY]);
     i64 nl = (i64)c[C_RETRY];
-    if (mult == (fast ? 1 : 8)) S->retried = nl;
+    if (mult == (fast ? 1 : 8) && !convex) S->retried = nl;
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
     S->zero = 0;
     SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));

@@ -347,9 +347,9 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
-template <bool CONVEX_ONLY>
+template <bool CONVEX_ONLY, class Blk>
 SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
-                    void *fast_ws, int fast_ws_bytes, szx::FastBlock *fast_blk) {
+                    void *fast_ws, int fast_ws_bytes, Blk *fast_blk) {
   i64 p = list ? (i64)list[t] : t;
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
@@ -418,11 +418,13 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
 // the general sweep for every clip of the pair
 SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
                   void *fast_ws = nullptr, int fast_ws_bytes = 0) {
-  narrow_t<false>(t, list, mult, F, P, W, fast_ws, fast_ws_bytes, nullptr);
+  narrow_t<false, szx::FastBlock>(t, list, mult, F, P, W, fast_ws, fast_ws_bytes, nullptr);
 }
 // the single-minimum fast path only (convex.hpp); pairs it does not cover go to the retry list for narrow()
-SZ_HD void narrow_convex(i64 p, const Floes &F, const Params &P, Work &W, szx::FastBlock *blk) {
-  narrow_t<true>(p, nullptr, 1, F, P, W, nullptr, 0, blk);
+// (list == nullptr: pair p itself; else the p-th entry of the list of pairs the 12-vertex pass deferred)
+template <class Blk>
+SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P, Work &W, Blk *blk) {
+  narrow_t<true, Blk>(p, list, 1, F, P, W, nullptr, 0, blk);
 }
 // ---- two-stage fast path: compact sweep records in a block of LDS (`fast_ws`), first clip for every pair
 // (narrow_a), the rest only for the pairs that overlap (narrow_b).  Pairs that do not fit the compact tier,

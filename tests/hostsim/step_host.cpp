@@ -188,11 +188,17 @@ struct Sim {
     } else {
       szx::FastBlock blk;
       for (i64 p = lo; p < hi; ++p) {
-        if (g_narrow_mode == 2) narrow_convex(p, F, P, W, &blk);
+        if (g_narrow_mode == 2) narrow_convex(p, nullptr, F, P, W, &blk);
         else narrow(p, nullptr, 1, F, P, W);
       }
     }
     retried = (i64)W.counters[C_RETRY];
+    if (g_narrow_mode == 2 && W.counters[C_RETRY] > 0) {     // second pass: the fast path with 32-vertex blocks
+      std::vector<int> l2(W.retry_list, W.retry_list + W.counters[C_RETRY]);
+      W.counters[C_RETRY] = 0;
+      szx::FastBlockBig big;
+      for (size_t t = 0; t < l2.size(); ++t) narrow_convex((i64)t, l2.data(), F, P, W, &big);
+    }
     int mult = (g_narrow_mode != 0) ? 0 : 1;   // the fast path's leftovers start at the 1x general tier
     std::vector<int> list;
     while (W.counters[C_RETRY] > 0) {

@@ -47,7 +47,7 @@ extern "C" int host_clip_batch(int npairs,
     // single-minimum fast path first (intersection, even-odd), as k_narrow does; ST_BAIL falls through
     if (g_try_fast && method == szv::OP_INTERSECTION && fill_s == 0 && fill_c == 0) {
       szx::FastBlock blk; szv::Pt deq[64];
-      szx::FastWs fw = {&blk, deq, 32};
+      szx::FastWsT<szx::FastBlock> fw = {&blk, deq, 32};
       szx::RingPtr pa = {(const szv::i64 *)a.x, (const szv::i64 *)a.y}, pb = {(const szv::i64 *)b.x, (const szv::i64 *)b.y};
       int fs = szx::clip_monotone(fw, pa, na, pb, nb, s);
       if (fs == szx::ST_BAIL) { s.nv = nv0; s.nr = nr0; }

@@ -39,6 +39,31 @@ def concave(n=60, periodic=True, seed=11, n_stress=16):
     return S, P
 
 
+def many_sided(n=64, periodic=True, seed=21, n_stress=16):
+    """Convex floes with 10 to 30 vertices (irregular polygons inscribed in circles) on a jittered lattice,
+    overlapping a little: rings too long for the 12-vertex blocks of the first narrow-phase pass -- they take
+    the 32-vertex second pass (convex.hpp FastBlockBig), the longest ones the general sweep."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(n)))
+    pitch = 2e5 / side
+    polys = []
+    for k in range(n):
+        m = int(rng.integers(10, 31)) if k % 7 else int(rng.integers(33, 40))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, m))
+        ang = ang[np.concatenate([[True], np.diff(ang) > 0.02])]
+        r = 0.53 * pitch * rng.uniform(0.9, 1.0)
+        gx, gy = k % side, k // side
+        ctr = np.array([-1e5 + (gx + 0.5) * pitch, -1e5 + (gy + 0.5) * pitch]) + rng.uniform(-0.03, 0.03, 2) * pitch
+        polys.append(np.stack([r * np.cos(-ang), r * np.sin(-ang)], 1) + ctr)
+    S = synth.build_state(polys, height=0.5, seed=seed, n_stress=n_stress)
+    vr = np.random.default_rng(seed + 1)
+    S.Ui[:] = vr.normal(0, 0.2, S.n); S.Vi[:] = vr.normal(0, 0.2, S.n)
+    S.ksi_ice[:] = vr.normal(0, 2e-6, S.n)
+    P = synth.StepParams(dt=10, periodic=periodic, height=0.5)
+    P.Modulus = synth.reference_modulus(S)
+    return S, P
+
+
 def two_boxes(offset=0.0):
     """test/conservation_test.m:22-33: two 20 km boxes approaching head-on (optionally offset in y)."""
     h = 1e4

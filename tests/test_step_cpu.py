@@ -103,6 +103,14 @@ def test_every_narrow_phase_variant_matches_oracle(mode):
         hoststep.set_narrow_mode(2)
 
 
+def test_long_convex_rings_take_the_second_pass():
+    S, P = scenes.many_sided(64)
+    h0, b0 = hoststep.fast_counts()
+    A, B, r = lockstep(S, P, 6)
+    h1, b1 = hoststep.fast_counts()
+    assert len(r.inter) > 0 and h1 - h0 > 100 and b1 - b0 > 100   # both the fast path and its bail-outs ran
+
+
 def test_device_pipeline_matches_oracle_walls():
     S, P = scenes.pack(200, periodic=False, seed=7, vel_seed=8, sigma=0.3)
     A, B, r = lockstep(S, P, 14)

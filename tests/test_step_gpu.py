@@ -102,6 +102,21 @@ def test_two_stage_lds_path_matches_oracle(ctx, monkeypatch):
     assert exact
 
 
+def test_general_sweep_for_every_pair_matches_oracle(ctx, monkeypatch):
+    # SUBZERO_CONVEX_FAST=0: no fast first pass, the general sweep clips every pair
+    monkeypatch.setenv("SUBZERO_CONVEX_FAST", "0")
+    S, P = scenes.pack(400, periodic=True)
+    A, G, exact = lockstep(ctx, S, P, 12)
+    assert exact
+
+
+def test_long_convex_rings(ctx):
+    # 10..39-vertex convex floes: first pass (12-vertex blocks), second pass (32-vertex blocks), general sweep
+    S, P = scenes.many_sided(64)
+    A, G, exact = lockstep(ctx, S, P, 12)
+    assert exact
+
+
 @pytest.mark.parametrize("periodic", [False, True])
 @pytest.mark.parametrize("nb,collision", [(0, 1), (2, 1), (0, 0)])
 def test_edge_cases(ctx, periodic, nb, collision):
