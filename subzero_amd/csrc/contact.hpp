@@ -38,18 +38,7 @@ SZ_HD bool is_inf(double v) { return v > 1.7976931348623157e308 || v < -1.797693
 #define SZC_INF (__builtin_huge_val())
 #define SZC_EPS 2.220446049250313e-16
 
-// MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
-SZ_HD i64 to_fixed(double v) {
-  double s = v * 4294967296.0;
-  if (s != s) return 0;
-  if (s >= 9223372036854775807.0) return 0x7FFFFFFFFFFFFFFFLL;
-  if (s <= -9223372036854775808.0) return (i64)0x8000000000000000ULL;
-  double t = (double)(i64)s; // trunc
-  double f = s - t;
-  if (f >= 0.5) t += 1.0;
-  else if (f <= -0.5) t -= 1.0;
-  return (i64)t;
-}
+using szx::to_fixed; // MATLAB int64(v * 2^32) (polyclip.m:63-66), convex.hpp
 SZ_HD double from_fixed(i64 v) { return (double)v / 4294967296.0; } // polyclip.m:67
 
 // ---- one shared, non-inlined instance of the sweep for all three clips of a pair ----
@@ -86,18 +75,29 @@ SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, con
   if (sink->ox != nullptr) sink->roff[0] = 0;
   return szv::clip_rings_compact(ws, a, na, b, nb, op, *sink);
 }
+#ifndef SZC_THIRD_PROBE
+#define SZC_THIRD_PROBE(tx, ty, nt, rx, ry, nr) ((void)0)
+#endif
 #ifndef SZC_FAST_PROBE
 #define SZC_FAST_PROBE(st) ((void)0)   // the host test build counts fast-path hits and bail-outs here
 #endif
-// single-minimum fast path (convex.hpp); ST_BAIL = not the plain case, nothing written
+// single-minimum fast path (convex.hpp) on the two rings held in the block in metres; ring 0 optionally shifted
+// (floe_interactions.m:148-149).  ST_BAIL = not the plain case, nothing written.
 template <class Blk>
-SZ_HD_NOINLINE int clip_fixed_fast(Blk *blk, void *deque_mem, const i64 *ax, const i64 *ay, int na,
-                                   const i64 *bx, const i64 *by, int nb, RegionSink *sink) {
-  szx::RingPtr a = {ax, ay}, b = {bx, by};
+SZ_HD_NOINLINE int clip_in_block(Blk *blk, void *deque_mem, int shifted, double sx, double sy, int na, int nb,
+                                 RegionSink *sink) {
   sink->nv = 0; sink->nr = 0;
   if (sink->ox != nullptr) sink->roff[0] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Launch contract of the kernels that call this (k_narrow_convex*): the block of lane t is at byte
+  // t * sizeof(Blk) of the dynamic LDS.  Re-deriving it here (instead of using the generic pointer, which is
+  // the same address) lets the compiler prove the accesses are LDS and emit ds_ instead of flat_ instructions.
+  extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
+  blk = (Blk *)(sz_dynamic_lds + (size_t)threadIdx.x * sizeof(Blk));
+#endif
+  blk->shifted = shifted; blk->shift_x = sx; blk->shift_y = sy;
   szx::FastWsT<Blk> fw = {blk, (Pt *)deque_mem, 24};
-  return szx::clip_monotone(fw, a, na, b, nb, *sink);
+  return szx::clip_monotone(fw, szx::VertsMetres(), na, nb, *sink);
 }
 // which sweep a pair uses: Wide records in the pair's HBM slice, or Compact records in a block of LDS
 struct ClipWide {
@@ -107,23 +107,6 @@ struct ClipWide {
   }
   SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
 };
-// The fast path alone: anything it does not cover (a bail-out, or the difference with the domain box) comes
-// back as ST_DEFER and the whole pair is redone by the general kernel.  A wave therefore never mixes the short
-// fast path with the long general sweep.  The 768-byte output deque borrows the start of the (idle) Wide
-// workspace of the pair's slice.
-enum { ST_DEFER = 101 };
-template <class Blk>
-struct ClipFastOnly {
-  Blk *blk;
-  void *deque_mem;
-  SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
-    if (op != szv::OP_INTERSECTION) return ST_DEFER;
-    int st = clip_fixed_fast(blk, deque_mem, ax, ay, na, bx, by, nb, sink);
-    SZC_FAST_PROBE(st);
-    return st == szx::ST_BAIL ? (int)ST_DEFER : st;
-  }
-  SZ_HD bool fits(int) const { return true; }
-};
 struct ClipCompact {
   void *ws;
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
@@ -131,6 +114,7 @@ struct ClipCompact {
   }
   SZ_HD bool fits(int nv) const { return nv <= szv::COMPACT_MAX_NV; }
 };
+enum { ST_DEFER = 101 };  // "redo this pair with the general sweep" (the fast path does not cover it)
 
 // ---- rings in metres: c_alpha + (Xi, Yi), optionally closed by one more vertex (:62-67) ----
 struct RingD {
@@ -141,6 +125,15 @@ struct RingD {
   SZ_HD int len() const { return n + extra; }
   SZ_HD double X(int k) const { return x[k >= n ? 0 : k] + ox; }
   SZ_HD double Y(int k) const { return y[k >= n ? 0 : k] + oy; }
+};
+
+// the same ring already summed (c_alpha + position) and held in a lane's block of LDS (the fast path)
+struct RingL {
+  const double *x, *y;
+  int n, extra;
+  SZ_HD int len() const { return n + extra; }
+  SZ_HD double X(int k) const { return x[k >= n ? 0 : k]; }
+  SZ_HD double Y(int k) const { return y[k >= n ? 0 : k]; }
 };
 
 struct Body { // floe_interactions.m reads these of floe1 / floe2
@@ -258,7 +251,8 @@ SZ_HD bool clearly_inside(double x, double y, const i64 *rx, const i64 *ry, int 
 }
 
 // |p_poly_dist| of one point against the closed ring c (p_poly_dist.m:143-281)
-SZ_HD double dist_to_ring(double xp, double yp, const RingD &c) {
+template <class Ring>
+SZ_HD double dist_to_ring(double xp, double yp, const Ring &c) {
   int nv = c.len();
   double dpv_min = SZC_INF; int I_dpv = 0;
   for (int k = 0; k < nv; ++k) {
@@ -286,7 +280,8 @@ SZ_HD double dist_to_ring(double xp, double yp, const RingD &c) {
 }
 
 // InterX.m:54-81.  Returns the number of unique crossings (sorted by x, then y), or -1 on overflow.
-SZ_HD int crossings(const RingD &c1, const RingD &c2, double *px, double *py, int cap) {
+template <class Ring>
+SZ_HD int crossings(const Ring &c1, const Ring &c2, double *px, double *py, int cap) {
   int m1 = c1.len() - 1, m2 = c2.len() - 1;
   int np = 0;
   for (int j = 0; j < m2; ++j) {
@@ -320,24 +315,78 @@ SZ_HD int crossings(const RingD &c1, const RingD &c2, double *px, double *py, in
   return np;
 }
 
+// How the three clips of the contact model are run.
+// ViaArrays: the rings go through int64 arrays of the pair's scratch slice into a sweep (Wide or Compact records).
+template <class Sweep>
+struct ViaArrays {
+  Sweep sweep;
+  template <class Ring>
+  SZ_HD int first(const Ring &ring1, const Ring &ring2, bool boundary, PairScratch &S, RegionSink *sink) const {   // :29 / :34
+    const int n1 = ring1.n, n2 = ring2.n;
+    for (int k = 0; k < n1; ++k) { S.f1x[k] = to_fixed(ring1.X(k)); S.f1y[k] = to_fixed(ring1.Y(k)); }
+    for (int k = 0; k < n2; ++k) { S.f2x[k] = to_fixed(ring2.X(k)); S.f2y[k] = to_fixed(ring2.Y(k)); }
+    return sweep(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION, sink);
+  }
+  // :140-155 ring 1 (closed) moved by the unit force direction, against ring 2 (closed)
+  template <class Ring>
+  SZ_HD int second(const Ring &c1, bool shifted, double fdx, double fdy, const Ring &c2, int op, PairScratch &S, RegionSink *sink) const {
+    const int nc1 = c1.len(), nc2 = c2.len(), n2 = c2.n;
+    for (int q = 0; q < nc1; ++q) {
+      if (!shifted) { S.fsx[q] = to_fixed(c1.X(q)); S.fsy[q] = to_fixed(c1.Y(q)); }
+      else { S.fsx[q] = to_fixed(c1.X(q) + fdx); S.fsy[q] = to_fixed(c1.Y(q) + fdy); }
+    }
+    // ring 2 after closure (clip 1 used the unclosed one; the closing vertex is a duplicate either way)
+    if (c2.extra) { S.f2x[n2] = S.f2x[0]; S.f2y[n2] = S.f2y[0]; }
+    return sweep(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, sink);
+  }
+  SZ_HD int third(const i64 *tx, const i64 *ty, int nt, const i64 *rx, const i64 *ry, int nr, RegionSink *sink) const {   // :158
+    if (!sweep.fits(nt + nr)) return szv::ST_WORKSPACE;
+    return sweep(tx, ty, nt, rx, ry, nr, szv::OP_INTERSECTION, sink);
+  }
+};
+// InBlock: the fast path alone, on the rings the caller has put into the lane's block (RingL views of it).
+// Anything it does not cover -- a bail-out, the difference with the domain box, a third clip whose outcome the
+// overlap certificate does not settle -- comes back as ST_DEFER and the whole pair is redone by the general
+// kernel, so a wave never mixes the short fast path with the long general sweep.  The 768-byte output deque
+// borrows the start of the (idle) Wide workspace of the pair's slice.
+template <class Blk>
+struct InBlock {
+  Blk *blk;
+  void *deque_mem;
+  SZ_HD int run(int shifted, double sx, double sy, int na, int nb, RegionSink *sink) const {
+    int st = clip_in_block(blk, deque_mem, shifted, sx, sy, na, nb, sink);
+    SZC_FAST_PROBE(st);
+    return st == szx::ST_BAIL ? (int)ST_DEFER : st;
+  }
+  SZ_HD int first(const RingL &ring1, const RingL &ring2, bool boundary, PairScratch &, RegionSink *sink) const {
+    if (boundary) return ST_DEFER;
+    return run(0, 0.0, 0.0, ring1.n, ring2.n, sink);
+  }
+  // (the closing vertices the reference appends are duplicates, which the sweep strips: the stored rings do)
+  SZ_HD int second(const RingL &c1, bool shifted, double fdx, double fdy, const RingL &c2, int op, PairScratch &, RegionSink *sink) const {
+    if (op != szv::OP_INTERSECTION) return ST_DEFER;
+    return run(shifted ? 1 : 0, fdx, fdy, c1.n, c2.n, sink);
+  }
+  SZ_HD int third(const i64 *tx, const i64 *ty, int nt, const i64 *rx, const i64 *ry, int nr, RegionSink *) const {
+    SZC_THIRD_PROBE(tx, ty, nt, rx, ry, nr);
+    return ST_DEFER;
+  }
+};
+
 // The contact model for one pair, in two parts so that candidates whose rings do not overlap stop after the
 // first clip (and free their lane): pair_clip1 -> regions in S.r1*, pair_finish -> contact rows.
 // Both return a szv::Status (ST_WORKSPACE / ST_OUT_CAPACITY ask for a larger tier; ST_CLIP_ERROR is the
 // reference's "Clipper Error.").
-template <class Clip>
-SZ_HD int pair_clip1(const RingD &ring1, const RingD &ring2, bool boundary, PairScratch &S, const Clip &clip, int &nreg) {
-  const int n1 = ring1.n, n2 = ring2.n;
-  for (int k = 0; k < n1; ++k) { S.f1x[k] = to_fixed(ring1.X(k)); S.f1y[k] = to_fixed(ring1.Y(k)); }
-  for (int k = 0; k < n2; ++k) { S.f2x[k] = to_fixed(ring2.X(k)); S.f2y[k] = to_fixed(ring2.Y(k)); }
-  const int op = boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION;
+template <class Ring, class Clip>
+SZ_HD int pair_clip1(const Ring &ring1, const Ring &ring2, bool boundary, PairScratch &S, const Clip &clip, int &nreg) {
   RegionSink s1 = {S.r1x, S.r1y, S.r1off, S.cap_v, S.cap_r, 0, 0};
-  int st = clip(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, op, &s1);                          // :29 / :34
+  int st = clip.first(ring1, ring2, boundary, S, &s1);                                 // :29 / :34
   nreg = (st == szv::ST_OK) ? s1.nr : 0;
   return st;
 }
 
-template <class Clip>
-SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+template <class Ring, class Clip>
+SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, const Body &f2, bool boundary,
                       const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
                       PairScratch &S, int nreg, const Clip &clip, PairOut &out) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
@@ -394,7 +443,7 @@ SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, co
     }
   }
   // :62-67 close the rings
-  RingD c1 = ring1, c2 = ring2;
+  Ring c1 = ring1, c2 = ring2;
   if (hyp(c1.X(0) - c1.X(n1 - 1), c1.Y(0) - c1.Y(n1 - 1)) > 1) c1.extra = 1;
   if (hyp(c2.X(0) - c2.X(n2 - 1), c2.Y(0) - c2.Y(n2 - 1)) > 1) c2.extra = 1;
 
@@ -466,24 +515,22 @@ SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, co
       } else { fdx = fdy = 0; dl = 0; }
     }
     // :140-155 shift ring 1 by the unit direction and clip again
-    if (dl < 0.1) { fdx = 0; fdy = 0; }
-    for (int q = 0; q < nc1; ++q) {
-      if (dl < 0.1) { S.fsx[q] = to_fixed(c1.X(q)); S.fsy[q] = to_fixed(c1.Y(q)); }
-      else { S.fsx[q] = to_fixed(c1.X(q) + fdx); S.fsy[q] = to_fixed(c1.Y(q) + fdy); }
-    }
-    // ring 2 after closure (clip 1 used the unclosed one; the closing vertex is a duplicate either way)
-    const int nc2 = c2.len();
-    if (c2.extra) { S.f2x[n2] = S.f2x[0]; S.f2y[n2] = S.f2y[0]; }
+    const bool shifted = !(dl < 0.1);
+    if (!shifted) { fdx = 0; fdy = 0; }
     RegionSink s2 = {S.r2x, S.r2y, S.r2off, S.cap_v, S.cap_r, 0, 0};
-    st = clip(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, &s2);
+    st = clip.second(c1, shifted, fdx, fdy, c2, op, S, &s2);
     if (st != szv::ST_OK) return st;
     for (int ii = 0; ii < s2.nr; ++ii) {                                               // :156-165
       const i64 *TX = S.r2x + S.r2off[ii], *TY = S.r2y + S.r2off[ii];
       const int nt = S.r2off[ii + 1] - S.r2off[ii];
+      // The third clip only decides whether the direction is reversed, and only when the shifted overlap is
+      // the larger one (:160-163): otherwise its outcome cannot matter and it is not run.
+      const double Anew = region_polyarea(TX, TY, nt);
+      if (!(Anew / Ar - 1 > 0)) continue;
       // A point with a 1e-6 m disc inside both regions certifies that the third clip is not empty (a disc of
       // 4295 fixed-point units cannot vanish in a sweep that rounds by one unit).  Try the centroid of the
-      // original overlap (the shifted one contains it when the shift deepens the overlap) and the centroid of
-      // the shifted overlap (when the shift makes it shallower); only if neither certifies run the clip.
+      // original overlap (the larger, shifted one normally contains it) and the centroid of the shifted
+      // overlap; only if neither certifies run the clip.
       bool overlaps = clearly_inside(cx, cy, RX, RY, nr, 1e-6) && clearly_inside(cx, cy, TX, TY, nt, 1e-6);
       if (!overlaps && nt >= 3) {
         double tx, ty;
@@ -491,16 +538,12 @@ SZ_HD int pair_finish(const RingD &ring1, const Body &f1, const RingD &ring2, co
         overlaps = clearly_inside(tx, ty, RX, RY, nr, 1e-6) && clearly_inside(tx, ty, TX, TY, nt, 1e-6);
       }
       if (!overlaps) {                                                                 // :158-159
-        if (!clip.fits(nt + nr)) return szv::ST_WORKSPACE;
         RegionSink s3 = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
-        st = clip(TX, TY, nt, RX, RY, nr, szv::OP_INTERSECTION, &s3);
+        st = clip.third(TX, TY, nt, RX, RY, nr, &s3);
         if (st != szv::ST_OK) return st;
         overlaps = s3.nr > 0;
       }
-      if (overlaps) {
-        double Anew = region_polyarea(TX, TY, nt);
-        if (Anew / Ar - 1 > 0) { fdx = -fdx; fdy = -fdy; }
-      }
+      if (overlaps) { fdx = -fdx; fdy = -fdy; }
     }
     double Fx = fdx * Ar * Force_factor, Fy = fdy * Ar * Force_factor;                 // :167
     // :170-183
@@ -530,24 +573,37 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
                        PairScratch &S, PairOut &out) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
-  ClipWide wide = {S.ws, S.cap_nv};
+  ViaArrays<ClipWide> clip = {{S.ws, S.cap_nv}};
   int nreg = 0;
-  int st = pair_clip1(ring1, ring2, boundary, S, wide, nreg);
+  int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
   if (st != szv::ST_OK) return st;
-  return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, wide, out);
+  return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
 }
-// Both parts through the single-minimum fast path only; ST_DEFER = redo this pair with pair_contact.
+// Both parts through the single-minimum fast path only, with both rings staged in the lane's block (so the
+// contact model reads them from LDS as well); ST_DEFER = redo this pair with pair_contact.
 template <class Blk>
 SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                             const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                            PairScratch &S, PairOut &out, Blk *fast) {
+                            PairScratch &S, PairOut &out, Blk *blk) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   if (boundary) return ST_DEFER;
-  ClipFastOnly<Blk> clip = {fast, S.ws};
+  // A ring stored closed (last vertex an exact copy of the first) that is one vertex too long for the block is
+  // staged without the copy when the closure rule of the contact model (:62-67, more than 1 m between the ends)
+  // puts it back: every function below then sees the same closed ring, and the sweep strips the copy anyway.
+  int n1 = ring1.n, n2 = ring2.n;
+  if (n1 == (int)Blk::NV + 1 && ring1.X(n1 - 1) == ring1.X(0) && ring1.Y(n1 - 1) == ring1.Y(0) &&
+      hyp(ring1.X(0) - ring1.X(n1 - 2), ring1.Y(0) - ring1.Y(n1 - 2)) > 1) --n1;
+  if (n2 == (int)Blk::NV + 1 && ring2.X(n2 - 1) == ring2.X(0) && ring2.Y(n2 - 1) == ring2.Y(0) &&
+      hyp(ring2.X(0) - ring2.X(n2 - 2), ring2.Y(0) - ring2.Y(n2 - 2)) > 1) --n2;
+  if (n1 > (int)Blk::NV || n2 > (int)Blk::NV || n1 < 1 || n2 < 1) return ST_DEFER;
+  for (int k = 0; k < n1; ++k) { blk->v.m.x[0][k] = ring1.X(k); blk->v.m.y[0][k] = ring1.Y(k); }
+  for (int k = 0; k < n2; ++k) { blk->v.m.x[1][k] = ring2.X(k); blk->v.m.y[1][k] = ring2.Y(k); }
+  RingL l1 = {blk->v.m.x[0], blk->v.m.y[0], n1, 0}, l2 = {blk->v.m.x[1], blk->v.m.y[1], n2, 0};
+  InBlock<Blk> clip = {blk, S.ws};
   int nreg = 0;
-  int st = pair_clip1(ring1, ring2, false, S, clip, nreg);
+  int st = pair_clip1(l1, l2, false, S, clip, nreg);
   if (st != szv::ST_OK) return st;
-  return pair_finish(ring1, f1, ring2, f2, false, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
+  return pair_finish(l1, f1, l2, f2, false, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
 }
 
 } // namespace szc

@@ -6,7 +6,7 @@
 // and the right bound of each ring -- and produces at most one output ring.  This file walks exactly the same
 // events in the same order and emits exactly the same points (same cross_point arithmetic, same front/back
 // insertion, same orientation fix-up, same first vertex), but its whole state is four edge records, the <= 12
-// vertices of each ring and six crossing slots (776 B, LDS-sized), and the output ring is a write-only deque.
+// vertices of each ring and six crossing slots (824 B, LDS-sized), and the output ring is a write-only deque.
 // There are no linked lists to chase.
 //
 // It NEVER guesses.  Anything outside the plain case makes it return ST_BAIL before anything is written to the
@@ -49,26 +49,60 @@ struct CCross {
   signed char e1, e2; // edge ids (poly * 2 + bound)
   short pad0; int pad1;
 };
-struct Mono {         // one cleaned ring: vertex count, bottom / top vertex, direction of the left bound
+struct Mono {         // one cleaned ring: vertex count, bottom / top vertex, direction of the left bound, bottom y
   short n, bot, top, dir_left;
+  i64 bot_y;
 };
 
-// per-lane state block: 392 + 32 NV bytes (776 for the 12-vertex block of the first pass)
+// per-lane state block: 440 + 32 NV bytes (824 for the 12-vertex block of the first pass)
 template <int NV_>
 struct FastBlockT {
   enum { NV = NV_ };   // most vertices a ring may have
-  Pt v[2][NV_];
+  // The vertices of the two rings, either as doubles in metres (VertsMetres: the step's fast path keeps the
+  // rings of the pair here for the whole contact model, and the sweep converts on access) or as fixed-point
+  // coordinates (VertsFixed: callers that start from int64 rings).
+  union {
+    struct { double x[2][NV_], y[2][NV_]; } m;
+    Pt f[2][NV_];
+  } v;
+  double shift_x, shift_y;  // VertsMetres: added to ring 0 before the conversion when `shifted`
+  int shifted, pad;
   CEdge ed[4];
   CCross X[MAX_CROSS];
-  Mono m[2];
+  Mono mono[2];
   signed char ord[4];  // edge ids in active-edge-list order
   signed char sel[4];
+  char tail[8];        // makes the size 8 x odd bytes: the same field of neighbouring lanes falls into different LDS banks
 };
-typedef FastBlockT<12> FastBlock;      // first pass over all pairs: 64 lanes x 776 B of LDS per wave
-typedef FastBlockT<32> FastBlockBig;   // second pass over the few pairs with longer rings: 1416 B per lane
-static_assert(sizeof(FastBlock) == 776 && sizeof(FastBlockBig) == 1416, "FastBlock layout changed: adjust the LDS lane strides");
+typedef FastBlockT<12> FastBlock;      // first pass over all pairs: 64 lanes x 824 B of LDS per wave
+typedef FastBlockT<32> FastBlockBig;   // second pass over the few pairs with longer rings: 1464 B per lane
+static_assert(sizeof(FastBlock) == 824 && sizeof(FastBlockBig) == 1464, "FastBlock layout changed: keep the size 8 x odd");
 
-struct RingPtr { const i64 *x, *y; };
+// MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
+SZ_HD i64 to_fixed(double v) {
+  double s = v * 4294967296.0;
+  if (s != s) return 0;
+  if (s >= 9223372036854775807.0) return 0x7FFFFFFFFFFFFFFFLL;
+  if (s <= -9223372036854775808.0) return (i64)0x8000000000000000ULL;
+  double t = (double)(i64)s; // trunc
+  double f = s - t;
+  if (f >= 0.5) t += 1.0;
+  else if (f <= -0.5) t -= 1.0;
+  return (i64)t;
+}
+// how the sweep reads vertex i of ring `poly` in fixed-point coordinates
+struct VertsMetres {
+  template <class Blk> SZ_HD Pt operator()(const Blk &K, int poly, int i) const {
+    double X = K.v.m.x[poly][i], Y = K.v.m.y[poly][i];
+    if (poly == 0 && K.shifted) { X = X + K.shift_x; Y = Y + K.shift_y; }   // floe_interactions.m:148-149
+    Pt p; p.x = to_fixed(X); p.y = to_fixed(Y);
+    return p;
+  }
+};
+struct VertsFixed {
+  template <class Blk> SZ_HD Pt operator()(const Blk &K, int poly, int i) const { return K.v.f[poly][i]; }
+};
+
 template <class Blk>
 struct FastWsT {
   Blk *blk;       // LDS on the GPU
@@ -110,44 +144,41 @@ SZ_HD Pt ccross_point(const CEdge &a, const CEdge &b, i64 cur_y) {
   return ip;
 }
 
-// Copies both rings into the block (closing duplicates stripped as clipper.cpp:1055-1058) and checks that the
-// general code would keep every vertex; finds each ring's single bottom / top vertex and which way its left
-// bound runs.  0, or the reason for the bail-out.
-template <class Blk>
-SZ_HD int load_rings(Blk &K, const RingPtr &ra, int na, const RingPtr &rb, int nb) {
+// Checks that the general code would keep every vertex of both rings (closing duplicates stripped as
+// clipper.cpp:1055-1058); finds each ring's single bottom / top vertex and which way its left bound runs.
+// 0, or the reason for the bail-out.
+template <class Blk, class Verts>
+SZ_HD int scan_rings(Blk &K, const Verts &vert, int na, int nb) {
   for (int poly = 0; poly < 2; ++poly) {
-    const i64 *xs = poly ? rb.x : ra.x, *ys = poly ? rb.y : ra.y;
     int hi = (poly ? nb : na) - 1;
-    while (hi > 0 && xs[hi] == xs[0] && ys[hi] == ys[0]) --hi;
-    while (hi > 0 && xs[hi] == xs[hi - 1] && ys[hi] == ys[hi - 1]) --hi;
-    if (hi < 2) return 1;
     if (hi + 1 > (int)Blk::NV) return 2;
+    if (hi < 2) return 1;
+    const Pt first = vert(K, poly, 0);
+    Pt last = vert(K, poly, hi);
+    while (hi > 0 && same(last, first)) { --hi; last = vert(K, poly, hi); }
+    while (hi > 0) { const Pt before = vert(K, poly, hi - 1); if (!same(last, before)) break; --hi; last = before; }
+    if (hi < 2) return 1;
     const int n = hi + 1;
-    Pt *dst = K.v[poly];
-    for (int i = 0; i < n; ++i) {
-      Pt p; p.x = xs[i]; p.y = ys[i];
-      const i64 lim = 0x3FFFFFFFFFFFFFFFLL;
-      if (p.x > lim || p.y > lim || -p.x > lim || -p.y > lim) return 3;
-      dst[i] = p;
-    }
     int nmin = 0, nmax = 0, bot = 0, top = 0;
-    Pt p = dst[n - 1], c = dst[0];
+    Pt p = last, c = first, at_bot = first, bot_next = first, bot_prev = first;
     for (int i = 0; i < n; ++i) {
-      const Pt q = dst[i + 1 == n ? 0 : i + 1];
+      const Pt q = (i + 1 == n) ? first : vert(K, poly, i + 1);
+      const i64 lim = 0x3FFFFFFFFFFFFFFFLL;
+      if (c.x > lim || c.y > lim || -c.x > lim || -c.y > lim) return 3;
       if (same(c, q) || szv::collinear3(p, c, q)) return 4;   // the general code would drop this vertex
       if (c.y == q.y) return 5;                               // horizontal edge
-      if (c.y > p.y && c.y > q.y) { ++nmin; bot = i; }
+      if (c.y > p.y && c.y > q.y) { ++nmin; bot = i; at_bot = c; bot_next = q; bot_prev = p; }
       if (c.y < p.y && c.y < q.y) { ++nmax; top = i; }
       p = c; c = q;
     }
     if (nmin != 1 || nmax != 1) return 6;
     // the left bound starts with the edge of larger slope (clipper.cpp:1194-1204)
-    const Pt b = dst[bot], fn = dst[bot + 1 == n ? 0 : bot + 1], fp = dst[bot == 0 ? n - 1 : bot - 1];
-    double s_next = (double)(fn.x - b.x) / (double)(fn.y - b.y);
-    double s_prev = (double)(fp.x - b.x) / (double)(fp.y - b.y);
+    double s_next = (double)(bot_next.x - at_bot.x) / (double)(bot_next.y - at_bot.y);
+    double s_prev = (double)(bot_prev.x - at_bot.x) / (double)(bot_prev.y - at_bot.y);
     if (s_next == s_prev) return 7;
     Mono m; m.n = (short)n; m.bot = (short)bot; m.top = (short)top; m.dir_left = (short)((s_next < s_prev) ? -1 : +1);
-    K.m[poly] = m;
+    m.bot_y = at_bot.y;
+    K.mono[poly] = m;
   }
   return 0;
 }
@@ -174,10 +205,11 @@ SZ_HD void dq_emit(Deque &q, int side, const Pt &pt) {
   if (to_front) q.front = pt; else q.back = pt;
 }
 
-template <class Blk, class Sink>
-SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const RingPtr &rb, int nb, Sink &sink) {
+// The rings are in w.blk->v (see FastBlockT); na, nb = vertex counts as stored (a closing duplicate may follow).
+template <class Blk, class Verts, class Sink>
+SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb, Sink &sink) {
   Blk &K = *w.blk;
-  if (int why = load_rings(K, ra, na, rb, nb)) SZX_BAIL(30 + why);
+  if (int why = scan_rings(K, vert, na, nb)) SZX_BAIL(30 + why);
   CEdge *ed = K.ed;
   signed char *ord = K.ord;
   int k = 0;                   // active edges
@@ -187,7 +219,34 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const 
   q.front.x = q.front.y = q.back.x = q.back.y = 0;
   i64 y = 0;                   // current scanline (unused until the first ring is inserted)
 
+  bool done_early = false;
   for (int guard = 0; guard < 64; ++guard) {
+    // Scanbeams with the edges of only one ring cannot cross or emit anything (its edges are outside the
+    // other ring, winding 0), in the general sweep as here: skip them.  (1) Only the lower ring is in and the
+    // upper one is still pending: walk the two bounds up to the scanline of the pending ring's bottom; if the
+    // ring ends first the y-ranges are disjoint and the result is empty.  (2) One ring has ended and no output
+    // ring is open: nothing more can happen.
+    if (k == 2 && pending != 0) {
+      const int pp = (pending & 1) ? 0 : 1;
+      const i64 by = K.mono[pp].bot_y;
+      bool ended = false;
+      for (int i = 0; i < 2; ++i) {
+        CEdge &e = ed[ord[i]];
+        const Mono m = K.mono[e.poly];
+        while (e.top.y > by) {
+          if (e.last) { ended = true; break; }
+          int vt = e.vtop + e.dir;
+          if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
+          e.bot = e.top; e.top = vert(K, e.poly, vt); e.vtop = (short)vt;
+          e.last = (vt == m.top);
+          cset_slope(e);
+        }
+        if (ended) break;
+      }
+      if (ended) return szv::ST_OK;
+      y = by + 1;                 // any scanline below by: cross points are clamped to it only from above
+    }
+    if (k == 2 && pending == 0 && !q.open) { done_early = true; break; }
     // next scanline: the highest y still below the current one
     bool have = false;
     i64 top_y = 0;
@@ -200,7 +259,7 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const 
     int insert = -1;            // ring whose local minimum lies on the next scanline
     for (int p = 0; p < 2; ++p) {
       if (!(pending >> p & 1)) continue;
-      i64 by = K.v[p][K.m[p].bot].y;
+      i64 by = K.mono[p].bot_y;
       if (!have || by > top_y) { have = true; top_y = by; sources = 1; insert = p; }
       else if (by == top_y) SZX_BAIL(5);
     }
@@ -303,10 +362,10 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const 
       // an intermediate vertex of a bound: emit it and step to the next edge of the bound.  (The general
       // code does this in a second pass over the list; with one vertex per scanline the order is the same.)
       if (e.ring >= 0) dq_emit(q, e.side, e.top);
-      const Mono m = K.m[e.poly];
+      const Mono m = K.mono[e.poly];
       int vt = e.vtop + e.dir;
       if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-      e.bot = e.top; e.top = K.v[e.poly][vt]; e.vtop = (short)vt;
+      e.bot = e.top; e.top = vert(K, e.poly, vt); e.vtop = (short)vt;
       e.last = (vt == m.top);
       cset_slope(e);
       e.curx = e.bot.x;
@@ -318,8 +377,8 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const 
 
     // ---- insertion of a ring's local minimum on this scanline (clipper.cpp:1978-2077) ----
     if (insert >= 0) {
-      const Mono m = K.m[insert];
-      const Pt bot = K.v[insert][m.bot];
+      const Mono m = K.mono[insert];
+      const Pt bot = vert(K, insert, m.bot);
       int pos = 0;
       while (pos < k) {
         const i64 ox = ed[ord[pos]].curx;
@@ -343,7 +402,7 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const 
         e.dir = (signed char)(bound == 0 ? m.dir_left : -m.dir_left);
         int vt = m.bot + e.dir;
         if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-        e.bot = bot; e.top = K.v[insert][vt]; e.vtop = (short)vt;
+        e.bot = bot; e.top = vert(K, insert, vt); e.vtop = (short)vt;
         e.last = (vt == m.top);
         cset_slope(e);
         e.curx = bot.x;
@@ -357,7 +416,7 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const RingPtr &ra, int na, const 
     }
     if (q.overflow) SZX_BAIL(20);
   }
-  if (k != 0 || pending != 0 || q.open || q.overflow) SZX_BAIL(21);
+  if ((k != 0 && !done_early) || pending != 0 || q.open || q.overflow) SZX_BAIL(21);
   if (!q.used) return szv::ST_OK;            // no overlap: empty result
   const int cnt = q.hi - q.lo;
   if (cnt < 3) SZX_BAIL(22);               // the general code disposes of such rings in FixupOutPolygon

@@ -481,7 +481,7 @@ SZ_HD void narrow_a(i64 p, const Floes &F, const Params &P, Work &W, void *fast_
   szc::PairScratch S;
   if (!pair_slice(p, u, W, S)) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); return; }
   if (u.n1 + u.n2 > szv::COMPACT_MAX_NV) { to_general_path(p, W); return; }
-  szc::ClipCompact clip = {fast_ws};
+  szc::ViaArrays<szc::ClipCompact> clip = {{fast_ws}};
   int nreg = 0;
   int st = szc::pair_clip1(u.ring1, u.ring2, u.boundary, S, clip, nreg);
   if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) { to_general_path(p, W); return; }
@@ -498,7 +498,7 @@ SZ_HD void narrow_b(i64 t, const Floes &F, const Params &P, Work &W, void *fast_
   pair_setup(p, F, P, W, u);
   szc::PairScratch S;
   pair_slice(p, u, W, S); // same slice as in narrow_a: regions of the first clip are in S.r1*
-  szc::ClipCompact clip = {fast_ws};
+  szc::ViaArrays<szc::ClipCompact> clip = {{fast_ws}};
   szc::PairOut out;
   int st = szc::pair_finish(u.ring1, u.b1, u.ring2, u.b2, u.boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                             P.mu, P.nu, S, W.pair_nreg[p], clip, out);

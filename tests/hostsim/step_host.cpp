@@ -4,6 +4,17 @@
 // (gloo).  Not part of the product; nothing in subzero_amd/ loads this.
 static long long g_fast_hits = 0, g_fast_bails = 0, g_bail_sites[64];
 #define SZX_BAIL_PROBE(site) (++g_bail_sites[(site) & 63])
+#include <stdio.h>
+static int g_dump_third = 0;
+static void dump_third(const long long *tx, const long long *ty, int nt, const long long *rx, const long long *ry, int nr) {
+  if (!g_dump_third) return;
+  printf("THIRD T");
+  for (int i = 0; i < nt; ++i) printf(" %.9f,%.9f", (double)tx[i] / 4294967296.0, (double)ty[i] / 4294967296.0);
+  printf(" R");
+  for (int i = 0; i < nr; ++i) printf(" %.9f,%.9f", (double)rx[i] / 4294967296.0, (double)ry[i] / 4294967296.0);
+  printf("\n"); fflush(stdout);
+}
+#define SZC_THIRD_PROBE(tx, ty, nt, rx, ry, nr) dump_third((const long long *)(tx), (const long long *)(ty), nt, (const long long *)(rx), (const long long *)(ry), nr)
 #define SZC_FAST_PROBE(st) ((st) == 100 ? ++g_fast_bails : ++g_fast_hits)
 #include "../../subzero_amd/csrc/step_core.hpp"
 #include <stdint.h>
@@ -15,6 +26,7 @@ using namespace szs;
 
 static int g_narrow_mode = 2;
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
+extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
 extern "C" void host_bail_sites(long long *out) { for (int i = 0; i < 64; ++i) out[i] = g_bail_sites[i]; }
 extern "C" void host_fast_counts(long long *hits, long long *bails) { *hits = g_fast_hits; *bails = g_fast_bails; }
 

@@ -46,10 +46,33 @@ extern "C" int host_clip_batch(int npairs,
     int st = szv::ST_WORKSPACE;
     // single-minimum fast path first (intersection, even-odd), as k_narrow does; ST_BAIL falls through
     if (g_try_fast && method == szv::OP_INTERSECTION && fill_s == 0 && fill_c == 0) {
+      // (the step keeps the rings as doubles in the block; this entry starts from int64 rings: VertsFixed)
       szx::FastBlock blk; szv::Pt deq[64];
       szx::FastWsT<szx::FastBlock> fw = {&blk, deq, 32};
-      szx::RingPtr pa = {(const szv::i64 *)a.x, (const szv::i64 *)a.y}, pb = {(const szv::i64 *)b.x, (const szv::i64 *)b.y};
-      int fs = szx::clip_monotone(fw, pa, na, pb, nb, s);
+      int fs = szx::ST_BAIL;
+      if (na <= (int)szx::FastBlock::NV + 1 && nb <= (int)szx::FastBlock::NV + 1 && na >= 1 && nb >= 1) {
+        int ma = na, mb = nb;     // a closing duplicate need not fit the block
+        if (ma > 1 && a.x[ma - 1] == a.x[0] && a.y[ma - 1] == a.y[0]) --ma;
+        if (mb > 1 && b.x[mb - 1] == b.x[0] && b.y[mb - 1] == b.y[0]) --mb;
+        if (ma <= (int)szx::FastBlock::NV && mb <= (int)szx::FastBlock::NV) {
+          blk.shifted = 0;
+          bool exact = true;      // mode 2: hand the rings over in metres, as the step does (needs |v| < 2^53)
+          if (g_try_fast == 2) {
+            const int64_t lim = (int64_t)1 << 53;
+            for (int i = 0; i < ma; ++i) exact = exact && a.x[i] < lim && a.x[i] > -lim && a.y[i] < lim && a.y[i] > -lim;
+            for (int i = 0; i < mb; ++i) exact = exact && b.x[i] < lim && b.x[i] > -lim && b.y[i] < lim && b.y[i] > -lim;
+          }
+          if (g_try_fast == 2 && exact) {
+            for (int i = 0; i < ma; ++i) { blk.v.m.x[0][i] = (double)a.x[i] / 4294967296.0; blk.v.m.y[0][i] = (double)a.y[i] / 4294967296.0; }
+            for (int i = 0; i < mb; ++i) { blk.v.m.x[1][i] = (double)b.x[i] / 4294967296.0; blk.v.m.y[1][i] = (double)b.y[i] / 4294967296.0; }
+            fs = szx::clip_monotone(fw, szx::VertsMetres(), ma, mb, s);
+          } else {
+            for (int i = 0; i < ma; ++i) blk.v.f[0][i] = a(i);
+            for (int i = 0; i < mb; ++i) blk.v.f[1][i] = b(i);
+            fs = szx::clip_monotone(fw, szx::VertsFixed(), ma, mb, s);
+          }
+        }
+      }
       if (fs == szx::ST_BAIL) { s.nv = nv0; s.nr = nr0; }
       else { st = fs; ++g_fast_done; }
     }
