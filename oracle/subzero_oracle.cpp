@@ -17,7 +17,11 @@
 // (SURVEY.md section 8c): polyshape area/centroid = shoelace (pinned against MATLAB's own cached values
 // in the FloeShapes.mat fixture), polyarea = its published one-liner, dsearchn = brute-force nearest
 // vertex, interp2 = bilinear, cart2pol = atan2/hypot, unique(...,'rows') = lexicographic sort + dedupe,
-// sum/mean = left-to-right.  sin/cos/atan2 come from or_math.h (self-contained, <= 1-2 ulp).
+// sum/mean = left-to-right, except the means over the Monte-Carlo points of calc_trajectory.m:139,163-165, which
+// use a fixed order that 256 parallel workers can follow: point q is added to partial q mod 256 (in increasing
+// q), then the partials are folded pairwise, p[t] += p[t + s] for s = 128, 64, ..., 1 (struct McSum).  MATLAB
+// documents no order for sum; this one is also more accurate than left-to-right.
+// sin/cos/atan2 come from or_math.h (self-contained, <= 1-2 ulp).
 //
 // PARITY STATUS: the C++ clip is pinned by the reference's own known answer (private/clipper_test.m)
 // and by being the reference's own source.  The MATLAB layers are "parity unpinned" by the reference
@@ -453,6 +457,17 @@ bool floe_interactions(const Vec &c1x_in, const Vec &c1y_in, const Body &f1, con
 // ---------------------------------------------------------------------------------------------
 // calc_trajectory.m
 // ---------------------------------------------------------------------------------------------
+// the fixed summation order of the Monte-Carlo means (see the header): 256 interleaved partials, then a binary fold
+struct McSum {
+  double p[256];
+  McSum() { for (int t = 0; t < 256; ++t) p[t] = 0.0; }
+  void add(int q, double v) { p[q & 255] += v; }
+  double total() {
+    for (int s = 128; s >= 1; s >>= 1)
+      for (int t = 0; t < s; ++t) p[t] += p[t + s];
+    return p[0];
+  }
+};
 double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, const double *V, double xq, double yq) {
   // V is ny x nx column-major.  NaN outside the grid, as interp2 does.
   if (!(xq >= Xo[0] && xq <= Xo[nx - 1] && yq >= Yo[0] && yq <= Yo[ny - 1])) return NaN;
@@ -567,7 +582,7 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
     orm_sincos(ta, &sta, &cta);
     const uint8_t *A = F->mcA + (size_t)i * nmc;
     // U10, V10: mean of the interpolated winds over the points inside the floe (:139)
-    double su = 0, sv = 0; int cnt = 0;
+    McSum su, sv; int cnt = 0;
     Vec Uo(nmc), Vo(nmc), th(nmc), rho(nmc);
     for (int q = 0; q < nmc; ++q) {
       double Xg = xr1[q] + Xi, Yg = xr2[q] + Yi;                // :122
@@ -575,16 +590,16 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
       Uo[q] = interp2_linear(Xo, nxo, Yo, nyo, P->Uocn, Xg, Yg);
       Vo[q] = interp2_linear(Xo, nxo, Yo, nyo, P->Vocn, Xg, Yg);
       if (A[q]) {
-        su += interp2_linear(Xo, nxo, Yo, nyo, P->Uwind, Xg, Yg);
-        sv += interp2_linear(Xo, nxo, Yo, nyo, P->Vwind, Xg, Yg);
+        su.add(q, interp2_linear(Xo, nxo, Yo, nyo, P->Uwind, Xg, Yg));
+        sv.add(q, interp2_linear(Xo, nxo, Yo, nyo, P->Vwind, Xg, Yg));
         ++cnt;
       }
     }
-    double U10 = su / cnt, V10 = sv / cnt;
+    double U10 = su.total() / cnt, V10 = sv.total() / cnt;
     double w10 = sqrt(U10 * U10 + V10 * V10);
     double Fx_atm = rho_air * Cd_atm * w10 * U10;               // :140-141
     double Fy_atm = rho_air * Cd_atm * w10 * V10;
-    double sFx = 0, sFy = 0, sT = 0;
+    McSum sFx, sFy, sT;
     for (int q = 0; q < nmc; ++q) {
       double sth, cth;
       orm_sincos(th[q], &sth, &cth);
@@ -601,9 +616,9 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
       double tq = (-Fx * sth + Fy * cth) * rho[q];              // :156
       Fx = Fx + (floe_mass / floe_area) * fc * F->Vi[i];        // :159-160
       Fy = Fy - (floe_mass / floe_area) * fc * F->Ui[i];
-      if (A[q]) { sFx += Fx; sFy += Fy; sT += tq; }
+      if (A[q]) { sFx.add(q, Fx); sFy.add(q, Fy); sT.add(q, tq); }
     }
-    F->FxOA[i] = sFx / cnt; F->FyOA[i] = sFy / cnt; F->torqueOA[i] = sT / cnt; // :163-165
+    F->FxOA[i] = sFx.total() / cnt; F->FyOA[i] = sFy.total() / cnt; F->torqueOA[i] = sT.total() / cnt; // :163-165
   }
   // :174-177 positions, Adams-Bashforth 2
   double dx = 1.5 * dt * F->Ui[i] - 0.5 * dt * F->dXi_p[i];

@@ -333,20 +333,33 @@ __global__ void k_integrate_post(Floes F, Params P, Work W) {
   int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
   if (i < F.n) integrate_post(i, F, P, W);
 }
-// Ocean / wind forcing (calc_trajectory.m:95-98,121-166): one 256-thread workgroup per floe.  The threads evaluate the
-// Monte-Carlo points 64 at a time (contiguous reads of the floe's [point] row) into LDS; then single
-// lanes add the per-point values up left to right over the
-// points inside the floe -- the summation order of the serial form, so the result is bit-identical to it.
-#define FORCE_MAX_MC 1024
+// Ocean / wind forcing (calc_trajectory.m:95-98,121-166): one 256-thread workgroup per floe.  Thread t evaluates
+// the Monte-Carlo points t, t + 256, ... (contiguous reads of the floe's point rows) and keeps partial t of
+// the fixed summation order (step_core.hpp MC_PARTS); the workgroup then folds the 256 partials pairwise:
+// across the four waves through LDS, inside the first wave with shuffles.
+__device__ inline double mc_fold_block(double v, double *lds256) {
+  const int t = threadIdx.x;
+  lds256[t] = v;
+  __syncthreads();
+  if (t < 128) lds256[t] += lds256[t + 128];
+  __syncthreads();
+  double r = 0;
+  if (t < 64) {
+    r = lds256[t] + lds256[t + 64];
+    for (int s = 32; s >= 1; s >>= 1) r += __shfl_down(r, s);   // lane t: p[t] += p[t + s]; lane 0 ends with the total
+  }
+  __syncthreads();                                              // lds256 is reused by the next fold
+  return r;                                                     // valid in thread 0
+}
+static_assert(MC_PARTS == 256, "k_forcing folds exactly 256 partials");
 __global__ void __launch_bounds__(256) k_forcing(int first, int last, Floes F, Params P, Work W) {
-  __shared__ double s0[FORCE_MAX_MC], s1[FORCE_MAX_MC], s2[FORCE_MAX_MC];
-  __shared__ double red[4];
-  __shared__ unsigned char sA[FORCE_MAX_MC];
+  __shared__ double fold[256];
+  __shared__ double red[3];
   __shared__ int scnt;
   const int i = blockIdx.x + first;
   if (i >= last) return;
   if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
-  const int lane = threadIdx.x;
+  const int t = threadIdx.x;
   const int nmc = F.n_mc;
   const double *mx = F.mcX + i * F.mc_si, *my = F.mcY + i * F.mc_si;
   const unsigned char *A = F.mcA + i * F.mc_si;
@@ -354,43 +367,37 @@ __global__ void __launch_bounds__(256) k_forcing(int first, int last, Floes F, P
   ForceCtx c;
   force_ctx(i, F, P, c);
   // pass 1: winds at the points inside the floe
-  const int nthr = blockDim.x;
-  for (int q = lane; q < nmc; q += nthr) {
-    double uw = 0, vw = 0;
-    const unsigned char in = A[q * sq];
-    if (in) wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
-    s0[q] = uw; s1[q] = vw; sA[q] = in;
-  }
+  if (t == 0) scnt = 0;
   __syncthreads();
-  if (lane == 0) { double s = 0; int cnt = 0; for (int q = 0; q < nmc; ++q) if (sA[q]) { s += s0[q]; ++cnt; } red[0] = s; scnt = cnt; }
-  if (lane == 1) { double s = 0; for (int q = 0; q < nmc; ++q) if (sA[q]) s += s1[q]; red[1] = s; }
+  double a0 = 0.0, a1 = 0.0;
+  int mine = 0;
+  for (int q = t; q < nmc; q += 256) {
+    if (!A[q * sq]) continue;
+    double uw, vw;
+    wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
+    a0 += uw; a1 += vw; ++mine;
+  }
+  if (mine) atomicAdd(&scnt, mine);
+  const double su = mc_fold_block(a0, fold), sv = mc_fold_block(a1, fold);
+  if (t == 0) { red[0] = su; red[1] = sv; }
   __syncthreads();
   const int cnt = scnt;
   if (cnt == 0) { // calc_trajectory.m:100-110 would regenerate the points with rand()
-    if (lane == 0) { atomicAdd(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; }
+    if (t == 0) { atomicAdd(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; }
     return;
   }
   wind_stress(c, red[0], red[1], cnt);
-  __syncthreads();
   // pass 2: stresses and torque
-  for (int q = lane; q < nmc; q += nthr) {
-    double Fx = 0, Fy = 0, tq = 0;
-    if (sA[q]) force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
-    s0[q] = Fx; s1[q] = Fy; s2[q] = tq;
+  a0 = 0.0; a1 = 0.0;
+  double a2 = 0.0;
+  for (int q = t; q < nmc; q += 256) {
+    if (!A[q * sq]) continue;
+    double Fx, Fy, tq;
+    force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
+    a0 += Fx; a1 += Fy; a2 += tq;
   }
-  __syncthreads();
-  if (lane < 3) {
-    const double *src = (lane == 0) ? s0 : (lane == 1) ? s1 : s2;
-    double s = 0;
-    for (int q = 0; q < nmc; ++q) if (sA[q]) s += src[q];
-    red[lane] = s;
-  }
-  __syncthreads();
-  if (lane == 0) { F.FxOA[i] = red[0] / cnt; F.FyOA[i] = red[1] / cnt; F.torqueOA[i] = red[2] / cnt; }
-}
-__global__ void k_forcing_serial(int first, int last, Floes F, Params P, Work W) { // n_mc beyond the LDS staging size
-  int i = blockIdx.x * blockDim.x + threadIdx.x + first;
-  if (i < last) forcing_serial(i, F, P, W);
+  const double sFx = mc_fold_block(a0, fold), sFy = mc_fold_block(a1, fold), sT = mc_fold_block(a2, fold);
+  if (t == 0) { F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt; }
 }
 // sharded forcing: FxOA, FyOA, torqueOA of a floe range leave / arrive as three packed arrays of `cnt_max`
 __global__ void k_force_export(int first, int count, int cnt_max, Floes F, double *dst) {
@@ -708,8 +715,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
 
 static int step_forcing(szContext *ctx, StepState *S, int first, int last) {
   if (last <= first) return SZ_OK;
-  if (S->n_mc <= FORCE_MAX_MC) hipLaunchKernelGGL(k_forcing, dim3(last - first), dim3(256), 0, ctx->stream, first, last, S->F, S->P, S->W);
-  else hipLaunchKernelGGL(k_forcing_serial, grid_for(last - first, 64), dim3(64), 0, ctx->stream, first, last, S->F, S->P, S->W);
+  hipLaunchKernelGGL(k_forcing, dim3(last - first), dim3(256), 0, ctx->stream, first, last, S->F, S->P, S->W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }

@@ -848,8 +848,17 @@ SZ_HD void force_point(const ForceCtx &c, const Params &P, double mx, double my,
   Fx = Fx + (c.mass_per_area) * c.fc * c.Vi;
   Fy = Fy - (c.mass_per_area) * c.fc * c.Ui;
 }
-// whole forcing of one floe by one thread (host emulation; the GPU uses the wave-per-floe kernel in step.hip,
-// which evaluates the same per-point functions and adds them up in the same order)
+// The means over the Monte-Carlo points (calc_trajectory.m:139,163-165) are summed in a fixed order that 256
+// threads can follow: point q goes into partial q mod 256 (increasing q), then the partials are folded pairwise,
+// p[t] += p[t + s] for s = 128, 64, ..., 1.  MC_PARTS is part of the numerical definition (the oracle has the same).
+enum { MC_PARTS = 256 };
+SZ_HD double mc_fold(double *p) {
+  for (int s = MC_PARTS / 2; s >= 1; s >>= 1)
+    for (int t = 0; t < s; ++t) p[t] += p[t + s];
+  return p[0];
+}
+// whole forcing of one floe by one thread (host emulation of k_forcing in step.hip: the same per-point functions,
+// the same summation order)
 SZ_HD void forcing_serial(int i, const Floes &F, const Params &P, Work &W) {
   if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return;
   const int nmc = F.n_mc;
@@ -861,21 +870,24 @@ SZ_HD void forcing_serial(int i, const Floes &F, const Params &P, Work &W) {
   if (cnt == 0) { atomic_add(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; return; } // :100-110 needs rand()
   ForceCtx c;
   force_ctx(i, F, P, c);
-  double su = 0, sv = 0;
+  double p0[MC_PARTS], p1[MC_PARTS], p2[MC_PARTS];
+  for (int t = 0; t < MC_PARTS; ++t) { p0[t] = 0.0; p1[t] = 0.0; }
   for (int q = 0; q < nmc; ++q) {
     if (!A[q * sq]) continue;
     double uw, vw;
     wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
-    su += uw; sv += vw;
+    p0[q % MC_PARTS] += uw; p1[q % MC_PARTS] += vw;
   }
+  const double su = mc_fold(p0), sv = mc_fold(p1);
   wind_stress(c, su, sv, cnt);
-  double sFx = 0, sFy = 0, sT = 0;
+  for (int t = 0; t < MC_PARTS; ++t) { p0[t] = 0.0; p1[t] = 0.0; p2[t] = 0.0; }
   for (int q = 0; q < nmc; ++q) {
     if (!A[q * sq]) continue; // only the points inside the floe enter the means (:163-165)
     double Fx, Fy, tq;
     force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
-    sFx += Fx; sFy += Fy; sT += tq;
+    p0[q % MC_PARTS] += Fx; p1[q % MC_PARTS] += Fy; p2[q % MC_PARTS] += tq;
   }
+  const double sFx = mc_fold(p0), sFy = mc_fold(p1), sT = mc_fold(p2);
   F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt;
 }
 
