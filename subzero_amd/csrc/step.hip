@@ -29,12 +29,13 @@ struct StepState {
   // ocean grids on the device
   DevBuf oXo, oYo, oU, oV, oWu, oWv;
   int nxo = 0, nyo = 0;
+  double xo_max = 0, xo_min = 0, yo_max = 0, yo_min = 0; // extent of the uploaded grid axes
   bool have_ocean = false;
   // grow-only per-step buffers
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_items, cell_x, cell_y, cell_r;
-  DevBuf pair_rowoff, x_off, touch_list, pair_nreg;
+  DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
   long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
   int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
@@ -214,12 +215,17 @@ __global__ void k_broad_scan(Floes F, Params P, Work W) { // thread (i, c9): 9 c
   int i = (int)(t / 9) + F.nb, c9 = (int)(t % 9);
   if (i < N) broad_scan(i, c9, N, F, P, W);
 }
-__global__ void k_broad_filter(int lo_is_real, Floes F, Params P, Work W) {
+// 64 floes per workgroup; each thread sorts and filters its candidate list in its own slice of LDS
+// (2 * pot_cap + 1 ints: the odd stride spreads the threads over the banks), or of `spill` when that does not fit
+__global__ void __launch_bounds__(64) k_broad_filter(int lo_is_real, Floes F, Params P, Work W, int *spill) {
+  extern __shared__ int filter_lds[];
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = 2 * (size_t)W.pot_cap + 1;
+  int *tmp = spill ? spill + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
   if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
   else { i += F.n; if (i >= N) return; }
-  broad_filter(i, F, P, W);
+  broad_filter(i, F, P, W, tmp);
 }
 __global__ void k_pair_count(Floes F, Params P, Work W) {
   int N = dev_next(W);
@@ -304,10 +310,13 @@ __global__ void k_incoming(i64 np, Work W) {
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np) incoming(p, W);
 }
-__global__ void k_row_count(Work W) {
+__global__ void __launch_bounds__(64) k_row_count(Work W, int *spill) { // slices of LDS (or of `spill`) as in k_broad_filter
+  extern __shared__ int filter_lds[];
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) row_count(i, W);
+  const size_t stride = 2 * (size_t)W.pot_cap + 1;
+  int *tmp = spill ? spill + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
+  if (i < N) row_count(i, W, tmp);
 }
 __global__ void k_row_fill(Floes F, Params P, Work W) {
   int N = dev_next(W);
@@ -459,7 +468,7 @@ void sz_step_destroy(szContext *ctx) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->cell_x, &S->cell_y, &S->cell_r};
+                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->cell_x, &S->cell_y, &S->cell_r};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   delete S;
@@ -556,6 +565,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     SZ_HIP(ctx, hipMemcpyAsync(S->oWu.p, hp->Uwind, g, hipMemcpyHostToDevice, st));
     SZ_HIP(ctx, hipMemcpyAsync(S->oWv.p, hp->Vwind, g, hipMemcpyHostToDevice, st));
     S->nxo = hp->nxo; S->nyo = hp->nyo; S->have_ocean = true;
+    axis_extent(hp->Xo, hp->nxo, S->xo_max, S->xo_min); axis_extent(hp->Yo, hp->nyo, S->yo_max, S->yo_min);
   }
   Params &P = S->P;
   P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
@@ -564,6 +574,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   P.fb_h = hp->fb_h; P.fb_area = hp->fb_area; P.fb_Xi = hp->fb_Xi; P.fb_Yi = hp->fb_Yi; P.fb_Ui = hp->fb_Ui;
   P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
   P.nxo = S->nxo; P.nyo = S->nyo;
+  P.Xo_max = S->xo_max; P.Xo_min = S->xo_min; P.Yo_max = S->yo_max; P.Yo_min = S->yo_min;
   P.Xo = (const double *)S->oXo.p; P.Yo = (const double *)S->oYo.p;
   P.Uocn = (const double *)S->oU.p; P.Vocn = (const double *)S->oV.p;
   P.Uwind = (const double *)S->oWu.p; P.Vwind = (const double *)S->oWv.p;
@@ -611,8 +622,16 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
   }
   hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, F, P, W);
-  hipLaunchKernelGGL(k_broad_filter, grid_for(n, 64), dim3(64), 0, st, 1, F, P, W);
-  if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, 64), dim3(64), 0, st, 0, F, P, W);
+  {
+    const size_t per_thread = (2 * (size_t)W.pot_cap + 1) * 4, lds = 64 * per_thread;
+    int *spill = nullptr;
+    if (lds > 64 * 1024) {   // very long candidate lists: the slices live in HBM instead
+      if ((rc = sz_reserve(ctx, S->filter_spill, (size_t)(3 * (i64)n + 64) * per_thread))) return rc;
+      spill = (int *)S->filter_spill.p;
+    }
+    hipLaunchKernelGGL(k_broad_filter, grid_for(n, 64), dim3(64), spill ? 0 : lds, st, 1, F, P, W, spill);
+    if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, 64), dim3(64), spill ? 0 : lds, st, 0, F, P, W, spill);
+  }
   hipLaunchKernelGGL(k_pair_count, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
   launch_scan(st, S->scan_agg, cap, ScanPairs{W});
   SZ_HIP(ctx, hipGetLastError());
@@ -734,7 +753,15 @@ static int step_back_a(szContext *ctx, StepState *S) {
   const int n = S->n, cap = W.cap_ext;
   int rc;
   if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
-  hipLaunchKernelGGL(k_row_count, grid_for(cap, 256), dim3(256), 0, st, W);
+  {
+    const size_t per_thread = (2 * (size_t)W.pot_cap + 1) * 4, lds = 64 * per_thread;
+    int *spill = nullptr;
+    if (lds > 64 * 1024) {
+      if ((rc = sz_reserve(ctx, S->filter_spill, (size_t)((i64)cap + 64) * per_thread))) return rc;
+      spill = (int *)S->filter_spill.p;
+    }
+    hipLaunchKernelGGL(k_row_count, grid_for(cap, 64), dim3(64), spill ? 0 : lds, st, W, spill);
+  }
   launch_scan(st, S->scan_agg, cap, ScanRows{W});
   SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));

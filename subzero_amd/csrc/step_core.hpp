@@ -54,6 +54,7 @@ struct Params {
   const double *Xo, *Yo, *Uocn, *Vocn, *Uwind, *Vwind;
   double fCoriolis, turn_angle;
   double Lx, Ly; // max of c2_boundary rows (:9-10), filled by the host wrapper
+  double Xo_max, Xo_min, Yo_max, Yo_min; // extent of the ocean grid axes (calc_trajectory.m:116), filled by the host wrapper (axis_extent)
 };
 
 // counters living in device memory
@@ -104,7 +105,7 @@ struct Work {
   int *st_flag;   // ST_GO | ST_FORCE
   // sharded narrow-phase (multi-GPU): contact rows of all pairs gathered from the ranks that computed them
   double *g_rows;    // null on one GPU: rows are read from the pair's scratch slice
-  i64 *pair_rowoff;  // [cap_pairs] offset (in doubles) of pair p's rows inside g_rows
+  i64 *pair_rowoff;  // [cap_pairs] offset (in doubles) of pair p's rows inside g_rows (sharded step) or inside scratch
 };
 
 // per-pair scratch slice: linear bound so that offsets follow from prefix sums (see carve())
@@ -247,15 +248,20 @@ SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Wor
     mine[k] = j + 1;
   }
 }
-SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W) {
+// tmp: 2 * pot_cap ints of fast private memory (a slice of LDS on the GPU): the list is sorted and filtered
+// there, so that the dependent accesses of the insertion sort do not go to HBM
+SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W, int *tmp) {
   int *mine = W.pot_list + (size_t)i * W.pot_cap;
   int cnt = W.pot_cnt[i];
   if (cnt > W.pot_cap) cnt = W.pot_cap;
+  int *num = tmp + W.pot_cap;              // ext_num of the entries of tmp
+  for (int a = 0; a < cnt; ++a) tmp[a] = mine[a];
   for (int a = 1; a < cnt; ++a) {          // ascending j
-    int v = mine[a], b = a;
-    while (b > 0 && mine[b - 1] > v) { mine[b] = mine[b - 1]; --b; }
-    mine[b] = v;
+    int v = tmp[a], b = a;
+    while (b > 0 && tmp[b - 1] > v) { tmp[b] = tmp[b - 1]; --b; }
+    tmp[b] = v;
   }
+  for (int a = 0; a < cnt; ++a) num[a] = W.ext_num[tmp[a] - 1];
   const int *init = nullptr; int ninit = 0;
   if (W.ext_num[i] < 0) {
     int root = iabs(W.ext_num[i]) - 1;
@@ -266,15 +272,16 @@ SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W) {
   const double lim = szc::mind(2 * P.Lx, 2 * P.Ly);
   int kept = 0;
   for (int a = 0; a < cnt; ++a) {
-    const int j = mine[a] - 1;
-    const int key = iabs(W.ext_num[j]);
+    const int j = tmp[a] - 1;
+    const int key = iabs(num[a]);
     bool member = false;
     for (int q = 0; q < ninit && !member; ++q) member = (init[q] == key);
-    for (int q = 0; q < kept && !member; ++q) member = (W.ext_num[mine[q] - 1] == key);
+    for (int q = 0; q < kept && !member; ++q) member = (num[q] == key);
     const double R = ri + F.rmax[W.ext_src[j]];
     if (!(!member || 2 * R > lim)) continue;
-    mine[kept++] = j + 1;
+    tmp[kept] = j + 1; num[kept] = num[a]; ++kept;
   }
+  for (int a = 0; a < kept; ++a) mine[a] = tmp[a];
   W.pot_cnt[i] = kept;
 }
 
@@ -389,6 +396,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
     atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
     return;
   }
+  W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);   // where row_fill / export_pair find the rows
   // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
   if (fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes) S.ws = fast_ws;
   szc::PairOut out;
@@ -472,7 +480,9 @@ SZ_HD bool pair_slice(i64 p, const PairSetup &u, Work &W, szc::PairScratch &S) {
   i64 bytes = scratch_bytes_for((i64)u.n1 + u.n2, 1);
   i64 off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
   W.pair_scr[p] = off; W.pair_mult[p] = 1;
-  return !(off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, u.n1, u.n2, 1, S));
+  if (off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, u.n1, u.n2, 1, S)) return false;
+  W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);
+  return true;
 }
 SZ_HD void narrow_a(i64 p, const Floes &F, const Params &P, Work &W, void *fast_ws) {
   PairSetup u;
@@ -515,17 +525,9 @@ SZ_HD void narrow_b(i64 t, const Floes &F, const Params &P, Work &W, void *fast_
   if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
 }
 
-SZ_HD const double *pair_rows(i64 p, const Floes &F, const Work &W) {
-  if (W.g_rows) return W.g_rows + W.pair_rowoff[p];
-  // the rows are the last member of the slice; recompute the layout
-  const int i = W.pair_i[p], j = W.pair_j[p];
-  const int si = W.ext_src[i];
-  const int n1 = F.vert_off[si + 1] - F.vert_off[si];
-  int n2 = 4;
-  if (j != WALL) { int sj = W.ext_src[j]; n2 = F.vert_off[sj + 1] - F.vert_off[sj]; }
-  szc::PairScratch S;
-  carve(W.scratch + W.pair_scr[p], scratch_bytes_for((i64)n1 + n2, W.pair_mult[p]), n1, n2, W.pair_mult[p], S);
-  return S.rows;
+// contact rows of pair p: in the pair's scratch slice, or in the gathered exchange buffer (sharded step)
+SZ_HD const double *pair_rows(i64 p, const Floes &, const Work &W) {
+  return (W.g_rows ? W.g_rows : (const double *)W.scratch) + W.pair_rowoff[p];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -540,18 +542,22 @@ SZ_HD void incoming(i64 p, Work &W) {
   W.inc_list[(size_t)j * W.pot_cap + k] = (int)p;
 }
 
-SZ_HD void row_count(int i, Work &W) { // i < N
+// tmp: 2 * pot_cap ints of fast private memory, as for broad_filter
+SZ_HD void row_count(int i, Work &W, int *tmp) { // i < N
   int cnt = 0;
   for (i64 p = W.pair_base[i]; p < W.pair_base[i] + W.pair_cnt[i]; ++p) cnt += W.pair_nrows[p];
   int ninc = W.inc_cnt[i] < W.pot_cap ? W.inc_cnt[i] : W.pot_cap;
   int *inc = W.inc_list + (size_t)i * W.pot_cap;
+  int *src = tmp + W.pot_cap;              // source floe of the entries of tmp
+  for (int a = 0; a < ninc; ++a) tmp[a] = inc[a];
+  for (int a = 0; a < ninc; ++a) src[a] = W.pair_i[tmp[a]];
   // mirrored rows come in ascending order of the source floe (:187)
   for (int a = 1; a < ninc; ++a) {
-    int v = inc[a], b = a;
-    while (b > 0 && W.pair_i[inc[b - 1]] > W.pair_i[v]) { inc[b] = inc[b - 1]; --b; }
-    inc[b] = v;
+    int v = tmp[a], sv = src[a], b = a;
+    while (b > 0 && src[b - 1] > sv) { tmp[b] = tmp[b - 1]; src[b] = src[b - 1]; --b; }
+    tmp[b] = v; src[b] = sv;
   }
-  for (int a = 0; a < ninc; ++a) cnt += W.pair_nrows[inc[a]];
+  for (int a = 0; a < ninc; ++a) { inc[a] = tmp[a]; cnt += W.pair_nrows[tmp[a]]; }
   W.row_cnt[i] = cnt;
 }
 
@@ -602,15 +608,16 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
     }
   }
   W.ov_ext[i] = ov;
-  // torque about the floe position of this (possibly ghost) entry, then the sums (:221-239, :251-263)
+  // torque about the floe position of this (possibly ghost) entry, then the sums in row order (:221-239, :251-263)
   const i64 r0 = W.row_off[i];
   const double x = W.ext_x[i], y = W.ext_y[i];
   double sfx = 0, sfy = 0, stq = 0;
   for (i64 q = r0; q < r; ++q) {
     double *w = rows + 7 * q;
-    w[5] = (w[3] - x) * w[2] - (w[4] - y) * w[1];
+    const double tq = (w[3] - x) * w[2] - (w[4] - y) * w[1];
+    w[5] = tq;
+    sfx += w[1]; sfy += w[2]; stq += tq;
   }
-  for (i64 q = r0; q < r; ++q) { sfx += rows[7 * q + 1]; sfy += rows[7 * q + 2]; stq += rows[7 * q + 5]; }
   W.cf_ext[2 * i] = sfx; W.cf_ext[2 * i + 1] = sfy; W.ct_ext[i] = stq;
   // floe centre outside the box (:152-155)
   if (!P.PERIODIC && i >= F.nb && i < N0) {
@@ -711,6 +718,11 @@ SZ_HD double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, 
 // Values handed from one to the next live in Work::st_* (per real floe).
 enum { ST_GO = 1, ST_FORCE = 2 };
 
+// max(Xo), min(Xo) of a grid axis, the same for every floe: evaluated once by the host wrapper
+SZ_HD void axis_extent(const double *a, int n, double &mx, double &mn) {
+  mx = a[0]; mn = a[0];
+  for (int k = 1; k < n; ++k) { mx = szc::maxd(mx, a[k]); mn = szc::mind(mn, a[k]); }
+}
 SZ_HD void integrate_pre(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
   W.st_flag[i] = 0;
   // ghost sums first (:242-245): the X ghost, then the Y ghost, of this floe; then the floe's own (:262-263)
@@ -778,9 +790,7 @@ SZ_HD void integrate_pre(int i, const Floes &F, const Params &P, Work &W) { // n
       mxx = szc::maxd(mxx, F.cax[v0 + k]); mnx = szc::mind(mnx, F.cax[v0 + k]);
       mxy = szc::maxd(mxy, F.cay[v0 + k]); mny = szc::mind(mny, F.cay[v0 + k]);
     }
-    double Xomax = P.Xo[0], Xomin = P.Xo[0], Yomax = P.Yo[0], Yomin = P.Yo[0];
-    for (int k = 1; k < P.nxo; ++k) { Xomax = szc::maxd(Xomax, P.Xo[k]); Xomin = szc::mind(Xomin, P.Xo[k]); }
-    for (int k = 1; k < P.nyo; ++k) { Yomax = szc::maxd(Yomax, P.Yo[k]); Yomin = szc::mind(Yomin, P.Yo[k]); }
+    const double Xomax = P.Xo_max, Xomin = P.Xo_min, Yomax = P.Yo_max, Yomin = P.Yo_min;
     if (mxx + F.Xi[i] > Xomax || mnx + F.Xi[i] < Xomin || mxy + F.Yi[i] > Yomax || mny + F.Yi[i] < Yomin)
       removed = true;
   }

@@ -107,6 +107,7 @@ struct Sim {
     P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
     P.nxo = hp->nxo; P.nyo = hp->nyo; P.Xo = hp->Xo; P.Yo = hp->Yo; P.Uocn = hp->Uocn; P.Vocn = hp->Vocn;
     P.Uwind = hp->Uwind; P.Vwind = hp->Vwind; P.fCoriolis = hp->fCoriolis; P.turn_angle = hp->turn_angle;
+    axis_extent(P.Xo, P.nxo, P.Xo_max, P.Xo_min); axis_extent(P.Yo, P.nyo, P.Yo_max, P.Yo_min);
     P.Lx = P.c2_boundary[0]; P.Ly = P.c2_boundary[1];
     for (int k = 1; k < 5; ++k) { P.Lx = szc::maxd(P.Lx, P.c2_boundary[2 * k]); P.Ly = szc::maxd(P.Ly, P.c2_boundary[2 * k + 1]); }
     memset(&W, 0, sizeof(W));
@@ -163,8 +164,9 @@ struct Sim {
       for (int e = N - 1; e >= 0; --e) cell_fill(e, F, W);        // reversed on purpose: order must not matter
       for (int i = N - 1; i >= F.nb; --i)
         for (int c9 = 8; c9 >= 0; --c9) broad_scan(i, c9, N, F, P, W);   // any order
-      for (int i = F.nb; i < n; ++i) broad_filter(i, F, P, W);           // reals first: ghosts read their lists
-      for (int i = n; i < N; ++i) broad_filter(i, F, P, W);
+      std::vector<int> ftmp(2 * (size_t)W.pot_cap + 2);
+      for (int i = F.nb; i < n; ++i) broad_filter(i, F, P, W, ftmp.data());   // reals first: ghosts read their lists
+      for (int i = n; i < N; ++i) broad_filter(i, F, P, W, ftmp.data());
     }
     if (W.counters[C_ERR_POT]) return -7;
     for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
@@ -228,7 +230,7 @@ struct Sim {
   int back_a() {
     for (i64 p = np - 1; p >= 0; --p) incoming(p, W);        // reversed on purpose: order must not matter
     if (W.counters[C_ERR_INC]) return -7;
-    for (int i = 0; i < N; ++i) row_count(i, W);
+    { std::vector<int> rtmp(2 * (size_t)W.pot_cap + 2); for (int i = 0; i < N; ++i) row_count(i, W, rtmp.data()); }
     i64 nr = 0;
     for (int i = 0; i < N; ++i) { W.row_off[i] = nr; nr += W.row_cnt[i]; }
     W.row_off[N] = nr;
