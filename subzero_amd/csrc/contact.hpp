@@ -95,9 +95,9 @@ SZ_HD_NOINLINE int clip_in_block(Blk *blk, void *deque_mem, int shifted, double 
   extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
   blk = (Blk *)(sz_dynamic_lds + (size_t)threadIdx.x * sizeof(Blk));
 #endif
-  blk->shifted = shifted; blk->shift_x = sx; blk->shift_y = sy;
   szx::FastWsT<Blk> fw = {blk, (Pt *)deque_mem, 24};
-  return szx::clip_monotone(fw, szx::VertsMetres(), na, nb, *sink);
+  szx::VertsMetres verts = {shifted, sx, sy};
+  return szx::clip_monotone(fw, verts, na, nb, *sink);
 }
 // which sweep a pair uses: Wide records in the pair's HBM slice, or Compact records in a block of LDS
 struct ClipWide {

@@ -32,29 +32,43 @@ enum { ST_BAIL = 100, MAX_CROSS = 6 };
 #endif
 #define SZX_BAIL(site) do { SZX_BAIL_PROBE(site); return ST_BAIL; } while (0)
 
-struct CEdge {      // one active edge = the current edge of one bound of one ring
+// four copies of a statement with s = 0, 1, 2, 3 as literal constants (no loop: the slot arrays must be indexed
+// by constants from the first compiler pass on, or they are demoted from registers to memory)
+#define SZX_EACH(s, ...) { { const int s = 0; __VA_ARGS__ } { const int s = 1; __VA_ARGS__ } { const int s = 2; __VA_ARGS__ } { const int s = 3; __VA_ARGS__ } }
+// the sweep's lambdas must be inlined: a call would take the address of the slot arrays
+#define SZX_INLINE __attribute__((always_inline))
+// value of slot `id`: all four are read (constant indices), then values -- never addresses -- are selected; a
+// conditional read or write of a slot would be merged by the optimizer into one access through a selected address
+#define SZX_PICK(arr, id, F) szx::pick4((id), arr[0] F, arr[1] F, arr[2] F, arr[3] F)
+#define SZX_SET(lhs, cond, v) lhs = (cond) ? (v) : lhs
+
+// One active edge = the current edge of one bound of one ring.  The four of them live in REGISTERS: slot id =
+// ring * 2 + bound (0 left, 1 right), every access to the slot array uses a compile-time index (SZX_EACH or a
+// select chain), so the sweep has no dependent memory round trips between its events.
+template <class T>
+SZ_HD T pick4(int id, T a0, T a1, T a2, T a3) { return id == 1 ? a1 : id == 2 ? a2 : id == 3 ? a3 : a0; }
+
+struct CEdge {
   Pt bot, top;
   i64 curx;
   double slope;
-  short vtop;       // ring index of the top vertex
-  signed char dir;  // ring index step towards the ring's top vertex along this bound
-  signed char ring; // 0 = carries the output ring, -1 = not contributing
-  signed char side; // szv::SIDE_LEFT / SIDE_RIGHT of the output ring
-  signed char wind2;// inside (1) / outside (0) the other ring
-  signed char poly; // 0 subject, 1 clip
-  signed char last; // 1 when top is the ring's top vertex (no further edge in this bound)
+  int vtop;   // ring index of the top vertex
+  int dir;    // ring index step towards the ring's top vertex along this bound
+  int ring;   // 0 = carries the output ring, -1 = not contributing
+  int side;   // szv::SIDE_LEFT / SIDE_RIGHT of the output ring
+  int wind2;  // inside (1) / outside (0) the other ring
+  int last;   // 1 when top is the ring's top vertex (no further edge in this bound)
 };
 struct CCross {
   Pt pt;
-  signed char e1, e2; // edge ids (poly * 2 + bound)
-  short pad0; int pad1;
+  int e1, e2; // slot ids
 };
 struct Mono {         // one cleaned ring: vertex count, bottom / top vertex, direction of the left bound, bottom y
-  short n, bot, top, dir_left;
+  int n, bot, top, dir_left;
   i64 bot_y;
 };
 
-// per-lane state block: 440 + 32 NV bytes (824 for the 12-vertex block of the first pass)
+// per-lane block of fast memory (LDS on the GPU): the vertices of both rings and the crossings of one scanbeam
 template <int NV_>
 struct FastBlockT {
   enum { NV = NV_ };   // most vertices a ring may have
@@ -65,18 +79,13 @@ struct FastBlockT {
     struct { double x[2][NV_], y[2][NV_]; } m;
     Pt f[2][NV_];
   } v;
-  double shift_x, shift_y;  // VertsMetres: added to ring 0 before the conversion when `shifted`
-  int shifted, pad;
-  CEdge ed[4];
   CCross X[MAX_CROSS];
-  Mono mono[2];
-  signed char ord[4];  // edge ids in active-edge-list order
-  signed char sel[4];
   char tail[8];        // makes the size 8 x odd bytes: the same field of neighbouring lanes falls into different LDS banks
 };
-typedef FastBlockT<12> FastBlock;      // first pass over all pairs: 64 lanes x 824 B of LDS per wave
-typedef FastBlockT<32> FastBlockBig;   // second pass over the few pairs with longer rings: 1464 B per lane
-static_assert(sizeof(FastBlock) == 824 && sizeof(FastBlockBig) == 1464, "FastBlock layout changed: keep the size 8 x odd");
+typedef FastBlockT<12> FastBlock;      // first pass over all pairs: 64 lanes x 536 B of LDS per wave
+typedef FastBlockT<32> FastBlockBig;   // second pass over the few pairs with longer rings: 1176 B per lane
+static_assert(sizeof(FastBlock) == 536 && sizeof(FastBlockBig) == 1176, "FastBlock layout changed: keep the size 8 x odd");
+static_assert((sizeof(FastBlock) / 8) % 2 == 1 && (sizeof(FastBlockBig) / 8) % 2 == 1, "lane stride must be 8 x odd");
 
 // MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
 SZ_HD i64 to_fixed(double v) {
@@ -92,9 +101,10 @@ SZ_HD i64 to_fixed(double v) {
 }
 // how the sweep reads vertex i of ring `poly` in fixed-point coordinates
 struct VertsMetres {
+  int shifted; double shift_x, shift_y;   // ring 0 moved by this before the conversion (floe_interactions.m:148-149)
   template <class Blk> SZ_HD Pt operator()(const Blk &K, int poly, int i) const {
     double X = K.v.m.x[poly][i], Y = K.v.m.y[poly][i];
-    if (poly == 0 && K.shifted) { X = X + K.shift_x; Y = Y + K.shift_y; }   // floe_interactions.m:148-149
+    if (poly == 0 && shifted) { X = X + shift_x; Y = Y + shift_y; }
     Pt p; p.x = to_fixed(X); p.y = to_fixed(Y);
     return p;
   }
@@ -121,11 +131,15 @@ SZ_HD void cset_slope(CEdge &e) {
 SZ_HD Pt ccross_point(const CEdge &a, const CEdge &b, i64 cur_y) {
   Pt ip;
   const double fa = szv::dabs(a.slope), fb = szv::dabs(b.slope);
+  // (values, not references, are selected below: a reference chosen at run time would force both edges into memory)
   if (a.slope == 0 || b.slope == 0) {
-    const CEdge &vert = (a.slope == 0) ? a : b, &other = (a.slope == 0) ? b : a;
-    ip.x = vert.bot.x;
-    double k = (double)other.bot.y - ((double)other.bot.x / other.slope);
-    ip.y = szv::rnd((double)ip.x / other.slope + k);
+    const bool va = (a.slope == 0);
+    const i64 vx = va ? a.bot.x : b.bot.x;                       // the vertical edge
+    const i64 ox = va ? b.bot.x : a.bot.x, oy = va ? b.bot.y : a.bot.y;
+    const double os = va ? b.slope : a.slope;                    // the other one
+    ip.x = vx;
+    double k = (double)oy - ((double)ox / os);
+    ip.y = szv::rnd((double)ip.x / os + k);
   } else {
     double ka = (double)a.bot.x - (double)a.bot.y * a.slope;
     double kb = (double)b.bot.x - (double)b.bot.y * b.slope;
@@ -133,13 +147,20 @@ SZ_HD Pt ccross_point(const CEdge &a, const CEdge &b, i64 cur_y) {
     ip.y = szv::rnd(q);
     ip.x = (fa < fb) ? szv::rnd(a.slope * q + ka) : szv::rnd(b.slope * q + kb);
   }
+  bool clamp = false, use_a = false;
   if (ip.y < a.top.y || ip.y < b.top.y) {
     ip.y = (a.top.y > b.top.y) ? a.top.y : b.top.y;
-    ip.x = cx_at((fa < fb) ? a : b, ip.y);
+    clamp = true; use_a = (fa < fb);
   }
   if (ip.y > cur_y) {
     ip.y = cur_y;
-    ip.x = cx_at((fa > fb) ? b : a, ip.y);
+    clamp = true; use_a = !(fa > fb);
+  }
+  if (clamp) {   // x of the flatter edge at the clamped y (TopX)
+    const i64 tx = use_a ? a.top.x : b.top.x, ty = use_a ? a.top.y : b.top.y;
+    const i64 bx = use_a ? a.bot.x : b.bot.x, by = use_a ? a.bot.y : b.bot.y;
+    const double sl = use_a ? a.slope : b.slope;
+    ip.x = (ip.y == ty) ? tx : bx + szv::rnd(sl * (double)(ip.y - by));
   }
   return ip;
 }
@@ -148,7 +169,7 @@ SZ_HD Pt ccross_point(const CEdge &a, const CEdge &b, i64 cur_y) {
 // clipper.cpp:1055-1058); finds each ring's single bottom / top vertex and which way its left bound runs.
 // 0, or the reason for the bail-out.
 template <class Blk, class Verts>
-SZ_HD int scan_rings(Blk &K, const Verts &vert, int na, int nb) {
+SZ_HD int scan_rings(const Blk &K, const Verts &vert, int na, int nb, Mono &m0, Mono &m1) {
   for (int poly = 0; poly < 2; ++poly) {
     int hi = (poly ? nb : na) - 1;
     if (hi + 1 > (int)Blk::NV) return 2;
@@ -176,9 +197,9 @@ SZ_HD int scan_rings(Blk &K, const Verts &vert, int na, int nb) {
     double s_next = (double)(bot_next.x - at_bot.x) / (double)(bot_next.y - at_bot.y);
     double s_prev = (double)(bot_prev.x - at_bot.x) / (double)(bot_prev.y - at_bot.y);
     if (s_next == s_prev) return 7;
-    Mono m; m.n = (short)n; m.bot = (short)bot; m.top = (short)top; m.dir_left = (short)((s_next < s_prev) ? -1 : +1);
+    Mono m; m.n = n; m.bot = bot; m.top = top; m.dir_left = (s_next < s_prev) ? -1 : +1;
     m.bot_y = at_bot.y;
-    K.mono[poly] = m;
+    if (poly == 0) m0 = m; else m1 = m;
   }
   return 0;
 }
@@ -209,15 +230,52 @@ SZ_HD void dq_emit(Deque &q, int side, const Pt &pt) {
 template <class Blk, class Verts, class Sink>
 SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb, Sink &sink) {
   Blk &K = *w.blk;
-  if (int why = scan_rings(K, vert, na, nb)) SZX_BAIL(30 + why);
-  CEdge *ed = K.ed;
-  signed char *ord = K.ord;
-  int k = 0;                   // active edges
+  Mono m0, m1;
+  if (int why = scan_rings(K, vert, na, nb, m0, m1)) SZX_BAIL(30 + why);
+  CEdge ed[4];                 // slot = ring * 2 + bound; valid while its bit in `act` is set
+  SZX_EACH(s, ed[s].bot.x = ed[s].bot.y = ed[s].top.x = ed[s].top.y = ed[s].curx = 0; ed[s].slope = 0; ed[s].vtop = ed[s].dir = ed[s].wind2 = ed[s].last = 0; ed[s].ring = -1; ed[s].side = szv::SIDE_NONE;)
+  int ord[4] = {0, 0, 0, 0};   // slot ids in active-edge-list order, k of them
+  int k = 0, act = 0;
   int pending = 3;             // bit p: ring p not yet inserted
   Deque q;
   q.d = w.deq; q.cap_half = w.cap_half; q.lo = q.hi = w.cap_half; q.open = false; q.used = false; q.overflow = false;
   q.front.x = q.front.y = q.back.x = q.back.y = 0;
   i64 y = 0;                   // current scanline (unused until the first ring is inserted)
+
+  // ---- the register file by run-time index: field-by-field select chains, no memory ----
+  auto get = [&](int id) SZX_INLINE {
+    CEdge r;
+    r.bot.x = SZX_PICK(ed, id, .bot.x); r.bot.y = SZX_PICK(ed, id, .bot.y);
+    r.top.x = SZX_PICK(ed, id, .top.x); r.top.y = SZX_PICK(ed, id, .top.y);
+    r.curx = SZX_PICK(ed, id, .curx); r.slope = SZX_PICK(ed, id, .slope);
+    r.vtop = SZX_PICK(ed, id, .vtop); r.dir = SZX_PICK(ed, id, .dir); r.ring = SZX_PICK(ed, id, .ring);
+    r.side = SZX_PICK(ed, id, .side); r.wind2 = SZX_PICK(ed, id, .wind2); r.last = SZX_PICK(ed, id, .last);
+    return r;
+  };
+  auto put_state = [&](int id, const CEdge &r) SZX_INLINE {
+    SZX_EACH(s, SZX_SET(ed[s].ring, s == id, r.ring); SZX_SET(ed[s].side, s == id, r.side); SZX_SET(ed[s].wind2, s == id, r.wind2);)
+  };
+  auto put = [&](int id, const CEdge &r) SZX_INLINE {
+    SZX_EACH(s,
+      SZX_SET(ed[s].bot.x, s == id, r.bot.x); SZX_SET(ed[s].bot.y, s == id, r.bot.y);
+      SZX_SET(ed[s].top.x, s == id, r.top.x); SZX_SET(ed[s].top.y, s == id, r.top.y);
+      SZX_SET(ed[s].curx, s == id, r.curx); SZX_SET(ed[s].slope, s == id, r.slope);
+      SZX_SET(ed[s].vtop, s == id, r.vtop); SZX_SET(ed[s].dir, s == id, r.dir); SZX_SET(ed[s].ring, s == id, r.ring);
+      SZX_SET(ed[s].side, s == id, r.side); SZX_SET(ed[s].wind2, s == id, r.wind2); SZX_SET(ed[s].last, s == id, r.last);)
+  };
+  auto curx_of = [&](int id) SZX_INLINE { return SZX_PICK(ed, id, .curx); };
+  auto ord_at = [&](int pos) SZX_INLINE { return SZX_PICK(ord, pos, ); };
+  auto pos_of = [&](int id) SZX_INLINE { int v = -1; SZX_EACH(s, if (s < k && ord[s] == id) v = s;) return v; };
+  auto mono_of = [&](int poly) SZX_INLINE { return poly ? m1 : m0; };
+  // steps an edge to the next edge of its bound (the general code's UpdateEdgeIntoAEL)
+  auto advance = [&](CEdge &e, int poly) SZX_INLINE {
+    const Mono m = mono_of(poly);
+    int vt = e.vtop + e.dir;
+    if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
+    e.bot = e.top; e.top = vert(K, poly, vt); e.vtop = vt;
+    e.last = (vt == m.top);
+    cset_slope(e);
+  };
 
   bool done_early = false;
   for (int guard = 0; guard < 64; ++guard) {
@@ -227,75 +285,71 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb
     // ring ends first the y-ranges are disjoint and the result is empty.  (2) One ring has ended and no output
     // ring is open: nothing more can happen.
     if (k == 2 && pending != 0) {
-      const int pp = (pending & 1) ? 0 : 1;
-      const i64 by = K.mono[pp].bot_y;
+      const int pp = (pending & 1) ? 0 : 1, pin = 1 - pp;
+      const i64 by = mono_of(pp).bot_y;
       bool ended = false;
-      for (int i = 0; i < 2; ++i) {
-        CEdge &e = ed[ord[i]];
-        const Mono m = K.mono[e.poly];
+      for (int b = 0; b < 2 && !ended; ++b) {
+        CEdge e = get(pin * 2 + b);
         while (e.top.y > by) {
           if (e.last) { ended = true; break; }
-          int vt = e.vtop + e.dir;
-          if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-          e.bot = e.top; e.top = vert(K, e.poly, vt); e.vtop = (short)vt;
-          e.last = (vt == m.top);
-          cset_slope(e);
+          advance(e, pin);
         }
-        if (ended) break;
+        put(pin * 2 + b, e);
       }
       if (ended) return szv::ST_OK;
       y = by + 1;                 // any scanline below by: cross points are clamped to it only from above
     }
     if (k == 2 && pending == 0 && !q.open) { done_early = true; break; }
+
     // next scanline: the highest y still below the current one
     bool have = false;
     i64 top_y = 0;
-    int sources = 0, src_poly = -1;
-    for (int i = 0; i < k; ++i) {
-      const CEdge &e = ed[ord[i]];
-      if (!have || e.top.y > top_y) { have = true; top_y = e.top.y; sources = 1; src_poly = e.poly; }
-      else if (e.top.y == top_y) { if (e.poly != src_poly) SZX_BAIL(4); ++sources; }
-    }
+    int src_poly = -1;
+    SZX_EACH(s, if (act >> s & 1) {
+      const i64 ty = ed[s].top.y;
+      if (!have || ty > top_y) { have = true; top_y = ty; src_poly = s >> 1; }
+      else if (ty == top_y && (s >> 1) != src_poly) SZX_BAIL(4);
+    })
     int insert = -1;            // ring whose local minimum lies on the next scanline
     for (int p = 0; p < 2; ++p) {
       if (!(pending >> p & 1)) continue;
-      i64 by = K.mono[p].bot_y;
-      if (!have || by > top_y) { have = true; top_y = by; sources = 1; insert = p; }
+      const i64 by = mono_of(p).bot_y;
+      if (!have || by > top_y) { have = true; top_y = by; insert = p; src_poly = -1; }
       else if (by == top_y) SZX_BAIL(5);
     }
     if (!have) break;
     // two edges of one ring may only end together at that ring's top vertex
-    if (sources > 1) {
+    {
       int ends = 0, lasts = 0;
-      for (int i = 0; i < k; ++i) { const CEdge &e = ed[ord[i]]; if (e.top.y == top_y) { ++ends; lasts += e.last; } }
-      if (ends != 2 || lasts != 2) SZX_BAIL(6);
+      SZX_EACH(s, if ((act >> s & 1) && ed[s].top.y == top_y) { ++ends; lasts += ed[s].last; })
+      if (ends > 1 && (ends != 2 || lasts != 2)) SZX_BAIL(6);
     }
 
     // ---- crossings inside the scanbeam (clipper.cpp:2856-2955) ----
-    for (int i = 0; i < k; ++i) { CEdge &e = ed[ord[i]]; e.curx = cx_at(e, top_y); }
+    SZX_EACH(s, { const i64 cx = cx_at(ed[s], top_y); SZX_SET(ed[s].curx, (act >> s & 1) != 0, cx); })
     int nX = 0;
+    int sl[4];
+    SZX_EACH(s, sl[s] = ord[s];)
     {
-      signed char *sl = K.sel;
       int ns = k;
-      for (int i = 0; i < k; ++i) sl[i] = ord[i];
       bool modified;
       do {
         modified = false;
-        int i = 0;
-        while (i + 1 < ns) {
-          CEdge &e = ed[sl[i]], &en = ed[sl[i + 1]];
-          if (e.curx > en.curx) {
-            if (e.poly == en.poly) SZX_BAIL(7);             // bounds of one ring do not cross
-            if (e.slope == en.slope) SZX_BAIL(8);
-            if (nX >= MAX_CROSS) SZX_BAIL(9);
-            Pt pt = ccross_point(e, en, y);
-            if (pt.y < top_y) { pt.x = e.curx; pt.y = top_y; }
-            K.X[nX].e1 = sl[i]; K.X[nX].e2 = sl[i + 1]; K.X[nX].pt = pt; ++nX;
-            signed char t = sl[i]; sl[i] = sl[i + 1]; sl[i + 1] = t;
-            modified = true;
-          } else if (e.curx == en.curx && e.poly != en.poly) SZX_BAIL(10); // tie between the two rings
-          ++i;                                               // (after a swap the same edge keeps moving right)
-        }
+        SZX_EACH(i, if (i < 3 && i + 1 < ns) {
+            const int ia = sl[i], ib = sl[(i + 1) & 3];
+            const i64 xa = curx_of(ia), xb = curx_of(ib);
+            if (xa > xb) {
+              if ((ia >> 1) == (ib >> 1)) SZX_BAIL(7);        // bounds of one ring do not cross
+              const CEdge e = get(ia), en = get(ib);
+              if (e.slope == en.slope) SZX_BAIL(8);
+              if (nX >= MAX_CROSS) SZX_BAIL(9);
+              Pt pt = ccross_point(e, en, y);
+              if (pt.y < top_y) { pt.x = e.curx; pt.y = top_y; }
+              K.X[nX].e1 = ia; K.X[nX].e2 = ib; K.X[nX].pt = pt; ++nX;
+              sl[i] = ib; sl[(i + 1) & 3] = ia;   // (constant indices: this block is instantiated per i)
+              modified = true;
+            } else if (xa == xb && (ia >> 1) != (ib >> 1)) SZX_BAIL(10); // tie between the two rings
+          })                                                 // (after a swap the same edge keeps moving right)
         if (ns > 1) --ns; else break;
       } while (modified);
     }
@@ -307,29 +361,30 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb
         while (b > 0 && v.pt.y > K.X[b - 1].pt.y) { K.X[b] = K.X[b - 1]; --b; }
         K.X[b] = v;
       }
-      signed char *sl = K.sel;
-      for (int i = 0; i < k; ++i) sl[i] = ord[i];
+      SZX_EACH(s, sl[s] = ord[s];)
       for (int a = 0; a < nX; ++a) {
+        const int i1 = K.X[a].e1, i2 = K.X[a].e2;
         int p1 = -1, p2 = -1;
-        for (int i = 0; i < k; ++i) { if (sl[i] == K.X[a].e1) p1 = i; if (sl[i] == K.X[a].e2) p2 = i; }
+        SZX_EACH(s, if (s < k) { if (sl[s] == i1) p1 = s; if (sl[s] == i2) p2 = s; })
         if (p1 - p2 != 1 && p2 - p1 != 1) SZX_BAIL(11);      // the general code would reorder: leave it to it
-        signed char t = sl[p1]; sl[p1] = sl[p2]; sl[p2] = t;
+        SZX_EACH(s, sl[s] = (s == p1) ? i2 : (s == p2) ? i1 : sl[s];)
       }
     }
     for (int a = 0; a < nX; ++a) {
       // Clipper::IntersectEdges for two closed edges of different rings, even-odd, intersection
-      CEdge &e1 = ed[K.X[a].e1], &e2 = ed[K.X[a].e2];
+      const int i1 = K.X[a].e1, i2 = K.X[a].e2;
       const Pt pt = K.X[a].pt;
-      e1.wind2 = (signed char)(e1.wind2 == 0 ? 1 : 0);
-      e2.wind2 = (signed char)(e2.wind2 == 0 ? 1 : 0);
+      CEdge e1 = get(i1), e2 = get(i2);
+      e1.wind2 = (e1.wind2 == 0) ? 1 : 0;
+      e2.wind2 = (e2.wind2 == 0) ? 1 : 0;
       const bool c1 = e1.ring >= 0, c2 = e2.ring >= 0;
       if (c1 || c2) {
         // both: AddLocalMaxPoly, the ring closes here; one: that edge emits and hands ring and side over
         dq_emit(q, c1 ? e1.side : e2.side, pt);
         if (c1 && c2) { e1.ring = e2.ring = -1; q.open = false; }
         else {
-          signed char s = e1.side; e1.side = e2.side; e2.side = s;
-          signed char r = e1.ring; e1.ring = e2.ring; e2.ring = r;
+          int sd = e1.side; e1.side = e2.side; e2.side = sd;
+          int rg = e1.ring; e1.ring = e2.ring; e2.ring = rg;
         }
       } else {                              // AddLocalMinPoly(e1, e2): a ring starts at a crossing
         if (q.used) SZX_BAIL(12);
@@ -338,55 +393,60 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb
         e1.ring = e2.ring = 0;
         e1.side = szv::SIDE_RIGHT; e2.side = szv::SIDE_LEFT;
       }
-      int p1 = -1, p2 = -1;
-      for (int i = 0; i < k; ++i) { if (ord[i] == K.X[a].e1) p1 = i; if (ord[i] == K.X[a].e2) p2 = i; }
-      signed char t = ord[p1]; ord[p1] = ord[p2]; ord[p2] = t;
+      put_state(i1, e1); put_state(i2, e2);
+      const int p1 = pos_of(i1), p2 = pos_of(i2);
+      SZX_EACH(s, ord[s] = (s == p1) ? i2 : (s == p2) ? i1 : ord[s];)
     }
 
     // ---- top of the scanbeam (clipper.cpp:3009-3113); curx of every edge is already x(top_y) ----
-    for (int i = 0; i < k; ++i) {
-      CEdge &e = ed[ord[i]];
-      if (e.top.y != top_y) continue;
-      if (e.last) {
-        // DoMaxima: the other top edge of the ring must be the next active edge
-        if (i + 1 >= k) SZX_BAIL(14);
-        CEdge &mp = ed[ord[i + 1]];
-        if (mp.poly != e.poly || !(mp.top.y == top_y && mp.last)) SZX_BAIL(15);
-        if (e.ring >= 0 && mp.ring >= 0) { dq_emit(q, e.side, e.top); e.ring = mp.ring = -1; q.open = false; }
+    // One vertex per scanline: either the top vertex of a ring (its two edges leave together, DoMaxima) or an
+    // intermediate vertex of one bound.
+    {
+      int ending = -1, n_end = 0, n_last = 0;
+      SZX_EACH(s, if ((act >> s & 1) && ed[s].top.y == top_y) { ending = s; ++n_end; n_last += ed[s].last; })
+      if (n_end > 0 && n_last > 0) {
+        // DoMaxima: the two top edges of the ring must be neighbours in the active list
+        if (n_end != 2 || n_last != 2) SZX_BAIL(15);
+        const int pm = ending >> 1;
+        const int pa = pos_of(pm * 2), pb = pos_of(pm * 2 + 1);
+        if (pa < 0 || pb < 0 || (pa - pb != 1 && pb - pa != 1)) SZX_BAIL(14);
+        const int pf = pa < pb ? pa : pb;
+        const CEdge e = get(ord_at(pf)), mp = get(ord_at(pf + 1));
+        if (e.ring >= 0 && mp.ring >= 0) { dq_emit(q, e.side, e.top); q.open = false; }
         else if (e.ring >= 0 || mp.ring >= 0) SZX_BAIL(16);   // the general code reports an error here
-        for (int j = i + 2; j < k; ++j) ord[j - 2] = ord[j];
+        SZX_EACH(s, SZX_SET(ed[s].ring, (s >> 1) == pm, -1);)
+        SZX_EACH(s, SZX_SET(ord[s], s >= pf && s + 2 < 4, ord[s + 2 < 4 ? s + 2 : 3]);)
         k -= 2;
-        --i;                                 // the edge that slid into slot i is looked at next
-        continue;
+        act &= ~(3 << (pm * 2));
+      } else if (n_end == 1) {
+        // an intermediate vertex of a bound: emit it and step to the next edge of the bound
+        CEdge e = get(ending);
+        if (e.ring >= 0) dq_emit(q, e.side, e.top);
+        advance(e, ending >> 1);
+        e.curx = e.bot.x;
+        put(ending, e);
+        // a neighbour of the other ring passing through this vertex is the join case of the general code
+        const int pe = pos_of(ending);
+        if (pe > 0 && curx_of(ord_at(pe - 1)) == e.curx) SZX_BAIL(17);
+        if (pe + 1 < k && curx_of(ord_at(pe + 1)) == e.curx) SZX_BAIL(18);
       }
-      // an intermediate vertex of a bound: emit it and step to the next edge of the bound.  (The general
-      // code does this in a second pass over the list; with one vertex per scanline the order is the same.)
-      if (e.ring >= 0) dq_emit(q, e.side, e.top);
-      const Mono m = K.mono[e.poly];
-      int vt = e.vtop + e.dir;
-      if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-      e.bot = e.top; e.top = vert(K, e.poly, vt); e.vtop = (short)vt;
-      e.last = (vt == m.top);
-      cset_slope(e);
-      e.curx = e.bot.x;
-      // a neighbour of the other ring passing through this vertex is the join case of the general code
-      if (i > 0 && ed[ord[i - 1]].curx == e.curx) SZX_BAIL(17);
-      if (i + 1 < k && ed[ord[i + 1]].curx == e.curx) SZX_BAIL(18);
     }
     y = top_y;
 
     // ---- insertion of a ring's local minimum on this scanline (clipper.cpp:1978-2077) ----
     if (insert >= 0) {
-      const Mono m = K.mono[insert];
+      const Mono m = mono_of(insert);
       const Pt bot = vert(K, insert, m.bot);
       int pos = 0;
-      while (pos < k) {
-        const i64 ox = ed[ord[pos]].curx;
-        if (ox == bot.x) SZX_BAIL(19);        // a tie: vertex on an edge or coincident vertices
-        if (bot.x < ox) break;
-        ++pos;
-      }
-      for (int i = k - 1; i >= pos; --i) ord[i + 2] = ord[i];
+      bool tie = false, found = false;
+      SZX_EACH(s, if (s < k && !found) {
+        const i64 ox = curx_of(ord[s]);
+        if (ox == bot.x) tie = true;
+        if (bot.x < ox) found = true; else pos = s + 1;
+      })
+      if (tie) SZX_BAIL(19);                  // a tie: vertex on an edge or coincident vertices
+      SZX_SET(ord[3], 1 >= pos, ord[1]);
+      SZX_SET(ord[2], 0 >= pos, ord[0]);
       // even-odd winding against the other ring = parity of its edges to the left (clipper.cpp:1624-1729);
       // inside the other ring -> contributing -> AddLocalMinPoly (clipper.cpp:1841-1882)
       const int w2 = pos & 1;
@@ -396,22 +456,22 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb
       }
       for (int bound = 0; bound < 2; ++bound) {
         const int id = insert * 2 + bound;
-        ord[pos + bound] = (signed char)id;
+        SZX_EACH(s, SZX_SET(ord[s], s == pos + bound, id);)
         CEdge e;
-        e.poly = (signed char)insert;
-        e.dir = (signed char)(bound == 0 ? m.dir_left : -m.dir_left);
+        e.dir = (bound == 0) ? m.dir_left : -m.dir_left;
         int vt = m.bot + e.dir;
         if (vt < 0) vt += m.n; else if (vt >= m.n) vt -= m.n;
-        e.bot = bot; e.top = vert(K, insert, vt); e.vtop = (short)vt;
+        e.bot = bot; e.top = vert(K, insert, vt); e.vtop = vt;
         e.last = (vt == m.top);
         cset_slope(e);
         e.curx = bot.x;
-        e.wind2 = (signed char)w2;
-        e.ring = (signed char)(w2 ? 0 : -1);
-        e.side = (signed char)(w2 ? (bound == 0 ? szv::SIDE_LEFT : szv::SIDE_RIGHT) : szv::SIDE_NONE);
-        ed[id] = e;
+        e.wind2 = w2;
+        e.ring = w2 ? 0 : -1;
+        e.side = w2 ? (bound == 0 ? szv::SIDE_LEFT : szv::SIDE_RIGHT) : szv::SIDE_NONE;
+        put(id, e);
       }
       k += 2;
+      act |= 3 << (insert * 2);
       pending &= ~(1 << insert);
     }
     if (q.overflow) SZX_BAIL(20);

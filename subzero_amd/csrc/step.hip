@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(64, 4) k_narrow_occ4(i64 first, i64 count, con
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
 // k_narrow_convex_big: the same for the pairs that pass deferred, with room for 32-vertex rings, a few lanes per wave.
-#define CONVEX_STRIDE 824
-#define CONVEX_BIG_STRIDE 1464
+#define CONVEX_STRIDE 536
+#define CONVEX_BIG_STRIDE 1176
 static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
 static_assert(CONVEX_BIG_STRIDE % 16 == 8 && CONVEX_BIG_STRIDE == sizeof(szx::FastBlockBig), "lane stride must be 8 x odd and hold a FastBlockBig");
 __global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {

@@ -55,7 +55,6 @@ extern "C" int host_clip_batch(int npairs,
         if (ma > 1 && a.x[ma - 1] == a.x[0] && a.y[ma - 1] == a.y[0]) --ma;
         if (mb > 1 && b.x[mb - 1] == b.x[0] && b.y[mb - 1] == b.y[0]) --mb;
         if (ma <= (int)szx::FastBlock::NV && mb <= (int)szx::FastBlock::NV) {
-          blk.shifted = 0;
           bool exact = true;      // mode 2: hand the rings over in metres, as the step does (needs |v| < 2^53)
           if (g_try_fast == 2) {
             const int64_t lim = (int64_t)1 << 53;
@@ -65,7 +64,8 @@ extern "C" int host_clip_batch(int npairs,
           if (g_try_fast == 2 && exact) {
             for (int i = 0; i < ma; ++i) { blk.v.m.x[0][i] = (double)a.x[i] / 4294967296.0; blk.v.m.y[0][i] = (double)a.y[i] / 4294967296.0; }
             for (int i = 0; i < mb; ++i) { blk.v.m.x[1][i] = (double)b.x[i] / 4294967296.0; blk.v.m.y[1][i] = (double)b.y[i] / 4294967296.0; }
-            fs = szx::clip_monotone(fw, szx::VertsMetres(), ma, mb, s);
+            szx::VertsMetres vm = {0, 0.0, 0.0};
+            fs = szx::clip_monotone(fw, vm, ma, mb, s);
           } else {
             for (int i = 0; i < ma; ++i) blk.v.f[0][i] = a(i);
             for (int i = 0; i < mb; ++i) blk.v.f[1][i] = b(i);
