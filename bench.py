@@ -7,10 +7,12 @@ floe field; every 10th step refreshes the ocean/wind forcing, as the reference d
 concentration 1.0, periodic box, dt = 10 s (the configuration the metric's target is quoted on).
 
 One JSON line on stdout (rank 0).  `value` is floe-timesteps/s with all inputs resident in HBM.
-  roofline     : the pair-interaction kernel (k_narrow) priced by the ALGORITHMIC bytes of SURVEY.md 8(d)
-                 (16 B per ring vertex of both rings + 2 x 56 B of body scalars + 56 B per contact row)
-                 over its HIP-event duration, against the 8 TB/s HBM3E peak.  The kernel is bound by
-                 divergent int64/FP64 ALU work, not by HBM: the fraction is reported as computed.
+  roofline     : the pair-interaction kernel (k_narrow_convex: first pass of the narrow phase over every candidate
+                 pair) priced by the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per ring vertex of both rings +
+                 2 x 56 B of body scalars + 56 B per contact row) over its HIP-event duration, against the
+                 8 TB/s HBM3E peak.  The kernel is bound by the issue rate and latency of divergent int64/FP64
+                 code (one pair per lane), not by HBM: the fraction is reported as computed.  `traffic` is the
+                 PMC figure of profiles/r01_pmc_narrow.json (same command under rocprofv3 --pmc).
   cpu_baseline : the CPU oracle (C++ restatement of the MATLAB path around the reference's own Clipper)
                  on the host cores, a bounded sample of the same workload.  TEST INFRASTRUCTURE timed as a
                  baseline only; the product path never calls it.
@@ -129,7 +131,7 @@ def main():
         "candidate_pairs_per_s": pairs / el,
         "contact_rows_last_step": int(len(inter)), "collisions_last_step": collisions,
         "device_ms_per_step": dev_ms / k,
-        "roofline": {"bound": "hbm", "kernel": "k_narrow (pair interaction: clip + contact force)",
+        "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (pair interaction: clip + contact force, first pass over all pairs)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},

@@ -206,7 +206,7 @@ def bench_main(args, rank, local_rank, world):
             "timesteps_per_s": k / el,
             "contact_pairs_per_s": capi.collision_count(inter) * k / el,
             "candidate_pairs_per_s": pairs / el,
-            "roofline": {"bound": "hbm", "kernel": "k_narrow (rank 0's segment of the pair list)",
+            "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (rank 0's segment of the pair list)",
                          "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},

@@ -307,13 +307,19 @@ def run_ref(ps, method):
     return ClipResult(ox, oy, roff, proff, st)
 
 
-def run_host(ps, method, fill_s=0, fill_c=0):
+def run_host(ps, method, fill_s=0, fill_c=0, fast=0):
+    """fast = 1 / 2: try the single-minimum fast path (convex.hpp) first, from int64 rings / from rings in metres
+    as the step hands them over; what it declines goes to the general sweep.  r.fast = clips it completed."""
     L = host_lib()
+    L.host_clip_set_fast(int(fast))
     ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st = _alloc(ps)
     rc = L.host_clip_batch(len(ps), ax, ay, aoff, bx, by, boff, method, fill_s, fill_c,
                            ox, oy, cap_v, roff, cap_r, proff, st)
     assert rc == 0, rc
-    return ClipResult(ox, oy, roff, proff, st)
+    r = ClipResult(ox, oy, roff, proff, st)
+    r.fast = int(L.host_clip_fast_count())
+    L.host_clip_set_fast(0)
+    return r
 
 
 def compare(r1, r2, n):

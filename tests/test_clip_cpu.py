@@ -61,6 +61,44 @@ def test_device_engine_on_host_matches_live_reference(gen, n, kw):
         assert g.compare(r, h, len(ps)) == []
 
 
+# The single-minimum fast path (subzero_amd/csrc/convex.hpp): whatever it completes must be the reference's
+# answer bit for bit, whatever it declines must go to the general sweep -- on plainly convex input (all taken),
+# on input made of exact ties (mostly declined), on rings that share an edge and are then nudged by 1e-12..1e-1 of
+# their size, and on one-minimum rings with concave sides whose overlap has several rings.
+FAST_SETS = [
+    (g.convex_pairs, 6000, {}, 0.99),
+    (g.neighbour_pairs, 6000, {}, 0.9),
+    (g.monotone_pairs, 6000, {}, 0.5),
+    (g.hull_pairs, 6000, {"grid": 6}, 0.0),
+    (g.hull_pairs, 6000, {"grid": 40}, 0.2),
+    (g.hull_pairs, 6000, {"grid": 1000, "unit": 1 << 20}, 0.8),
+    (g.shape_pairs, 1500, {"max_verts": 9}, 0.5),
+    (g.lattice_pairs, 4000, {}, 0.0),
+    (g.rect_pairs, 2000, {}, 0.0),
+]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built and /root/reference absent")
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("gen,n,kw,min_taken", FAST_SETS)
+def test_fast_path_matches_live_reference(gen, n, kw, min_taken, mode):
+    ps = gen(n, seed=777, **kw)
+    r, h = g.run_ref(ps, 1), g.run_host(ps, 1, fast=mode)
+    assert g.compare(r, h, len(ps)) == []
+    assert h.fast >= min_taken * len(ps), (h.fast, len(ps))
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", g.GOLDEN_SETS)
+def test_fast_path_matches_golden(name, mode):
+    inp, res = g.load_golden(name)
+    ps = g.ArraysPairSet(inp)
+    h = g.run_host(ps, 1, fast=mode)
+    assert g.compare(res[1], h, len(ps)) == []
+    if name == "convex":
+        assert h.fast > 0.9 * len(ps)
+
+
 def test_matlab_int64_rounding():
     v = np.array([0.5, -0.5, 1.5, -1.5, 2.4999, -2.5, 1e30, -1e30, 0.49999999999999994])
     out = g.matlab_int64(v)
