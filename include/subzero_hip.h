@@ -37,7 +37,9 @@ enum {
   SZ_ERR_HIP = -3,       /* a HIP runtime call failed; see szLastError */
   SZ_ERR_CAPACITY = -4,  /* caller-provided output buffer too small */
   SZ_ERR_WORKSPACE = -5, /* a device-side list outgrew every workspace tier (never silent) */
-  SZ_ERR_STATE = -6      /* call out of order (e.g. szStep before szFloesUpload) */
+  SZ_ERR_STATE = -6,     /* call out of order (e.g. szStep before szFloesUpload) */
+  SZ_ERR_PEER = -7,      /* sharded step: another rank reported an error in its segment header */
+  SZ_SHARD_RESIZE = 1    /* sharded step, not an error: a segment has more contact rows than rows_max; exchange again */
 };
 
 /* per-clip status, one per pair (what the mex would have done for that call) */
@@ -61,6 +63,9 @@ int szAbiVersion(void);
 /* device = HIP device ordinal.  Fails with SZ_ERR_NO_DEVICE when no gfx950 GPU is usable. */
 int szCreate(szContext **ctx, int device);
 int szDestroy(szContext *ctx);
+/* Run everything on `hip_stream` (a hipStream_t of the context's device, owned by the caller, e.g. the stream a
+ * framework orders its collectives on) instead of the context's own stream; NULL switches back. */
+int szSetStream(szContext *ctx, void *hip_stream);
 /* text of the last failure on this context (static storage inside the context) */
 const char *szLastError(const szContext *ctx);
 
@@ -199,11 +204,21 @@ int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t ca
  * subzero_amd/multigpu.py).  After Finish every rank holds the same state a single-GPU szStep produces.
  *
  *   szStepShardBegin (params, rank, world) -> info        front stages + narrow-phase on my segment
- *   [caller: all-gather info.seg_rows -> rows_max = max over ranks]
- *   szStepShardExport(d_send, info.seg_max, rows_max)     my results into a device buffer of
- *                                                         szShardSegmentBytes(seg_max, rows_max) bytes
+ *   szStepShardExport(d_send, info.seg_max, rows_max, info.status)
+ *                                                         my results into a device buffer of
+ *                                                         szShardSegmentBytes(seg_max, rows_max) bytes; rows_max
+ *                                                         = the caller's guess of the most contact rows a segment
+ *                                                         has (the same on every rank, e.g. from the last step)
  *   [caller: all-gather d_send of every rank into d_recv (world x segment bytes, rank order)]
- *   szStepShardFinish(d_recv, seg_max, rows_max, stats, &fx)  import all segments, contact rows, sums
+ *   szStepShardFinish(d_recv, seg_max, rows_max, stats, &fx, &rows_needed)
+ *                                                         import all segments, contact rows, sums
+ * Each segment starts with a 32-byte header (pairs, contact rows, status, rows_max) written on the device, so no
+ * host round trip is needed between Begin and the all-gather.  Finish reads the headers first: if a rank reports
+ * an error every rank returns SZ_ERR_PEER; if a segment has more rows than rows_max every rank returns
+ * SZ_SHARD_RESIZE with the size that fits in *rows_needed, and the caller repeats Export / all-gather / Finish.
+ * A failure of the replicated front stages (info.replicated_failure = 1) is the same on every rank: nobody may
+ * enter the exchange.  With szSetStream(ctx, s) all of this runs on the caller's stream (the one its collectives
+ * are ordered on), otherwise Export and Forcing synchronise the context's own stream before they return.
  * d_recv must stay valid until Finish returns.  On steps that refresh the ocean/wind forcing (doInt) that
  * stage is sharded too: Finish evaluates the forcing of this rank's floe range only and sets fx = 1; then
  *   szStepShardForcing(d_send)    my FxOA / FyOA / torqueOA (szShardForcingBytes(ctx, world) bytes)
@@ -214,15 +229,15 @@ typedef struct szShardInfo {
   int64_t n_pairs;          /* candidate pairs of the step (same on every rank) */
   int64_t seg_lo, seg_hi;   /* my segment of the pair list */
   int64_t seg_max;          /* largest segment over all ranks */
-  int64_t seg_rows;         /* contact rows my segment produced */
-  int32_t status;           /* SZ_OK or the error of this rank; exchange it so that all ranks stop together */
-  int32_t reserved;
+  int64_t seg_rows;         /* -1: known on the device only (it travels in the segment header) */
+  int32_t status;           /* SZ_OK or the error of this rank; hand it to szStepShardExport so that all ranks stop together */
+  int32_t replicated_failure; /* 1: the error is in the replicated stages, identical on every rank */
 } szShardInfo;
 int64_t szShardSegmentBytes(int64_t seg_max, int64_t rows_max);
 int szStepShardBegin(szContext *ctx, const szStepParams *params, int rank, int world, szShardInfo *info);
-int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max);
+int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max, int32_t status);
 int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats,
-                      int32_t *forcing_exchange);
+                      int32_t *forcing_exchange, int64_t *rows_needed);
 int64_t szShardForcingBytes(szContext *ctx, int world);
 int szStepShardForcing(szContext *ctx, void *d_send);
 int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats);

@@ -115,7 +115,7 @@ EXPORTS = [
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
-    "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize",
+    "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
 ]
 
 _lib = None
@@ -155,6 +155,7 @@ def load():
     L.szCopyToDevice.argtypes = [_vp, _vp, _vp, ctypes.c_int64]
     L.szCopyToHost.argtypes = [_vp, _vp, _vp, ctypes.c_int64]
     L.szSynchronize.argtypes = [_vp]
+    L.szSetStream.argtypes = [_vp, _vp]
     _lib = L
     return L
 

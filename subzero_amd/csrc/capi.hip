@@ -19,11 +19,12 @@ int szCreate(szContext **out, int device) {
   if (hipSetDevice(device) != hipSuccess) return SZ_ERR_NO_DEVICE;
   szContext *ctx = new szContext();
   ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     delete ctx;
     return SZ_ERR_HIP;
   }
+  ctx->stream = ctx->own_stream;
   *out = ctx;
   return SZ_OK;
 }
@@ -40,8 +41,16 @@ int szDestroy(szContext *ctx) {
   for (DevBuf *b : bufs) sz_release(*b);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+  return SZ_OK;
+}
+
+int szSetStream(szContext *ctx, void *hip_stream) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));   // nothing of ours is left in flight on the old stream
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return SZ_OK;
 }
 

@@ -16,7 +16,8 @@ struct DevBuf {
 
 struct szContext {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream everything runs on: own_stream, or the caller's (szSetStream)
+  hipStream_t own_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = {0};
   std::vector<DevBuf *> owned;

@@ -5,13 +5,13 @@
 // For such input the general sweep (clipper.cpp:1560-3113) never holds more than four active edges -- the left
 // and the right bound of each ring -- and produces at most one output ring.  This file walks exactly the same
 // events in the same order and emits exactly the same points (same cross_point arithmetic, same front/back
-// insertion, same orientation fix-up, same first vertex), but its whole state is four edge records, the <= 12
-// vertices of each ring and six crossing slots (824 B, LDS-sized), and the output ring is a write-only deque.
+// insertion, same orientation fix-up, same first vertex), but its whole state is four edge records (registers), the
+// <= 16 vertices of each ring and six crossing slots (664 B of LDS), and the output ring is a write-only deque.
 // There are no linked lists to chase.
 //
 // It NEVER guesses.  Anything outside the plain case makes it return ST_BAIL before anything is written to the
 // sink, and the caller runs the general sweep instead:
-//   more vertices than the block holds (12 in the first pass, 32 in the second), duplicate or collinear input vertices (the general code would drop them),
+//   more vertices than the block holds (16), duplicate or collinear input vertices (the general code would drop them),
 //   more than one local minimum, a horizontal edge, two vertices on one scanline, parallel crossing edges,
 //   any tie in x between edges of the two rings (a vertex on an edge, coincident vertices, shared edges),
 //   a second output ring, an edge between the two top edges of a ring, collinear or duplicate output points,
@@ -82,10 +82,8 @@ struct FastBlockT {
   CCross X[MAX_CROSS];
   char tail[8];        // makes the size 8 x odd bytes: the same field of neighbouring lanes falls into different LDS banks
 };
-typedef FastBlockT<12> FastBlock;      // first pass over all pairs: 64 lanes x 536 B of LDS per wave
-typedef FastBlockT<32> FastBlockBig;   // second pass over the few pairs with longer rings: 1176 B per lane
-static_assert(sizeof(FastBlock) == 536 && sizeof(FastBlockBig) == 1176, "FastBlock layout changed: keep the size 8 x odd");
-static_assert((sizeof(FastBlock) / 8) % 2 == 1 && (sizeof(FastBlockBig) / 8) % 2 == 1, "lane stride must be 8 x odd");
+typedef FastBlockT<16> FastBlock;      // the step's fast pass: 64 lanes x 664 B of LDS per wave; longer rings take the general sweep
+static_assert(sizeof(FastBlock) == 664 && (sizeof(FastBlock) / 8) % 2 == 1, "FastBlock layout changed: keep the size 8 x odd");
 
 // MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
 SZ_HD i64 to_fixed(double v) {

@@ -36,6 +36,7 @@ struct StepState {
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_items, cell_x, cell_y, cell_r;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
+  std::vector<long long> hdr;     // segment headers of all ranks (szStepShardFinish)
   long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
   int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
@@ -49,7 +50,7 @@ struct StepState {
   int force_exchange = 0;
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 64;          // pairs per wave of that pass (SUBZERO_CONVEX_LANES)
-  int retry_lanes = 8;            // pairs per wave when the general kernel redoes what the first pass deferred (SUBZERO_RETRY_LANES)
+  int retry_lanes = 8;            // pairs per wave when the general kernel redoes what the fast pass deferred (SUBZERO_RETRY_LANES)
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
   int narrow_occ4 = -1;           // -1: choose per launch; 0 / 1 force the 1- / 4-waves-per-SIMD build (SUBZERO_NARROW_OCC4)
@@ -261,22 +262,13 @@ __global__ void __launch_bounds__(64, 4) k_narrow_occ4(i64 first, i64 count, con
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
-// k_narrow_convex_big: the same for the pairs that pass deferred, with room for 32-vertex rings, a few lanes per wave.
-#define CONVEX_STRIDE 536
-#define CONVEX_BIG_STRIDE 1176
+#define CONVEX_STRIDE 664
 static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
-static_assert(CONVEX_BIG_STRIDE % 16 == 8 && CONVEX_BIG_STRIDE == sizeof(szx::FastBlockBig), "lane stride must be 8 x odd and hold a FastBlockBig");
 __global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)threadIdx.x >= lanes) return;
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   if (t < count) narrow_convex(first + t, (const int *)nullptr, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
-}
-__global__ void __launch_bounds__(64) k_narrow_convex_big(i64 count, const int *list, int lanes, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow_convex(t, list, F, P, W, (szx::FastBlockBig *)(smem + (size_t)threadIdx.x * CONVEX_BIG_STRIDE));
 }
 
 // Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
@@ -297,6 +289,9 @@ __global__ void __launch_bounds__(64) k_narrow_b(int lanes, Floes F, Params P, W
   const i64 count = (i64)W.counters[C_TOUCH];
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   if (t < count) narrow_b(t, F, P, W, smem + (size_t)threadIdx.x * FAST_WS_STRIDE);
+}
+__global__ void k_export_header(char *base, i64 ns, const unsigned long long *rows, i64 status, i64 rows_max) {
+  seg_header(base, ns, status ? 0 : (i64)*rows, status, rows_max);
 }
 __global__ void k_export(i64 ns, i64 p_lo, Floes F, Work W, Xfer X) {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,7 +493,6 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
-  SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_convex_big, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CONVEX_BIG_STRIDE));
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int n = h->n;
   const int nv = h->vert_off[n];
@@ -698,25 +692,12 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
   SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
-  if (convex && c[C_RETRY] > 0) {
-    // second pass: what the 12-vertex blocks deferred, through the same fast path with 32-vertex blocks
-    const i64 nl = (i64)c[C_RETRY];
-    S->retried = nl;
-    SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
-    S->zero = 0;
-    SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
-    const int L = S->retry_lanes;
-    hipLaunchKernelGGL(k_narrow_convex_big, grid_for(nl, L), dim3(64), (size_t)L * CONVEX_BIG_STRIDE, st, nl, (const int *)S->retry_copy.p, L, F, P, W);
-    SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
-    SZ_HIP(ctx, hipStreamSynchronize(st));
-  }
   int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
   while (c[C_RETRY] > 0) {
     mult = mult ? mult * 8 : 1;
     if (mult > 512) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) outgrew the 512x scratch tier", c[C_RETRY]);
     i64 nl = (i64)c[C_RETRY];
-    if (mult == (fast ? 1 : 8) && !convex) S->retried = nl;
+    if (mult == (fast ? 1 : 8)) S->retried = nl;
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
     S->zero = 0;
     SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
@@ -825,9 +806,6 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
 }
 
 // ---- sharded form: Begin (front + my segment of the narrow-phase) / Export / Finish (import all + back) ----
-static size_t seg_bytes_for(i64 seg_max, i64 rows_max) {
-  return 16 + (size_t)((8 * seg_max + 7) / 8) * 8 + 40 * (size_t)rows_max; // header, nrows+flag (int32 each), rows
-}
 int64_t szShardSegmentBytes(int64_t seg_max, int64_t rows_max) { return (int64_t)seg_bytes_for(seg_max, rows_max); }
 
 int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world, szShardInfo *info) {
@@ -836,8 +814,9 @@ int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardBegin: no floes uploaded");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   memset(info, 0, sizeof(*info));
+  info->seg_rows = -1;
   int rc;
-  if ((rc = step_front(ctx, S, hp))) { info->status = rc; return rc; }
+  if ((rc = step_front(ctx, S, hp))) { info->status = rc; info->replicated_failure = 1; return rc; }
   S->rank = rank; S->world = world;
   shard_range(S->np, rank, world, S->seg_lo, S->seg_hi);
   rc = step_narrow(ctx, S, S->seg_lo, S->seg_hi);
@@ -845,46 +824,59 @@ int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world
   info->n_pairs = S->np; info->seg_lo = S->seg_lo; info->seg_hi = S->seg_hi;
   info->seg_max = shard_max(S->np, world);
   if (rc) return rc;
-  // rows before each pair of my segment (exclusive scan of pair_nrows over the segment)
+  // rows before each pair of my segment (exclusive scan of pair_nrows over the segment); the total stays on
+  // the device (counters[C_PAIRROWS]) and goes into the segment header
   const i64 ns = S->seg_hi - S->seg_lo;
-  if ((rc = sz_reserve(ctx, S->x_off, (size_t)(info->seg_max + 1) * 8))) return rc;
+  if ((rc = sz_reserve(ctx, S->x_off, (size_t)(info->seg_max + 1) * 8))) { info->status = rc; return rc; }
   launch_scan(ctx->stream, S->scan_agg, ns, ScanSegment{(const int *)S->W.pair_nrows + S->seg_lo, (i64 *)S->x_off.p, (int)ns,
                                                        &S->W.counters[C_PAIRROWS]});
   SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipMemcpyAsync(S->c, S->W.counters, sizeof(S->c), hipMemcpyDeviceToHost, ctx->stream));
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  info->seg_rows = (int64_t)S->c[C_PAIRROWS];
-  S->pair_rows_local = info->seg_rows;
   return SZ_OK;
 }
 
-int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max) {
+int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t rows_max, int32_t status) {
   if (!ctx || !d_send) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardExport: no floes uploaded");
-  const i64 ns = S->seg_hi - S->seg_lo;
-  if (ns > seg_max || S->pair_rows_local > rows_max) return sz_fail(ctx, SZ_ERR_CAPACITY, "szStepShardExport: segment does not fit");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 ns = status ? 0 : S->seg_hi - S->seg_lo;   // a failed rank sends its header only
+  if (ns > seg_max) return sz_fail(ctx, SZ_ERR_CAPACITY, "szStepShardExport: segment does not fit");
   char *base = (char *)d_send;
-  long long hdr[2] = {(long long)ns, (long long)S->pair_rows_local};
-  SZ_HIP(ctx, hipMemcpyAsync(base, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
-  Xfer X;
-  X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
-  X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
-  X.off = (i64 *)S->x_off.p;
+  Xfer X = seg_view(base, seg_max, rows_max, (i64 *)S->x_off.p);
+  hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, ctx->stream, base, ns, (const unsigned long long *)&S->W.counters[C_PAIRROWS],
+                     (i64)status, (i64)rows_max);
   if (ns > 0) hipLaunchKernelGGL(k_export, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, S->seg_lo, S->F, S->W, X);
   SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // hdr is a stack variable; the collective runs on another stream
+  if (ctx->stream == ctx->own_stream) SZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the collective runs on another stream
   return SZ_OK;
 }
 
 int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64_t rows_max, szStepStats *stats,
-                      int32_t *forcing_exchange) {
+                      int32_t *forcing_exchange, int64_t *rows_needed) {
   if (!ctx || !d_recv) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardFinish: no floes uploaded");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   const size_t seg_bytes = seg_bytes_for(seg_max, rows_max);
   int rc;
+  // the headers first: did every rank succeed, does every segment fit?
+  S->hdr.resize(4 * (size_t)S->world);
+  SZ_HIP(ctx, hipMemcpy2DAsync(S->hdr.data(), SEG_HDR, d_recv, seg_bytes, SEG_HDR, (size_t)S->world, hipMemcpyDeviceToHost, ctx->stream));
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  i64 need = 0;
+  for (int r = 0; r < S->world; ++r) {
+    const long long *h = &S->hdr[4 * (size_t)r];
+    if (h[2] != 0) return sz_fail(ctx, SZ_ERR_PEER, "sharded step: rank %d reported error %lld", r, h[2]);
+    i64 lo, hi;
+    shard_range(S->np, r, S->world, lo, hi);
+    if (h[0] != hi - lo || h[3] != rows_max)
+      return sz_fail(ctx, SZ_ERR_STATE, "sharded step: rank %d sent %lld pairs (rows_max %lld), expected %lld (%lld): the ranks are out of step",
+                     r, h[0], h[3], (long long)(hi - lo), (long long)rows_max);
+    if (h[1] > need) need = h[1];
+  }
+  if (rows_needed) *rows_needed = need;
+  if (need > rows_max) return SZ_SHARD_RESIZE;
+  S->pair_rows_local = S->hdr[4 * (size_t)S->rank + 1];
   if ((rc = sz_reserve(ctx, S->x_off, (size_t)(seg_max + 1) * 8))) return rc;
   S->W.g_rows = (double *)d_recv; // offsets below are in doubles from the start of the gathered buffer
   for (int r = 0; r < S->world; ++r) {
@@ -892,10 +884,7 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
     shard_range(S->np, r, S->world, lo, hi);
     const i64 ns = hi - lo;
     char *base = (char *)d_recv + (size_t)r * seg_bytes;
-    Xfer X;
-    X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
-    X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
-    X.off = (i64 *)S->x_off.p;
+    Xfer X = seg_view(base, seg_max, rows_max, (i64 *)S->x_off.p);
     if (ns == 0) continue;
     launch_scan(ctx->stream, S->scan_agg, ns, ScanSegment{(const int *)X.nrows, X.off, (int)ns, (unsigned long long *)nullptr});
     const i64 rows_base = (i64)(((char *)X.rows - (char *)d_recv) / 8);
@@ -932,7 +921,7 @@ int szStepShardForcing(szContext *ctx, void *d_send) {
   const int cm = force_cnt_max(S, S->world);
   if (f1 > f0) hipLaunchKernelGGL(k_force_export, grid_for(f1 - f0, 256), dim3(256), 0, ctx->stream, f0, f1 - f0, cm, S->F, (double *)d_send);
   SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream == ctx->own_stream) SZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the collective runs on another stream
   return SZ_OK;
 }
 

@@ -429,7 +429,6 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
   narrow_t<false, szx::FastBlock>(t, list, mult, F, P, W, fast_ws, fast_ws_bytes, nullptr);
 }
 // the single-minimum fast path only (convex.hpp); pairs it does not cover go to the retry list for narrow()
-// (list == nullptr: pair p itself; else the p-th entry of the list of pairs the 12-vertex pass deferred)
 template <class Blk>
 SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P, Work &W, Blk *blk) {
   narrow_t<true, Blk>(p, list, 1, F, P, W, nullptr, 0, blk);
@@ -656,16 +655,34 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
 // sharded narrow-phase: the pairs [p_lo, p_hi) a rank computed leave as (nrows, flag) per pair plus their
 // rows packed back to back; every rank imports every segment, after which all ranks hold identical results
 // ---------------------------------------------------------------------------------------------
+// One exported segment: [header 32 B: pairs, contact rows, status, rows_max as int64][rows-per-pair int32 x seg_max]
+// [flags int32 x seg_max][pad to 8][contact rows: 5 doubles each, rows_max of them]
+enum { SEG_HDR = 32 };
+SZ_HD size_t seg_bytes_for(i64 seg_max, i64 rows_max) {
+  return SEG_HDR + (size_t)((8 * seg_max + 7) / 8) * 8 + 40 * (size_t)rows_max;
+}
 struct Xfer {
   int *nrows, *flag; // per pair of the segment
   double *rows;      // 5 doubles per row, packed
   i64 *off;          // exclusive prefix sum of nrows over the segment (rows before pair k)
+  i64 rows_max;      // rows the buffer holds
 };
+SZ_HD Xfer seg_view(char *base, i64 seg_max, i64 rows_max, i64 *off) {
+  Xfer X;
+  X.nrows = (int *)(base + SEG_HDR); X.flag = X.nrows + seg_max;
+  X.rows = (double *)(base + SEG_HDR + (size_t)((8 * seg_max + 7) / 8) * 8);
+  X.off = off; X.rows_max = rows_max;
+  return X;
+}
+SZ_HD void seg_header(char *base, i64 ns, i64 rows, i64 status, i64 rows_max) {
+  i64 *h = (i64 *)base;
+  h[0] = ns; h[1] = rows; h[2] = status; h[3] = rows_max;
+}
 SZ_HD void export_pair(i64 k, i64 p_lo, const Floes &F, const Work &W, const Xfer &X) {
   const i64 p = p_lo + k;
   const int nr = W.pair_nrows[p];
   X.nrows[k] = nr; X.flag[k] = W.pair_flag[p];
-  if (nr > 0) {
+  if (nr > 0 && X.off[k] + nr <= X.rows_max) {     // (a segment that does not fit is exchanged again, larger)
     const double *src = pair_rows(p, F, W);
     double *dst = X.rows + 5 * X.off[k];
     for (int q = 0; q < 5 * nr; ++q) dst[q] = src[q];

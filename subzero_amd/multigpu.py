@@ -35,7 +35,7 @@ class ShardInfo(ctypes.Structure):
     """szShardInfo"""
     _fields_ = [("n_pairs", ctypes.c_int64), ("seg_lo", ctypes.c_int64), ("seg_hi", ctypes.c_int64),
                 ("seg_max", ctypes.c_int64), ("seg_rows", ctypes.c_int64), ("status", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("replicated_failure", ctypes.c_int32)]
 
 
 class GpuBackend:
@@ -54,9 +54,13 @@ class GpuBackend:
         L.szShardSegmentBytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
         L.szStepShardBegin.argtypes = [ctypes.c_void_p, ctypes.POINTER(capi.StepParamsC), ctypes.c_int, ctypes.c_int,
                                        ctypes.POINTER(ShardInfo)]
-        L.szStepShardExport.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        L.szStepShardExport.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]
         L.szStepShardFinish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                        ctypes.POINTER(capi.StepStats), ctypes.POINTER(ctypes.c_int32)]
+                                        ctypes.POINTER(capi.StepStats), ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.POINTER(ctypes.c_int64)]
+        # kernels and collectives on one stream: the exchange is then ordered by the stream, not by the host
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx.check(L.szSetStream(self.ctx.h, ctypes.c_void_p(self.stream.cuda_stream)), "szSetStream")
         L.szShardForcingBytes.restype = ctypes.c_int64
         L.szShardForcingBytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.szStepShardForcing.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -83,24 +87,23 @@ class GpuBackend:
             self._bufs[name] = b
         return b[:nbytes]
 
-    def small(self, values):
-        return self.torch.tensor(values, dtype=self.torch.int64, device=self.device)
+    def stream_scope(self):
+        """Context manager under which the caller issues its collectives (torch's current stream = ours)."""
+        return self.torch.cuda.stream(self.stream)
 
-    def export(self, send, seg_max, rows_max):
-        self.ctx.check(self.ctx.L.szStepShardExport(self.ctx.h, ctypes.c_void_p(send.data_ptr()), seg_max, rows_max),
-                       "szStepShardExport")
-
-    def after_collective(self):
-        # the exchange ran on torch's RCCL stream, the kernels run on the context's stream: join on the host
-        self.torch.cuda.synchronize(self.device)
+    def export(self, send, seg_max, rows_max, status):
+        self.ctx.check(self.ctx.L.szStepShardExport(self.ctx.h, ctypes.c_void_p(send.data_ptr()), seg_max, rows_max,
+                                                    int(status)), "szStepShardExport")
 
     def finish(self, recv, seg_max, rows_max):
-        """-> (stats, forcing_exchange_pending)"""
+        """-> (code, rows_needed, stats, forcing_exchange_pending); code 0, or capi.SHARD_RESIZE, or an error"""
         self._st = self.capi.StepStats()
         fx = ctypes.c_int32(0)
-        self.ctx.check(self.ctx.L.szStepShardFinish(self.ctx.h, ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max,
-                                                    ctypes.byref(self._st), ctypes.byref(fx)), "szStepShardFinish")
-        return self._st, bool(fx.value)
+        need = ctypes.c_int64(0)
+        rc = self.ctx.L.szStepShardFinish(self.ctx.h, ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max,
+                                          ctypes.byref(self._st), ctypes.byref(fx), ctypes.byref(need))
+        self._err = self.ctx.L.szLastError(self.ctx.h).decode() if rc < 0 else ""
+        return rc, int(need.value), self._st, bool(fx.value)
 
     def forcing_bytes(self, world):
         return int(self.ctx.L.szShardForcingBytes(self.ctx.h, world))
@@ -124,25 +127,37 @@ class ShardedInteractions:
         import torch.distributed as dist
         self.dist, self.backend, self.rank, self.world, self.group = dist, backend, rank, world, group
 
+    SHARD_RESIZE = 1   # szStepShardFinish: a segment has more contact rows than the buffers were sized for
+    min_rows = 64      # smallest row capacity of a segment buffer
+
     def step(self, P):
         be, dist = self.backend, self.dist
+        with be.stream_scope():
+            return self._step(P, be, dist)
+
+    def _step(self, P, be, dist):
         info = be.begin(P, self.rank, self.world)
-        mine = be.small([int(info.status), int(info.seg_rows)])
-        allc = [be.small([0, 0]) for _ in range(self.world)]
-        dist.all_gather(allc, mine, group=self.group)
-        allc = [t.tolist() for t in allc]
-        bad = [(r, c[0]) for r, c in enumerate(allc) if c[0] != 0]
-        if bad:   # every rank sees the same list and stops together: no rank is left waiting in a collective
-            raise RuntimeError("sharded step failed on rank(s) %s%s" % (bad, (": " + be.last_error()) if info.status else ""))
-        rows_max = max(c[1] for c in allc)
+        if info.status and info.replicated_failure:
+            # the replicated stages failed: the same error on every rank, nobody enters the exchange
+            raise RuntimeError("sharded step failed in the replicated stages (%d): %s" % (info.status, be.last_error()))
         seg_max = int(info.seg_max)
-        nbytes = be.segment_bytes(seg_max, rows_max)
-        send = be.buffer("send", nbytes)
-        recv = be.buffer("recv", nbytes * self.world)
-        be.export(send, seg_max, rows_max)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        be.after_collective()
-        st, forcing_pending = be.finish(recv, seg_max, rows_max)
+        # rows per segment: sized from the last step (the same number on every rank); a segment that does not
+        # fit is reported by every rank's Finish, and the exchange is repeated with the size that does
+        rows_max = max(self.min_rows, int(1.25 * getattr(self, "_rows_seen", seg_max)) + 64)
+        while True:
+            nbytes = be.segment_bytes(seg_max, rows_max)
+            send = be.buffer("send", nbytes)
+            recv = be.buffer("recv", nbytes * self.world)
+            be.export(send, seg_max, rows_max, info.status)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            rc, need, st, forcing_pending = be.finish(recv, seg_max, rows_max)
+            if rc == self.SHARD_RESIZE:
+                rows_max = need + 64
+                continue
+            if rc != 0:   # every rank sees the same headers and stops together: no rank is left in a collective
+                raise RuntimeError("sharded step failed (%d): %s" % (rc, be.last_error()))
+            self._rows_seen = need
+            break
         if forcing_pending:
             # forcing step: every rank evaluated the ocean / wind forcing of its own floe range
             fb = be.forcing_bytes(self.world)
@@ -150,7 +165,6 @@ class ShardedInteractions:
             frecv = be.buffer("frecv", fb * self.world)
             be.forcing_export(fsend)
             dist.all_gather_into_tensor(frecv, fsend, group=self.group)
-            be.after_collective()
             st = be.end(frecv)
         self.last_info = info
         return st

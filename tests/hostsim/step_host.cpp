@@ -207,12 +207,6 @@ struct Sim {
       }
     }
     retried = (i64)W.counters[C_RETRY];
-    if (g_narrow_mode == 2 && W.counters[C_RETRY] > 0) {     // second pass: the fast path with 32-vertex blocks
-      std::vector<int> l2(W.retry_list, W.retry_list + W.counters[C_RETRY]);
-      W.counters[C_RETRY] = 0;
-      szx::FastBlockBig big;
-      for (size_t t = 0; t < l2.size(); ++t) narrow_convex((i64)t, l2.data(), F, P, W, &big);
-    }
     int mult = (g_narrow_mode != 0) ? 0 : 1;   // the fast path's leftovers start at the 1x general tier
     std::vector<int> list;
     while (W.counters[C_RETRY] > 0) {
@@ -283,10 +277,6 @@ struct Sim {
 
 Sim g_sim; // the sharded entry points keep their state between calls, as the GPU context does
 
-size_t seg_bytes_for(i64 seg_max, i64 rows_max) {
-  return 16 + (size_t)((8 * seg_max + 7) / 8) * 8 + 40 * (size_t)rows_max; // same layout as step.hip
-}
-
 } // namespace
 
 extern "C" {
@@ -309,12 +299,13 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
 // ---- sharded form, mirroring szStepShardBegin / Export / Finish ----
 int64_t host_shard_segment_bytes(int64_t seg_max, int64_t rows_max) { return (int64_t)seg_bytes_for(seg_max, rows_max); }
 
-// info: [n_pairs, seg_lo, seg_hi, seg_max, seg_rows, status]
+// info: [n_pairs, seg_lo, seg_hi, seg_max, seg_rows (-1: in the segment header), status, replicated_failure]
 int host_shard_begin(HFloes *hf, const HParams *hp, int rank, int world, int64_t *info) {
   Sim &s = g_sim;
   s.bind(hf, hp, 32);
   s.rank = rank; s.world = world;
   int rc = s.front(false);
+  info[6] = rc ? 1 : 0;
   if (!rc) {
     shard_range(s.np, rank, world, s.seg_lo, s.seg_hi);
     rc = s.narrow_range(s.seg_lo, s.seg_hi);
@@ -323,28 +314,35 @@ int host_shard_begin(HFloes *hf, const HParams *hp, int rank, int world, int64_t
   i64 acc = 0;
   if (!rc) for (i64 k = 0; k < s.seg_hi - s.seg_lo; ++k) { s.x_off[k] = acc; acc += s.W.pair_nrows[s.seg_lo + k]; }
   s.seg_rows = acc;
-  info[0] = s.np; info[1] = s.seg_lo; info[2] = s.seg_hi; info[3] = shard_max(s.np, world); info[4] = acc; info[5] = rc;
+  info[0] = s.np; info[1] = s.seg_lo; info[2] = s.seg_hi; info[3] = shard_max(s.np, world); info[4] = -1; info[5] = rc;
   return rc;
 }
-int host_shard_export(void *send, int64_t seg_max, int64_t rows_max) {
+int host_shard_export(void *send, int64_t seg_max, int64_t rows_max, int32_t status) {
   Sim &s = g_sim;
-  const i64 ns = s.seg_hi - s.seg_lo;
-  if (ns > seg_max || s.seg_rows > rows_max) return -1;
+  const i64 ns = status ? 0 : s.seg_hi - s.seg_lo;
+  if (ns > seg_max) return -1;
   char *base = (char *)send;
-  long long hdr[2] = {(long long)ns, (long long)s.seg_rows};
-  memcpy(base, hdr, 16);
-  Xfer X;
-  X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
-  X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
-  X.off = s.x_off.data();
+  seg_header(base, ns, status ? 0 : s.seg_rows, status, rows_max);
+  Xfer X = seg_view(base, seg_max, rows_max, s.x_off.data());
   for (i64 k = 0; k < ns; ++k) export_pair(k, s.seg_lo, s.F, s.W, X);
   return 0;
 }
-// Finish: import + contact rows + sums; on a forcing step with world > 1 only this rank's floe range is
-// forced and *fx = 1 (then host_shard_forcing / host_shard_end complete the step)
-int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32_t *fx) {
+// Finish: headers, import + contact rows + sums; on a forcing step with world > 1 only this rank's floe range is
+// forced and *fx = 1 (then host_shard_forcing / host_shard_end complete the step).  Return codes as szStepShardFinish.
+int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32_t *fx, int64_t *rows_needed) {
   Sim &s = g_sim;
   const size_t seg_bytes = seg_bytes_for(seg_max, rows_max);
+  i64 need = 0;
+  for (int r = 0; r < s.world; ++r) {
+    const i64 *h = (const i64 *)((const char *)recv + (size_t)r * seg_bytes);
+    if (h[2] != 0) return -7;
+    i64 lo, hi;
+    shard_range(s.np, r, s.world, lo, hi);
+    if (h[0] != hi - lo || h[3] != rows_max) return -6;
+    if (h[1] > need) need = h[1];
+  }
+  *rows_needed = need;
+  if (need > rows_max) return 1;
   s.W.g_rows = (double *)recv;
   std::vector<i64> off;
   for (int r = 0; r < s.world; ++r) {
@@ -352,13 +350,10 @@ int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32
     shard_range(s.np, r, s.world, lo, hi);
     const i64 ns = hi - lo;
     char *base = (char *)recv + (size_t)r * seg_bytes;
-    Xfer X;
-    X.nrows = (int *)(base + 16); X.flag = X.nrows + seg_max;
-    X.rows = (double *)(base + 16 + (size_t)((8 * seg_max + 7) / 8) * 8);
     off.assign((size_t)ns + 1, 0);
+    Xfer X = seg_view(base, seg_max, rows_max, off.data());
     i64 acc = 0;
     for (i64 k = 0; k < ns; ++k) { off[k] = acc; acc += X.nrows[k]; }
-    X.off = off.data();
     const i64 rows_base = (i64)(((char *)X.rows - (char *)recv) / 8);
     for (i64 k = 0; k < ns; ++k) import_pair(k, lo, rows_base, s.W, X);
   }

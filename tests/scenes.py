@@ -40,15 +40,15 @@ def concave(n=60, periodic=True, seed=11, n_stress=16):
 
 
 def many_sided(n=64, periodic=True, seed=21, n_stress=16):
-    """Convex floes with 10 to 30 vertices (irregular polygons inscribed in circles) on a jittered lattice,
-    overlapping a little: rings too long for the 12-vertex blocks of the first narrow-phase pass -- they take
-    the 32-vertex second pass (convex.hpp FastBlockBig), the longest ones the general sweep."""
+    """Convex floes with 8 to 39 vertices (irregular polygons inscribed in circles) on a jittered lattice,
+    overlapping a little: rings of up to 16 vertices take the fast pass of the narrow phase (convex.hpp
+    FastBlock), the longer ones are handed to the general sweep."""
     rng = np.random.default_rng(seed)
     side = int(np.ceil(np.sqrt(n)))
     pitch = 2e5 / side
     polys = []
     for k in range(n):
-        m = int(rng.integers(10, 31)) if k % 7 else int(rng.integers(33, 40))
+        m = int(rng.integers(8, 25)) if k % 7 else int(rng.integers(33, 40))
         ang = np.sort(rng.uniform(0, 2 * np.pi, m))
         ang = ang[np.concatenate([[True], np.diff(ang) > 0.02])]
         r = 0.53 * pitch * rng.uniform(0.9, 1.0)

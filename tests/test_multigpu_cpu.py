@@ -39,8 +39,9 @@ class HostBackend:
         self.L.host_shard_segment_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
         self.L.host_shard_begin.argtypes = [ctypes.POINTER(oracle.CFloes), ctypes.POINTER(oracle.CParams), ctypes.c_int,
                                             ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
-        self.L.host_shard_export.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
-        self.L.host_shard_finish.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, oracle._ip]
+        self.L.host_shard_export.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]
+        self.L.host_shard_finish.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, oracle._ip,
+                                             ctypes.POINTER(ctypes.c_int64)]
         self.L.host_shard_forcing_bytes.restype = ctypes.c_int64
         self.L.host_shard_forcing_bytes.argtypes = [ctypes.c_int]
         self.L.host_shard_forcing.argtypes = [ctypes.c_void_p]
@@ -48,15 +49,17 @@ class HostBackend:
         self.L.host_shard_outputs.argtypes = [oracle._ip, oracle._dp, ctypes.c_int64, oracle._ip, oracle._ip,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), oracle._ip]
         self.exchanges = 0
+        self.finish_codes = []
         self._bufs = {}
 
     def begin(self, P, rank, world):
         from subzero_amd.multigpu import ShardInfo
         self.cp = self.orc.pack_params(P)
-        raw = (ctypes.c_int64 * 6)()
+        raw = (ctypes.c_int64 * 7)()
         self.L.host_shard_begin(ctypes.byref(self.cf), ctypes.byref(self.cp), rank, world, raw)
         info = ShardInfo()
-        info.n_pairs, info.seg_lo, info.seg_hi, info.seg_max, info.seg_rows, info.status = [int(v) for v in raw]
+        (info.n_pairs, info.seg_lo, info.seg_hi, info.seg_max, info.seg_rows, info.status,
+         info.replicated_failure) = [int(v) for v in raw]
         return info
 
     def last_error(self):
@@ -72,14 +75,12 @@ class HostBackend:
             self._bufs[name] = b
         return b[:nbytes]
 
-    def small(self, values):
-        return self.torch.tensor(values, dtype=self.torch.int64)
+    def stream_scope(self):
+        import contextlib
+        return contextlib.nullcontext()
 
-    def export(self, send, seg_max, rows_max):
-        assert self.L.host_shard_export(ctypes.c_void_p(send.data_ptr()), seg_max, rows_max) == 0
-
-    def after_collective(self):
-        pass
+    def export(self, send, seg_max, rows_max, status):
+        assert self.L.host_shard_export(ctypes.c_void_p(send.data_ptr()), seg_max, rows_max, int(status)) == 0
 
     def _outputs(self):
         S = self.S
@@ -96,11 +97,12 @@ class HostBackend:
 
     def finish(self, recv, seg_max, rows_max):
         fx = ctypes.c_int32(0)
-        rc = self.L.host_shard_finish(ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max, ctypes.byref(fx))
-        assert rc == 0, rc
-        if not fx.value:
+        need = ctypes.c_int64(0)
+        rc = self.L.host_shard_finish(ctypes.c_void_p(recv.data_ptr()), seg_max, rows_max, ctypes.byref(fx), ctypes.byref(need))
+        self.finish_codes.append(rc)
+        if rc == 0 and not fx.value:
             self._outputs()
-        return None, bool(fx.value)
+        return rc, int(need.value), None, bool(fx.value)
 
     def forcing_bytes(self, world):
         return int(self.L.host_shard_forcing_bytes(world))
@@ -133,6 +135,8 @@ def _worker(rank, world, port, scene, steps, q):
         for it in range(steps):
             P.doInt = int(it % 5 == 0)
             r1 = hoststep.step(ref, P)             # single-process device pipeline (pinned to the oracle elsewhere)
+            if it == 3:                            # buffers far too small: the exchange must repeat, larger
+                sim.min_rows, sim._rows_seen = 1, -1000
             sim.step(P)
             info = sim.last_info
             segs.append((int(info.n_pairs), int(info.seg_lo), int(info.seg_hi)))
@@ -140,6 +144,18 @@ def _worker(rank, world, port, scene, steps, q):
             assert np.array_equal(r1.inter_off, be.inter_off) and np.array_equal(r1.inter, be.inter), "rows differ at step %d" % it
             bad = hoststep.compare_states(ref, S)
             assert bad == [], "state differs at step %d: %s" % (it, bad)
+        assert multigpu.ShardedInteractions.SHARD_RESIZE in be.finish_codes     # step 3 went round twice
+        # an error on one rank travels in its segment header: every rank stops, none is left in a collective
+        real_begin = be.begin
+        def failing_begin(P_, rank_, world_):
+            info = real_begin(P_, rank_, world_)
+            if rank_ == 1:
+                info.status = -5
+            return info
+        be.begin = failing_begin
+        with pytest.raises(RuntimeError):
+            sim.step(P)
+        assert be.finish_codes[-1] == -7
         dist.destroy_process_group()
         assert be.exchanges == 2, be.exchanges        # forcing steps 0 and 5 went through the second all-gather
         assert np.abs(S.FxOA).max() > 0

@@ -25,23 +25,35 @@ def test_two_emulated_ranks_equal_single_gpu_step():
     world = 2
     copies = [S.copy() for _ in range(world)]
     bes = [multigpu.GpuBackend(copies[r], 0) for r in range(world)]
+    resized_any = False
     for it in range(10):
         P.doInt = int(it % 5 == 0)
         ref_sim.step(P)
         infos = [bes[r].begin(P, r, world) for r in range(world)]
         assert all(i.status == 0 for i in infos)
         assert infos[0].seg_lo == 0 and infos[0].seg_hi == infos[1].seg_lo and infos[1].seg_hi == infos[1].n_pairs
-        rows_max = max(int(i.seg_rows) for i in infos)
         seg_max = int(infos[0].seg_max)
-        nbytes = bes[0].segment_bytes(seg_max, rows_max)
-        sends = []
-        for r in range(world):
-            s = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
-            bes[r].export(s, seg_max, rows_max)
-            sends.append(s)
-        recv = torch.cat(sends)             # what all_gather_into_tensor delivers, rank order
-        torch.cuda.synchronize()
-        pend = [bes[r].finish(recv, seg_max, rows_max)[1] for r in range(world)]
+        rows_max, resized = 8, False            # far too small on purpose: Finish must ask for a larger exchange
+        while True:
+            nbytes = bes[0].segment_bytes(seg_max, rows_max)
+            sends = []
+            for r in range(world):
+                s = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+                bes[r].export(s, seg_max, rows_max, infos[r].status)
+                sends.append(s)
+            torch.cuda.synchronize()            # the backends run on streams of their own
+            recv = torch.cat(sends)             # what all_gather_into_tensor delivers, rank order
+            torch.cuda.synchronize()
+            res = [bes[r].finish(recv, seg_max, rows_max) for r in range(world)]
+            codes = [x[0] for x in res]
+            if codes == [multigpu.ShardedInteractions.SHARD_RESIZE] * world:
+                assert res[0][1] == res[1][1] > rows_max
+                rows_max, resized = res[0][1], True
+                continue
+            assert codes == [0] * world, codes
+            break
+        resized_any = resized_any or resized
+        pend = [x[3] for x in res]
         assert pend == [bool(P.doInt)] * world
         if pend[0]:                          # forcing step: the second exchange, again concatenated by hand
             fb = bes[0].forcing_bytes(world)
@@ -50,6 +62,7 @@ def test_two_emulated_ranks_equal_single_gpu_step():
                 t = torch.empty(fb, dtype=torch.uint8, device="cuda:0")
                 bes[r].forcing_export(t)
                 fs.append(t)
+            torch.cuda.synchronize()
             frecv = torch.cat(fs)
             torch.cuda.synchronize()
             for r in range(world):
@@ -61,7 +74,7 @@ def test_two_emulated_ranks_equal_single_gpu_step():
             off, rows = bes[r].sim.interactions()
             assert np.array_equal(off, off0) and np.array_equal(rows, rows0), "rank %d step %d" % (r, it)
             assert hoststep.compare_states(ref, copies[r]) == [], "rank %d step %d" % (r, it)
-    assert len(rows0) > 0
+    assert len(rows0) > 0 and resized_any
     for b in bes:
         b.close()
     c0.close()

@@ -110,8 +110,16 @@ def test_general_sweep_for_every_pair_matches_oracle(ctx, monkeypatch):
     assert exact
 
 
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
+def test_more_fields_through_the_fast_pass(ctx, seed):
+    # different Voronoi fields, speeds and boundary types: every one bit-identical to the oracle
+    S, P = scenes.pack(260 + seed % 7 * 20, periodic=bool(seed % 2), seed=seed, vel_seed=seed + 1, sigma=0.1 + 0.05 * (seed % 5))
+    A, G, exact = lockstep(ctx, S, P, 9)
+    assert exact
+
+
 def test_long_convex_rings(ctx):
-    # 10..39-vertex convex floes: first pass (12-vertex blocks), second pass (32-vertex blocks), general sweep
+    # 8..39-vertex convex floes: fast pass (16-vertex blocks) and general sweep for the longer rings
     S, P = scenes.many_sided(64)
     A, G, exact = lockstep(ctx, S, P, 12)
     assert exact
