@@ -225,6 +225,7 @@ int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t ca
  *   [caller: all-gather]
  *   szStepShardEnd(d_recv, stats) import the other ranks' values, finish the step (calc_trajectory.m:174-234)
  * When fx = 0 the step is complete after Finish (szStepShardEnd is then a no-op). */
+/* Segment bytes: header 32 + 12 per pair slot (rows, flags, rows-before as int32) + 40 per contact row. */
 typedef struct szShardInfo {
   int64_t n_pairs;          /* candidate pairs of the step (same on every rank) */
   int64_t seg_lo, seg_hi;   /* my segment of the pair list */

@@ -293,13 +293,13 @@ __global__ void __launch_bounds__(64) k_narrow_b(int lanes, Floes F, Params P, W
 __global__ void k_export_header(char *base, i64 ns, const unsigned long long *rows, i64 status, i64 rows_max) {
   seg_header(base, ns, status ? 0 : (i64)*rows, status, rows_max);
 }
-__global__ void k_export(i64 ns, i64 p_lo, Floes F, Work W, Xfer X) {
+__global__ void k_export(i64 ns, i64 p_lo, const i64 *off, Floes F, Work W, Xfer X) {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < ns) export_pair(k, p_lo, F, W, X);
+  if (k < ns) export_pair(k, p_lo, off, F, W, X);
 }
-__global__ void k_import(i64 ns, i64 p_lo, i64 rows_base, Work W, Xfer X) {
-  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < ns) import_pair(k, p_lo, rows_base, W, X);
+__global__ void k_import(i64 np, int world, i64 seg_max, i64 rows_max, char *recv, Work W) {
+  i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < np) import_pair(p, np, world, seg_max, rows_max, recv, W);
 }
 __global__ void k_incoming(i64 np, Work W) {
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -842,10 +842,10 @@ int szStepShardExport(szContext *ctx, void *d_send, int64_t seg_max, int64_t row
   const i64 ns = status ? 0 : S->seg_hi - S->seg_lo;   // a failed rank sends its header only
   if (ns > seg_max) return sz_fail(ctx, SZ_ERR_CAPACITY, "szStepShardExport: segment does not fit");
   char *base = (char *)d_send;
-  Xfer X = seg_view(base, seg_max, rows_max, (i64 *)S->x_off.p);
+  Xfer X = seg_view(base, seg_max, rows_max);
   hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, ctx->stream, base, ns, (const unsigned long long *)&S->W.counters[C_PAIRROWS],
                      (i64)status, (i64)rows_max);
-  if (ns > 0) hipLaunchKernelGGL(k_export, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, S->seg_lo, S->F, S->W, X);
+  if (ns > 0) hipLaunchKernelGGL(k_export, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, S->seg_lo, (const i64 *)S->x_off.p, S->F, S->W, X);
   SZ_HIP(ctx, hipGetLastError());
   if (ctx->stream == ctx->own_stream) SZ_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the collective runs on another stream
   return SZ_OK;
@@ -877,19 +877,8 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
   if (rows_needed) *rows_needed = need;
   if (need > rows_max) return SZ_SHARD_RESIZE;
   S->pair_rows_local = S->hdr[4 * (size_t)S->rank + 1];
-  if ((rc = sz_reserve(ctx, S->x_off, (size_t)(seg_max + 1) * 8))) return rc;
-  S->W.g_rows = (double *)d_recv; // offsets below are in doubles from the start of the gathered buffer
-  for (int r = 0; r < S->world; ++r) {
-    i64 lo, hi;
-    shard_range(S->np, r, S->world, lo, hi);
-    const i64 ns = hi - lo;
-    char *base = (char *)d_recv + (size_t)r * seg_bytes;
-    Xfer X = seg_view(base, seg_max, rows_max, (i64 *)S->x_off.p);
-    if (ns == 0) continue;
-    launch_scan(ctx->stream, S->scan_agg, ns, ScanSegment{(const int *)X.nrows, X.off, (int)ns, (unsigned long long *)nullptr});
-    const i64 rows_base = (i64)(((char *)X.rows - (char *)d_recv) / 8);
-    hipLaunchKernelGGL(k_import, grid_for(ns, 256), dim3(256), 0, ctx->stream, ns, lo, rows_base, S->W, X);
-  }
+  S->W.g_rows = (double *)d_recv; // pair_rowoff is in doubles from the start of the gathered buffer
+  if (S->np > 0) hipLaunchKernelGGL(k_import, grid_for(S->np, 256), dim3(256), 0, ctx->stream, S->np, S->world, (i64)seg_max, (i64)rows_max, (char *)d_recv, S->W);
   SZ_HIP(ctx, hipGetLastError());
   rc = step_back_a(ctx, S);
   S->W.g_rows = nullptr; // the rows have been copied into the CSR; d_recv may be reused by the caller

@@ -656,46 +656,53 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
 // rows packed back to back; every rank imports every segment, after which all ranks hold identical results
 // ---------------------------------------------------------------------------------------------
 // One exported segment: [header 32 B: pairs, contact rows, status, rows_max as int64][rows-per-pair int32 x seg_max]
-// [flags int32 x seg_max][pad to 8][contact rows: 5 doubles each, rows_max of them]
+// [flags int32 x seg_max][rows-before-pair int32 x seg_max][pad to 8][contact rows: 5 doubles each, rows_max of them]
 enum { SEG_HDR = 32 };
-SZ_HD size_t seg_bytes_for(i64 seg_max, i64 rows_max) {
-  return SEG_HDR + (size_t)((8 * seg_max + 7) / 8) * 8 + 40 * (size_t)rows_max;
-}
+SZ_HD size_t seg_rows_at(i64 seg_max) { return SEG_HDR + (size_t)((12 * seg_max + 7) / 8) * 8; }
+SZ_HD size_t seg_bytes_for(i64 seg_max, i64 rows_max) { return seg_rows_at(seg_max) + 40 * (size_t)rows_max; }
 struct Xfer {
-  int *nrows, *flag; // per pair of the segment
-  double *rows;      // 5 doubles per row, packed
-  i64 *off;          // exclusive prefix sum of nrows over the segment (rows before pair k)
-  i64 rows_max;      // rows the buffer holds
+  int *nrows, *flag, *before; // per pair of the segment
+  double *rows;               // 5 doubles per row, packed
+  i64 rows_max;               // rows the buffer holds
 };
-SZ_HD Xfer seg_view(char *base, i64 seg_max, i64 rows_max, i64 *off) {
+SZ_HD Xfer seg_view(char *base, i64 seg_max, i64 rows_max) {
   Xfer X;
-  X.nrows = (int *)(base + SEG_HDR); X.flag = X.nrows + seg_max;
-  X.rows = (double *)(base + SEG_HDR + (size_t)((8 * seg_max + 7) / 8) * 8);
-  X.off = off; X.rows_max = rows_max;
+  X.nrows = (int *)(base + SEG_HDR); X.flag = X.nrows + seg_max; X.before = X.flag + seg_max;
+  X.rows = (double *)(base + seg_rows_at(seg_max));
+  X.rows_max = rows_max;
   return X;
 }
 SZ_HD void seg_header(char *base, i64 ns, i64 rows, i64 status, i64 rows_max) {
   i64 *h = (i64 *)base;
   h[0] = ns; h[1] = rows; h[2] = status; h[3] = rows_max;
 }
-SZ_HD void export_pair(i64 k, i64 p_lo, const Floes &F, const Work &W, const Xfer &X) {
+// off = exclusive prefix sum of pair_nrows over my segment (rows before pair k)
+SZ_HD void export_pair(i64 k, i64 p_lo, const i64 *off, const Floes &F, const Work &W, const Xfer &X) {
   const i64 p = p_lo + k;
   const int nr = W.pair_nrows[p];
-  X.nrows[k] = nr; X.flag[k] = W.pair_flag[p];
-  if (nr > 0 && X.off[k] + nr <= X.rows_max) {     // (a segment that does not fit is exchanged again, larger)
+  X.nrows[k] = nr; X.flag[k] = W.pair_flag[p]; X.before[k] = (int)off[k];
+  if (nr > 0 && off[k] + nr <= X.rows_max) {       // (a segment that does not fit is exchanged again, larger)
     const double *src = pair_rows(p, F, W);
-    double *dst = X.rows + 5 * X.off[k];
+    double *dst = X.rows + 5 * off[k];
     for (int q = 0; q < 5 * nr; ++q) dst[q] = src[q];
   }
-}
-SZ_HD void import_pair(i64 k, i64 p_lo, i64 rows_base, Work &W, const Xfer &X) {
-  const i64 p = p_lo + k;
-  W.pair_nrows[p] = X.nrows[k]; W.pair_flag[p] = X.flag[k];
-  W.pair_rowoff[p] = rows_base + 5 * X.off[k];
 }
 // segment of the global pair list computed by rank r of w (all ranks derive the same split)
 SZ_HD void shard_range(i64 np, int r, int w, i64 &lo, i64 &hi) { lo = np * r / w; hi = np * (r + 1) / w; }
 SZ_HD i64 shard_max(i64 np, int w) { return (np + w - 1) / w; }
+// pair p of the global list out of the gathered buffer (`world` segments of seg_bytes each, rank order)
+SZ_HD void import_pair(i64 p, i64 np, int world, i64 seg_max, i64 rows_max, char *recv, Work &W) {
+  int r = (int)(p * world / np);
+  i64 lo, hi;
+  shard_range(np, r, world, lo, hi);
+  while (p < lo) { --r; shard_range(np, r, world, lo, hi); }
+  while (p >= hi) { ++r; shard_range(np, r, world, lo, hi); }
+  char *base = recv + (size_t)r * seg_bytes_for(seg_max, rows_max);
+  const Xfer X = seg_view(base, seg_max, rows_max);
+  const i64 k = p - lo;
+  W.pair_nrows[p] = X.nrows[k]; W.pair_flag[p] = X.flag[k];
+  W.pair_rowoff[p] = (i64)((X.rows - (const double *)recv) + 5 * (i64)X.before[k]);  // in doubles from the start of recv
+}
 
 // transfer(kill(i)) = i for the largest such i (:175-179): first collect, then apply
 SZ_HD void transfer_collect(int i, const Floes &F, Work &W) { // i < N

@@ -323,8 +323,8 @@ int host_shard_export(void *send, int64_t seg_max, int64_t rows_max, int32_t sta
   if (ns > seg_max) return -1;
   char *base = (char *)send;
   seg_header(base, ns, status ? 0 : s.seg_rows, status, rows_max);
-  Xfer X = seg_view(base, seg_max, rows_max, s.x_off.data());
-  for (i64 k = 0; k < ns; ++k) export_pair(k, s.seg_lo, s.F, s.W, X);
+  Xfer X = seg_view(base, seg_max, rows_max);
+  for (i64 k = 0; k < ns; ++k) export_pair(k, s.seg_lo, s.x_off.data(), s.F, s.W, X);
   return 0;
 }
 // Finish: headers, import + contact rows + sums; on a forcing step with world > 1 only this rank's floe range is
@@ -344,19 +344,7 @@ int host_shard_finish(const void *recv, int64_t seg_max, int64_t rows_max, int32
   *rows_needed = need;
   if (need > rows_max) return 1;
   s.W.g_rows = (double *)recv;
-  std::vector<i64> off;
-  for (int r = 0; r < s.world; ++r) {
-    i64 lo, hi;
-    shard_range(s.np, r, s.world, lo, hi);
-    const i64 ns = hi - lo;
-    char *base = (char *)recv + (size_t)r * seg_bytes;
-    off.assign((size_t)ns + 1, 0);
-    Xfer X = seg_view(base, seg_max, rows_max, off.data());
-    i64 acc = 0;
-    for (i64 k = 0; k < ns; ++k) { off[k] = acc; acc += X.nrows[k]; }
-    const i64 rows_base = (i64)(((char *)X.rows - (char *)recv) / 8);
-    for (i64 k = 0; k < ns; ++k) import_pair(k, lo, rows_base, s.W, X);
-  }
+  for (i64 p = s.np - 1; p >= 0; --p) import_pair(p, s.np, s.world, seg_max, rows_max, (char *)recv, s.W);   // any order
   int rc = s.back_a();
   s.W.g_rows = nullptr;
   if (rc) return rc;
