@@ -3,10 +3,10 @@
 //
 // Launch shapes (all 1-D, 256-thread workgroups unless noted; the work is irregular FP64/int64 geometry,
 // so the rules that matter are occupancy, coalesced SoA loads and short dependent chains -- no MFMA):
-//   k_ext_clear / k_ext_init / k_ghost_flag / k_ghost_emit   one thread per (extended) floe
-//   k_scan_*                                                  one 1024-thread workgroup, chunked scan
+//   k_ext_clear (+ init)                                      one thread per (extended) floe; ghosts are made inside their scan
+//   k_scan_reduce / k_scan_write                              exclusive scans, two launches of <= 256 workgroups
 //   k_cell_* / k_broad_scan / k_broad_filter                  uniform grid; thread per (floe, neighbour cell); thread per floe
-//   k_pair_count / k_pair_expand                              one thread per extended floe
+//   k_pair_expand                                             one thread per extended floe (the counts come from k_broad_filter)
 //   k_narrow                                                  one thread per candidate pair, 64-thread
 //                                                             workgroups (one wave) for fine-grained dispatch
 //   k_incoming / k_row_count / k_row_fill / k_transfer_*      per pair / per extended floe
@@ -73,22 +73,12 @@ __global__ void k_ext_clear(Floes F, Work W) {
   if (e < F.n) ext_init(e, F, W);
   if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
 }
-__global__ void k_ghost_flag(int dim, Floes F, Params P, Work W) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  int n1 = (dim == 0) ? F.n : F.n + (int)W.counters[C_GX];
-  if (e < n1) ghost_flag(e, dim, F, P, W);
-}
-__global__ void k_ghost_emit(int dim, Floes F, Params P, Work W) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  int n1 = (dim == 0) ? F.n : F.n + (int)W.counters[C_GX];
-  if (e < n1) ghost_emit(e, dim, n1, F, P, W);
-}
-
 // ---- exclusive scans: two launches of <= 256 workgroups (one per CU), no spinning --------------------------
 // k_scan_reduce: workgroup b sums its tile of the input -> agg[b]; k_scan_write: workgroup b adds up the
 // aggregates before it, scans its tile (coalesced 1024-element slabs, wave shuffles + 16 LDS words) and writes;
-// the last workgroup stores the total.  A Job names the arrays: n(), load(ch, k), store(ch, k, v),
-// finish(totals), CH channels scanned side by side.
+// the last workgroup stores the total.  A Job names the arrays: n(), first(ch, k) (the value, read or produced in
+// the first launch), load(ch, k) (read again in the second), store(ch, k, v) (may act on the element right there),
+// finish(totals), CH channels side by side.
 __device__ inline long long wave_scan_incl(long long v) {
   const int lane = threadIdx.x & 63;
   for (int d = 1; d < 64; d <<= 1) {
@@ -116,7 +106,7 @@ __global__ void __launch_bounds__(1024) k_scan_reduce(Job job, int tile, long lo
   const long long lo = (long long)blockIdx.x * tile;
   for (int ch = 0; ch < Job::CH; ++ch) {
     long long s = 0;
-    for (long long k = lo + threadIdx.x; k < lo + tile && k < n; k += 1024) s += job.load(ch, (int)k);
+    for (long long k = lo + threadIdx.x; k < lo + tile && k < n; k += 1024) s += job.first(ch, (int)k);
     long long tot;
     (void)block_scan_incl(s, lds16, &tot);
     if (threadIdx.x == 0) agg[ch * 256 + blockIdx.x] = tot;
@@ -143,12 +133,13 @@ __global__ void __launch_bounds__(1024) k_scan_write(Job job, int tile, const lo
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) job.finish(totals);
 }
-struct ScanGhost {
+struct ScanGhost { // ghost creation of one dimension fused into its scan: flags in the first launch, ghosts in the second
   enum { CH = 1 };
-  int dim; Floes F; Work W;
+  int dim; Floes F; Params P; Work W;
   __device__ int n() const { return (dim == 0) ? F.n : F.n + (int)W.counters[C_GX]; }
+  __device__ long long first(int, int k) const { Work w = W; ghost_flag(k, dim, F, P, w); return W.flag[k]; }
   __device__ long long load(int, int k) const { return W.flag[k]; }
-  __device__ void store(int, int k, long long v) const { W.scan[k] = (int)v; }
+  __device__ void store(int, int k, long long v) const { Work w = W; W.scan[k] = (int)v; ghost_emit(k, dim, n(), F, P, w); }
   __device__ void finish(const long long *t) const {
     W.counters[dim == 0 ? C_GX : C_GY] = (unsigned long long)t[0];
     W.counters[C_NEXT] = (unsigned long long)(n() + t[0]);
@@ -158,6 +149,7 @@ struct ScanPairs { // pair counts -> pair_base, pair vertex counts -> nv_base
   enum { CH = 2 };
   Work W;
   __device__ int n() const { return dev_next(W); }
+  __device__ long long first(int ch, int k) const { return load(ch, k); }
   __device__ long long load(int ch, int k) const { return ch == 0 ? (long long)W.pair_cnt[k] : (long long)W.pair_nv[k]; }
   __device__ void store(int ch, int k, long long v) const { if (ch == 0) W.pair_base[k] = v; else W.nv_base[k] = v; }
   __device__ void finish(const long long *t) const {
@@ -170,6 +162,7 @@ struct ScanRows {
   enum { CH = 1 };
   Work W;
   __device__ int n() const { return dev_next(W); }
+  __device__ long long first(int ch, int k) const { return load(ch, k); }
   __device__ long long load(int, int k) const { return W.row_cnt[k]; }
   __device__ void store(int, int k, long long v) const { W.row_off[k] = v; }
   __device__ void finish(const long long *t) const { W.counters[C_NROWS] = (unsigned long long)t[0]; W.row_off[n()] = t[0]; }
@@ -178,6 +171,7 @@ struct ScanCells {
   enum { CH = 1 };
   Work W;
   __device__ int n() const { return W.cells_x * W.cells_y; }
+  __device__ long long first(int ch, int k) const { return load(ch, k); }
   __device__ long long load(int, int k) const { return W.cell_cnt[k]; }
   __device__ void store(int, int k, long long v) const { W.cell_off[k] = (int)v; }
   __device__ void finish(const long long *t) const { W.cell_off[n()] = (int)t[0]; }
@@ -186,6 +180,7 @@ struct ScanSegment {
   enum { CH = 1 };
   const int *in; i64 *out; int count; unsigned long long *total;
   __device__ int n() const { return count; }
+  __device__ long long first(int ch, int k) const { return load(ch, k); }
   __device__ long long load(int, int k) const { return in[k]; }
   __device__ void store(int, int k, long long v) const { out[k] = v; }
   __device__ void finish(const long long *t) const { if (total) *total = (unsigned long long)t[0]; }
@@ -227,11 +222,7 @@ __global__ void __launch_bounds__(64) k_broad_filter(int lo_is_real, Floes F, Pa
   if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
   else { i += F.n; if (i >= N) return; }
   broad_filter(i, F, P, W, tmp);
-}
-__global__ void k_pair_count(Floes F, Params P, Work W) {
-  int N = dev_next(W);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) pair_count(i, N, F, P, W);
+  pair_count(i, N, F, P, W);   // the list of i is final: its pairs and their vertex total
 }
 __global__ void k_pair_expand(Floes F, Params P, Work W) {
   int N = dev_next(W);
@@ -589,9 +580,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   if (P.PERIODIC) {
     for (int dim = 0; dim < 2; ++dim) {
       int bound = (dim == 0) ? n : 2 * n;
-      hipLaunchKernelGGL(k_ghost_flag, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
-      launch_scan(st, S->scan_agg, cap, ScanGhost{dim, F, W});
-      hipLaunchKernelGGL(k_ghost_emit, grid_for(bound, 256), dim3(256), 0, st, dim, F, P, W);
+      launch_scan(st, S->scan_agg, bound, ScanGhost{dim, F, P, W});   // flags, slots and the ghosts themselves
     }
   }
   // uniform grid over [-L - cs, L + cs]^2, cell edge cs = 2 max(rmax); positions outside clamp to the border
@@ -626,7 +615,6 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     hipLaunchKernelGGL(k_broad_filter, grid_for(n, 64), dim3(64), spill ? 0 : lds, st, 1, F, P, W, spill);
     if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, 64), dim3(64), spill ? 0 : lds, st, 0, F, P, W, spill);
   }
-  hipLaunchKernelGGL(k_pair_count, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
   launch_scan(st, S->scan_agg, cap, ScanPairs{W});
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
