@@ -42,7 +42,8 @@ struct StepState {
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
   double rmax_max = 0;
   Params P;                       // parameters of the step in flight
-  unsigned long long c[C_COUNT];  // host copy of the device counters
+  unsigned long long *c = nullptr; // host copy of the device counters (pinned: read back without a staging kernel)
+  i64 pair_rows_total = 0;        // contact rows of all pairs of the step (bounds the rows of the CSR)
   unsigned long long bump = 0, zero = 0;
   i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
   int N = 0, rank = 0, world = 1;
@@ -457,6 +458,7 @@ void sz_step_destroy(szContext *ctx) {
                     &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->cell_x, &S->cell_y, &S->cell_r};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
+  if (S->c) (void)hipHostFree(S->c);
   delete S;
   ctx->step = nullptr;
 }
@@ -474,6 +476,8 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   ctx->step = S;
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
   { int rc0 = dev_alloc(ctx, S, S->scan_agg, 512); if (rc0) return rc0; }
+  SZ_HIP(ctx, hipHostMalloc((void **)&S->c, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(S->c, 0, C_COUNT * sizeof(unsigned long long));
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_NARROW_OCC4")) S->narrow_occ4 = atoi(v);
@@ -619,7 +623,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
   unsigned long long *c = S->c;
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (c[C_ERR_POT]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "broad-phase: %llu floe(s) have more than %d candidates", c[C_ERR_POT], W.pot_cap);
   const i64 np = (i64)c[C_NPAIRS], nvt = (i64)c[C_NVTOT];
@@ -678,7 +682,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
   int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
   while (c[C_RETRY] > 0) {
@@ -692,12 +696,13 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     const int RL = fast ? S->retry_lanes : S->narrow_lanes;
     hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
+    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
   if (c[C_ERR_ARENA]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) did not fit the scratch arena", c[C_ERR_ARENA]);
   if (c[C_ERR_CLIP]) return sz_fail(ctx, SZ_ERR_HIP, "narrow-phase: %llu pair(s) hit the reference's \"Clipper Error.\" condition", c[C_ERR_CLIP]);
   S->pair_rows_local = (i64)c[C_PAIRROWS];
+  S->pair_rows_total = S->pair_rows_local;   // (the sharded step replaces this by the sum over the ranks)
   return SZ_OK;
 }
 
@@ -732,19 +737,18 @@ static int step_back_a(szContext *ctx, StepState *S) {
     hipLaunchKernelGGL(k_row_count, grid_for(cap, 64), dim3(64), spill ? 0 : lds, st, W, spill);
   }
   launch_scan(st, S->scan_agg, cap, ScanRows{W});
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
-  SZ_HIP(ctx, hipStreamSynchronize(st));
-  if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
-  const i64 nr = (i64)c[C_NROWS];
-  if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)(nr + 1)))) return rc;
-  W.rows = (double *)S->rows.p; W.cap_rows = nr + 1;
+  // No host round trip here: every contact row of a pair appears at most twice in the CSR (once for each floe
+  // of the pair), so the pair rows counted by the narrow phase bound it; the exact count and the overflow flag
+  // of the mirror lists are read with the counters at the end of the step.
+  const i64 nr_cap = 2 * S->pair_rows_total + 1;
+  if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)nr_cap))) return rc;
+  W.rows = (double *)S->rows.p; W.cap_rows = nr_cap;
   hipLaunchKernelGGL(k_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
   hipLaunchKernelGGL(k_transfer_collect, grid_for(cap, 256), dim3(256), 0, st, F, W);
   hipLaunchKernelGGL(k_transfer_apply, grid_for(cap, 256), dim3(256), 0, st, F, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
   hipLaunchKernelGGL(k_integrate_pre, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
-  S->nr = nr;
   return SZ_OK;
 }
 
@@ -752,13 +756,15 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   unsigned long long *c = S->c;
-  const i64 np = S->np, nr = S->nr;
+  const i64 np = S->np;
   const int n = S->n;
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, sizeof(S->c), hipMemcpyDeviceToHost, st));
+  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   SZ_HIP(ctx, hipStreamSynchronize(st));
+  S->nr = (i64)c[C_NROWS];
+  if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
   if (c[C_ERR_MC])
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
@@ -769,7 +775,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[2], S->ev[3])); stats->narrow_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[3], S->ev[4])); stats->rows_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[4], S->ev[5])); stats->integrate_ms = ms;
-    stats->n_ext = S->N; stats->n_pairs = np; stats->n_rows = nr; stats->pair_vertices = S->nvt;
+    stats->n_ext = S->N; stats->n_pairs = np; stats->n_rows = S->nr; stats->pair_vertices = S->nvt;
     stats->retried = S->retried; stats->pair_rows = S->pair_rows_local;
   }
   return SZ_OK;
@@ -865,6 +871,8 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
   if (rows_needed) *rows_needed = need;
   if (need > rows_max) return SZ_SHARD_RESIZE;
   S->pair_rows_local = S->hdr[4 * (size_t)S->rank + 1];
+  S->pair_rows_total = 0;
+  for (int r = 0; r < S->world; ++r) S->pair_rows_total += S->hdr[4 * (size_t)r + 1];
   S->W.g_rows = (double *)d_recv; // pair_rowoff is in doubles from the start of the gathered buffer
   if (S->np > 0) hipLaunchKernelGGL(k_import, grid_for(S->np, 256), dim3(256), 0, ctx->stream, S->np, S->world, (i64)seg_max, (i64)rows_max, (char *)d_recv, S->W);
   SZ_HIP(ctx, hipGetLastError());
