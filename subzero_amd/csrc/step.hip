@@ -34,7 +34,7 @@ struct StepState {
   // grow-only per-step buffers
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
   DevBuf scratch, rows;
-  DevBuf cell_cnt, cell_off, cell_fill, cell_items, cell_x, cell_y, cell_r;
+  DevBuf cell_cnt, cell_off, cell_fill, cell_item;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
   std::vector<long long> hdr;     // segment headers of all ranks (szStepShardFinish)
   long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
@@ -455,7 +455,7 @@ void sz_step_destroy(szContext *ctx) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_items, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->cell_x, &S->cell_y, &S->cell_r};
+                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   if (S->c) (void)hipHostFree(S->c);
@@ -597,12 +597,9 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     W.cells_y = (ny > 2048 || !(ny > 0)) ? 2048 : (int)ny;
     const size_t nc = (size_t)W.cells_x * W.cells_y + 1;
     if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
-        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_items, (size_t)cap * 4)) ||
-        (rc = sz_reserve(ctx, S->cell_x, (size_t)cap * 8)) || (rc = sz_reserve(ctx, S->cell_y, (size_t)cap * 8)) ||
-        (rc = sz_reserve(ctx, S->cell_r, (size_t)cap * 8))) return rc;
-    W.cell_x = (double *)S->cell_x.p; W.cell_y = (double *)S->cell_y.p; W.cell_r = (double *)S->cell_r.p;
+        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, (size_t)cap * sizeof(CellItem)))) return rc;
+    W.cell_item = (CellItem *)S->cell_item.p;
     W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
-    W.cell_items = (int *)S->cell_items.p;
     hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
     hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
     launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});

@@ -63,6 +63,10 @@ enum {
   C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_COUNT
 };
 
+// one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
+// reads one 32-byte record
+struct CellItem { double x, y, r; int e, pad; };
+
 struct Work {
   int cap_ext;   // 4 * n
   int pot_cap;   // candidates per floe
@@ -98,8 +102,8 @@ struct Work {
   // uniform grid over the extended list for the broad-phase (cell edge >= 2 * max rmax)
   double cell_size, cell_x0, cell_y0;
   int cells_x, cells_y;
-  int *cell_cnt, *cell_off, *cell_fill, *cell_items; // [cells_x * cells_y (+1)], items: cap_ext
-  double *cell_x, *cell_y, *cell_r;                  // position and rmax of the items, in cell order (cap_ext)
+  int *cell_cnt, *cell_off, *cell_fill;              // [cells_x * cells_y (+1)]
+  struct CellItem *cell_item;                        // the floes of all cells, in cell order (cap_ext)
   // calc_trajectory values handed from integrate_pre to forcing / integrate_post (per real floe)
   double *st_ext; // [3 n] external force x, y and torque after the limiter (:42-46)
   int *st_flag;   // ST_GO | ST_FORCE
@@ -220,11 +224,14 @@ SZ_HD void cell_fill(int e, const Floes &F, Work &W) {
   if (!F.alive[s]) return;
   int c = cell_of(e, W);
   int k = W.cell_off[c] + atomic_add(&W.cell_fill[c], 1);
-  W.cell_items[k] = e; W.cell_x[k] = W.ext_x[e]; W.cell_y[k] = W.ext_y[e]; W.cell_r[k] = F.rmax[s];
+  CellItem it; it.x = W.ext_x[e]; it.y = W.ext_y[e]; it.r = F.rmax[s]; it.e = e; it.pad = 0;
+  W.cell_item[k] = it;
 }
 // broad_scan: thread (i, c9) tests floe i against the items of ONE of its 3 x 3 cells and appends the hits to
-// i's list (unordered, one atomic per hit).  broad_filter: thread i sorts its list by j and applies the `mems`
-// filter in order (:93-99, :103, :113); real floes first, ghosts afterwards (they read their root's list).
+// i's list (unordered, one atomic per hit; nine short loops run side by side -- a thread per row of three cells was
+// measured slower at 1e4 floes, where this stage is latency-bound).  broad_filter: thread i sorts its list by j and
+// applies the `mems` filter in order (:93-99, :103, :113); real floes first, ghosts afterwards (they read their
+// root's list).
 SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Work &W) {
   (void)N;
   const int si = W.ext_src[i];
@@ -236,10 +243,11 @@ SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Wor
   const int c = gy * W.cells_x + gx;
   int *mine = W.pot_list + (size_t)i * W.pot_cap;
   for (int q = W.cell_off[c]; q < W.cell_off[c + 1]; ++q) {
-    const int j = W.cell_items[q];
+    const CellItem it = W.cell_item[q];
+    const int j = it.e;
     if (j <= i) continue;
-    double dx = xi - W.cell_x[q], dy = yi - W.cell_y[q];
-    double R = ri + W.cell_r[q];
+    double dx = xi - it.x, dy = yi - it.y;
+    double R = ri + it.r;
     double d2 = dx * dx + dy * dy;
     if (d2 > R * R * 1.000001) continue;
     if (!(::sqrt(d2) < R)) continue;      // :103

@@ -155,8 +155,7 @@ struct Sim {
       if (W.cells_y > 2048) W.cells_y = 2048;
       const int nc = W.cells_x * W.cells_y;
       W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
-      W.cell_items = alloc<int>(pool, cap);
-      W.cell_x = alloc<double>(pool, cap); W.cell_y = alloc<double>(pool, cap); W.cell_r = alloc<double>(pool, cap);
+      W.cell_item = alloc<CellItem>(pool, cap);
       for (int e = 0; e < N; ++e) cell_count(e, F, W);
       int acc = 0;
       for (int c = 0; c < nc; ++c) { W.cell_off[c] = acc; acc += W.cell_cnt[c]; }
