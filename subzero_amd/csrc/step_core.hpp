@@ -285,8 +285,10 @@ SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W, int *tm
     bool member = false;
     for (int q = 0; q < ninit && !member; ++q) member = (init[q] == key);
     for (int q = 0; q < kept && !member; ++q) member = (num[q] == key);
-    const double R = ri + F.rmax[W.ext_src[j]];
-    if (!(!member || 2 * R > lim)) continue;
+    if (member) {   // (:113) a floe already listed through another image stays only if the pair spans the domain
+      const double R = ri + F.rmax[W.ext_src[j]];
+      if (!(2 * R > lim)) continue;
+    }
     tmp[kept] = j + 1; num[kept] = num[a]; ++kept;
   }
   for (int a = 0; a < kept; ++a) mine[a] = tmp[a];
