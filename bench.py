@@ -42,7 +42,9 @@ def build_workload(n_floes, seed=4, box_scale=1.0):
 
 
 def cpu_baseline(S, P, budget_s=20.0):
-    """Oracle steps on the host cores from the same (already colliding) state; bounded sample."""
+    """Oracle steps on the host cores from the same (already colliding) state; bounded sample.
+    Parallel structure of the reference: narrow phase and calc_trajectory are parfor loops (OpenMP here), the
+    broad phase is its serial O(N^2) loop (floe_interactions_all.m:76-120)."""
     import oracle
     threads = os.cpu_count() or 1
     A = S.copy()
@@ -56,10 +58,14 @@ def cpu_baseline(S, P, budget_s=20.0):
         el = time.time() - t0
         if el > budget_s or steps >= 12:
             break
+    P.doInt = 0
+    t1 = time.time()
+    oracle.step(A, P, threads=1)          # also at one thread (one step, no forcing refresh)
+    el1 = time.time() - t1
     return {"value": S.n * steps / el, "unit": "floe-timesteps/s", "cores": threads,
-            "kind": "port", "clip": oracle.lib().clip_kind,
-            "sample": "%d oracle timesteps of the same %d-floe field (state after the GPU run), %d threads, %.1f s"
-                      % (steps, S.n, threads, el)}
+            "kind": "port", "clip": oracle.lib().clip_kind, "value_1_thread": S.n / el1,
+            "sample": "%d oracle timesteps of the same %d-floe field (state after the GPU run), %d threads, %.1f s; "
+                      "then 1 timestep on 1 thread, %.1f s" % (steps, S.n, threads, el, el1)}
 
 
 def main():

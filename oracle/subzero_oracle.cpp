@@ -950,6 +950,8 @@ int or_step(OrFloes *F, const OrParams *P, int32_t *inter_off, double *inter, in
 
   // ---- :249-285 real floes: torque, sums, wrap, integrate ----
   int rc_all = 0;
+  // (a parfor in the reference, floe_interactions_all.m:249: every floe touches only its own fields)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 0 ? threads : 1)
   for (int i = Nb; i < N0; ++i) {
     if (!inter_rows[i].empty()) {
       double a, b, c;
@@ -973,7 +975,10 @@ int or_step(OrFloes *F, const OrParams *P, int32_t *inter_off, double *inter, in
       int cnt0 = F->StressCount[i], alive0 = F->alive[i];
       double h0 = F->h[i], m0 = F->mass[i], in0 = F->inertia_moment[i];
       int rc = calc_trajectory(F, i, P, inter_rows[i].empty() ? nullptr : &inter_rows[i][0], (int)(inter_rows[i].size() / 7));
-      if (rc < 0) rc_all = rc;
+      if (rc < 0) {
+#pragma omp atomic write
+        rc_all = rc;
+      }
       if (rc == 1) {
         for (int q = 0; q < 4; ++q) { F->StressH[((size_t)i * Nz + (sc0 - 1)) * 4 + q] = slot0[q]; F->Stress[4 * i + q] = st0[q]; }
         F->StressCount[i] = cnt0; F->alive[i] = alive0; F->h[i] = h0; F->mass[i] = m0; F->inertia_moment[i] = in0;
