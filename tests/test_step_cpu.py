@@ -112,6 +112,22 @@ def test_long_convex_rings_are_handed_to_the_general_sweep():
     assert len(r.inter) > 0 and h1 - h0 > 50 and hoststep.step(B.copy(), P).retried > 10
 
 
+@pytest.mark.parametrize("name,steps", [("plumbing10", 30), ("convex1000", 5), ("uniaxial200", 12)])
+def test_baseline_configs_match_oracle(name, steps):
+    S, P = scenes.baseline_config(name)
+    A, B = S.copy(), S.copy()
+    for it in range(steps):
+        P.doInt = int(it % 10 == 0)
+        if name == "uniaxial200":
+            scenes.squeeze_walls(P, it)
+        ra = oracle.step(A, P, threads=4)
+        rb = hoststep.step(B, P)
+        assert np.array_equal(ra.pairs, rb.pairs) and np.array_equal(ra.inter, rb.inter), "step %d" % it
+        assert [b for b in hoststep.compare_states(A, B) if b[0] != "StressH"] == [], "step %d" % it
+    if name == "uniaxial200":
+        assert (ra.inter[:, 0] == np.inf).any()        # the moving walls push on the pack
+
+
 def test_device_pipeline_matches_oracle_walls():
     S, P = scenes.pack(200, periodic=False, seed=7, vel_seed=8, sigma=0.3)
     A, B, r = lockstep(S, P, 14)

@@ -118,6 +118,24 @@ def test_more_fields_through_the_fast_pass(ctx, seed):
     assert exact
 
 
+@pytest.mark.parametrize("name,steps", [("plumbing10", 30), ("convex1000", 8), ("uniaxial200", 15)])
+def test_baseline_configs(ctx, name, steps):
+    # BASELINE.json configs 0-2 at test size; the uniaxial case moves its N/S walls between steps
+    S, P = scenes.baseline_config(name)
+    A, G = S.copy(), S.copy()
+    sim = capi.FloeInteractions(ctx, G)
+    for it in range(steps):
+        P.doInt = int(it % 10 == 0)
+        if name == "uniaxial200":
+            scenes.squeeze_walls(P, it)
+        ra = oracle.step(A, P, threads=16)
+        sim.step(P)
+        sim.download(capi.SYNC_ALL)
+        off, rows = sim.interactions()
+        assert np.array_equal(ra.inter_off, off) and np.array_equal(ra.inter, rows), "step %d" % it
+        assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
+
+
 def test_long_convex_rings(ctx):
     # 8..39-vertex convex floes: fast pass (16-vertex blocks) and general sweep for the longer rings
     S, P = scenes.many_sided(64)
