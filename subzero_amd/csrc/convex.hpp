@@ -91,7 +91,7 @@ SZ_HD i64 to_fixed(double v) {
   if (s != s) return 0;
   if (s >= 9223372036854775807.0) return 0x7FFFFFFFFFFFFFFFLL;
   if (s <= -9223372036854775808.0) return (i64)0x8000000000000000ULL;
-  double t = (double)(i64)s; // trunc
+  double t = __builtin_trunc(s);   // == (double)(int64)s in this range, without the two conversions
   double f = s - t;
   if (f >= 0.5) t += 1.0;
   else if (f <= -0.5) t -= 1.0;
