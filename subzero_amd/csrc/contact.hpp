@@ -456,7 +456,6 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
   }
   int N1 = c1.len() - 1, N2 = c2.len() - 1;                                            // :78-79
   double Amin = (double)(N1 < N2 ? N1 : N2) * 100 / 1.75;
-  const int nc1 = c1.len();
   for (int k = 0; k < nreg; ++k) {
     const i64 *RX = S.r1x + S.r1off[k], *RY = S.r1y + S.r1off[k];
     const int nr = S.r1off[k + 1] - S.r1off[k];

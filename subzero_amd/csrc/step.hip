@@ -7,13 +7,13 @@
 //   k_scan_reduce / k_scan_write                              exclusive scans, two launches of <= 256 workgroups
 //   k_cell_* / k_broad_scan / k_broad_filter                  uniform grid; thread per (floe, neighbour cell); thread per floe
 //   k_pair_expand                                             one thread per extended floe (the counts come from k_broad_filter)
-//   k_narrow                                                  one thread per candidate pair, 64-thread
-//                                                             workgroups (one wave) for fine-grained dispatch
+//   k_narrow_convex / k_narrow                                one lane per candidate pair, 64-lane workgroups: fast pass over all
+//                                                             pairs, general sweep for what it defers
 //   k_incoming / k_row_count / k_row_fill / k_transfer_*      per pair / per extended floe
 //   k_integrate_pre / k_integrate_post                        one thread per real floe
-//   k_forcing                                                 one wave per real floe (Monte-Carlo forcing)
-// Two host read-backs per step size the pair scratch and the contact-row buffer (grow-only, owned by the
-// context).  No CPU fallback exists: every failure is an error code.
+//   k_forcing                                                 one 256-thread workgroup per real floe (Monte-Carlo forcing)
+// Host read-backs per step: the pair count (sizes the pair scratch), the deferred / retried pairs of the narrow
+// phase, and the counters at the end (buffers are grow-only, owned by the context).  No CPU fallback exists: every failure is an error code.
 #include <stdlib.h>
 #include "context.hpp"
 #include "step_core.hpp"
@@ -54,7 +54,6 @@ struct StepState {
   int retry_lanes = 8;            // pairs per wave when the general kernel redoes what the fast pass deferred (SUBZERO_RETRY_LANES)
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
-  int narrow_occ4 = -1;           // -1: choose per launch; 0 / 1 force the 1- / 4-waves-per-SIMD build (SUBZERO_NARROW_OCC4)
   i64 last_npairs = 0, last_nrows_real = 0;
   int last_next = 0;
   bool stepped = false;
@@ -240,17 +239,6 @@ __global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *
   void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
   if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
 }
-// The same kernel compiled for 4 waves per SIMD (128 VGPRs, more spilling): slower per wave, but when a step
-// has more waves than the chip has SIMDs (> ~6e4 pairs) the extra resident waves overlap each other's
-// memory waits -- the choice is made per launch from the pair count.
-__global__ void __launch_bounds__(64, 4) k_narrow_occ4(i64 first, i64 count, const int *list, int mult, int lanes, int lds_per_lane, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
-  if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
-}
-
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
@@ -480,7 +468,6 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   memset(S->c, 0, C_COUNT * sizeof(unsigned long long));
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
-  if (const char *v = getenv("SUBZERO_NARROW_OCC4")) S->narrow_occ4 = atoi(v);
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->retry_lanes = l; }
@@ -669,12 +656,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
       hipLaunchKernelGGL(k_narrow_a, grid_for(hi - lo, L), dim3(64), lds, st, lo, hi - lo, L, F, P, W);
       hipLaunchKernelGGL(k_narrow_b, grid_for(hi - lo, L), dim3(64), lds, st, L, F, P, W);
     } else {
-      const i64 waves = (hi - lo + S->narrow_lanes - 1) / S->narrow_lanes;
-      const bool occ4 = S->narrow_occ4 == 1 || (S->narrow_occ4 < 0 && waves > 1536); // 1024 SIMDs on the chip
-      if (occ4)
-        hipLaunchKernelGGL(k_narrow_occ4, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
-      else
-        hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
+      hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
     }
     SZ_HIP(ctx, hipGetLastError());
   }
@@ -719,7 +701,6 @@ static int force_cnt_max(const StepState *S, int w) { return (S->n - S->nb + w -
 static int step_back_a(szContext *ctx, StepState *S) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
-  unsigned long long *c = S->c;
   const i64 np = S->np;
   const int n = S->n, cap = W.cap_ext;
   int rc;
