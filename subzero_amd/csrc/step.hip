@@ -350,12 +350,26 @@ __global__ void __launch_bounds__(256) k_forcing(int first, int last, Floes F, P
   const long long sq = F.mc_sq;
   ForceCtx c;
   force_ctx(i, F, P, c);
-  // pass 1: winds at the points inside the floe
+  // pass 1: every point inside the floe is sampled once -- winds for the first mean, ocean velocities and polar
+  // angle kept in registers for the second (up to KEEP points per thread: n_mc <= 1024; beyond that they are
+  // sampled again in pass 2)
+  enum { KEEP = 4 };
+  McPoint kept[KEEP];
   if (t == 0) scnt = 0;
   __syncthreads();
+  const bool keep = nmc <= 256 * KEEP;
   double a0 = 0.0, a1 = 0.0;
   int mine = 0;
-  for (int q = t; q < nmc; q += 256) {
+#pragma unroll
+  for (int s = 0; s < KEEP; ++s) {
+    const int q = t + 256 * s;
+    if (q < nmc && A[q * sq]) {
+      double uw, vw;
+      point_sample(c, P, mx[q * sq], my[q * sq], true, keep, uw, vw, kept[s]);
+      a0 += uw; a1 += vw; ++mine;
+    }
+  }
+  for (int q = t + 256 * KEEP; q < nmc; q += 256) {
     if (!A[q * sq]) continue;
     double uw, vw;
     wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
@@ -374,7 +388,17 @@ __global__ void __launch_bounds__(256) k_forcing(int first, int last, Floes F, P
   // pass 2: stresses and torque
   a0 = 0.0; a1 = 0.0;
   double a2 = 0.0;
-  for (int q = t; q < nmc; q += 256) {
+#pragma unroll
+  for (int s = 0; s < KEEP; ++s) {
+    const int q = t + 256 * s;
+    if (q < nmc && A[q * sq]) {
+      double Fx, Fy, tq;
+      if (keep) point_force(c, kept[s], Fx, Fy, tq);
+      else force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);
+      a0 += Fx; a1 += Fy; a2 += tq;
+    }
+  }
+  for (int q = t + 256 * KEEP; q < nmc; q += 256) {
     if (!A[q * sq]) continue;
     double Fx, Fy, tq;
     force_point(c, P, mx[q * sq], my[q * sq], Fx, Fy, tq);

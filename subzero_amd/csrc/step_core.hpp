@@ -726,8 +726,12 @@ SZ_HD void transfer_apply(int i, const Floes &F, Work &W) {
 // ---------------------------------------------------------------------------------------------
 // calc_trajectory.m for real floe i (plus :242-245 ghost sums, :262-277 own sums and periodic wrap)
 // ---------------------------------------------------------------------------------------------
-SZ_HD double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, const double *V, double xq, double yq) {
-  if (!(xq >= Xo[0] && xq <= Xo[nx - 1] && yq >= Yo[0] && yq <= Yo[ny - 1])) return __builtin_nan("");
+// interp2(Xo, Yo, V, xq, yq) (linear) in two parts, so that several fields sampled at one point share the cell search
+struct Interp2 { int ix, iy; double tx, ty; bool inside; };
+SZ_HD Interp2 interp2_locate(const double *Xo, int nx, const double *Yo, int ny, double xq, double yq) {
+  Interp2 w; w.ix = 0; w.iy = 0; w.tx = 0; w.ty = 0;
+  w.inside = (xq >= Xo[0] && xq <= Xo[nx - 1] && yq >= Yo[0] && yq <= Yo[ny - 1]);
+  if (!w.inside) return w;
   int ix = (int)::floor((xq - Xo[0]) / (Xo[1] - Xo[0]));
   int iy = (int)::floor((yq - Yo[0]) / (Yo[1] - Yo[0]));
   if (ix > nx - 2) ix = nx - 2;
@@ -738,13 +742,22 @@ SZ_HD double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, 
   while (ix < nx - 2 && xq > Xo[ix + 1]) ++ix;
   while (iy > 0 && yq < Yo[iy]) --iy;
   while (iy < ny - 2 && yq > Yo[iy + 1]) ++iy;
-  double tx = (xq - Xo[ix]) / (Xo[ix + 1] - Xo[ix]);
-  double ty = (yq - Yo[iy]) / (Yo[iy + 1] - Yo[iy]);
+  w.ix = ix; w.iy = iy;
+  w.tx = (xq - Xo[ix]) / (Xo[ix + 1] - Xo[ix]);
+  w.ty = (yq - Yo[iy]) / (Yo[iy + 1] - Yo[iy]);
+  return w;
+}
+SZ_HD double interp2_at(const Interp2 &w, int ny, const double *V) {
+  if (!w.inside) return __builtin_nan("");
+  const int ix = w.ix, iy = w.iy;
   double v00 = V[iy + (size_t)ny * ix], v01 = V[iy + (size_t)ny * (ix + 1)];
   double v10 = V[iy + 1 + (size_t)ny * ix], v11 = V[iy + 1 + (size_t)ny * (ix + 1)];
-  double a = v00 * (1 - tx) + v01 * tx;
-  double b = v10 * (1 - tx) + v11 * tx;
-  return a * (1 - ty) + b * ty;
+  double a = v00 * (1 - w.tx) + v01 * w.tx;
+  double b = v10 * (1 - w.tx) + v11 * w.tx;
+  return a * (1 - w.ty) + b * w.ty;
+}
+SZ_HD double interp2_linear(const double *Xo, int nx, const double *Yo, int ny, const double *V, double xq, double yq) {
+  return interp2_at(interp2_locate(Xo, nx, Yo, ny, xq, yq), ny, V);
 }
 
 // calc_trajectory is split in three kernels so that the Monte-Carlo forcing (1000 points per floe, every
@@ -856,11 +869,43 @@ SZ_HD void force_ctx(int i, const Floes &F, const Params &P, ForceCtx &c) {
   c.mass_per_area = F.mass[i] / F.area[i]; c.fc = P.fCoriolis;
   c.Fx_atm = 0; c.Fy_atm = 0;
 }
-SZ_HD void wind_point(const ForceCtx &c, const Params &P, double mx, double my, double &uw, double &vw) {
+// Everything of one Monte-Carlo point that depends only on its position (:95-98, :122-137): winds for the first
+// mean, ocean velocities and the polar angle for the second.  McPoint keeps the latter between the two passes.
+struct McPoint { double Uo, Vo, sth, cth, rho; };
+SZ_HD void point_sample(const ForceCtx &c, const Params &P, double mx, double my, bool want_wind, bool want_ocean,
+                        double &uw, double &vw, McPoint &m) {
   double xr1 = c.ca * mx + (-c.sa) * my, xr2 = c.sa * mx + c.ca * my;
   double Xg = xr1 + c.Xi, Yg = xr2 + c.Yi;
-  uw = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uwind, Xg, Yg);
-  vw = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vwind, Xg, Yg);
+  const Interp2 w = interp2_locate(P.Xo, P.nxo, P.Yo, P.nyo, Xg, Yg);
+  if (want_wind) { uw = interp2_at(w, P.nyo, P.Uwind); vw = interp2_at(w, P.nyo, P.Vwind); }
+  if (want_ocean) {
+    double th = szm::atan2(xr2, xr1);
+    m.rho = szc::hyp(xr1, xr2);
+    m.Uo = interp2_at(w, P.nyo, P.Uocn);
+    m.Vo = interp2_at(w, P.nyo, P.Vocn);
+    szm::sincos(th, m.sth, m.cth);
+  }
+}
+// stresses and torque of one point from its sample (:127-160); needs the wind stress of the floe (wind_stress)
+SZ_HD void point_force(const ForceCtx &c, const McPoint &m, double &Fx, double &Fy, double &tq) {
+  const double rho0 = 1027, Cd = 3e-3;
+  double Uice = c.Ui - m.rho * c.ksi * m.sth;
+  double Vice = c.Vi + m.rho * c.ksi * m.cth;
+  double Fx_p = -(c.mass_per_area) * c.fc * m.Vo;
+  double Fy_p = +(c.mass_per_area) * c.fc * m.Uo;
+  double du = m.Uo - Uice, dv = m.Vo - Vice;
+  double sp = ::sqrt(du * du + dv * dv);
+  double tauX = rho0 * Cd * sp * (c.cta * du - c.sta * dv);
+  double tauY = rho0 * Cd * sp * (c.sta * du + c.cta * dv);
+  Fx = tauX + c.Fx_atm + Fx_p;
+  Fy = tauY + c.Fy_atm + Fy_p;
+  tq = (-Fx * m.sth + Fy * m.cth) * m.rho;
+  Fx = Fx + (c.mass_per_area) * c.fc * c.Vi;
+  Fy = Fy - (c.mass_per_area) * c.fc * c.Ui;
+}
+SZ_HD void wind_point(const ForceCtx &c, const Params &P, double mx, double my, double &uw, double &vw) {
+  McPoint unused;
+  point_sample(c, P, mx, my, true, false, uw, vw, unused);
 }
 SZ_HD void wind_stress(ForceCtx &c, double su, double sv, int cnt) {            // :139-141
   const double rho_air = 1.2, Cd_atm = 1e-3;
@@ -870,27 +915,10 @@ SZ_HD void wind_stress(ForceCtx &c, double su, double sv, int cnt) {            
   c.Fy_atm = rho_air * Cd_atm * w10 * V10;
 }
 SZ_HD void force_point(const ForceCtx &c, const Params &P, double mx, double my, double &Fx, double &Fy, double &tq) {
-  const double rho0 = 1027, Cd = 3e-3;
-  double xr1 = c.ca * mx + (-c.sa) * my, xr2 = c.sa * mx + c.ca * my;
-  double Xg = xr1 + c.Xi, Yg = xr2 + c.Yi;
-  double th = szm::atan2(xr2, xr1), rho = szc::hyp(xr1, xr2);
-  double Uo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Uocn, Xg, Yg);
-  double Vo = interp2_linear(P.Xo, P.nxo, P.Yo, P.nyo, P.Vocn, Xg, Yg);
-  double sth, cth;
-  szm::sincos(th, sth, cth);
-  double Uice = c.Ui - rho * c.ksi * sth;
-  double Vice = c.Vi + rho * c.ksi * cth;
-  double Fx_p = -(c.mass_per_area) * c.fc * Vo;
-  double Fy_p = +(c.mass_per_area) * c.fc * Uo;
-  double du = Uo - Uice, dv = Vo - Vice;
-  double sp = ::sqrt(du * du + dv * dv);
-  double tauX = rho0 * Cd * sp * (c.cta * du - c.sta * dv);
-  double tauY = rho0 * Cd * sp * (c.sta * du + c.cta * dv);
-  Fx = tauX + c.Fx_atm + Fx_p;
-  Fy = tauY + c.Fy_atm + Fy_p;
-  tq = (-Fx * sth + Fy * cth) * rho;
-  Fx = Fx + (c.mass_per_area) * c.fc * c.Vi;
-  Fy = Fy - (c.mass_per_area) * c.fc * c.Ui;
+  McPoint m;
+  double uw, vw;
+  point_sample(c, P, mx, my, false, true, uw, vw, m);
+  point_force(c, m, Fx, Fy, tq);
 }
 // The means over the Monte-Carlo points (calc_trajectory.m:139,163-165) are summed in a fixed order that 256
 // threads can follow: point q goes into partial q mod 256 (increasing q), then the partials are folded pairwise,

@@ -136,6 +136,15 @@ def test_baseline_configs(ctx, name, steps):
         assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
 
 
+def test_forcing_with_more_points_than_the_kernel_keeps(ctx):
+    # k_forcing keeps the samples of 4 points per thread between its two passes (n_mc <= 1024); 1300 points per
+    # floe take the path that samples the rest again
+    S, P = scenes.pack(60, periodic=True, seed=9, vel_seed=10, sigma=0.2, n_mc=1300)
+    P.set_reference_ocean()
+    A, G, exact = lockstep(ctx, S, P, 6, do_int_every=2)
+    assert exact
+
+
 def test_long_convex_rings(ctx):
     # 8..39-vertex convex floes: fast pass (16-vertex blocks) and general sweep for the longer rings
     S, P = scenes.many_sided(64)
