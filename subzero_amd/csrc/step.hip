@@ -527,7 +527,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   const size_t cap = 4 * (size_t)n;
   W.cap_ext = (int)cap; W.pot_cap = S->pot_cap;
 #define NEW(field, count) if ((rc = dev_alloc(ctx, S, W.field, (size_t)(count)))) return rc;
-  NEW(ext_src, cap) NEW(ext_num, cap) NEW(ext_parent, cap) NEW(xg_of, cap) NEW(yg_of, cap)
+  NEW(ext_src, cap) NEW(ext_num, cap) NEW(ext_parent, cap) NEW(xg_of, cap) NEW(yg_of, cap) NEW(ext_nv, cap)
   NEW(ext_x, cap) NEW(ext_y, cap) NEW(flag, cap) NEW(scan, cap) NEW(counters, C_COUNT)
   NEW(pot_cnt, cap) NEW(pot_list, cap * W.pot_cap)
   NEW(pair_cnt, cap) NEW(pair_nv, cap) NEW(pair_base, cap + 1) NEW(nv_base, cap + 1)

@@ -73,6 +73,7 @@ struct Work {
   i64 cap_pairs; // pairs the scratch arena is sized for
   // extended list: real floes then ghosts
   int *ext_src, *ext_num, *ext_parent, *xg_of, *yg_of;
+  int *ext_nv;                  // stored ring length of the entry's floe (vert_off difference), so that pair sizing needs one lookup
   double *ext_x, *ext_y;
   int *flag, *scan;             // cap_ext
   unsigned long long *counters; // C_COUNT
@@ -134,6 +135,7 @@ inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; 
 // ---------------------------------------------------------------------------------------------
 SZ_HD void ext_init(int i, const Floes &F, Work &W) { // i < n
   W.ext_src[i] = i; W.ext_x[i] = F.Xi[i]; W.ext_y[i] = F.Yi[i]; W.ext_num[i] = i + 1;
+  W.ext_nv[i] = F.vert_off[i + 1] - F.vert_off[i];
 }
 SZ_HD void ext_clear(int e, Work &W) { // e < cap_ext
   W.xg_of[e] = -1; W.yg_of[e] = -1; W.pot_cnt[e] = 0; W.inc_cnt[e] = 0; W.tmax[e] = 0;
@@ -144,6 +146,13 @@ SZ_HD void marks_clear(int e, const Floes &F) { F.kill[e] = 0; F.transfer[e] = 0
 // flag[e] = alive and the translated ring reaches beyond the box in dimension dim (:31,:52)
 SZ_HD void ghost_flag(int e, int dim, const Floes &F, const Params &P, Work &W) {
   int s = W.ext_src[e], v0 = F.vert_off[s], nv = F.vert_off[s + 1] - v0;
+  // no vertex is farther from the floe position than rmax (initialize_floe_values.m:26 defines it so, and the
+  // rotation of c0 into c_alpha keeps the distances): a floe well inside the box needs no look at its ring
+  // (the 1e-9 relative margin is far above the rounding of the rotated ring and of the sums below)
+  {
+    const double L = (dim == 0) ? P.Lx : P.Ly, c = (dim == 0) ? W.ext_x[e] : W.ext_y[e];
+    if (absd(c) + F.rmax[s] < L * (1 - 1e-9)) { W.flag[e] = 0; return; }
+  }
   double m = 0;
   for (int k = 0; k < nv; ++k) {
     double v = (dim == 0) ? F.cax[v0 + k] + W.ext_x[e] : F.cay[v0 + k] + W.ext_y[e];
@@ -156,7 +165,7 @@ SZ_HD void ghost_emit(int e, int dim, int base, const Floes &F, const Params &P,
   if (!W.flag[e]) return;
   int g = base + W.scan[e];
   if (g >= W.cap_ext) return; // cannot happen: cap_ext = 4 n
-  W.ext_src[g] = W.ext_src[e];
+  W.ext_src[g] = W.ext_src[e]; W.ext_nv[g] = W.ext_nv[e];
   W.ext_x[g] = (dim == 0) ? W.ext_x[e] - 2 * P.Lx * sgn(W.ext_x[e]) : W.ext_x[e];
   W.ext_y[g] = (dim == 1) ? W.ext_y[e] - 2 * P.Ly * sgn(W.ext_y[e]) : W.ext_y[e];
   W.ext_num[g] = -iabs(W.ext_num[e]);
@@ -303,13 +312,10 @@ SZ_HD bool has_wall_pair(int i, int N, const Floes &F, const Params &P) { return
 SZ_HD void pair_count(int i, int N, const Floes &F, const Params &P, Work &W) { // i < N
   int cnt = 0; i64 nv = 0;
   if (i >= F.nb) {
-    const int si = W.ext_src[i], ni = F.vert_off[si + 1] - F.vert_off[si];
+    const int ni = W.ext_nv[i];
     cnt = W.pot_cnt[i];
     const int *mine = W.pot_list + (size_t)i * W.pot_cap;
-    for (int q = 0; q < cnt; ++q) {
-      int sj = W.ext_src[mine[q] - 1];
-      nv += ni + (F.vert_off[sj + 1] - F.vert_off[sj]);
-    }
+    for (int q = 0; q < cnt; ++q) nv += ni + W.ext_nv[mine[q] - 1];
     if (has_wall_pair(i, N, F, P)) { ++cnt; nv += ni + 4; }
   }
   W.pair_cnt[i] = cnt; W.pair_nv[i] = nv;
@@ -317,13 +323,13 @@ SZ_HD void pair_count(int i, int N, const Floes &F, const Params &P, Work &W) { 
 SZ_HD void pair_expand(int i, int N, const Floes &F, const Params &P, Work &W) { // after scans
   if (i < F.nb) return;
   i64 p = W.pair_base[i], nvo = W.nv_base[i];
-  const int si = W.ext_src[i], ni = F.vert_off[si + 1] - F.vert_off[si];
+  const int ni = W.ext_nv[i];
   const int *mine = W.pot_list + (size_t)i * W.pot_cap;
   for (int q = 0; q < W.pot_cnt[i]; ++q, ++p) {
     if (p >= W.cap_pairs) return;
-    int j = mine[q] - 1, sj = W.ext_src[j];
+    int j = mine[q] - 1;
     W.pair_i[p] = i; W.pair_j[p] = j; W.pair_nvoff[p] = nvo;
-    nvo += ni + (F.vert_off[sj + 1] - F.vert_off[sj]);
+    nvo += ni + W.ext_nv[j];
   }
   if (has_wall_pair(i, N, F, P) && p < W.cap_pairs) {
     W.pair_i[p] = i; W.pair_j[p] = WALL; W.pair_nvoff[p] = nvo;

@@ -113,7 +113,7 @@ struct Sim {
     memset(&W, 0, sizeof(W));
     cap = 4 * n;
     W.cap_ext = cap; W.pot_cap = pot_cap < 0 ? -pot_cap : pot_cap;
-    W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap);
+    W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap); W.ext_nv = alloc<int>(pool, cap);
     W.xg_of = alloc<int>(pool, cap); W.yg_of = alloc<int>(pool, cap);
     W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap);
     W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
