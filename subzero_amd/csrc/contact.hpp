@@ -280,21 +280,29 @@ SZ_HD double dist_to_ring(double xp, double yp, const Ring &c) {
 }
 
 // InterX.m:54-81.  Returns the number of unique crossings (sorted by x, then y), or -1 on overflow.
+// The segment pairs are visited ring-1-major with the cross products of the ring-2 vertices carried from one
+// segment to the next (every product is the expression of InterX, evaluated once instead of twice); the result
+// is a sorted set, so the order of discovery does not matter.
 template <class Ring>
 SZ_HD int crossings(const Ring &c1, const Ring &c2, double *px, double *py, int cap) {
   int m1 = c1.len() - 1, m2 = c2.len() - 1;
   int np = 0;
-  for (int j = 0; j < m2; ++j) {
-    double x2a = c2.X(j), y2a = c2.Y(j), x2b = c2.X(j + 1), y2b = c2.Y(j + 1);
-    double dx2 = x2b - x2a, dy2 = y2b - y2a;
-    double S2 = dx2 * y2a - dy2 * x2a;
-    for (int i = 0; i < m1; ++i) {
-      double x1a = c1.X(i), y1a = c1.Y(i), x1b = c1.X(i + 1), y1b = c1.Y(i + 1);
-      double dx1 = x1b - x1a, dy1 = y1b - y1a;
-      double S1 = dx1 * y1a - dy1 * x1a;
-      double a = dx1 * y2a - dy1 * x2a;
-      double b = dx1 * y2b - dy1 * x2b;
+  if (m1 <= 0 || m2 <= 0) return 0;
+  double x1b = c1.X(0), y1b = c1.Y(0);
+  for (int i = 0; i < m1; ++i) {
+    const double x1a = x1b, y1a = y1b;
+    x1b = c1.X(i + 1); y1b = c1.Y(i + 1);
+    const double dx1 = x1b - x1a, dy1 = y1b - y1a;
+    const double S1 = dx1 * y1a - dy1 * x1a;
+    double x2b = c2.X(0), y2b = c2.Y(0);
+    double b = dx1 * y2b - dy1 * x2b;
+    for (int j = 0; j < m2; ++j) {
+      const double x2a = x2b, y2a = y2b, a = b;
+      x2b = c2.X(j + 1); y2b = c2.Y(j + 1);
+      b = dx1 * y2b - dy1 * x2b;
       if (!(((a - S1) * (b - S1)) <= 0)) continue;
+      const double dx2 = x2b - x2a, dy2 = y2b - y2a;
+      const double S2 = dx2 * y2a - dy2 * x2a;
       double c = y1a * dx2 - x1a * dy2;
       double d = y1b * dx2 - x1b * dy2;
       if (!(((c - S2) * (d - S2)) <= 0)) continue;
