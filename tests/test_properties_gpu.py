@@ -1,7 +1,7 @@
-"""Size-independent properties at BASELINE.json's full sizes (1e4 floes / 6e4 ring pairs), where the oracle
-is too slow to be the checker: Newton's third law on the contact rows, force sums equal to the row sums,
+"""Size-independent properties at BASELINE.json's full sizes (1e4 floes / 6e4 ring pairs), over more steps and
+pairs than the oracle is asked to follow: Newton's third law on the contact rows, force sums equal to the row sums,
 momentum and energy, CSR consistency; for the clip primitive commutativity, idempotence and
-inclusion-exclusion of areas."""
+inclusion-exclusion of areas.  Plus one direct comparison with the oracle at the full size (12 timesteps)."""
 import numpy as np
 import pytest
 
@@ -99,3 +99,28 @@ def test_full_size_step_properties(ctx):
     # test/conservation_test.m's criterion: K(end) / K(1) < 1 (elastic overlap energy may return in between)
     assert ke[-1] < ke[0]
     assert np.isfinite(S.Xi).all() and np.isfinite(S.cax).all() and S.alive.all()
+
+
+def test_full_size_parity_with_the_oracle(ctx):
+    """BASELINE.json configs[3] at full size (1e4 floes, ~4.4e4 candidate pairs per step): every field after every
+    one of 12 timesteps bit-identical to the CPU oracle (the north-star bar is 1e-10 relative), including a
+    forcing refresh.  The oracle needs ~0.3 s per step on the box's host cores."""
+    import os
+    import hoststep
+    import oracle
+    S = synth.voronoi_field(10000, 1.0, seed=4, vel_seed=2, vel_sigma=0.1, n_stress=8)
+    P = synth.StepParams(dt=10, periodic=True)
+    P.Modulus = synth.reference_modulus(S)
+    P.set_reference_ocean()
+    A, G = S.copy(), S.copy()
+    sim = capi.FloeInteractions(ctx, G)
+    threads = min(os.cpu_count() or 1, 64)
+    for it in range(12):
+        P.doInt = int(it % 10 == 0)
+        ra = oracle.step(A, P, threads=threads)
+        sim.step(P)
+        sim.download(capi.SYNC_ALL)
+        off, rows = sim.interactions()
+        assert np.array_equal(ra.inter_off, off) and np.array_equal(ra.inter, rows), "step %d" % it
+        assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
+    assert len(rows) > 20000
