@@ -603,8 +603,21 @@ SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &rin
   if (n2 == (int)Blk::NV + 1 && ring2.X(n2 - 1) == ring2.X(0) && ring2.Y(n2 - 1) == ring2.Y(0) &&
       hyp(ring2.X(0) - ring2.X(n2 - 2), ring2.Y(0) - ring2.Y(n2 - 2)) > 1) --n2;
   if (n1 > (int)Blk::NV || n2 > (int)Blk::NV || n1 < 1 || n2 < 1) return ST_DEFER;
-  for (int k = 0; k < n1; ++k) { blk->v.m.x[0][k] = ring1.X(k); blk->v.m.y[0][k] = ring1.Y(k); }
-  for (int k = 0; k < n2; ++k) { blk->v.m.x[1][k] = ring2.X(k); blk->v.m.y[1][k] = ring2.Y(k); }
+  // (the sweep converts with to_fixed_in_range: coordinates must be finite and, with the <= 1 m shift of the
+  // second clip, within its range -- anything else, e.g. a NaN floe, goes to the general sweep)
+  const double safe = SZX_FIXED_SAFE_METRES - 2;
+  bool in_range = true;
+  for (int k = 0; k < n1; ++k) {
+    const double X = ring1.X(k), Y = ring1.Y(k);
+    in_range = in_range && absd(X) < safe && absd(Y) < safe;
+    blk->v.m.x[0][k] = X; blk->v.m.y[0][k] = Y;
+  }
+  for (int k = 0; k < n2; ++k) {
+    const double X = ring2.X(k), Y = ring2.Y(k);
+    in_range = in_range && absd(X) < safe && absd(Y) < safe;
+    blk->v.m.x[1][k] = X; blk->v.m.y[1][k] = Y;
+  }
+  if (!in_range) return ST_DEFER;
   RingL l1 = {blk->v.m.x[0], blk->v.m.y[0], n1, 0}, l2 = {blk->v.m.x[1], blk->v.m.y[1], n2, 0};
   InBlock<Blk> clip = {blk, S.ws};
   int nreg = 0;

@@ -97,13 +97,23 @@ SZ_HD i64 to_fixed(double v) {
   else if (f <= -0.5) t -= 1.0;
   return (i64)t;
 }
+// the same for |v| < 2^30 m (FIXED_SAFE_METRES): no NaN, no saturation, so those branches are dropped
+#define SZX_FIXED_SAFE_METRES 1.0e9
+SZ_HD i64 to_fixed_in_range(double v) {
+  double s = v * 4294967296.0;
+  double t = __builtin_trunc(s);
+  double f = s - t;
+  if (f >= 0.5) t += 1.0;
+  else if (f <= -0.5) t -= 1.0;
+  return (i64)t;
+}
 // how the sweep reads vertex i of ring `poly` in fixed-point coordinates
-struct VertsMetres {
+struct VertsMetres { // the caller has checked that every coordinate, shifted or not, is within +-FIXED_SAFE_METRES
   int shifted; double shift_x, shift_y;   // ring 0 moved by this before the conversion (floe_interactions.m:148-149)
   template <class Blk> SZ_HD Pt operator()(const Blk &K, int poly, int i) const {
     double X = K.v.m.x[poly][i], Y = K.v.m.y[poly][i];
     if (poly == 0 && shifted) { X = X + shift_x; Y = Y + shift_y; }
-    Pt p; p.x = to_fixed(X); p.y = to_fixed(Y);
+    Pt p; p.x = to_fixed_in_range(X); p.y = to_fixed_in_range(Y);
     return p;
   }
 };

@@ -57,7 +57,7 @@ extern "C" int host_clip_batch(int npairs,
         if (ma <= (int)szx::FastBlock::NV && mb <= (int)szx::FastBlock::NV) {
           bool exact = true;      // mode 2: hand the rings over in metres, as the step does (needs |v| < 2^53)
           if (g_try_fast == 2) {
-            const int64_t lim = (int64_t)1 << 53;
+            const int64_t lim = (int64_t)1 << 53;   // exact in a double, and 2^21 m is well inside the range VertsMetres needs
             for (int i = 0; i < ma; ++i) exact = exact && a.x[i] < lim && a.x[i] > -lim && a.y[i] < lim && a.y[i] > -lim;
             for (int i = 0; i < mb; ++i) exact = exact && b.x[i] < lim && b.x[i] > -lim && b.y[i] < lim && b.y[i] > -lim;
           }
