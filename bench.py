@@ -41,12 +41,24 @@ def build_workload(n_floes, seed=4, box_scale=1.0):
     return S, P
 
 
+def usable_cores():
+    """Cores this process may really use: the cgroup CPU quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(S, P, budget_s=20.0):
     """Oracle steps on the host cores from the same (already colliding) state; bounded sample.
     Parallel structure of the reference: narrow phase and calc_trajectory are parfor loops (OpenMP here), the
     broad phase is its serial O(N^2) loop (floe_interactions_all.m:76-120)."""
     import oracle
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     A = S.copy()
     t0 = time.time()
     steps = 0

@@ -114,7 +114,7 @@ def test_full_size_parity_with_the_oracle(ctx):
     P.set_reference_ocean()
     A, G = S.copy(), S.copy()
     sim = capi.FloeInteractions(ctx, G)
-    threads = min(os.cpu_count() or 1, 64)
+    threads = min(os.cpu_count() or 1, 32)
     for it in range(12):
         P.doInt = int(it % 10 == 0)
         ra = oracle.step(A, P, threads=threads)
