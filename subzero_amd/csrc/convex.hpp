@@ -271,6 +271,13 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb
       SZX_SET(ed[s].vtop, s == id, r.vtop); SZX_SET(ed[s].dir, s == id, r.dir); SZX_SET(ed[s].ring, s == id, r.ring);
       SZX_SET(ed[s].side, s == id, r.side); SZX_SET(ed[s].wind2, s == id, r.wind2); SZX_SET(ed[s].last, s == id, r.last);)
   };
+  auto put_geometry = [&](int id, const CEdge &r) SZX_INLINE {
+    SZX_EACH(s,
+      SZX_SET(ed[s].bot.x, s == id, r.bot.x); SZX_SET(ed[s].bot.y, s == id, r.bot.y);
+      SZX_SET(ed[s].top.x, s == id, r.top.x); SZX_SET(ed[s].top.y, s == id, r.top.y);
+      SZX_SET(ed[s].curx, s == id, r.curx); SZX_SET(ed[s].slope, s == id, r.slope);
+      SZX_SET(ed[s].vtop, s == id, r.vtop); SZX_SET(ed[s].last, s == id, r.last);)
+  };
   auto curx_of = [&](int id) SZX_INLINE { return SZX_PICK(ed, id, .curx); };
   auto ord_at = [&](int pos) SZX_INLINE { return SZX_PICK(ord, pos, ); };
   auto pos_of = [&](int id) SZX_INLINE { int v = -1; SZX_EACH(s, if (s < k && ord[s] == id) v = s;) return v; };
@@ -432,7 +439,7 @@ SZ_HD int clip_monotone(const FastWsT<Blk> &w, const Verts &vert, int na, int nb
         if (e.ring >= 0) dq_emit(q, e.side, e.top);
         advance(e, ending >> 1);
         e.curx = e.bot.x;
-        put(ending, e);
+        put_geometry(ending, e);          // ring, side, winding and direction stay
         // a neighbour of the other ring passing through this vertex is the join case of the general code
         const int pe = pos_of(ending);
         if (pe > 0 && curx_of(ord_at(pe - 1)) == e.curx) SZX_BAIL(17);
