@@ -53,7 +53,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(S, P, budget_s=20.0):
+def cpu_baseline(S, P, budget_s=12.0):
     """Oracle steps on the host cores from the same (already colliding) state; bounded sample.
     Parallel structure of the reference: narrow phase and calc_trajectory are parfor loops (OpenMP here), the
     broad phase is its serial O(N^2) loop (floe_interactions_all.m:76-120)."""
@@ -68,7 +68,7 @@ def cpu_baseline(S, P, budget_s=20.0):
         oracle.step(A, P, threads=threads)
         steps += 1; it += 1
         el = time.time() - t0
-        if el > budget_s or steps >= 12:
+        if el > budget_s or steps >= 200:
             break
     P.doInt = 0
     t1 = time.time()
