@@ -575,11 +575,33 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
   return szv::ST_OK;
 }
 
+// Axis-aligned boxes of two rings further apart than 1e-6 m: no edge of one can meet the other and neither lies
+// inside the other, so the clip is empty and floe_interactions.m returns its no-contact form ([0 0], [0 0], 0;
+// :43-74 with no regions and no crossings) -- exactly what the full path would produce, without running it.
+// (1e-6 m is 4295 units of the fixed-point grid: the boxes stay apart after the conversion.  NaN compares false.)
+struct Box { double x0, x1, y0, y1; };
+SZ_HD void box_start(Box &b) { b.x0 = SZC_INF; b.x1 = -SZC_INF; b.y0 = SZC_INF; b.y1 = -SZC_INF; }
+SZ_HD void box_add(Box &b, double x, double y) {
+  b.x0 = mind(b.x0, x); b.x1 = maxd(b.x1, x); b.y0 = mind(b.y0, y); b.y1 = maxd(b.y1, y);
+}
+SZ_HD bool boxes_apart(const Box &a, const Box &b) {
+  const double gap = 1e-6;
+  return a.x1 + gap < b.x0 || b.x1 + gap < a.x0 || a.y1 + gap < b.y0 || b.y1 + gap < a.y0;
+}
+SZ_HD void no_contact(PairOut &out) { out.nrows = 0; out.sentinel = 0; out.has_sentinel = 1; }
+
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
                        PairScratch &S, PairOut &out) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
+  if (!boundary) {
+    Box b1, b2;
+    box_start(b1); box_start(b2);
+    for (int k = 0; k < ring1.n; ++k) box_add(b1, ring1.X(k), ring1.Y(k));
+    for (int k = 0; k < ring2.n; ++k) box_add(b2, ring2.X(k), ring2.Y(k));
+    if (ring1.n > 0 && ring2.n > 0 && boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
+  }
   ViaArrays<ClipWide> clip = {{S.ws, S.cap_nv}};
   int nreg = 0;
   int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
@@ -607,17 +629,22 @@ SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &rin
   // second clip, within its range -- anything else, e.g. a NaN floe, goes to the general sweep)
   const double safe = SZX_FIXED_SAFE_METRES - 2;
   bool in_range = true;
+  Box b1, b2;
+  box_start(b1); box_start(b2);
   for (int k = 0; k < n1; ++k) {
     const double X = ring1.X(k), Y = ring1.Y(k);
     in_range = in_range && absd(X) < safe && absd(Y) < safe;
+    box_add(b1, X, Y);
     blk->v.m.x[0][k] = X; blk->v.m.y[0][k] = Y;
   }
   for (int k = 0; k < n2; ++k) {
     const double X = ring2.X(k), Y = ring2.Y(k);
     in_range = in_range && absd(X) < safe && absd(Y) < safe;
+    box_add(b2, X, Y);
     blk->v.m.x[1][k] = X; blk->v.m.y[1][k] = Y;
   }
   if (!in_range) return ST_DEFER;
+  if (boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
   RingL l1 = {blk->v.m.x[0], blk->v.m.y[0], n1, 0}, l2 = {blk->v.m.x[1], blk->v.m.y[1], n2, 0};
   InBlock<Blk> clip = {blk, S.ws};
   int nreg = 0;
