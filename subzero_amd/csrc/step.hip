@@ -51,7 +51,8 @@ struct StepState {
   int force_exchange = 0;
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 64;          // pairs per wave of that pass (SUBZERO_CONVEX_LANES)
-  int retry_lanes = 8;            // pairs per wave when the general kernel redoes what the fast pass deferred (SUBZERO_RETRY_LANES)
+  int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
+                                  // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
   i64 last_npairs = 0, last_nrows_real = 0;
@@ -494,7 +495,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->convex_lanes = l; }
-  if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->retry_lanes = l; }
+  if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -696,7 +697,13 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipMemcpyAsync(S->retry_copy.p, S->retry_list.p, (size_t)nl * 4, hipMemcpyDeviceToDevice, st));
     S->zero = 0;
     SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->zero, 8, hipMemcpyHostToDevice, st));
-    const int RL = fast ? S->retry_lanes : S->narrow_lanes;
+    // the general sweep of one pair is a chain of dependent accesses that takes milliseconds for long rings: few
+    // pairs per wave keep the wave as short as its longest pair, as long as the waves still fit the chip
+    int RL = S->narrow_lanes;
+    if (fast) {
+      RL = S->retry_lanes;
+      if (RL == 0) { i64 want = (nl + 2047) / 2048; RL = (int)(want < 1 ? 1 : want > 64 ? 64 : want); }
+    }
     hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
