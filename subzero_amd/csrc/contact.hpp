@@ -589,18 +589,37 @@ SZ_HD bool boxes_apart(const Box &a, const Box &b) {
   return a.x1 + gap < b.x0 || b.x1 + gap < a.x0 || a.y1 + gap < b.y0 || b.y1 + gap < a.y0;
 }
 SZ_HD void no_contact(PairOut &out) { out.nrows = 0; out.sentinel = 0; out.has_sentinel = 1; }
+// Floe against the domain box (floe_interactions.m:31-40: the part of the floe outside the box): a floe whose
+// bounding box lies more than 1e-6 m inside an axis-aligned rectangular box has nothing outside and crosses no
+// wall, so the result is the no-contact form as well.  c2b = the 5 closed corners (x, y interleaved).
+SZ_HD bool well_inside_box(const Box &b, const double *c2b) {
+  double x0 = c2b[0], x1 = c2b[0], y0 = c2b[1], y1 = c2b[1];
+  for (int k = 1; k < 4; ++k) { x0 = mind(x0, c2b[2 * k]); x1 = maxd(x1, c2b[2 * k]); y0 = mind(y0, c2b[2 * k + 1]); y1 = maxd(y1, c2b[2 * k + 1]); }
+  for (int k = 0; k < 4; ++k) {   // every corner must be a corner of that rectangle, each one used
+    const double x = c2b[2 * k], y = c2b[2 * k + 1];
+    if (!((x == x0 || x == x1) && (y == y0 || y == y1))) return false;
+    const int k1 = (k + 1) & 3;
+    if (!((x == c2b[2 * k1]) != (y == c2b[2 * k1 + 1]))) return false;   // consecutive corners share exactly one coordinate
+  }
+  const double gap = 1e-6;
+  return b.x0 > x0 + gap && b.x1 < x1 - gap && b.y0 > y0 + gap && b.y1 < y1 - gap;
+}
 
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
                        PairScratch &S, PairOut &out) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
-  if (!boundary) {
+  {
     Box b1, b2;
     box_start(b1); box_start(b2);
     for (int k = 0; k < ring1.n; ++k) box_add(b1, ring1.X(k), ring1.Y(k));
-    for (int k = 0; k < ring2.n; ++k) box_add(b2, ring2.X(k), ring2.Y(k));
-    if (ring1.n > 0 && ring2.n > 0 && boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
+    if (boundary) {
+      if (ring1.n > 0 && well_inside_box(b1, c2b)) { no_contact(out); return szv::ST_OK; }
+    } else {
+      for (int k = 0; k < ring2.n; ++k) box_add(b2, ring2.X(k), ring2.Y(k));
+      if (ring1.n > 0 && ring2.n > 0 && boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
+    }
   }
   ViaArrays<ClipWide> clip = {{S.ws, S.cap_nv}};
   int nreg = 0;
@@ -615,7 +634,13 @@ SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &rin
                             const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
                             PairScratch &S, PairOut &out, Blk *blk) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
-  if (boundary) return ST_DEFER;
+  if (boundary) {   // only floes at the walls need the clip against the box (general sweep: the box has horizontal edges)
+    Box b1;
+    box_start(b1);
+    for (int k = 0; k < ring1.n; ++k) box_add(b1, ring1.X(k), ring1.Y(k));
+    if (ring1.n > 0 && well_inside_box(b1, c2b)) { no_contact(out); return szv::ST_OK; }
+    return ST_DEFER;
+  }
   // A ring stored closed (last vertex an exact copy of the first) that is one vertex too long for the block is
   // staged without the copy when the closure rule of the contact model (:62-67, more than 1 m between the ends)
   // puts it back: every function below then sees the same closed ring, and the sweep strips the copy anyway.
