@@ -106,6 +106,32 @@ def squeeze_walls(P, step, every=3, by=15.0):
         P.fb_area = float(16 * Lx * Ly - 4 * Lx * Ly)
 
 
+def random_scene(seed):
+    """A small scene drawn from the seed: Voronoi pack (concentration 0.6-1), real concave outlines or many-sided
+    convex floes; periodic or walled; 20-120 floes; random speeds, time step, topography count Nb and forcing.
+    -> (FloeState, StepParams, number of steps)"""
+    rng = np.random.default_rng(seed)
+    kind = int(rng.integers(4))
+    periodic = bool(rng.integers(2))
+    n = int(rng.integers(20, 120))
+    if kind == 0:
+        S, P = pack(n, periodic=periodic, seed=seed, vel_seed=seed + 1, sigma=float(rng.uniform(0.05, 0.6)), n_stress=4, n_mc=200)
+    elif kind == 1:
+        S, P = concave(max(9, n // 3), periodic=periodic, seed=seed, n_stress=4)
+    elif kind == 2:
+        S, P = many_sided(max(9, n // 2), periodic=periodic, seed=seed, n_stress=4)
+    else:
+        S = synth.voronoi_field(n, float(rng.uniform(0.6, 1.0)), seed=seed, vel_seed=seed + 2,
+                                vel_sigma=float(rng.uniform(0.05, 0.5)), n_stress=4, n_mc=200)
+        P = synth.StepParams(dt=float(rng.choice([5, 10, 20])), periodic=periodic)
+        P.Modulus = synth.reference_modulus(S)
+    if rng.integers(2):
+        P.set_reference_ocean()
+    if rng.integers(4) == 0:
+        S.nb = int(rng.integers(1, 3))
+    return S, P, int(rng.integers(3, 9))
+
+
 def kinetic_energy(S):
     return 0.5 * (S.mass * (S.Ui ** 2 + S.Vi ** 2)).sum() + 0.5 * (S.inertia_moment * S.ksi_ice ** 2).sum()
 

@@ -128,6 +128,18 @@ def test_baseline_configs_match_oracle(name, steps):
         assert (ra.inter[:, 0] == np.inf).any()        # the moving walls push on the pack
 
 
+@pytest.mark.parametrize("seed", range(2000, 2024))
+def test_random_scenes_match_oracle(seed):
+    S, P, steps = scenes.random_scene(seed)
+    A, B = S.copy(), S.copy()
+    for it in range(steps):
+        P.doInt = int(it % 3 == 0)
+        ra = oracle.step(A, P, threads=4)
+        rb = hoststep.step(B, P)
+        assert np.array_equal(ra.pairs, rb.pairs) and np.array_equal(ra.inter, rb.inter), "step %d" % it
+        assert [b for b in hoststep.compare_states(A, B) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
+
+
 def test_device_pipeline_matches_oracle_walls():
     S, P = scenes.pack(200, periodic=False, seed=7, vel_seed=8, sigma=0.3)
     A, B, r = lockstep(S, P, 14)

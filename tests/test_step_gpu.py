@@ -145,6 +145,14 @@ def test_forcing_with_more_points_than_the_kernel_keeps(ctx):
     assert exact
 
 
+@pytest.mark.parametrize("seed", range(3000, 3030))
+def test_random_scenes(ctx, seed):
+    # random small scenes (Voronoi packs, concave outlines, many-sided floes; walls or periodic; Nb, forcing)
+    S, P, steps = scenes.random_scene(seed)
+    A, G, exact = lockstep(ctx, S, P, steps, do_int_every=3)
+    assert exact
+
+
 def test_long_convex_rings(ctx):
     # 8..39-vertex convex floes: fast pass (16-vertex blocks) and general sweep for the longer rings
     S, P = scenes.many_sided(64)
