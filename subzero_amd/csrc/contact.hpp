@@ -67,6 +67,24 @@ SZ_HD_NOINLINE int clip_fixed(void *ws, int cap_nv, const i64 *ax, const i64 *ay
   return szv::clip_rings(ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
 }
 
+// The same sweep with its Wide records in the lane's slice of the dynamic LDS: lane t's workspace starts at byte
+// t * lds_stride (launch contract of k_narrow_lds).  The address is formed here from the LDS symbol, so that the
+// compiler emits ds_ instructions for the whole sweep (a generic pointer to the same bytes gives flat_ accesses).
+SZ_HD_NOINLINE int clip_fixed_lds(void *host_ws, int lds_stride, int cap_nv, const i64 *ax, const i64 *ay, int na, const i64 *bx,
+                                  const i64 *by, int nb, int op, RegionSink *sink) {
+  FixedRing a = {ax, ay}, b = {bx, by};
+  sink->nv = 0; sink->nr = 0;
+  if (sink->ox != nullptr) sink->roff[0] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
+  void *ws = sz_dynamic_lds + (size_t)threadIdx.x * (size_t)lds_stride;
+  (void)host_ws;
+#else
+  void *ws = host_ws; (void)lds_stride;
+#endif
+  return szv::clip_rings(ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
+}
+
 // compact-record form (inlined: the workspace pointer then stays provably in LDS for the GPU compiler)
 SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb,
                              int op, RegionSink *sink) {
@@ -104,6 +122,13 @@ struct ClipWide {
   void *ws; int cap_nv;
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
     return clip_fixed(ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
+  }
+  SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
+};
+struct ClipWideLds {
+  void *host_ws; int lds_stride, cap_nv;
+  SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
+    return clip_fixed_lds(host_ws, lds_stride, cap_nv, ax, ay, na, bx, by, nb, op, sink);
   }
   SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
 };
@@ -608,7 +633,7 @@ SZ_HD bool well_inside_box(const Box &b, const double *c2b) {
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out) {
+                       PairScratch &S, PairOut &out, int lds_stride = 0) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   {
     Box b1, b2;
@@ -621,8 +646,14 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
       if (ring1.n > 0 && ring2.n > 0 && boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
     }
   }
-  ViaArrays<ClipWide> clip = {{S.ws, S.cap_nv}};
   int nreg = 0;
+  if (lds_stride > 0) {   // the sweep workspace of this lane is its slice of LDS (k_narrow_lds)
+    ViaArrays<ClipWideLds> clip = {{S.ws, lds_stride, S.cap_nv}};
+    int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
+    if (st != szv::ST_OK) return st;
+    return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
+  }
+  ViaArrays<ClipWide> clip = {{S.ws, S.cap_nv}};
   int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
   if (st != szv::ST_OK) return st;
   return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);

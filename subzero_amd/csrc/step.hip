@@ -53,6 +53,7 @@ struct StepState {
   int convex_lanes = 64;          // pairs per wave of that pass (SUBZERO_CONVEX_LANES)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
                                   // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
+  int retry_lds = 16384;          // bytes of LDS per pair for that pass when its list is short (SUBZERO_RETRY_LDS, 0: HBM workspace)
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
   i64 last_npairs = 0, last_nrows_real = 0;
@@ -239,6 +240,14 @@ __global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
   if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
+}
+// k_narrow with the sweep workspace of every lane in LDS (ds_ addressing): for deferred pairs of short rings (ties,
+// floes at the walls), whose general sweeps are chains of dependent accesses to a few KB of records
+__global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, int mult, int lanes, int lds_per_lane, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (t < count) narrow_lds(t, list, mult, F, P, W, (void *)(smem + (size_t)threadIdx.x * lds_per_lane), lds_per_lane);
 }
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
@@ -496,10 +505,12 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
+  if (const char *v = getenv("SUBZERO_RETRY_LDS")) { int b = atoi(v); if (b >= 0 && b <= 40 * 1024) S->retry_lds = b; }
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
+  (void)hipFuncSetAttribute((const void *)k_narrow_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int n = h->n;
   const int nv = h->vert_off[n];
@@ -704,7 +715,13 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
       RL = S->retry_lanes;
       if (RL == 0) { i64 want = (nl + 2047) / 2048; RL = (int)(want < 1 ? 1 : want > 64 ? 64 : want); }
     }
-    hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
+    // deferred pairs at the 1x tier: a short list of short rings (ties, floes at the walls) runs with the sweep
+    // workspace in LDS, one to four pairs per wave; a pair that needs more than the slice keeps its HBM workspace
+    const int retry_lds = (fast && mult == 1 && RL <= 4) ? S->retry_lds : 0;
+    if (retry_lds > 0)
+      hipLaunchKernelGGL(k_narrow_lds, grid_for(nl, RL), dim3(64), (size_t)retry_lds * RL, st, nl, (const int *)S->retry_copy.p, mult, RL, retry_lds, F, P, W);
+    else
+      hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SZ_HIP(ctx, hipStreamSynchronize(st));

@@ -370,7 +370,7 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
-template <bool CONVEX_ONLY, class Blk>
+template <bool CONVEX_ONLY, class Blk, bool LDS_WS = false>
 SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
                     void *fast_ws, int fast_ws_bytes, Blk *fast_blk) {
   i64 p = list ? (i64)list[t] : t;
@@ -414,7 +414,8 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   }
   W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);   // where row_fill / export_pair find the rows
   // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
-  if (fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes) S.ws = fast_ws;
+  const bool ws_fits_fast = fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes;
+  if (ws_fits_fast && !LDS_WS) S.ws = fast_ws;
   szc::PairOut out;
   int st;
   if (CONVEX_ONLY)
@@ -422,7 +423,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
                                 P.mu, P.nu, S, out, fast_blk);
   else
     st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
-                           P.mu, P.nu, S, out);
+                           P.mu, P.nu, S, out, (LDS_WS && ws_fits_fast) ? fast_ws_bytes : 0);
   W.pair_status[p] = st;
   if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY || st == szc::ST_DEFER) {
     unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
@@ -443,6 +444,10 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
 SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
                   void *fast_ws = nullptr, int fast_ws_bytes = 0) {
   narrow_t<false, szx::FastBlock>(t, list, mult, F, P, W, fast_ws, fast_ws_bytes, nullptr);
+}
+// the general sweep with its workspace in the lane's slice of LDS when that is large enough (k_narrow_lds)
+SZ_HD void narrow_lds(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W, void *lds_ws, int lds_stride) {
+  narrow_t<false, szx::FastBlock, true>(t, list, mult, F, P, W, lds_ws, lds_stride, nullptr);
 }
 // the single-minimum fast path only (convex.hpp); pairs it does not cover go to the retry list for narrow()
 template <class Blk>

@@ -153,6 +153,15 @@ def test_random_scenes(ctx, seed):
     assert exact
 
 
+def test_deferred_pairs_with_hbm_workspace(ctx, monkeypatch):
+    # SUBZERO_RETRY_LDS=0: the general pass over deferred pairs keeps its sweep workspace in HBM (the default puts
+    # it into LDS when the list is short); walls make every step defer the floes along them
+    monkeypatch.setenv("SUBZERO_RETRY_LDS", "0")
+    S, P = scenes.pack(300, periodic=False, seed=7, vel_seed=8, sigma=0.3)
+    A, G, exact = lockstep(ctx, S, P, 10)
+    assert exact
+
+
 def test_long_convex_rings(ctx):
     # 8..39-vertex convex floes: fast pass (16-vertex blocks) and general sweep for the longer rings
     S, P = scenes.many_sided(64)
