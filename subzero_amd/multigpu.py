@@ -68,7 +68,8 @@ class GpuBackend:
         self._bufs = {}
 
     def begin(self, P, rank, world):
-        self._cp = self.capi.pack_params(P)
+        self._cp = self.capi.pack_params(P, repack_grids=not getattr(self, "_grids_uploaded", False))
+        self._grids_uploaded = True
         info = ShardInfo()
         rc = self.ctx.L.szStepShardBegin(self.ctx.h, ctypes.byref(self._cp), rank, world, ctypes.byref(info))
         self._err = self.ctx.L.szLastError(self.ctx.h).decode() if rc else ""
