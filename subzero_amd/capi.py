@@ -110,6 +110,25 @@ def pack_params(P, repack_grids=True):
     return c
 
 
+class ParamPacker:
+    """szStepParams for successive steps of one uploaded floe field.  The packed block is reused while nothing but
+    doInt changes, and the ocean / wind grids are repacked only when the library reads them (on forcing steps and
+    on the first step after an upload): the call should cost microseconds, not the packing."""
+    _SCALARS = ("dt", "HFo", "Modulus", "mu", "nu", "COLLISION", "PERIODIC", "fb_h", "fb_area", "fb_Xi", "fb_Yi",
+                "fb_Ui", "fb_Vi", "fb_ksi_ice", "fCoriolis", "turn_angle")
+
+    def __init__(self):
+        self._cp = self._key = None
+
+    def pack(self, P):
+        key = tuple(getattr(P, k) for k in self._SCALARS) + (np.asarray(P.c2_boundary, np.float64).tobytes(),)
+        if self._cp is not None and not P.doInt and key == self._key:
+            self._cp.doInt = 0
+            return self._cp
+        self._cp, self._key = pack_params(P, repack_grids=self._cp is None), key
+        return self._cp
+
+
 # every symbol include/subzero_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
@@ -249,22 +268,10 @@ class FloeInteractions:
         self.ctx, self.floes = ctx, floes
         self._c = pack_floes(floes)
         ctx.check(ctx.L.szFloesUpload(ctx.h, ctypes.byref(self._c)), "szFloesUpload")
-        self._grids_uploaded = False
-
-    _SCALARS = ("dt", "HFo", "Modulus", "mu", "nu", "COLLISION", "PERIODIC", "fb_h", "fb_area", "fb_Xi", "fb_Yi",
-                "fb_Ui", "fb_Vi", "fb_ksi_ice", "fCoriolis", "turn_angle")
+        self._packer = ParamPacker()
 
     def step(self, params):
-        # the packed argument block is reused while nothing but doInt changes (and the grids are only read by the
-        # library on forcing steps and on the first step): the call itself should cost microseconds, not the packing
-        key = tuple(getattr(params, k) for k in self._SCALARS) + (np.asarray(params.c2_boundary, np.float64).tobytes(),)
-        if self._grids_uploaded and not params.doInt and key == getattr(self, "_key", None):
-            cp = self._cp
-            cp.doInt = 0
-        else:
-            cp = pack_params(params, repack_grids=not self._grids_uploaded)
-            self._cp, self._key = cp, key
-        self._grids_uploaded = True
+        cp = self._packer.pack(params)
         st = StepStats()
         self.ctx.check(self.ctx.L.szStep(self.ctx.h, ctypes.byref(cp), ctypes.byref(st)), "szStep")
         return st

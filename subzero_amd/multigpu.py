@@ -49,6 +49,7 @@ class GpuBackend:
         self.device = torch.device("cuda", local_rank)
         self.ctx = capi.Context(local_rank)
         self.sim = capi.FloeInteractions(self.ctx, floes)
+        self._packer = capi.ParamPacker()
         L = self.ctx.L
         L.szShardSegmentBytes.restype = ctypes.c_int64
         L.szShardSegmentBytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
@@ -68,8 +69,7 @@ class GpuBackend:
         self._bufs = {}
 
     def begin(self, P, rank, world):
-        self._cp = self.capi.pack_params(P, repack_grids=not getattr(self, "_grids_uploaded", False))
-        self._grids_uploaded = True
+        self._cp = self._packer.pack(P)
         info = ShardInfo()
         rc = self.ctx.L.szStepShardBegin(self.ctx.h, ctypes.byref(self._cp), rank, world, ctypes.byref(info))
         self._err = self.ctx.L.szLastError(self.ctx.h).decode() if rc else ""
