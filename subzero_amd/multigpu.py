@@ -141,23 +141,31 @@ class ShardedInteractions:
         if info.status and info.replicated_failure:
             # the replicated stages failed: the same error on every rank, nobody enters the exchange
             raise RuntimeError("sharded step failed in the replicated stages (%d): %s" % (info.status, be.last_error()))
-        seg_max = int(info.seg_max)
-        # rows per segment: sized from the last step (the same number on every rank); a segment that does not
-        # fit is reported by every rank's Finish, and the exchange is repeated with the size that does
-        rows_max = max(self.min_rows, int(1.25 * getattr(self, "_rows_seen", seg_max)) + 64)
+        # Capacities of a segment, the same on every rank (they follow from values every rank has): pairs rounded up
+        # so that the layout -- and with it the buffers -- changes rarely; rows from the last step, kept while
+        # they fit with some room, and a segment that does not fit is reported by every rank's Finish, after which
+        # the exchange is repeated with the size that does.
+        seg_max = (int(info.seg_max) + 1023) // 1024 * 1024
+        seen = getattr(self, "_rows_seen", seg_max)
+        rows_max = getattr(self, "_rows_max", 0)
+        if rows_max < 1.1 * seen + 16 or rows_max > 4 * seen + 4096 or rows_max < self.min_rows:
+            rows_max = max(self.min_rows, int(1.25 * seen) + 64)
         while True:
-            nbytes = be.segment_bytes(seg_max, rows_max)
-            send = be.buffer("send", nbytes)
-            recv = be.buffer("recv", nbytes * self.world)
+            if (seg_max, rows_max) != getattr(self, "_sized_for", None):   # same sizes as last step: same views
+                nbytes = be.segment_bytes(seg_max, rows_max)
+                self._send = be.buffer("send", nbytes)
+                self._recv = be.buffer("recv", nbytes * self.world)
+                self._sized_for = (seg_max, rows_max)
+            send, recv = self._send, self._recv
             be.export(send, seg_max, rows_max, info.status)
             dist.all_gather_into_tensor(recv, send, group=self.group)
             rc, need, st, forcing_pending = be.finish(recv, seg_max, rows_max)
             if rc == self.SHARD_RESIZE:
-                rows_max = need + 64
+                rows_max = int(1.25 * need) + 64
                 continue
             if rc != 0:   # every rank sees the same headers and stops together: no rank is left in a collective
                 raise RuntimeError("sharded step failed (%d): %s" % (rc, be.last_error()))
-            self._rows_seen = need
+            self._rows_seen, self._rows_max = need, rows_max
             break
         if forcing_pending:
             # forcing step: every rank evaluated the ocean / wind forcing of its own floe range
