@@ -18,6 +18,7 @@
 #include <math.h>
 #include "vatti.hpp"
 #include "convex.hpp"
+#include "trim.hpp"
 
 #if defined(__HIPCC__)
 #define SZ_HD_NOINLINE static __host__ __device__ __attribute__((noinline))
@@ -349,27 +350,50 @@ SZ_HD int crossings(const Ring &c1, const Ring &c2, double *px, double *py, int 
 }
 
 // How the three clips of the contact model are run.
+#ifndef SZC_TRIM_OFF
+#define SZC_TRIM_OFF false
+#endif
+#ifndef SZC_TRIM_PROBE
+#define SZC_TRIM_PROBE(before, after) ((void)0)
+#endif
 // ViaArrays: the rings go through int64 arrays of the pair's scratch slice into a sweep (Wide or Compact records).
 template <class Sweep>
 struct ViaArrays {
   Sweep sweep;
   template <class Ring>
   SZ_HD int first(const Ring &ring1, const Ring &ring2, bool boundary, PairScratch &S, RegionSink *sink) const {   // :29 / :34
-    const int n1 = ring1.n, n2 = ring2.n;
-    for (int k = 0; k < n1; ++k) { S.f1x[k] = to_fixed(ring1.X(k)); S.f1y[k] = to_fixed(ring1.Y(k)); }
-    for (int k = 0; k < n2; ++k) { S.f2x[k] = to_fixed(ring2.X(k)); S.f2y[k] = to_fixed(ring2.Y(k)); }
+    int n1 = ring1.n, n2 = ring2.n;
+    fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y);
+    fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y);
+    // an intersection sees only what lies in the box the two rings share (trim.hpp); on a tie the rings go in whole
+    if (!boundary && !SZC_TRIM_OFF && !szt::trim_pair(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2)) {
+      n1 = ring1.n; n2 = ring2.n;
+      fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y);
+      fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y);
+    }
+    SZC_TRIM_PROBE(ring1.n + ring2.n, n1 + n2);
     return sweep(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION, sink);
+  }
+  template <class Ring>
+  SZ_HD static void fill(const Ring &r, int n, bool shifted, double dx, double dy, i64 *fx, i64 *fy) {
+    for (int k = 0; k < n; ++k) {
+      if (!shifted) { fx[k] = to_fixed(r.X(k)); fy[k] = to_fixed(r.Y(k)); }
+      else { fx[k] = to_fixed(r.X(k) + dx); fy[k] = to_fixed(r.Y(k) + dy); }
+    }
   }
   // :140-155 ring 1 (closed) moved by the unit force direction, against ring 2 (closed)
   template <class Ring>
   SZ_HD int second(const Ring &c1, bool shifted, double fdx, double fdy, const Ring &c2, int op, PairScratch &S, RegionSink *sink) const {
-    const int nc1 = c1.len(), nc2 = c2.len(), n2 = c2.n;
-    for (int q = 0; q < nc1; ++q) {
-      if (!shifted) { S.fsx[q] = to_fixed(c1.X(q)); S.fsy[q] = to_fixed(c1.Y(q)); }
-      else { S.fsx[q] = to_fixed(c1.X(q) + fdx); S.fsy[q] = to_fixed(c1.Y(q) + fdy); }
+    int nc1 = c1.len(), nc2 = c2.len();
+    // (both rings closed here, :62-70; ring 2 is converted again: clip 1 may have trimmed its copy)
+    fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy);
+    fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y);
+    if (op == szv::OP_INTERSECTION && !SZC_TRIM_OFF && !szt::trim_pair(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2)) {
+      nc1 = c1.len(); nc2 = c2.len();
+      fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy);
+      fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y);
     }
-    // ring 2 after closure (clip 1 used the unclosed one; the closing vertex is a duplicate either way)
-    if (c2.extra) { S.f2x[n2] = S.f2x[0]; S.f2y[n2] = S.f2y[0]; }
+    SZC_TRIM_PROBE(c1.len() + c2.len(), nc1 + nc2);
     return sweep(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, sink);
   }
   SZ_HD int third(const i64 *tx, const i64 *ty, int nt, const i64 *rx, const i64 *ry, int nr, RegionSink *sink) const {   // :158

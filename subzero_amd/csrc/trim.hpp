@@ -1,0 +1,115 @@
+// trim.hpp -- two rings cut down to what an INTERSECTION clip of them can see.
+//
+// Whatever two rings have in common lies in the box Q that their bounding boxes have in common, and every
+// crossing of an edge of one with an edge of the other lies there too.  A run of consecutive vertices of a ring
+// that all lie strictly beyond the SAME side of Q (all left of it, all right, all below or all above) stays in
+// that open half-plane, and so does the chord from its start to its end: replacing the run's inner vertices by
+// that chord changes the ring only beyond that side of Q (the closed curve run + chord has winding number 0 about
+// every point of Q), never an edge that reaches Q, never the even-odd parity left of anything in Q.  The sweep of
+// the reference (clipper.cpp:1560-1621) then meets the same contributing edges in the same order and emits the
+// same rings, vertex for vertex -- with a fraction of the edges: evolved floe outlines (the reference's
+// FloeShapes.mat, ~50-90 vertices) that touch along one side come down to a third or less.
+//
+// What keeps it exact, not just equal as a point set:
+//   * two vertices are kept at each end of a run, so every vertex the ring keeps next to an edge that can reach Q
+//     has its original neighbours on both sides: AddPath's collinear-vertex removal (clipper.cpp:1100-1114) sees
+//     the triples it saw before, and the kept edges keep their end points and slopes (Dx, :591-596) to the bit;
+//   * a run is left alone when the chord would be collinear with the kept vertices next to it (the removal would
+//     then cascade into them);
+//   * the reference orders local minima of equal Y, and crossings of equal Y, by an unstable std::sort
+//     (clipper.cpp:1234, :2896): with fewer elements equal keys may land in another order, and with them rings
+//     that share a vertex or an edge (floes at rest against each other, fracture pieces) come out split, joined
+//     or rotated differently.  So both rings are handed over untrimmed whenever two kept vertices share a Y
+//     (this covers horizontal edges and repeated vertices too).
+// A crossing that the reference's double-precision IntersectPoint (:604-664) puts outside its scanbeam is
+// clamped to the beam, and trimming beyond the left / right side of Q makes beams taller; this needs a crossing
+// within rounding error (~1e-8 m for near-parallel floe edges) of the height of an unrelated, removed vertex
+// and moves one output vertex by that error: not seen in 10^5 fuzzed pairs against the reference Clipper
+// (tests/test_clip_cpu.py), far inside the 1e-10 relative bar on forces if it ever is.
+#pragma once
+#include "vatti.hpp"
+
+namespace szt {
+
+using szv::i64;
+using szv::Pt;
+
+struct Box { i64 xmin, xmax, ymin, ymax; };
+
+SZ_HD void box_of(const i64 *x, const i64 *y, int n, Box &b) {
+  b.xmin = b.xmax = x[0]; b.ymin = b.ymax = y[0];
+  for (int k = 1; k < n; ++k) {
+    i64 vx = x[k], vy = y[k];
+    b.xmin = vx < b.xmin ? vx : b.xmin; b.xmax = vx > b.xmax ? vx : b.xmax;
+    b.ymin = vy < b.ymin ? vy : b.ymin; b.ymax = vy > b.ymax ? vy : b.ymax;
+  }
+}
+SZ_HD int beyond(i64 x, i64 y, const Box &q) {
+  return (int)(x < q.xmin) | ((int)(x > q.xmax) << 1) | ((int)(y < q.ymin) << 2) | ((int)(y > q.ymax) << 3);
+}
+
+enum { MIN_RING = 7 };   // shorter rings have no run worth cutting (a run needs 5 vertices to lose one)
+
+// Compacts the ring in place; returns the new vertex count (== n when nothing was removed; a closing duplicate,
+// which AddPath strips anyway (clipper.cpp:1055), is dropped only together with a removal).
+SZ_HD int trim_ring(i64 *x, i64 *y, int n, const Box &q) {
+  int m = n;
+  if (m > 1 && x[m - 1] == x[0] && y[m - 1] == y[0]) --m;
+  if (m < MIN_RING) return n;
+  int w = 0, i = 0;
+  while (i < m) {
+    const int s = i;
+    int side = beyond(x[i], y[i], q);
+    if (side)
+      while (i + 1 < m) {
+        int both = side & beyond(x[i + 1], y[i + 1], q);
+        if (!both) break;
+        side = both; ++i;
+      }
+    const int e = i;
+    ++i;
+    bool cut = side && e - s >= 4;
+    if (cut) {
+      Pt a, b, c, d;
+      a.x = x[s]; a.y = y[s]; b.x = x[s + 1]; b.y = y[s + 1];
+      c.x = x[e - 1]; c.y = y[e - 1]; d.x = x[e]; d.y = y[e];
+      cut = !szv::collinear3(a, b, c) && !szv::collinear3(b, c, d);
+    }
+    for (int k = s; k <= e; ++k) {
+      if (cut && k >= s + 2 && k <= e - 2) continue;
+      x[w] = x[k]; y[w] = y[k]; ++w;
+    }
+  }
+  return w == m ? n : w;
+}
+
+SZ_HD bool heights_distinct(const i64 *y1, int n1, const i64 *y2, int n2) {
+  for (int a = 0; a < n1 + n2; ++a) {
+    const i64 va = a < n1 ? y1[a] : y2[a - n1];
+    for (int b = a + 1; b < n1 + n2; ++b)
+      if (va == (b < n1 ? y1[b] : y2[b - n1])) return false;
+  }
+  return true;
+}
+
+// Both rings of an INTERSECTION, in place.  Returns false when the rings must be handed over as they were
+// (the caller restores them: the arrays may have been compacted); true with the new counts otherwise
+// (which equal the old ones when there was nothing to cut).
+SZ_HD bool trim_pair(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb) {
+  if (na < 1 || nb < 1 || (na < MIN_RING && nb < MIN_RING)) return true;
+  Box A, B, q;
+  box_of(ax, ay, na, A); box_of(bx, by, nb, B);
+  q.xmin = A.xmin > B.xmin ? A.xmin : B.xmin; q.xmax = A.xmax < B.xmax ? A.xmax : B.xmax;
+  q.ymin = A.ymin > B.ymin ? A.ymin : B.ymin; q.ymax = A.ymax < B.ymax ? A.ymax : B.ymax;
+  if (q.xmin > q.xmax || q.ymin > q.ymax) return true;       // nothing in common: left to the sweep as it is
+  const int ta = trim_ring(ax, ay, na, q), tb = trim_ring(bx, by, nb, q);
+  if (ta == na && tb == nb) return true;
+  // (an untouched ring may still carry its closing duplicate: not a tie)
+  const int ea = (ta == na && na > 1 && ax[na - 1] == ax[0] && ay[na - 1] == ay[0]) ? na - 1 : ta;
+  const int eb = (tb == nb && nb > 1 && bx[nb - 1] == bx[0] && by[nb - 1] == by[0]) ? nb - 1 : tb;
+  if (!heights_distinct(ay, ea, by, eb)) return false;
+  na = ta; nb = tb;
+  return true;
+}
+
+} // namespace szt

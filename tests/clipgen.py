@@ -92,6 +92,63 @@ def shape_pairs(n, seed=0, max_verts=None):
     return ps
 
 
+def cut_pairs(n, seed=0):
+    """A real floe outline cut in two by a chord (as a fracture leaves it), one piece moved and turned a little:
+    long near-coincident edges, T-junctions, crossings at grazing angles."""
+    rng = np.random.default_rng(seed)
+    shapes, _ = load_shapes()
+    shapes = [s for s in shapes if 20 <= len(s) <= 90]
+    ps = PairSet()
+    while len(ps) < n:
+        s = shapes[rng.integers(len(shapes))]
+        c = s.mean(0); th = rng.uniform(0, np.pi)
+        nrm = np.array([np.cos(th), np.sin(th)])
+        d = (s - c) @ nrm - rng.normal(0, 0.1) * np.sqrt(((s - c) ** 2).sum(1).max())
+        sgn = d > 0
+        flips = np.nonzero(sgn != np.roll(sgn, -1))[0]
+        if len(flips) != 2:
+            continue
+        i, j = flips
+
+        def on_chord(k):
+            a, b = s[k], s[(k + 1) % len(s)]
+            return a + d[k] / (d[k] - d[(k + 1) % len(s)]) * (b - a)
+        pi_, pj = on_chord(i), on_chord(j)
+        A = np.vstack([s[i + 1:j + 1], pj, pi_])
+        B = np.vstack([s[j + 1:], s[:i + 1], pi_, pj])
+        if len(A) < 4 or len(B) < 4:
+            continue
+        move = rng.normal(0, 1, 2) * 10.0 ** rng.uniform(-4, 1.5)
+        turn = rng.normal(0, 1) * 10.0 ** rng.uniform(-7, -3)
+        if rng.random() < 0.1:
+            move[:] = 0; turn = 0          # still joined: shared vertices, coincident edges
+        cb = B.mean(0)
+        B2 = _rot(B - cb, turn) + cb + move
+        ps.add(np.vstack([A, A[:1]]), np.vstack([B2, B2[:1]]))
+    return ps
+
+
+def snapped_shape_pairs(n, seed=0, grid=400, mode=0):
+    """shape_pairs with coordinates snapped to a coarse lattice (metres): mode 0 both axes (horizontal edges, spikes,
+    repeated vertices removed), 1 x only (vertical coincidences), 2 both with every other vertex lifted by a quarter
+    cell (shared scanlines, T-junctions, no horizontal edges)."""
+    src = shape_pairs(n, seed=seed, max_verts=90)
+    q = PairSet()
+    g = np.int64(grid) << 32
+
+    def snap(x, y):
+        x = (x // g) * g
+        if mode == 0:
+            y = (y // g) * g
+        elif mode == 2:
+            y = (y // g) * g + (np.arange(len(y)) % 2) * (g // 4)
+        k = np.ones(len(x), bool); k[1:] = (x[1:] != x[:-1]) | (y[1:] != y[:-1])
+        return np.stack([x[k], y[k]], 1)
+    for p in range(len(src)):
+        q.add(snap(src.ax[p], src.ay[p]), snap(src.bx[p], src.by[p]), fixed=True)
+    return q
+
+
 def convex_pairs(n, seed=0):
     """Random convex polygons (6-9 vertices, km scale) like fresh Voronoi floes, overlapping a little."""
     rng = np.random.default_rng(seed)
@@ -265,7 +322,7 @@ def ref_lib():
 def host_lib():
     path = os.path.join(ROOT, "tests", "hostsim", "libvatti_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "vatti_host.cpp")
-    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("vatti.hpp", "convex.hpp")]
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("vatti.hpp", "convex.hpp", "trim.hpp")]
     if (not os.path.exists(path)) or os.path.getmtime(path) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
                                src, "-o", path])
@@ -307,18 +364,25 @@ def run_ref(ps, method):
     return ClipResult(ox, oy, roff, proff, st)
 
 
-def run_host(ps, method, fill_s=0, fill_c=0, fast=0):
+def run_host(ps, method, fill_s=0, fill_c=0, fast=0, trim=0):
     """fast = 1 / 2: try the single-minimum fast path (convex.hpp) first, from int64 rings / from rings in metres
-    as the step hands them over; what it declines goes to the general sweep.  r.fast = clips it completed."""
+    as the step hands them over; what it declines goes to the general sweep.  r.fast = clips it completed.
+    trim = 1: the rings of an intersection are first cut down to their common box (trim.hpp), as the step's general
+    path does; r.trim = (vertices before, after, pairs handed over untrimmed because of a tie)."""
     L = host_lib()
     L.host_clip_set_fast(int(fast))
+    L.host_clip_set_trim(int(trim))
     ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st = _alloc(ps)
     rc = L.host_clip_batch(len(ps), ax, ay, aoff, bx, by, boff, method, fill_s, fill_c,
                            ox, oy, cap_v, roff, cap_r, proff, st)
     assert rc == 0, rc
     r = ClipResult(ox, oy, roff, proff, st)
     r.fast = int(L.host_clip_fast_count())
+    c = [ctypes.c_longlong() for _ in range(3)]
+    L.host_clip_trim_counts(*[ctypes.byref(v) for v in c])
+    r.trim = tuple(int(v.value) for v in c)
     L.host_clip_set_fast(0)
+    L.host_clip_set_trim(0)
     return r
 
 

@@ -16,6 +16,10 @@ static void dump_third(const long long *tx, const long long *ty, int nt, const l
 }
 #define SZC_THIRD_PROBE(tx, ty, nt, rx, ry, nr) dump_third((const long long *)(tx), (const long long *)(ty), nt, (const long long *)(rx), (const long long *)(ry), nr)
 #define SZC_FAST_PROBE(st) ((st) == 100 ? ++g_fast_bails : ++g_fast_hits)
+static bool g_trim_off = false;
+static long long g_trim_before = 0, g_trim_after = 0;
+#define SZC_TRIM_OFF g_trim_off
+#define SZC_TRIM_PROBE(before, after) (g_trim_before += (before), g_trim_after += (after))
 #include "../../subzero_amd/csrc/step_core.hpp"
 #include <stdint.h>
 #include <stdlib.h>
@@ -27,6 +31,8 @@ using namespace szs;
 static int g_narrow_mode = 2;
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
 extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
+extern "C" void host_set_trim(int on) { g_trim_off = !on; }
+extern "C" void host_trim_counts(long long *before, long long *after) { *before = g_trim_before; *after = g_trim_after; }
 extern "C" void host_bail_sites(long long *out) { for (int i = 0; i < 64; ++i) out[i] = g_bail_sites[i]; }
 extern "C" void host_fast_counts(long long *hits, long long *bails) { *hits = g_fast_hits; *bails = g_fast_bails; }
 

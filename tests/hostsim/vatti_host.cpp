@@ -3,6 +3,7 @@
 // (oracle/_ref) without a GPU.  Not part of the product; nothing in subzero_amd/ loads this.
 #include "../../subzero_amd/csrc/vatti.hpp"
 #include "../../subzero_amd/csrc/convex.hpp"
+#include "../../subzero_amd/csrc/trim.hpp"
 #include <stdint.h>
 #include <stdlib.h>
 #include <vector>
@@ -29,6 +30,14 @@ static long long g_fast_done = 0;
 extern "C" void host_clip_set_fast(int on) { g_try_fast = on; g_fast_done = 0; }
 extern "C" long long host_clip_fast_count(void) { return g_fast_done; }
 
+// rings trimmed to their common box first (trim.hpp), as the step's general path does for intersections
+static int g_try_trim = 0;
+static long long g_trim_before = 0, g_trim_after = 0, g_trim_declined = 0;
+extern "C" void host_clip_set_trim(int on) { g_try_trim = on; g_trim_before = g_trim_after = g_trim_declined = 0; }
+extern "C" void host_clip_trim_counts(long long *before, long long *after, long long *declined) {
+  *before = g_trim_before; *after = g_trim_after; *declined = g_trim_declined;
+}
+
 extern "C" int host_clip_batch(int npairs,
                    const int64_t *ax, const int64_t *ay, const int32_t *aoff,
                    const int64_t *bx, const int64_t *by, const int32_t *boff,
@@ -42,6 +51,16 @@ extern "C" int host_clip_batch(int npairs,
   for (int p = 0; p < npairs; ++p) {
     int na = aoff[p + 1] - aoff[p], nb = boff[p + 1] - boff[p];
     RingView a = {ax + aoff[p], ay + aoff[p]}, b = {bx + boff[p], by + boff[p]};
+    std::vector<int64_t> tx1, ty1, tx2, ty2;
+    if (g_try_trim && method == szv::OP_INTERSECTION && fill_s == 0 && fill_c == 0) {
+      tx1.assign(a.x, a.x + na); ty1.assign(a.y, a.y + na); tx2.assign(b.x, b.x + nb); ty2.assign(b.y, b.y + nb);
+      int ta = na, tb = nb;
+      g_trim_before += na + nb;
+      if (szt::trim_pair((szv::i64 *)tx1.data(), (szv::i64 *)ty1.data(), ta, (szv::i64 *)tx2.data(), (szv::i64 *)ty2.data(), tb)) {
+        a.x = tx1.data(); a.y = ty1.data(); b.x = tx2.data(); b.y = ty2.data(); na = ta; nb = tb;
+      } else ++g_trim_declined;
+      g_trim_after += na + nb;
+    }
     int64_t nv0 = s.nv, nr0 = s.nr;
     int st = szv::ST_WORKSPACE;
     // single-minimum fast path first (intersection, even-odd), as k_narrow does; ST_BAIL falls through

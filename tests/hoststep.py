@@ -17,7 +17,7 @@ def lib():
         return _lib
     path = os.path.join(ROOT, "tests", "hostsim", "libstep_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "step_host.cpp")
-    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "convex.hpp", "detmath.hpp")]
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "convex.hpp", "trim.hpp", "detmath.hpp")]
     if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unused-function", src, "-o", path])
@@ -87,3 +87,15 @@ def fast_counts():
     h, b = ctypes.c_longlong(), ctypes.c_longlong()
     lib().host_fast_counts(ctypes.byref(h), ctypes.byref(b))
     return h.value, b.value
+
+
+def set_trim(on):
+    """Rings of the general path's intersections cut down to their common box first (trim.hpp); on by default."""
+    lib().host_set_trim(int(on))
+
+
+def trim_counts():
+    """(ring vertices handed to the general path's clips, vertices that reached the sweep) so far."""
+    b, a = ctypes.c_longlong(), ctypes.c_longlong()
+    lib().host_trim_counts(ctypes.byref(b), ctypes.byref(a))
+    return b.value, a.value

@@ -88,6 +88,40 @@ def test_fast_path_matches_live_reference(gen, n, kw, min_taken, mode):
     assert h.fast >= min_taken * len(ps), (h.fast, len(ps))
 
 
+# Rings cut down to their common box before an intersection (trim.hpp): same rings out, vertex for vertex, as the
+# reference on the untrimmed input -- on real outlines (most vertices gone), on fracture pieces rubbing along their cut,
+# and on lattice-snapped outlines full of ties, where the trim must step aside rather than reorder anything.
+TRIM_SETS = [
+    (g.shape_pairs, 4000, {"max_verts": 90}, 0.7),
+    (g.shape_pairs, 600, {}, 0.7),
+    (g.cut_pairs, 4000, {}, 0.7),
+    (g.snapped_shape_pairs, 3000, {"grid": 400, "mode": 0}, 1.0),
+    (g.snapped_shape_pairs, 3000, {"grid": 400, "mode": 1}, 0.75),
+    (g.snapped_shape_pairs, 3000, {"grid": 400, "mode": 2}, 1.0),
+    (g.snapped_shape_pairs, 3000, {"grid": 100, "mode": 2}, 1.0),
+    (g.convex_pairs, 3000, {}, 1.0),
+    (g.lattice_pairs, 2000, {}, 1.0),
+]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built and /root/reference absent")
+@pytest.mark.parametrize("gen,n,kw,max_left", TRIM_SETS)
+def test_trimmed_intersection_matches_live_reference(gen, n, kw, max_left):
+    ps = gen(n, seed=4242, **kw)
+    r, h = g.run_ref(ps, 1), g.run_host(ps, 1, trim=1)
+    assert g.compare(r, h, len(ps)) == []
+    before, after, declined = h.trim
+    assert before > 0 and after <= max_left * before, h.trim
+
+
+@pytest.mark.parametrize("name", g.GOLDEN_SETS)
+def test_trimmed_intersection_matches_golden(name):
+    inp, res = g.load_golden(name)
+    ps = g.ArraysPairSet(inp)
+    h = g.run_host(ps, 1, trim=1)
+    assert g.compare(res[1], h, len(ps)) == []
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("name", g.GOLDEN_SETS)
 def test_fast_path_matches_golden(name, mode):
