@@ -97,6 +97,15 @@ SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, con
 #ifndef SZC_THIRD_PROBE
 #define SZC_THIRD_PROBE(tx, ty, nt, rx, ry, nr) ((void)0)
 #endif
+#ifndef SZC_PRUNE_OFF
+#define SZC_PRUNE_OFF false           // (tests switch the pruning of crossings_long off to compare)
+#endif
+#ifndef SZC_PRUNE_PROBE
+#define SZC_PRUNE_PROBE(skipped) ((void)0)
+#endif
+#ifndef SZC_PHASE
+#define SZC_PHASE(k) ((void)0)        // the host test build attributes time to the parts of the contact model here
+#endif
 #ifndef SZC_FAST_PROBE
 #define SZC_FAST_PROBE(st) ((void)0)   // the host test build counts fast-path hits and bail-outs here
 #endif
@@ -121,20 +130,46 @@ SZ_HD_NOINLINE int clip_in_block(Blk *blk, void *deque_mem, int shifted, double 
 // which sweep a pair uses: Wide records in the pair's HBM slice, or Compact records in a block of LDS
 struct ClipWide {
   void *ws; int cap_nv;
+  SZ_HD double *idle(int &bytes) const { bytes = 0; return nullptr; }
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
     return clip_fixed(ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
   }
   SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
 };
+// k_narrow_lds: each clip takes the lane's slice of LDS when its (trimmed) rings fit it, the pair's HBM slice
+// otherwise -- or when the records of the clip outgrow the slice after all
 struct ClipWideLds {
-  void *host_ws; int lds_stride, cap_nv;
+  void *host_ws; int lds_stride, lds_ws_bytes, cap_nv;    // the slice's stride / what of it the sweep may use; cap_nv: what the HBM slice holds
+  // the sweep's part of the slice, free between two clips (device only)
+  SZ_HD double *idle(int &bytes) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
+    bytes = lds_ws_bytes;
+    return (double *)(sz_dynamic_lds + (size_t)threadIdx.x * (size_t)lds_stride);
+#else
+    bytes = 0; return nullptr;
+#endif
+  }
+  SZ_HD int lds_cap() const {
+    int c = (lds_ws_bytes - (int)szv::WS_PER_CLIP) / (int)szv::WS_PER_VERTEX;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (c > cap_nv) c = cap_nv;             // (the host build has no LDS: the slice stands in for it)
+#endif
+    return c;
+  }
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
-    return clip_fixed_lds(host_ws, lds_stride, cap_nv, ax, ay, na, bx, by, nb, op, sink);
+    const int lc = lds_cap();
+    if (na + nb <= lc) {
+      int st = clip_fixed_lds(host_ws, lds_stride, lc, ax, ay, na, bx, by, nb, op, sink);
+      if (st != szv::ST_WORKSPACE || lc >= cap_nv) return st;
+    }
+    return clip_fixed(host_ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
   }
   SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
 };
 struct ClipCompact {
   void *ws;
+  SZ_HD double *idle(int &bytes) const { bytes = 0; return nullptr; }
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
     return clip_fixed_compact(ws, ax, ay, na, bx, by, nb, op, sink);
   }
@@ -305,6 +340,52 @@ SZ_HD double dist_to_ring(double xp, double yp, const Ring &c) {
   return (cond1 || cond2) ? dpv_min : cr_min;
 }
 
+// dist_to_ring(xp, yp, c) < 1e-8 -- all the contact model asks of that distance (floe_interactions.m:127) -- for
+// long rings, from the vertices and edges within 1e-3 m of the point alone (a vertex is "near" when both coordinate
+// differences are within 1e-3 m, an edge when the point lies in its bounding box grown by 1e-3 m).  The elements
+// left out have |distance| > 5e-4 m by a wide margin over the rounding of these expressions (1e-10 m at 1e5 m
+// coordinates, 1e-6 m at the 1e9 m limit of the fixed-point range), so:
+//   * a minimum below 5e-4 m -- of the vertex distances, of the edge distances -- is attained by near elements
+//     only, at the same (first) index, and is found with the same arithmetic;
+//   * a minimum that is not below 5e-4 m cannot make the result smaller than 1e-8 whichever branch of
+//     p_poly_dist.m:266-281 selects it, and the one branch that compares indices (I_cr ~= I_dpv) cannot be
+//     flipped by a far edge: the edge that starts at a vertex within 5e-4 m is near itself.
+// Hence the same truth value as dist_to_ring(...) < 1e-8, without the square root and the two divisions per far
+// edge.  NaN coordinates compare false everywhere, in both forms (nothing near: not closer).
+SZ_HD bool closer_than_1e8(double xp, double yp, const RingD &c) {
+  const int nv = c.len();
+  if (SZC_PRUNE_OFF || nv < 24) return dist_to_ring(xp, yp, c) < 1e-8;
+  const double near = 1e-3;
+  double dpv_min = SZC_INF; int I_dpv = 0;
+  double cr_min = 0; int I_cr = 0; bool have = false;
+  double x1 = c.X(0), y1 = c.Y(0);
+  for (int k = 0; k < nv; ++k) {
+    const double x0 = x1, y0 = y1;
+    if (absd(x0 - xp) <= near && absd(y0 - yp) <= near) {
+      double d = hyp(x0 - xp, y0 - yp);
+      if (d < dpv_min) { dpv_min = d; I_dpv = k; }
+    }
+    if (k + 1 >= nv) break;
+    x1 = c.X(k + 1); y1 = c.Y(k + 1);
+    if (!(xp >= mind(x0, x1) - near && xp <= maxd(x0, x1) + near && yp >= mind(y0, y1) - near && yp <= maxd(y0, y1) + near)) continue;
+    double dvx = x1 - x0, dvy = y1 - y0;
+    double vds = hyp(dvx, dvy);
+    double ct = dvx / vds, st = dvy / vds;
+    double p1r1 = ct * x0 + st * y0;
+    double p1r2 = -st * x0 + ct * y0;
+    double r = (xp * ct + yp * st) - p1r1;
+    double cr = (xp * (-st) + yp * ct) - p1r2;
+    if (r > 0 && r < vds) {
+      double a = absd(cr);
+      if (!have || a < cr_min) { cr_min = a; I_cr = k; have = true; }
+    }
+  }
+  bool cond1 = !have;
+  bool cond2 = have && (I_cr != I_dpv) && ((cr_min - dpv_min) > 0);
+  return ((cond1 || cond2) ? dpv_min : cr_min) < 1e-8;
+}
+SZ_HD bool closer_than_1e8(double xp, double yp, const RingL &c) { return dist_to_ring(xp, yp, c) < 1e-8; }
+
 // InterX.m:54-81.  Returns the number of unique crossings (sorted by x, then y), or -1 on overflow.
 // The segment pairs are visited ring-1-major with the cross products of the ring-2 vertices carried from one
 // segment to the next (every product is the expression of InterX, evaluated once instead of twice); the result
@@ -349,10 +430,109 @@ SZ_HD int crossings(const Ring &c1, const Ring &c2, double *px, double *py, int 
   return np;
 }
 
+// insertion into the sorted unique list (unique(...,'rows'), InterX.m:76); -1 when the list is full
+SZ_HD_NOINLINE int crossing_insert(double *px, double *py, int np, int cap, double X, double Y) {
+  int k = np;
+  while (k > 0 && (px[k - 1] > X || (px[k - 1] == X && py[k - 1] > Y))) --k;
+  if (k > 0 && px[k - 1] == X && py[k - 1] == Y) return np;
+  if (np >= cap) return -1;
+  for (int q = np; q > k; --q) { px[q] = px[q - 1]; py[q] = py[q - 1]; }
+  px[k] = X; py[k] = Y;
+  return np + 1;
+}
+// The same crossings for long rings (the general path: evolved floe outlines of 50-600 vertices), where the dense
+// n1 x n2 sign test of InterX is most of a pair's time.  Ring 2 is laid out once (closed, position added) together
+// with the bounding box of every run of CHUNK edges; for an edge of ring 1 a run is skipped when the first sign
+// test of InterX.m:60-64 is certain to fail for each of its edges: the value a = dx1*y - dy1*x that the test
+// compares with S1 is linear in the vertex, so over the run it lies between its values at two corners of the
+// run's box, and the floating-point a of every vertex within 3u(|dx1||y| + |dy1||x|) of the exact one (u = 2^-53;
+// two products, one difference).  With S1 outside that range by more than the margin every (a - S1) of the run
+// has the same sign and is not zero, every product is positive, and the reference's test fails: the edges
+// skipped are edges InterX rejects, the rest go through the unchanged arithmetic in the unchanged order.
+// (margin > 1e-100 keeps the products away from underflow, where a positive product could round to zero.)
+// x2 must hold len + 4 * (len / CROSS_CHUNK + 1) doubles, y2 len doubles (len = closed length of ring 2).
+enum { CROSS_CHUNK = 8, CROSS_PRUNE_MIN = 256 };
+template <class Ring>
+SZ_HD int crossings_long(const Ring &c1, const Ring &c2, double *px, double *py, int cap, double *x2, double *y2) {
+  const int m1 = c1.len() - 1, m2 = c2.len() - 1;
+  int np = 0;
+  if (m1 <= 0 || m2 <= 0) return 0;
+  for (int k = 0; k <= m2; ++k) { x2[k] = c2.X(k); y2[k] = c2.Y(k); }
+  double *box = x2 + (m2 + 1);
+  const int nch = (m2 + CROSS_CHUNK - 1) / CROSS_CHUNK;
+  for (int c = 0; c < nch; ++c) {
+    const int j0 = c * CROSS_CHUNK, j1 = (j0 + CROSS_CHUNK < m2) ? j0 + CROSS_CHUNK : m2;
+    double xl = x2[j0], xh = xl, yl = y2[j0], yh = yl;
+    for (int k = j0 + 1; k <= j1; ++k) { xl = mind(xl, x2[k]); xh = maxd(xh, x2[k]); yl = mind(yl, y2[k]); yh = maxd(yh, y2[k]); }
+    box[4 * c] = xl; box[4 * c + 1] = xh; box[4 * c + 2] = yl; box[4 * c + 3] = yh;
+  }
+  double x1b = c1.X(0), y1b = c1.Y(0);
+  for (int i = 0; i < m1; ++i) {
+    const double x1a = x1b, y1a = y1b;
+    x1b = c1.X(i + 1); y1b = c1.Y(i + 1);
+    const double dx1 = x1b - x1a, dy1 = y1b - y1a;
+    const double S1 = dx1 * y1a - dy1 * x1a;
+    const double adx = absd(dx1), ady = absd(dy1);
+    // 64 runs at a time: first which of them survive (no branches: the loads of the boxes overlap), then those
+    for (int cb = 0; cb < nch; cb += 64) {
+      const int ce = (cb + 64 < nch) ? cb + 64 : nch;
+      unsigned long long keep = 0;
+#pragma unroll 4
+      for (int c = cb; c < ce; ++c) {
+        const double xl = box[4 * c], xh = box[4 * c + 1], yl = box[4 * c + 2], yh = box[4 * c + 3];
+        const double lo = dx1 * (dx1 >= 0 ? yl : yh) - dy1 * (dy1 >= 0 ? xh : xl);
+        const double hi = dx1 * (dx1 >= 0 ? yh : yl) - dy1 * (dy1 >= 0 ? xl : xh);
+        const double margin = 8.9e-16 * (adx * maxd(absd(yl), absd(yh)) + ady * maxd(absd(xl), absd(xh)));
+        const bool skip = margin > 1e-100 && (lo - margin > S1 || hi + margin < S1);
+        SZC_PRUNE_PROBE(skip ? 1 : 0);
+        keep |= (unsigned long long)(skip ? 0 : 1) << (c - cb);
+      }
+      while (keep) {
+        const int c = cb + __builtin_ctzll(keep);
+        keep &= keep - 1;
+        const int j0 = c * CROSS_CHUNK, left = m2 - j0;     // edges j0 .. j0 + min(CHUNK, left) - 1
+        double vx[CROSS_CHUNK + 1], vy[CROSS_CHUNK + 1];      // their vertices, all loads issued at once
+#pragma unroll
+        for (int k = 0; k <= CROSS_CHUNK; ++k) { const int q = j0 + (k < left ? k : left); vx[k] = x2[q]; vy[k] = y2[q]; }
+        double b = dx1 * vy[0] - dy1 * vx[0];
+#pragma unroll
+        for (int k = 0; k < CROSS_CHUNK; ++k) {
+          if (k >= left) break;
+          const double x2a = vx[k], y2a = vy[k], a = b;
+          const double x2b = vx[k + 1], y2b = vy[k + 1];
+          b = dx1 * y2b - dy1 * x2b;
+          if (!(((a - S1) * (b - S1)) <= 0)) continue;
+          const double dx2 = x2b - x2a, dy2 = y2b - y2a;
+          const double S2 = dx2 * y2a - dy2 * x2a;
+          const double cc = y1a * dx2 - x1a * dy2;
+          const double d = y1b * dx2 - x1b * dy2;
+          if (!(((cc - S2) * (d - S2)) <= 0)) continue;
+          const double L = dy2 * dx1 - dy1 * dx2;
+          if (L == 0) continue;
+          const double X = (dx2 * S1 - dx1 * S2) / L;
+          const double Y = (dy2 * S1 - dy1 * S2) / L;
+          np = crossing_insert(px, py, np, cap, X, Y);
+          if (np < 0) return -1;
+        }
+      }
+    }
+  }
+  return np;
+}
+// (rings held in LDS by the fast path are short: nothing to prune)
+SZ_HD int crossings_any(const RingL &c1, const RingL &c2, double *px, double *py, int cap, double *, double *) {
+  return crossings(c1, c2, px, py, cap);
+}
+SZ_HD int crossings_any(const RingD &c1, const RingD &c2, double *px, double *py, int cap, double *x2, double *y2) {
+  if (SZC_PRUNE_OFF || (c1.len() - 1) * (c2.len() - 1) < (int)CROSS_PRUNE_MIN) return crossings(c1, c2, px, py, cap);
+  return crossings_long(c1, c2, px, py, cap, x2, y2);
+}
+
 // How the three clips of the contact model are run.
 #ifndef SZC_TRIM_OFF
 #define SZC_TRIM_OFF false
 #endif
+
 #ifndef SZC_TRIM_PROBE
 #define SZC_TRIM_PROBE(before, after) ((void)0)
 #endif
@@ -360,11 +540,14 @@ SZ_HD int crossings(const Ring &c1, const Ring &c2, double *px, double *py, int 
 template <class Sweep>
 struct ViaArrays {
   Sweep sweep;
+  SZ_HD double *idle(int &bytes) const { return sweep.idle(bytes); }
   template <class Ring>
   SZ_HD int first(const Ring &ring1, const Ring &ring2, bool boundary, PairScratch &S, RegionSink *sink) const {   // :29 / :34
     int n1 = ring1.n, n2 = ring2.n;
+    SZC_PHASE(10);
     fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y);
     fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y);
+    SZC_PHASE(11);
     // an intersection sees only what lies in the box the two rings share (trim.hpp); on a tie the rings go in whole
     if (!boundary && !SZC_TRIM_OFF && !szt::trim_pair(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2)) {
       n1 = ring1.n; n2 = ring2.n;
@@ -372,10 +555,12 @@ struct ViaArrays {
       fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y);
     }
     SZC_TRIM_PROBE(ring1.n + ring2.n, n1 + n2);
+    SZC_PHASE(1);
     return sweep(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION, sink);
   }
   template <class Ring>
   SZ_HD static void fill(const Ring &r, int n, bool shifted, double dx, double dy, i64 *fx, i64 *fy) {
+#pragma unroll 4
     for (int k = 0; k < n; ++k) {
       if (!shifted) { fx[k] = to_fixed(r.X(k)); fy[k] = to_fixed(r.Y(k)); }
       else { fx[k] = to_fixed(r.X(k) + dx); fy[k] = to_fixed(r.Y(k) + dy); }
@@ -386,14 +571,17 @@ struct ViaArrays {
   SZ_HD int second(const Ring &c1, bool shifted, double fdx, double fdy, const Ring &c2, int op, PairScratch &S, RegionSink *sink) const {
     int nc1 = c1.len(), nc2 = c2.len();
     // (both rings closed here, :62-70; ring 2 is converted again: clip 1 may have trimmed its copy)
+    SZC_PHASE(10);
     fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy);
     fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y);
+    SZC_PHASE(11);
     if (op == szv::OP_INTERSECTION && !SZC_TRIM_OFF && !szt::trim_pair(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2)) {
       nc1 = c1.len(); nc2 = c2.len();
       fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy);
       fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y);
     }
     SZC_TRIM_PROBE(c1.len() + c2.len(), nc1 + nc2);
+    SZC_PHASE(6);
     return sweep(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, op, sink);
   }
   SZ_HD int third(const i64 *tx, const i64 *ty, int nt, const i64 *rx, const i64 *ry, int nr, RegionSink *sink) const {   // :158
@@ -410,6 +598,7 @@ template <class Blk>
 struct InBlock {
   Blk *blk;
   void *deque_mem;
+  SZ_HD double *idle(int &bytes) const { bytes = 0; return nullptr; }
   SZ_HD int run(int shifted, double sx, double sy, int na, int nb, RegionSink *sink) const {
     int st = clip_in_block(blk, deque_mem, shifted, sx, sy, na, nb, sink);
     SZC_FAST_PROBE(st);
@@ -437,7 +626,9 @@ struct InBlock {
 template <class Ring, class Clip>
 SZ_HD int pair_clip1(const Ring &ring1, const Ring &ring2, bool boundary, PairScratch &S, const Clip &clip, int &nreg) {
   RegionSink s1 = {S.r1x, S.r1y, S.r1off, S.cap_v, S.cap_r, 0, 0};
+  SZC_PHASE(1);
   int st = clip.first(ring1, ring2, boundary, S, &s1);                                 // :29 / :34
+  SZC_PHASE(2);
   nreg = (st == szv::ST_OK) ? s1.nr : 0;
   return st;
 }
@@ -504,7 +695,18 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
   if (hyp(c1.X(0) - c1.X(n1 - 1), c1.Y(0) - c1.Y(n1 - 1)) > 1) c1.extra = 1;
   if (hyp(c2.X(0) - c2.X(n2 - 1), c2.Y(0) - c2.Y(n2 - 1)) > 1) c2.extra = 1;
 
-  int np = crossings(c1, c2, S.px, S.py, S.cap_p);                                     // :70
+  SZC_PHASE(3);
+  // (ring 2 and its chunk boxes are laid out in the sweep's idle LDS when the kernel has it, else in the region
+  // slots of clip 2, idle until :140)
+  double *lay_x = (double *)S.r2x, *lay_y = (double *)S.r2y;
+  {
+    int room = 0;
+    double *blk = clip.idle(room);
+    const int len2 = c2.len(), nx = len2 + 4 * (len2 / (int)CROSS_CHUNK + 1);
+    if (blk && 8 * (nx + len2) <= room) { lay_x = blk; lay_y = blk + nx; }
+  }
+  int np = crossings_any(c1, c2, S.px, S.py, S.cap_p, lay_x, lay_y);                   // :70
+  SZC_PHASE(4);
   if (np < 0) return szv::ST_WORKSPACE;
   if (np < 2 || is_inf(overlap0) || nreg == 0) {                                       // :71-74
     out.has_sentinel = 1;
@@ -545,6 +747,7 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
       dl = b;
     } else if (m == 0) { fdx = fdy = 0; dl = 0; }                                      // :113-116
     else {                                                                             // :117-137
+      SZC_PHASE(5);
       int non = 0;
       double sfx = 0, sfy = 0, sb = 0;
       for (int e = 0; e < nr; ++e) {
@@ -556,8 +759,7 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
         double nx = -ygh / b, ny = xgh / b;
         double xt = xm + nx / 100, yt = ym + ny / 100;
         if (!in_region(xt, yt, RX, RY, nr)) { nx = -nx; ny = -ny; }
-        double d = dist_to_ring(xm, ym, c1);
-        if (d < 1e-8) {
+        if (closer_than_1e8(xm, ym, c1)) {                                            // p_poly_dist(...) < 1e-8, :127
           ++non;
           sfx += (-Force_factor * b) * nx;
           sfy += (-Force_factor * b) * ny;
@@ -574,7 +776,9 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
     const bool shifted = !(dl < 0.1);
     if (!shifted) { fdx = 0; fdy = 0; }
     RegionSink s2 = {S.r2x, S.r2y, S.r2off, S.cap_v, S.cap_r, 0, 0};
+    SZC_PHASE(6);
     st = clip.second(c1, shifted, fdx, fdy, c2, op, S, &s2);
+    SZC_PHASE(7);
     if (st != szv::ST_OK) return st;
     for (int ii = 0; ii < s2.nr; ++ii) {                                               // :156-165
       const i64 *TX = S.r2x + S.r2off[ii], *TY = S.r2y + S.r2off[ii];
@@ -633,6 +837,12 @@ SZ_HD void box_start(Box &b) { b.x0 = SZC_INF; b.x1 = -SZC_INF; b.y0 = SZC_INF; 
 SZ_HD void box_add(Box &b, double x, double y) {
   b.x0 = mind(b.x0, x); b.x1 = maxd(b.x1, x); b.y0 = mind(b.y0, y); b.y1 = maxd(b.y1, y);
 }
+template <class Ring>
+SZ_HD void ring_box(const Ring &r, Box &b) {
+  box_start(b);
+#pragma unroll 4
+  for (int k = 0; k < r.n; ++k) box_add(b, r.X(k), r.Y(k));
+}
 SZ_HD bool boxes_apart(const Box &a, const Box &b) {
   const double gap = 1e-6;
   return a.x1 + gap < b.x0 || b.x1 + gap < a.x0 || a.y1 + gap < b.y0 || b.y1 + gap < a.y0;
@@ -657,22 +867,21 @@ SZ_HD bool well_inside_box(const Box &b, const double *c2b) {
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out, int lds_stride = 0) {
+                       PairScratch &S, PairOut &out, int lds_stride = 0, int lds_ws_bytes = 0) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   {
     Box b1, b2;
-    box_start(b1); box_start(b2);
-    for (int k = 0; k < ring1.n; ++k) box_add(b1, ring1.X(k), ring1.Y(k));
+    ring_box(ring1, b1);
     if (boundary) {
       if (ring1.n > 0 && well_inside_box(b1, c2b)) { no_contact(out); return szv::ST_OK; }
     } else {
-      for (int k = 0; k < ring2.n; ++k) box_add(b2, ring2.X(k), ring2.Y(k));
+      ring_box(ring2, b2);
       if (ring1.n > 0 && ring2.n > 0 && boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
     }
   }
   int nreg = 0;
   if (lds_stride > 0) {   // the sweep workspace of this lane is its slice of LDS (k_narrow_lds)
-    ViaArrays<ClipWideLds> clip = {{S.ws, lds_stride, S.cap_nv}};
+    ViaArrays<ClipWideLds> clip = {{S.ws, lds_stride, lds_ws_bytes, S.cap_nv}};
     int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
     if (st != szv::ST_OK) return st;
     return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
@@ -704,7 +913,16 @@ SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &rin
       hyp(ring1.X(0) - ring1.X(n1 - 2), ring1.Y(0) - ring1.Y(n1 - 2)) > 1) --n1;
   if (n2 == (int)Blk::NV + 1 && ring2.X(n2 - 1) == ring2.X(0) && ring2.Y(n2 - 1) == ring2.Y(0) &&
       hyp(ring2.X(0) - ring2.X(n2 - 2), ring2.Y(0) - ring2.Y(n2 - 2)) > 1) --n2;
-  if (n1 > (int)Blk::NV || n2 > (int)Blk::NV || n1 < 1 || n2 < 1) return ST_DEFER;
+  if (n1 > (int)Blk::NV || n2 > (int)Blk::NV || n1 < 1 || n2 < 1) {
+    // too long for the block: the general kernel's business -- unless the boxes are apart, which is its first
+    // question too (pair_contact) and costs one pass over the rings here instead of a place in its work list
+    if (ring1.n > 0 && ring2.n > 0) {
+      Box b1, b2;
+      ring_box(ring1, b1); ring_box(ring2, b2);
+      if (boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
+    }
+    return ST_DEFER;
+  }
   // (the sweep converts with to_fixed_in_range: coordinates must be finite and, with the <= 1 m shift of the
   // second clip, within its range -- anything else, e.g. a NaN floe, goes to the general sweep)
   const double safe = SZX_FIXED_SAFE_METRES - 2;

@@ -16,7 +16,51 @@
 // phase, and the counters at the end (buffers are grow-only, owned by the context).  No CPU fallback exists: every failure is an error code.
 #include <stdlib.h>
 #include "context.hpp"
+#if defined(SZ_PHASE_PROFILE)
+// Diagnostic build only (make EXTRA=-DSZ_PHASE_PROFILE): wall-clock time of the parts of the contact model per
+// pair of the general kernels, summed and for the slowest pair; read with szDebugPhases.  Not in the product build.
+#include <hip/hip_runtime.h>
+struct SzPhaseState { unsigned long long last, t[12]; int cur, trim[4], ntrim; };
+__device__ unsigned long long sz_phase_acc[12];
+__device__ unsigned long long sz_phase_worst[20];
+__device__ SzPhaseState sz_phase_state[1 << 17];
+static __host__ __device__ inline void sz_phase_mark(int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  SzPhaseState &s = sz_phase_state[(blockIdx.x * blockDim.x + threadIdx.x) & 0x1ffff];
+  const unsigned long long now = wall_clock64();
+  if (k == 8) { for (int i = 0; i < 12; ++i) s.t[i] = 0; s.ntrim = 0; }
+  else s.t[s.cur < 12 ? s.cur : 9] += now - s.last;
+  s.last = now; s.cur = k;
+  if (k == 0) {
+    unsigned long long tot = 0;
+    for (int i = 1; i < 12; ++i) { tot += s.t[i]; atomicAdd(&sz_phase_acc[i], s.t[i]); }
+    if (atomicMax(&sz_phase_worst[0], tot) < tot) {
+      for (int i = 1; i < 12; ++i) sz_phase_worst[i] = s.t[i];
+      for (int i = 0; i < 4; ++i) sz_phase_worst[12 + i] = i < s.ntrim ? (unsigned long long)s.trim[i] : 0ull;
+      sz_phase_worst[16] = (unsigned long long)s.ntrim;
+    }
+  }
+#endif
+}
+static __host__ __device__ inline void sz_trim_mark(int before, int after) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  SzPhaseState &s = sz_phase_state[(blockIdx.x * blockDim.x + threadIdx.x) & 0x1ffff];
+  if (s.ntrim < 4) { s.trim[s.ntrim] = before; s.trim[s.ntrim + 1] = after; } s.ntrim += 2;
+#endif
+}
+#define SZC_PHASE(k) sz_phase_mark(k)
+#define SZC_TRIM_PROBE(before, after) sz_trim_mark(before, after)
+#endif
 #include "step_core.hpp"
+#if defined(SZ_PHASE_PROFILE)
+extern "C" int szDebugPhases(unsigned long long *out26, int reset) {
+  unsigned long long z[20] = {0};
+  if (hipMemcpyFromSymbol(out26, HIP_SYMBOL(sz_phase_acc), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out26 + 12, HIP_SYMBOL(sz_phase_worst), sizeof(unsigned long long) * 20) != hipSuccess) return -1;
+  if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_acc), z, 96); (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_worst), z, 160); }
+  return 0;
+}
+#endif
 
 using namespace szs;
 
@@ -717,7 +761,15 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     }
     // deferred pairs at the 1x tier: a short list of short rings (ties, floes at the walls) runs with the sweep
     // workspace in LDS, one to four pairs per wave; a pair that needs more than the slice keeps its HBM workspace
-    const int retry_lds = (fast && mult == 1 && RL <= 4) ? S->retry_lds : 0;
+    // (the slice grows from SUBZERO_RETRY_LDS, 16 KB, up to 64 KB while every workgroup of the launch still finds
+    // a place on the 256 CUs at once: a 64 KB slice holds the sweep of 119 trimmed vertices)
+    int retry_lds = (fast && mult == 1 && RL <= 4) ? S->retry_lds : 0;
+    if (retry_lds > 0) {
+      const i64 wgs = (nl + RL - 1) / RL, per_cu = (wgs + 255) / 256;
+      i64 room = (i64)160 * 1024 / (per_cu * RL);
+      room = (room > 64 * 1024 ? 64 * 1024 : room) & ~(i64)1023;
+      if (room > retry_lds) retry_lds = (int)room;
+    }
     if (retry_lds > 0)
       hipLaunchKernelGGL(k_narrow_lds, grid_for(nl, RL), dim3(64), (size_t)retry_lds * RL, st, nl, (const int *)S->retry_copy.p, mult, RL, retry_lds, F, P, W);
     else

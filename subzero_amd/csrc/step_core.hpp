@@ -416,14 +416,33 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
   const bool ws_fits_fast = fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes;
   if (ws_fits_fast && !LDS_WS) S.ws = fast_ws;
+  // k_narrow_lds: both rings (position added) move to the end of the lane's slice of LDS, where every loop of the
+  // contact model over their vertices reads them at LDS latency; the sweep keeps the rest of the slice.
+  // (x + -0.0 == x for every x, signed zeros included: the views below return the staged values unchanged)
+  int lds_ws_bytes = fast_ws_bytes;
+  if (LDS_WS && fast_ws) {
+    const int ring_bytes = (int)up16(16 * (size_t)(n1 + n2));
+    if (ring_bytes + (int)szv::WS_PER_CLIP + 8 * (int)szv::WS_PER_VERTEX <= fast_ws_bytes) {
+      lds_ws_bytes = fast_ws_bytes - ring_bytes;
+      double *lx1 = (double *)((char *)fast_ws + lds_ws_bytes), *ly1 = lx1 + n1, *lx2 = ly1 + n1, *ly2 = lx2 + n2;
+#pragma unroll 4
+      for (int k = 0; k < n1; ++k) { lx1[k] = ring1.X(k); ly1[k] = ring1.Y(k); }
+#pragma unroll 4
+      for (int k = 0; k < n2; ++k) { lx2[k] = ring2.X(k); ly2[k] = ring2.Y(k); }
+      szc::RingD s1 = {lx1, ly1, -0.0, -0.0, n1, 0}, s2 = {lx2, ly2, -0.0, -0.0, n2, 0};
+      ring1 = s1; ring2 = s2;
+    }
+  }
   szc::PairOut out;
   int st;
+  SZC_PHASE(8);
   if (CONVEX_ONLY)
     st = szc::pair_contact_fast(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                                 P.mu, P.nu, S, out, fast_blk);
   else
     st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
-                           P.mu, P.nu, S, out, (LDS_WS && ws_fits_fast) ? fast_ws_bytes : 0);
+                           P.mu, P.nu, S, out, (LDS_WS && fast_ws) ? fast_ws_bytes : 0, lds_ws_bytes);
+  SZC_PHASE(0);
   W.pair_status[p] = st;
   if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY || st == szc::ST_DEFER) {
     unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);

@@ -38,6 +38,7 @@ struct Box { i64 xmin, xmax, ymin, ymax; };
 
 SZ_HD void box_of(const i64 *x, const i64 *y, int n, Box &b) {
   b.xmin = b.xmax = x[0]; b.ymin = b.ymax = y[0];
+#pragma unroll 4
   for (int k = 1; k < n; ++k) {
     i64 vx = x[k], vy = y[k];
     b.xmin = vx < b.xmin ? vx : b.xmin; b.xmax = vx > b.xmax ? vx : b.xmax;
@@ -84,10 +85,15 @@ SZ_HD int trim_ring(i64 *x, i64 *y, int n, const Box &q) {
 }
 
 SZ_HD bool heights_distinct(const i64 *y1, int n1, const i64 *y2, int n2) {
+  // (no early exit inside a row: the loads of a row are independent and overlap)
   for (int a = 0; a < n1 + n2; ++a) {
     const i64 va = a < n1 ? y1[a] : y2[a - n1];
-    for (int b = a + 1; b < n1 + n2; ++b)
-      if (va == (b < n1 ? y1[b] : y2[b - n1])) return false;
+    bool same = false;
+#pragma unroll 4
+    for (int b = a + 1; b < n1; ++b) same |= (va == y1[b]);
+#pragma unroll 4
+    for (int b = (a + 1 > n1 ? a + 1 - n1 : 0); b < n2; ++b) same |= (va == y2[b]);
+    if (same) return false;
   }
   return true;
 }

@@ -16,10 +16,29 @@ static void dump_third(const long long *tx, const long long *ty, int nt, const l
 }
 #define SZC_THIRD_PROBE(tx, ty, nt, rx, ry, nr) dump_third((const long long *)(tx), (const long long *)(ty), nt, (const long long *)(rx), (const long long *)(ry), nr)
 #define SZC_FAST_PROBE(st) ((st) == 100 ? ++g_fast_bails : ++g_fast_hits)
-static bool g_trim_off = false;
+#include <x86intrin.h>
+static unsigned long long g_phase_t[16], g_phase_last = 0; static int g_phase_cur = 0;
 static long long g_trim_before = 0, g_trim_after = 0;
+static int g_last_trim[4], g_last_k = 0, g_worst_trim[4];
+#define SZC_TRIM_PROBE(before, after) (g_trim_before += (before), g_trim_after += (after), g_last_trim[g_last_k & 3] = (before), g_last_trim[(g_last_k + 1) & 3] = (after), g_last_k += 2)
+static unsigned long long g_pair_t[16], g_worst_t[16], g_worst_total = 0;
+static inline void phase_mark(int k) {
+  unsigned long long now = __rdtsc();
+  g_phase_t[g_phase_cur & 15] += now - g_phase_last; g_pair_t[g_phase_cur & 15] += now - g_phase_last;
+  g_phase_last = now; g_phase_cur = k;
+  if (k == 8) for (int i = 0; i < 16; ++i) g_pair_t[i] = 0;            // a pair starts
+  if (k == 0) {                                                          // a pair ends
+    unsigned long long tot = 0; for (int i = 1; i < 16; ++i) tot += g_pair_t[i];
+    if (tot > g_worst_total) { g_worst_total = tot; for (int i = 0; i < 16; ++i) g_worst_t[i] = g_pair_t[i]; for (int i = 0; i < 4; ++i) g_worst_trim[i] = g_last_k > i ? g_last_trim[i] : -1; }
+    g_last_k = 0;
+  }
+}
+#define SZC_PHASE(k) phase_mark(k)
+static bool g_trim_off = false, g_prune_off = false;
+#define SZC_PRUNE_OFF g_prune_off
+static long long g_prune_runs[2];
+#define SZC_PRUNE_PROBE(skipped) (++g_prune_runs[(skipped)])
 #define SZC_TRIM_OFF g_trim_off
-#define SZC_TRIM_PROBE(before, after) (g_trim_before += (before), g_trim_after += (after))
 #include "../../subzero_amd/csrc/step_core.hpp"
 #include <stdint.h>
 #include <stdlib.h>
@@ -32,6 +51,24 @@ static int g_narrow_mode = 2;
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
 extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
 extern "C" void host_set_trim(int on) { g_trim_off = !on; }
+extern "C" void host_set_prune(int on) { g_prune_off = !on; }
+extern "C" void host_prune_counts(long long *kept, long long *skipped) { *kept = g_prune_runs[0]; *skipped = g_prune_runs[1]; }
+// floe_interactions.m:127's test of p_poly_dist against 1e-8 on a closed ring: the full distance / the near-elements form
+extern "C" int host_closer(double xp, double yp, const double *x, const double *y, int n, int pruned) {
+  szc::RingD c = {x, y, 0.0, 0.0, n, 0};
+  return pruned ? (int)szc::closer_than_1e8(xp, yp, c) : (int)(szc::dist_to_ring(xp, yp, c) < 1e-8);
+}
+// InterX on two closed rings in metres: the plain dense form (pruned = 0) or the one for long rings
+extern "C" int host_crossings(const double *x1, const double *y1, int n1, const double *x2, const double *y2, int n2,
+                              int pruned, double *px, double *py, int cap) {
+  szc::RingD c1 = {x1, y1, 0.0, 0.0, n1, 0}, c2 = {x2, y2, 0.0, 0.0, n2, 0};
+  if (!pruned) return szc::crossings(c1, c2, px, py, cap);
+  std::vector<double> sx((size_t)n2 + 4 * ((size_t)n2 / szc::CROSS_CHUNK + 1) + 8), sy((size_t)n2 + 8);
+  return szc::crossings_long(c1, c2, px, py, cap, sx.data(), sy.data());
+}
+extern "C" void host_worst_trim(int *out) { for (int i = 0; i < 4; ++i) out[i] = g_worst_trim[i]; }
+extern "C" void host_worst_pair(unsigned long long *out) { for (int i = 0; i < 16; ++i) { out[i] = g_worst_t[i]; g_worst_t[i] = 0; } g_worst_total = 0; }
+extern "C" void host_phase_times(unsigned long long *out) { phase_mark(0); for (int i = 0; i < 16; ++i) { out[i] = g_phase_t[i]; g_phase_t[i] = 0; } }
 extern "C" void host_trim_counts(long long *before, long long *after) { *before = g_trim_before; *after = g_trim_after; }
 extern "C" void host_bail_sites(long long *out) { for (int i = 0; i < 64; ++i) out[i] = g_bail_sites[i]; }
 extern "C" void host_fast_counts(long long *hits, long long *bails) { *hits = g_fast_hits; *bails = g_fast_bails; }
@@ -219,7 +256,14 @@ struct Sim {
       if (mult > 512) return -5;
       list.assign(W.retry_list, W.retry_list + W.counters[C_RETRY]);
       W.counters[C_RETRY] = 0;
-      for (size_t t = 0; t < list.size(); ++t) narrow((i64)t, list.data(), mult, F, P, W);
+      // as step_narrow does: the fast path's leftovers at 1x go through k_narrow_lds (16 KB of LDS per lane)
+      const bool lds = g_narrow_mode == 2 && mult == 1;
+      std::vector<char> slice(16384 + 64);              // stands in for the lane's slice of LDS
+      void *sl = (void *)(((uintptr_t)slice.data() + 15) & ~(uintptr_t)15);
+      for (size_t t = 0; t < list.size(); ++t) {
+        if (lds) narrow_lds((i64)t, list.data(), mult, F, P, W, sl, 16384);
+        else narrow((i64)t, list.data(), mult, F, P, W);
+      }
     }
     if (W.counters[C_ERR_ARENA]) return -5;
     if (W.counters[C_ERR_CLIP]) return -8;

@@ -99,3 +99,8 @@ def trim_counts():
     b, a = ctypes.c_longlong(), ctypes.c_longlong()
     lib().host_trim_counts(ctypes.byref(b), ctypes.byref(a))
     return b.value, a.value
+
+
+def set_prune(on):
+    """Crossings of long rings skip runs of edges that InterX's first sign test is certain to reject; on by default."""
+    lib().host_set_prune(int(on))

@@ -180,3 +180,61 @@ def test_edge_cases_match_oracle(periodic, nb, collision):
         assert A.kill[5] == 6                                # NaN position: removed by calc_trajectory (:282)
     else:
         assert A.alive[3] == 0 and A.alive[5] == 0           # centre outside the box (:152-155)
+
+
+# ---- the long-ring forms of InterX and of the p_poly_dist test (contact.hpp) against the plain ones ----------------
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _d(v):
+    return np.ascontiguousarray(v, np.float64).ctypes.data_as(_dp)
+
+
+def test_crossings_of_long_rings_match_the_dense_form():
+    """crossings_long skips runs of edges that InterX's first sign test is certain to reject: same points, same order."""
+    L = hoststep.lib()
+    ps = clipgen.shape_pairs(1500, seed=5)
+    k0, s0 = ctypes.c_longlong(), ctypes.c_longlong()
+    L.host_prune_counts(ctypes.byref(k0), ctypes.byref(s0))
+    found = 0
+    for p in range(len(ps)):
+        a = np.stack([ps.ax[p], ps.ay[p]], 1) / 2.0 ** 32
+        b = np.stack([ps.bx[p], ps.by[p]], 1) / 2.0 ** 32
+        if p % 5 == 0:                       # exact ties too: ring 2 shares vertices and edges with ring 1
+            b = np.vstack([a[: len(a) // 2], b[len(b) // 2:], a[:1]])
+        ax, ay, bx, by = (np.ascontiguousarray(v) for v in (a[:, 0], a[:, 1], b[:, 0], b[:, 1]))
+        out = []
+        for pruned in (0, 1):
+            px, py = np.zeros(4096), np.zeros(4096)
+            n = L.host_crossings(_d(ax), _d(ay), len(ax), _d(bx), _d(by), len(bx), pruned, _d(px), _d(py), 4096)
+            out.append((n, px[:max(n, 0)].copy(), py[:max(n, 0)].copy()))
+        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]), p
+        found += out[0][0]
+    k1, s1 = ctypes.c_longlong(), ctypes.c_longlong()
+    L.host_prune_counts(ctypes.byref(k1), ctypes.byref(s1))
+    assert found > 1000 and (s1.value - s0.value) > 5 * (k1.value - k0.value)      # most runs are skipped
+
+
+def test_distance_test_from_near_elements_matches_the_full_distance():
+    """closer_than_1e8 == (|p_poly_dist| < 1e-8), on and around the outline, at the 1e-8 and the 1e-3 m thresholds."""
+    L = hoststep.lib()
+    L.host_closer.argtypes = [ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.c_int, ctypes.c_int]
+    shapes, _ = clipgen.load_shapes()
+    rng = np.random.default_rng(3)
+    n_true = n_all = 0
+    for trial in range(1500):
+        s = shapes[rng.integers(len(shapes))] + rng.uniform(-9e4, 9e4, 2)
+        c = np.vstack([s, s[:1]])
+        x, y = np.ascontiguousarray(c[:, 0]), np.ascontiguousarray(c[:, 1])
+        for _ in range(12):
+            k = rng.integers(len(s))
+            t = rng.choice([0.0, 1.0, 0.5, rng.uniform(0, 1), 1e-9, 1 - 1e-9])
+            a, b = c[k], c[k + 1]
+            nrm = np.array([-(b - a)[1], (b - a)[0]]); nrm /= np.linalg.norm(nrm) + 1e-300
+            off = rng.choice([0.0, 0.0, 5e-9, -5e-9, 1.00001e-8, 0.99999e-8, 2e-8, 4e-4, 6e-4, 9.9e-4, 1.01e-3, 1.0, -1.0, 100.0])
+            q = a + t * (b - a) + off * nrm
+            r = [L.host_closer(float(q[0]), float(q[1]), _d(x), _d(y), len(x), pruned) for pruned in (0, 1)]
+            assert r[0] == r[1], (trial, q.tolist(), r)
+            n_all += 1; n_true += r[0]
+    assert 0.2 * n_all < n_true < 0.8 * n_all
