@@ -97,6 +97,7 @@ struct StepState {
   int convex_lanes = 64;          // pairs per wave of that pass (SUBZERO_CONVEX_LANES)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
                                   // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
+  int retry_lds_max = 65536;      // ... and what it may grow to while the launch still fits the chip at once (SUBZERO_RETRY_LDS_MAX)
   int retry_lds = 16384;          // bytes of LDS per pair for that pass when its list is short (SUBZERO_RETRY_LDS, 0: HBM workspace)
   int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
   int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
@@ -550,6 +551,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LDS")) { int b = atoi(v); if (b >= 0 && b <= 40 * 1024) S->retry_lds = b; }
+  if (const char *v = getenv("SUBZERO_RETRY_LDS_MAX")) { int b = atoi(v); if (b >= 0 && b <= 64 * 1024) S->retry_lds_max = b; }
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -767,7 +769,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     if (retry_lds > 0) {
       const i64 wgs = (nl + RL - 1) / RL, per_cu = (wgs + 255) / 256;
       i64 room = (i64)160 * 1024 / (per_cu * RL);
-      room = (room > 64 * 1024 ? 64 * 1024 : room) & ~(i64)1023;
+      room = (room > S->retry_lds_max ? S->retry_lds_max : room) & ~(i64)1023;
       if (room > retry_lds) retry_lds = (int)room;
     }
     if (retry_lds > 0)

@@ -162,6 +162,23 @@ def test_deferred_pairs_with_hbm_workspace(ctx, monkeypatch):
     assert exact
 
 
+def test_evolved_outlines_at_scale(ctx):
+    # 600 outlines of the reference's FloeShapes.mat (up to 90 vertices): every pair goes to the general kernel, which
+    # trims the rings to their common box, keeps rings, crossings layout and sweep workspace in 64 KB slices of LDS
+    S, P = scenes.concave(600, periodic=True)
+    A, G, exact = lockstep(ctx, S, P, 5)
+    assert exact
+
+
+def test_evolved_outlines_with_small_lds_slices(ctx, monkeypatch):
+    # 8 KB slices: sweeps of more than 13 trimmed vertices fall back to the HBM workspace clip by clip
+    monkeypatch.setenv("SUBZERO_RETRY_LDS", "8192")
+    monkeypatch.setenv("SUBZERO_RETRY_LDS_MAX", "8192")
+    S, P = scenes.concave(150, periodic=False)
+    A, G, exact = lockstep(ctx, S, P, 6)
+    assert exact
+
+
 def test_long_convex_rings(ctx):
     # 8..39-vertex convex floes: fast pass (16-vertex blocks) and general sweep for the longer rings
     S, P = scenes.many_sided(64)
