@@ -216,6 +216,14 @@ def config(name, n_stress=N_STRESS, n_mc=N_MC):
     elif name == "pack10000":     # configs[3]: 1e4 floes, concentration 1.0, periodic
         S = voronoi_field(10000, 1.0, seed=4, vel_seed=2, n_stress=n_stress, n_mc=n_mc)
         P = StepParams(dt=10, periodic=True)
+    elif name == "nares_standin":
+        # configs[4] stand-in (the real case needs files that are absent from the reference checkout):
+        # a 2e5 x 1e6 m channel with walls (initialize_boundaries.m:14-16), Nb static concave floes first in the
+        # array (outlines from the reference's FloeShapes.mat when the caller passes them, see tests/scenes.py),
+        # Voronoi floes around them, wind V = -10 m/s (README.md:126).  As shipped, the candidate search
+        # (floe_interactions_all.m:76-120) starts at 1+Nb and only looks at j > i: nothing is ever paired with the
+        # static floes.  Reproduced as shipped.
+        raise ValueError("nares_standin needs the fixture outlines: use tests/scenes.py baseline_config")
     else:
         raise ValueError(name)
     P.Modulus = reference_modulus(S)

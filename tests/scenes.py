@@ -92,9 +92,41 @@ def boxes_and_triangle():
 def baseline_config(name):
     """BASELINE.json configs 0-2 at test size (subzero_amd.synth.config): the out-of-box 10-floe case, 1000 convex
     floes at concentration 0.8 in a periodic box, and the uniaxial-compression case whose N/S walls move inward."""
+    if name == "nares_standin":
+        return nares_standin()
     S, P = synth.config(name, n_stress=8)
     if name == "convex1000":
         P.set_reference_ocean()
+    return S, P
+
+
+def nares_standin(n=260, nb=3, seed=5):
+    """BASELINE configs[4] at test size (the real case's files are absent from the reference checkout):
+    a 2e5 x 1e6 m walled channel, `nb` static floes with outlines of the reference's FloeShapes.mat first in the
+    array (Nb), Voronoi floes around them, wind V = -10 m/s (README.md:126), ocean at rest.  As shipped the candidate
+    search (floe_interactions_all.m:76-120: i from 1+Nb, j > i) never pairs anything with the static floes."""
+    Lx, Ly = 1e5, 5e5
+    rng = np.random.default_rng(seed)
+    shapes, _ = clipgen.load_shapes()
+    shapes = [s for s in shapes if 30 <= len(s) <= 90]
+    islands, centres, radii = [], [], []
+    for k in range(nb):
+        s = shapes[rng.integers(len(shapes))]
+        c = s.mean(0); r = np.sqrt(((s - c) ** 2).sum(1).max())
+        R = rng.uniform(1.5e4, 3e4)
+        ctr = np.array([rng.uniform(-0.5, 0.5) * Lx, (-0.6 + 1.2 * (k + 0.5) / nb) * Ly])
+        islands.append((s - c) * (R / r) + ctr); centres.append(ctr); radii.append(R)
+    seeds = np.stack([rng.uniform(-Lx, Lx, n), rng.uniform(-Ly, Ly, n)], 1)
+    cells = [v for v in synth.bounded_voronoi(seeds, Lx, Ly) if v is not None]
+    keep = [v for v in cells if all(np.hypot(*(v.mean(0) - c)) > 1.15 * R for c, R in zip(centres, radii))]
+    S = synth.build_state(islands + keep, height=0.5, seed=seed + 1000, nb=nb, n_stress=8)
+    vr = np.random.default_rng(seed + 1)
+    S.Ui[nb:] = vr.normal(0, 0.1, S.n - nb); S.Vi[nb:] = vr.normal(0, 0.1, S.n - nb)
+    P = synth.StepParams(dt=10, Lx=Lx, Ly=Ly, periodic=False, height=0.5)
+    P.Yo = np.arange(-6e5, 6e5 + 1, 1e4)
+    shape = (len(P.Yo), len(P.Xo))
+    P.Uocn = np.zeros(shape); P.Vocn = np.zeros(shape); P.Uwind = np.zeros(shape); P.Vwind = np.full(shape, -10.0)
+    P.Modulus = synth.reference_modulus(S)
     return S, P
 
 

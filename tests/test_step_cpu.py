@@ -112,7 +112,7 @@ def test_long_convex_rings_are_handed_to_the_general_sweep():
     assert len(r.inter) > 0 and h1 - h0 > 50 and hoststep.step(B.copy(), P).retried > 10
 
 
-@pytest.mark.parametrize("name,steps", [("plumbing10", 30), ("convex1000", 5), ("uniaxial200", 12)])
+@pytest.mark.parametrize("name,steps", [("plumbing10", 30), ("convex1000", 5), ("uniaxial200", 12), ("nares_standin", 8)])
 def test_baseline_configs_match_oracle(name, steps):
     S, P = scenes.baseline_config(name)
     A, B = S.copy(), S.copy()

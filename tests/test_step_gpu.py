@@ -118,9 +118,9 @@ def test_more_fields_through_the_fast_pass(ctx, seed):
     assert exact
 
 
-@pytest.mark.parametrize("name,steps", [("plumbing10", 30), ("convex1000", 8), ("uniaxial200", 15)])
+@pytest.mark.parametrize("name,steps", [("plumbing10", 30), ("convex1000", 8), ("uniaxial200", 15), ("nares_standin", 10)])
 def test_baseline_configs(ctx, name, steps):
-    # BASELINE.json configs 0-2 at test size; the uniaxial case moves its N/S walls between steps
+    # BASELINE.json configs 0-2 and the configs[4] stand-in at test size; the uniaxial case moves its N/S walls between steps
     S, P = scenes.baseline_config(name)
     A, G = S.copy(), S.copy()
     sim = capi.FloeInteractions(ctx, G)
