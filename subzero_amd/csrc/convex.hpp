@@ -6,7 +6,7 @@
 // and the right bound of each ring -- and produces at most one output ring.  This file walks exactly the same
 // events in the same order and emits exactly the same points (same cross_point arithmetic, same front/back
 // insertion, same orientation fix-up, same first vertex), but its whole state is four edge records (registers), the
-// <= 16 vertices of each ring and six crossing slots (664 B of LDS), and the output ring is a write-only deque.
+// <= 16 vertices of each ring and four crossing slots (616 B of LDS), and the output ring is a write-only deque.
 // There are no linked lists to chase.
 //
 // It NEVER guesses.  Anything outside the plain case makes it return ST_BAIL before anything is written to the
@@ -26,7 +26,7 @@ using szv::i64;
 using szv::Pt;
 using szv::same;
 
-enum { ST_BAIL = 100, MAX_CROSS = 6 };
+enum { ST_BAIL = 100, MAX_CROSS = 4 };   // crossings in one scanbeam: each bound of one ring with each bound of the other
 #ifndef SZX_BAIL_PROBE
 #define SZX_BAIL_PROBE(site) ((void)(site))  // the host test build histograms the bail-out sites
 #endif
@@ -82,8 +82,8 @@ struct FastBlockT {
   CCross X[MAX_CROSS];
   char tail[8];        // makes the size 8 x odd bytes: the same field of neighbouring lanes falls into different LDS banks
 };
-typedef FastBlockT<16> FastBlock;      // the step's fast pass: 64 lanes x 664 B of LDS per wave; longer rings take the general sweep
-static_assert(sizeof(FastBlock) == 664 && (sizeof(FastBlock) / 8) % 2 == 1, "FastBlock layout changed: keep the size 8 x odd");
+typedef FastBlockT<16> FastBlock;      // the step's fast pass: 64 lanes x 616 B of LDS per wave (four waves per CU); longer rings take the general sweep
+static_assert(sizeof(FastBlock) == 616 && (sizeof(FastBlock) / 8) % 2 == 1, "FastBlock layout changed: keep the size 8 x odd");
 
 // MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
 SZ_HD i64 to_fixed(double v) {

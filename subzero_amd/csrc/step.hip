@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, i
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
-#define CONVEX_STRIDE 664
+#define CONVEX_STRIDE 616
 static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
 __global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
