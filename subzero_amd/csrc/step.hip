@@ -20,24 +20,24 @@
 // Diagnostic build only (make EXTRA=-DSZ_PHASE_PROFILE): wall-clock time of the parts of the contact model per
 // pair of the general kernels, summed and for the slowest pair; read with szDebugPhases.  Not in the product build.
 #include <hip/hip_runtime.h>
-struct SzPhaseState { unsigned long long last, t[12]; int cur, trim[4], ntrim; };
-__device__ unsigned long long sz_phase_acc[12];
-__device__ unsigned long long sz_phase_worst[20];
+struct SzPhaseState { unsigned long long last, t[20]; int cur, trim[4], ntrim; };
+__device__ unsigned long long sz_phase_acc[20];
+__device__ unsigned long long sz_phase_worst[28];
 __device__ SzPhaseState sz_phase_state[1 << 17];
 static __host__ __device__ inline void sz_phase_mark(int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
   SzPhaseState &s = sz_phase_state[(blockIdx.x * blockDim.x + threadIdx.x) & 0x1ffff];
   const unsigned long long now = wall_clock64();
-  if (k == 8) { for (int i = 0; i < 12; ++i) s.t[i] = 0; s.ntrim = 0; }
-  else s.t[s.cur < 12 ? s.cur : 9] += now - s.last;
+  if (k == 8) { for (int i = 0; i < 20; ++i) s.t[i] = 0; s.ntrim = 0; }
+  else s.t[s.cur < 20 ? s.cur : 9] += now - s.last;
   s.last = now; s.cur = k;
   if (k == 0) {
     unsigned long long tot = 0;
-    for (int i = 1; i < 12; ++i) { tot += s.t[i]; atomicAdd(&sz_phase_acc[i], s.t[i]); }
+    for (int i = 1; i < 20; ++i) { tot += s.t[i]; atomicAdd(&sz_phase_acc[i], s.t[i]); }
     if (atomicMax(&sz_phase_worst[0], tot) < tot) {
-      for (int i = 1; i < 12; ++i) sz_phase_worst[i] = s.t[i];
-      for (int i = 0; i < 4; ++i) sz_phase_worst[12 + i] = i < s.ntrim ? (unsigned long long)s.trim[i] : 0ull;
-      sz_phase_worst[16] = (unsigned long long)s.ntrim;
+      for (int i = 1; i < 20; ++i) sz_phase_worst[i] = s.t[i];
+      for (int i = 0; i < 4; ++i) sz_phase_worst[20 + i] = i < s.ntrim ? (unsigned long long)s.trim[i] : 0ull;
+      sz_phase_worst[24] = (unsigned long long)s.ntrim;
     }
   }
 #endif
@@ -49,15 +49,16 @@ static __host__ __device__ inline void sz_trim_mark(int before, int after) {
 #endif
 }
 #define SZC_PHASE(k) sz_phase_mark(k)
+#define SZV_PHASE(k) sz_phase_mark(k)
 #define SZC_TRIM_PROBE(before, after) sz_trim_mark(before, after)
 #endif
 #include "step_core.hpp"
 #if defined(SZ_PHASE_PROFILE)
 extern "C" int szDebugPhases(unsigned long long *out26, int reset) {
-  unsigned long long z[20] = {0};
-  if (hipMemcpyFromSymbol(out26, HIP_SYMBOL(sz_phase_acc), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out26 + 12, HIP_SYMBOL(sz_phase_worst), sizeof(unsigned long long) * 20) != hipSuccess) return -1;
-  if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_acc), z, 96); (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_worst), z, 160); }
+  unsigned long long z[28] = {0};
+  if (hipMemcpyFromSymbol(out26, HIP_SYMBOL(sz_phase_acc), sizeof(unsigned long long) * 20) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out26 + 20, HIP_SYMBOL(sz_phase_worst), sizeof(unsigned long long) * 28) != hipSuccess) return -1;
+  if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_acc), z, 160); (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_worst), z, 224); }
   return 0;
 }
 #endif

@@ -341,28 +341,46 @@ SZ_HD void pair_expand(int i, int N, const Floes &F, const Params &P, Work &W) {
 // ---------------------------------------------------------------------------------------------
 SZ_HD size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// Everything of a PairScratch but the sweep workspace and the contact rows: the rings in fixed point, the two
+// region slots, the crossing points (offsets from a 16-byte aligned base; `end` = bytes used).
+struct SmallLayout { size_t f1x, f1y, f2x, f2y, fsx, fsy, r1x, r1y, r2x, r2y, r1off, r2off, px, py, end; };
+SZ_HD SmallLayout small_layout(int n1, int n2, int cap_v, int cap_r, int cap_p) {
+  SmallLayout L;
+  size_t p = 0;
+  L.f1x = p; p += up16(8 * (size_t)(n1 + 1));
+  L.f1y = p; p += up16(8 * (size_t)(n1 + 1));
+  L.f2x = p; p += up16(8 * (size_t)(n2 + 1));
+  L.f2y = p; p += up16(8 * (size_t)(n2 + 1));
+  L.fsx = p; p += up16(8 * (size_t)(n1 + 1));
+  L.fsy = p; p += up16(8 * (size_t)(n1 + 1));
+  L.r1x = p; p += up16(8 * (size_t)cap_v);
+  L.r1y = p; p += up16(8 * (size_t)cap_v);
+  L.r2x = p; p += up16(8 * (size_t)cap_v);
+  L.r2y = p; p += up16(8 * (size_t)cap_v);
+  L.r1off = p; p += up16(4 * (size_t)(cap_r + 1));
+  L.r2off = p; p += up16(4 * (size_t)(cap_r + 1));
+  L.px = p; p += up16(8 * (size_t)cap_p);
+  L.py = p; p += up16(8 * (size_t)cap_p);
+  L.end = p;
+  return L;
+}
+SZ_HD void point_small(char *base, const SmallLayout &L, szc::PairScratch &S) {
+  S.f1x = (i64 *)(base + L.f1x); S.f1y = (i64 *)(base + L.f1y); S.f2x = (i64 *)(base + L.f2x); S.f2y = (i64 *)(base + L.f2y);
+  S.fsx = (i64 *)(base + L.fsx); S.fsy = (i64 *)(base + L.fsy);
+  S.r1x = (i64 *)(base + L.r1x); S.r1y = (i64 *)(base + L.r1y); S.r2x = (i64 *)(base + L.r2x); S.r2y = (i64 *)(base + L.r2y);
+  S.r1off = (int *)(base + L.r1off); S.r2off = (int *)(base + L.r2off);
+  S.px = (double *)(base + L.px); S.py = (double *)(base + L.py);
+}
 // Lays the PairScratch out inside [base, base + bytes).  Returns false when it does not fit.
 SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScratch &S) {
   const int cap_nv = mult * (n1 + n2 + 2);
   char *p = base, *end = base + bytes;
   S.cap_nv = cap_nv;
   S.ws = p; p += up16((size_t)szv::WS_PER_VERTEX * cap_nv + szv::WS_PER_CLIP);
-  S.f1x = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
-  S.f1y = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
-  S.f2x = (i64 *)p; p += up16(8 * (size_t)(n2 + 1));
-  S.f2y = (i64 *)p; p += up16(8 * (size_t)(n2 + 1));
-  S.fsx = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
-  S.fsy = (i64 *)p; p += up16(8 * (size_t)(n1 + 1));
   S.cap_v = 2 * cap_nv + 8; S.cap_r = cap_nv / 2 + 4;
-  S.r1x = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
-  S.r1y = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
-  S.r2x = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
-  S.r2y = (i64 *)p; p += up16(8 * (size_t)S.cap_v);
-  S.r1off = (int *)p; p += up16(4 * (size_t)(S.cap_r + 1));
-  S.r2off = (int *)p; p += up16(4 * (size_t)(S.cap_r + 1));
   S.cap_p = cap_nv + 8;
-  S.px = (double *)p; p += up16(8 * (size_t)S.cap_p);
-  S.py = (double *)p; p += up16(8 * (size_t)S.cap_p);
+  const SmallLayout L = small_layout(n1, n2, S.cap_v, S.cap_r, S.cap_p);
+  point_small(p, L, S); p += L.end;
   S.cap_rows = S.cap_r;
   S.rows = (double *)p; p += up16(40 * (size_t)S.cap_rows);
   return p <= end;
@@ -431,6 +449,14 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
       for (int k = 0; k < n2; ++k) { lx2[k] = ring2.X(k); ly2[k] = ring2.Y(k); }
       szc::RingD s1 = {lx1, ly1, -0.0, -0.0, n1, 0}, s2 = {lx2, ly2, -0.0, -0.0, n2, 0};
       ring1 = s1; ring2 = s2;
+      // ... and, while the sweep still keeps room for 24 vertices, the rings in fixed point, the region slots and
+      // the crossing points (the trim, the conversion and every loop over a region then run at LDS latency too);
+      // the contact rows stay in the pair's HBM slice, where the kernels after this one read them
+      const SmallLayout L = small_layout(n1, n2, S.cap_v, S.cap_r, S.cap_p);
+      if ((i64)L.end + (i64)szv::WS_PER_CLIP + 24 * (i64)szv::WS_PER_VERTEX <= (i64)lds_ws_bytes) {
+        lds_ws_bytes -= (int)L.end;
+        point_small((char *)fast_ws + lds_ws_bytes, L, S);
+      }
     }
   }
   szc::PairOut out;

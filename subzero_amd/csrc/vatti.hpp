@@ -36,6 +36,9 @@
 #define SZ_HD inline
 #endif
 
+#ifndef SZV_PHASE
+#define SZV_PHASE(k) ((void)0)   // a diagnostic build attributes time to the parts of the sweep here
+#endif
 namespace szv {
 
 typedef long long i64;
@@ -1675,6 +1678,7 @@ struct SweepT {
   // ---- driver ----
   SZ_HD bool run() {
     if (nM == 0) return false;
+    SZV_PHASE(13);
     gnu_sort(M, nM, LocMinLess<LocMin>());
     nB = 0;
     for (int i = 0; i < nM; ++i) {
@@ -1692,19 +1696,25 @@ struct SweepT {
     bool ok = true;
     i64 bot_y, top_y = 0;
     if (!pop_beam(bot_y)) return false;
+    SZV_PHASE(14);
     insert_minima(bot_y);
     for (;;) {
       if (err) break;
       bool have = pop_beam(top_y);
       if (!have && !(cur_lm < nM)) break;
+      SZV_PHASE(15);
       do_horizontals();
       nG = 0;
       if (err) break;
+      SZV_PHASE(16);
       if (!do_crossings(top_y)) { ok = false; break; }
+      SZV_PHASE(17);
       do_top_of_beam(top_y);
       bot_y = top_y;
+      SZV_PHASE(14);
       insert_minima(bot_y);
     }
+    SZV_PHASE(18);
     if (err) {
       // list overflow and range errors are reported as such; an internal inconsistency is the
       // reference's "Clipper Error."
@@ -1761,11 +1771,13 @@ SZ_HD int clip_rings_t(void *workspace, const Caps &caps, const RingA &a, int na
   s.op = op;
   s.fill_s = fill_subject;
   s.fill_c = fill_clip;
+  SZV_PHASE(12);
   s.add_ring(a, na, KIND_SUBJECT);
   if (s.err) return s.err;
   s.add_ring(b, nb, KIND_CLIP);
   if (s.err) return s.err;
   if (!s.run()) return s.err ? s.err : ST_CLIP_ERROR;
+  SZV_PHASE(19);
   if (!s.write(sink)) return ST_OUT_CAPACITY;
   return ST_OK;
 }
