@@ -170,10 +170,13 @@ def test_evolved_outlines_at_scale(ctx):
     assert exact
 
 
-def test_evolved_outlines_with_small_lds_slices(ctx, monkeypatch):
-    # 8 KB slices: sweeps of more than 13 trimmed vertices fall back to the HBM workspace clip by clip
-    monkeypatch.setenv("SUBZERO_RETRY_LDS", "8192")
-    monkeypatch.setenv("SUBZERO_RETRY_LDS_MAX", "8192")
+@pytest.mark.parametrize("slice_bytes", [8192, 24576, 32768])
+def test_evolved_outlines_with_small_lds_slices(ctx, monkeypatch, slice_bytes):
+    # 8 KB slices hold the rings only and sweeps of a few vertices; 24 KB also the small arrays of short pairs;
+    # 32 KB those of every pair, and sweeps of up to ~36 trimmed vertices -- the rest falls back to the pair's HBM
+    # slice array by array, clip by clip
+    monkeypatch.setenv("SUBZERO_RETRY_LDS", str(slice_bytes))
+    monkeypatch.setenv("SUBZERO_RETRY_LDS_MAX", str(slice_bytes))
     S, P = scenes.concave(150, periodic=False)
     A, G, exact = lockstep(ctx, S, P, 6)
     assert exact
