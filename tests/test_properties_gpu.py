@@ -124,3 +124,27 @@ def test_full_size_parity_with_the_oracle(ctx):
         assert np.array_equal(ra.inter_off, off) and np.array_equal(ra.inter, rows), "step %d" % it
         assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
     assert len(rows) > 20000
+
+
+def test_evolved_field_parity_with_the_oracle(ctx):
+    """The second shape distribution of SURVEY 8(d): 2500 evolved outlines of the reference's FloeShapes.mat (up to 90
+    vertices), the field the general path is measured on -- every field after every one of 4 timesteps
+    bit-identical to the CPU oracle, and the general kernel really took the pairs."""
+    import os
+    import hoststep
+    import oracle
+    S, P = scenes.concave(2500, periodic=True)
+    P.set_reference_ocean()
+    A, G = S.copy(), S.copy()
+    sim = capi.FloeInteractions(ctx, G)
+    threads = min(os.cpu_count() or 1, 32)
+    retried = 0
+    for it in range(4):
+        P.doInt = int(it % 10 == 0)
+        ra = oracle.step(A, P, threads=threads)
+        st = sim.step(P); retried += st.retried
+        sim.download(capi.SYNC_ALL)
+        off, rows = sim.interactions()
+        assert np.array_equal(ra.inter_off, off) and np.array_equal(ra.inter, rows), "step %d" % it
+        assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
+    assert len(rows) > 500 and retried > 2000
