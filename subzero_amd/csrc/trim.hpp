@@ -24,7 +24,7 @@
 // A crossing that the reference's double-precision IntersectPoint (:604-664) puts outside its scanbeam is
 // clamped to the beam, and trimming beyond the left / right side of Q makes beams taller; this needs a crossing
 // within rounding error (~1e-8 m for near-parallel floe edges) of the height of an unrelated, removed vertex
-// and moves one output vertex by that error: not seen in 1.7e5 fuzzed pairs against the reference Clipper
+// and moves one output vertex by that error: not seen in 1.2e6 fuzzed pairs against the reference Clipper
 // (tests/test_clip_cpu.py), far inside the 1e-10 relative bar on forces if it ever is.
 #pragma once
 #include "vatti.hpp"
