@@ -137,3 +137,41 @@ def test_matlab_int64_rounding():
     v = np.array([0.5, -0.5, 1.5, -1.5, 2.4999, -2.5, 1e30, -1e30, 0.49999999999999994])
     out = g.matlab_int64(v)
     assert out.tolist() == [1, -1, 2, -2, 2, -3, 2 ** 63 - 1, -2 ** 63, 0]
+
+
+def _one_pair(a, b):
+    ps = g.PairSet()
+    ps.add(np.asarray(a, np.int64) << 32, np.asarray(b, np.int64) << 32, fixed=True)
+    return ps
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built and /root/reference absent")
+def test_trim_rules_on_hand_made_rings():
+    """What trim.hpp cuts and what it leaves alone, on rings small enough to read (coordinates in metres)."""
+    # B: a square; A: a ring whose right part overlaps B and whose left part is a long tail of 9 vertices beyond B
+    B = [(10, 0), (20, 3), (21, 11), (9, 12)]
+    tail = [(-5, 1), (-9, 2), (-14, 4), (-20, 5), (-22, 6), (-19, 7), (-12, 8), (-8, 9), (-4, 10)]
+    A = [(15, -1)] + [(2, 0.5)] + tail + [(3, 10.5), (15, 13)]
+    A = [(int(2 * x), int(2 * y)) for x, y in A]; B2 = [(2 * x, 2 * y) for x, y in B]      # integers, no ties in y
+    ps = _one_pair(A, B2)
+    r, h = g.run_ref(ps, 1), g.run_host(ps, 1, trim=1)
+    assert g.compare(r, h, 1) == [] and len(r.rings(0)) == 1
+    before, after, declined = h.trim
+    assert declined == 0 and 0 < before - after <= len(tail)         # inner vertices of the tail are gone, its ends kept
+    # the same pair with one tail vertex moved to the height of a vertex of B: a tie, both rings go in whole
+    A_tie = list(A); A_tie[2] = (A_tie[2][0], B2[1][1])            # (vertex 2 is one of the two kept at the start of the run)
+    ps = _one_pair(A_tie, B2)
+    r, h = g.run_ref(ps, 1), g.run_host(ps, 1, trim=1)
+    assert g.compare(r, h, 1) == []
+    assert h.trim[2] == 1 and h.trim[0] == h.trim[1]
+    # rings whose boxes are apart, and rings too short to have a run: nothing is touched
+    far = [(x + 1000, y) for x, y in B2]
+    for a_, b_ in ((A, far), (B2, [(x + 5, y + 1) for x, y in B2])):
+        ps = _one_pair(a_, b_)
+        r, h = g.run_ref(ps, 1), g.run_host(ps, 1, trim=1)
+        assert g.compare(r, h, 1) == [] and h.trim[0] == h.trim[1] and h.trim[2] == 0
+    # other operations are never trimmed (the union needs every vertex)
+    ps = _one_pair(A, B2)
+    for m in (0, 2, 3):
+        h = g.run_host(ps, m, trim=1)
+        assert g.compare(g.run_ref(ps, m), h, 1) == [] and h.trim == (0, 0, 0)
