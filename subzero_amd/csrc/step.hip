@@ -87,7 +87,8 @@ struct StepState {
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
   double rmax_max = 0;
   Params P;                       // parameters of the step in flight
-  unsigned long long *c = nullptr; // host copy of the device counters (pinned: read back without a staging kernel)
+  unsigned long long *c = nullptr; // host copy of the device counters (pinned; k_publish writes it)
+  unsigned long long *c_dev = nullptr; // the same buffer as the device sees it
   i64 pair_rows_total = 0;        // contact rows of all pairs of the step (bounds the rows of the CSR)
   unsigned long long bump = 0, zero = 0;
   i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
@@ -272,11 +273,18 @@ __global__ void __launch_bounds__(64) k_broad_filter(int lo_is_real, Floes F, Pa
   broad_filter(i, F, P, W, tmp);
   pair_count(i, N, F, P, W);   // the list of i is final: its pairs and their vertex total
 }
-__global__ void k_pair_expand(Floes F, Params P, Work W) {
+__global__ void k_pair_expand(Floes F, Params P, Work W, unsigned long long scratch_bump) {
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) W.counters[C_SCR_BUMP] = scratch_bump;   // where the retry tiers of the narrow phase start to allocate
   if (i < N) pair_expand(i, N, F, P, W);
 }
+// The step's counters for the host, written straight into its pinned buffer (a launch back to back with the kernel
+// before it; a hipMemcpyAsync of 150 bytes costs a copy-engine start of ~6 us in the middle of the step)
+__global__ void k_publish(const unsigned long long *counters, unsigned long long *host_copy) {
+  if (threadIdx.x < (unsigned)C_COUNT) host_copy[threadIdx.x] = counters[threadIdx.x];
+}
+static_assert(C_COUNT <= 64, "k_publish is launched with one wave");
 // `lanes` of the 64 lanes of each wave carry a pair (the rest stay idle): with only ~4e4 pairs per step the
 // chip is short of waves, not of lanes; fewer pairs per wave means more waves in flight to overlap the
 // latency of the workspace accesses, and fewer divergent paths per wave.
@@ -546,6 +554,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   { int rc0 = dev_alloc(ctx, S, S->scan_agg, 512); if (rc0) return rc0; }
   SZ_HIP(ctx, hipHostMalloc((void **)&S->c, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
   memset(S->c, 0, C_COUNT * sizeof(unsigned long long));
+  SZ_HIP(ctx, hipHostGetDevicePointer((void **)&S->c_dev, S->c, 0));
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
@@ -690,7 +699,8 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
   unsigned long long *c = S->c;
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+  SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (c[C_ERR_POT]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "broad-phase: %llu floe(s) have more than %d candidates", c[C_ERR_POT], W.pot_cap);
   const i64 np = (i64)c[C_NPAIRS], nvt = (i64)c[C_NVTOT];
@@ -715,9 +725,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   W.pair_rowoff = (i64 *)S->pair_rowoff.p;
   W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
   W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
-  S->bump = (unsigned long long)main_bytes;
-  SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_SCR_BUMP], &S->bump, 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W, (unsigned long long)main_bytes);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -744,7 +752,8 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+  SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
   while (c[C_RETRY] > 0) {
@@ -778,7 +787,8 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     else
       hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+    SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
   if (c[C_ERR_ARENA]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "narrow-phase: %llu pair(s) did not fit the scratch arena", c[C_ERR_ARENA]);
@@ -842,7 +852,8 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  SZ_HIP(ctx, hipMemcpyAsync(c, W.counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+  SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   S->nr = (i64)c[C_NROWS];
   if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
