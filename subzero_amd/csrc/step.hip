@@ -13,7 +13,8 @@
 //   k_integrate_pre / k_integrate_post                        one thread per real floe
 //   k_forcing                                                 one 256-thread workgroup per real floe (Monte-Carlo forcing)
 // Host read-backs per step: the pair count (sizes the pair scratch), the deferred / retried pairs of the narrow
-// phase, and the counters at the end (buffers are grow-only, owned by the context).  No CPU fallback exists: every failure is an error code.
+// phase, and the counters at the end, each published by k_publish into a pinned host buffer (buffers are grow-only,
+// owned by the context).  No CPU fallback exists: every failure is an error code.
 #include <stdlib.h>
 #include "context.hpp"
 #if defined(SZ_PHASE_PROFILE)
