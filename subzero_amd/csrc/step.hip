@@ -97,7 +97,7 @@ struct StepState {
   i64 nr = 0;
   int force_exchange = 0;
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
-  int convex_lanes = 64;          // pairs per wave of that pass (SUBZERO_CONVEX_LANES)
+  int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
                                   // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
   int retry_lds_max = 65536;      // ... and what it may grow to while the launch still fits the chip at once (SUBZERO_RETRY_LDS_MAX)
@@ -559,7 +559,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
-  if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->convex_lanes = l; }
+  if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LDS")) { int b = atoi(v); if (b >= 0 && b <= 40 * 1024) S->retry_lds = b; }
   if (const char *v = getenv("SUBZERO_RETRY_LDS_MAX")) { int b = atoi(v); if (b >= 0 && b <= 64 * 1024) S->retry_lds_max = b; }
@@ -740,7 +740,10 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
   if (hi > lo) {
     if (convex) {
-      const int L = S->convex_lanes;
+      // one wave per SIMD is all this kernel can use (it is bound by the path of its longest lane): as few pairs
+      // per wave as still give every one of the 1024 SIMDs at most one wave -- fewer lanes, less divergence
+      int L = S->convex_lanes;
+      if (L == 0) { const i64 want = (hi - lo + 1023) / 1024; L = (int)(want < 16 ? 16 : want > 64 ? 64 : want); }
       hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo, L, F, P, W);
     } else if (fast) {
       const int L = S->fast_lanes;
