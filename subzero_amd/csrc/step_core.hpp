@@ -632,6 +632,10 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
   i64 r = W.row_off[i];
   double *rows = W.rows;
   double ov = 0;
+  // torque about the floe position of this (possibly ghost) entry and the sums, as the rows are written: the same
+  // values in the same (row) order as a pass over the finished rows (:221-239, :251-263)
+  const double x = W.ext_x[i], y = W.ext_y[i];
+  double sfx = 0, sfy = 0, stq = 0;
   // own pairs, ascending partner, wall last (:129-172)
   for (i64 p = W.pair_base[i]; p < W.pair_base[i] + W.pair_cnt[i]; ++p) {
     const int j = W.pair_j[p];
@@ -648,7 +652,10 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
           if (absd(pr[5 * k + 2]) == P.Lx) fy = 0;            // :163-165
           w[0] = SZC_INF;
         } else w[0] = (double)(j + 1);
-        w[1] = fx; w[2] = fy; w[3] = pr[5 * k + 2]; w[4] = pr[5 * k + 3]; w[5] = 0; w[6] = pr[5 * k + 4];
+        const double px = pr[5 * k + 2], py = pr[5 * k + 3];
+        const double tq = (px - x) * fy - (py - y) * fx;       // :221-239 / :251-263, in row order
+        w[1] = fx; w[2] = fy; w[3] = px; w[4] = py; w[5] = tq; w[6] = pr[5 * k + 4];
+        sfx += fx; sfy += fy; stq += tq;
         so += pr[5 * k + 4];
       }
       ov = so + ov;                                           // :137 / :168
@@ -667,22 +674,15 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
     for (int k = 0; k < W.pair_nrows[p]; ++k, ++r) {
       if (r >= W.cap_rows) return;
       double *w = rows + 7 * r;
-      w[0] = (double)(src + 1); w[1] = -pr[5 * k]; w[2] = -pr[5 * k + 1];
-      w[3] = pr[5 * k + 2]; w[4] = pr[5 * k + 3]; w[5] = 0; w[6] = pr[5 * k + 4];
+      const double fx = -pr[5 * k], fy = -pr[5 * k + 1], px = pr[5 * k + 2], py = pr[5 * k + 3];
+      const double tq = (px - x) * fy - (py - y) * fx;
+      w[0] = (double)(src + 1); w[1] = fx; w[2] = fy;
+      w[3] = px; w[4] = py; w[5] = tq; w[6] = pr[5 * k + 4];
+      sfx += fx; sfy += fy; stq += tq;
       ov = ov + pr[5 * k + 4];                                // :199
     }
   }
   W.ov_ext[i] = ov;
-  // torque about the floe position of this (possibly ghost) entry, then the sums in row order (:221-239, :251-263)
-  const i64 r0 = W.row_off[i];
-  const double x = W.ext_x[i], y = W.ext_y[i];
-  double sfx = 0, sfy = 0, stq = 0;
-  for (i64 q = r0; q < r; ++q) {
-    double *w = rows + 7 * q;
-    const double tq = (w[3] - x) * w[2] - (w[4] - y) * w[1];
-    w[5] = tq;
-    sfx += w[1]; sfy += w[2]; stq += tq;
-  }
   W.cf_ext[2 * i] = sfx; W.cf_ext[2 * i + 1] = sfy; W.ct_ext[i] = stq;
   // floe centre outside the box (:152-155)
   if (!P.PERIODIC && i >= F.nb && i < N0) {
