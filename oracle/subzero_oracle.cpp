@@ -46,6 +46,20 @@ const double INF = std::numeric_limits<double>::infinity();
 const double NaN = std::numeric_limits<double>::quiet_NaN();
 const double EPS = 2.220446049250313e-16;
 
+// Which definitions the run uses where the reference leaves a MathWorks builtin unspecified (or_set_mode):
+//   bit 0 (OR_MODE_LIBM)    sin / cos / atan2 from the host's libm instead of or_math.h
+//   bit 1 (OR_MODE_SEQSUM)  the means over the Monte-Carlo points (calc_trajectory.m:139,163-165) summed left to
+//                           right, as the .m text reads, instead of the 256-partial fold
+//   bits 8-10               start vertex (0-3) and direction (bit 10) of the domain-box ring handed to the 'dif' clip
+//                           (floe_interactions.m:31-32: holes(floe2.poly) fixes neither)
+// Mode 0 is the definition the device path reproduces bit for bit; mode 3 is independent of the kernels' own trig code
+// and summation order, and the device must stay within the north-star tolerance (1e-10 relative) of it.
+int g_mode = 0;
+inline void t_sincos(double x, double *s, double *c) {
+  if (g_mode & 1) { *s = sin(x); *c = cos(x); } else orm_sincos(x, s, c);
+}
+inline double t_atan2(double y, double x) { return (g_mode & 1) ? atan2(y, x) : orm_atan2(y, x); }
+
 struct Ring {
   Vec x, y;
 };
@@ -461,8 +475,9 @@ bool floe_interactions(const Vec &c1x_in, const Vec &c1y_in, const Body &f1, con
 struct McSum {
   double p[256];
   McSum() { for (int t = 0; t < 256; ++t) p[t] = 0.0; }
-  void add(int q, double v) { p[q & 255] += v; }
+  void add(int q, double v) { if (g_mode & 2) p[0] += v; else p[q & 255] += v; }
   double total() {
+    if (g_mode & 2) return p[0];
     for (int s = 128; s >= 1; s >>= 1)
       for (int t = 0; t < s; ++t) p[t] += p[t + s];
     return p[0];
@@ -553,7 +568,7 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
   Vec xr1, xr2;
   if (doforce) {
     double sa, ca;
-    orm_sincos(F->alpha_i[i], &sa, &ca);                        // :97
+    t_sincos(F->alpha_i[i], &sa, &ca);                        // :97
     const double *mx = F->mcX + (size_t)i * nmc, *my = F->mcY + (size_t)i * nmc;
     xr1.resize(nmc); xr2.resize(nmc);
     for (int q = 0; q < nmc; ++q) { xr1[q] = ca * mx[q] + (-sa) * my[q]; xr2[q] = sa * mx[q] + ca * my[q]; } // :98
@@ -579,14 +594,14 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
     const double Xi = F->Xi[i], Yi = F->Yi[i];
     const double ta = P->turn_angle;
     double sta, cta;
-    orm_sincos(ta, &sta, &cta);
+    t_sincos(ta, &sta, &cta);
     const uint8_t *A = F->mcA + (size_t)i * nmc;
     // U10, V10: mean of the interpolated winds over the points inside the floe (:139)
     McSum su, sv; int cnt = 0;
     Vec Uo(nmc), Vo(nmc), th(nmc), rho(nmc);
     for (int q = 0; q < nmc; ++q) {
       double Xg = xr1[q] + Xi, Yg = xr2[q] + Yi;                // :122
-      th[q] = orm_atan2(xr2[q], xr1[q]); rho[q] = hyp(xr1[q], xr2[q]); // :124
+      th[q] = t_atan2(xr2[q], xr1[q]); rho[q] = hyp(xr1[q], xr2[q]); // :124
       Uo[q] = interp2_linear(Xo, nxo, Yo, nyo, P->Uocn, Xg, Yg);
       Vo[q] = interp2_linear(Xo, nxo, Yo, nyo, P->Vocn, Xg, Yg);
       if (A[q]) {
@@ -602,7 +617,7 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
     McSum sFx, sFy, sT;
     for (int q = 0; q < nmc; ++q) {
       double sth, cth;
-      orm_sincos(th[q], &sth, &cth);
+      t_sincos(th[q], &sth, &cth);
       double Uice = F->Ui[i] - rho[q] * F->ksi_ice[i] * sth;    // :127-128
       double Vice = F->Vi[i] + rho[q] * F->ksi_ice[i] * cth;
       double Fx_p = -(floe_mass / floe_area) * fc * Vo[q];      // :143-144
@@ -660,7 +675,7 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
   F->dksi_ice_p[i] = dksi;
   // :221-222 rotate the ring
   double sa, ca;
-  orm_sincos(F->alpha_i[i], &sa, &ca);
+  t_sincos(F->alpha_i[i], &sa, &ca);
   for (int k = 0; k < nvr; ++k) {
     F->cax[v0 + k] = ca * F->c0x[v0 + k] + (-sa) * F->c0y[v0 + k];
     F->cay[v0 + k] = sa * F->c0x[v0 + k] + ca * F->c0y[v0 + k];
@@ -668,9 +683,9 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
   if (P->doInt) {                                              // :224-234 strain
     Vec Uice(nvr), Vice(nvr);
     for (int k = 0; k < nvr; ++k) {
-      double th = orm_atan2(F->cay[v0 + k], F->cax[v0 + k]), rh = hyp(F->cax[v0 + k], F->cay[v0 + k]);
+      double th = t_atan2(F->cay[v0 + k], F->cax[v0 + k]), rh = hyp(F->cax[v0 + k], F->cay[v0 + k]);
       double sth, cth;
-      orm_sincos(th, &sth, &cth);
+      t_sincos(th, &sth, &cth);
       Uice[k] = F->Ui[i] - rh * F->ksi_ice[i] * sth;
       Vice[k] = F->Vi[i] + rh * F->ksi_ice[i] * cth;
     }
@@ -696,6 +711,8 @@ int calc_trajectory(OrFloes *F, int i, const OrParams *P, const double *rows, in
 
 // =================================================================================================
 extern "C" {
+
+int or_set_mode(int mode) { int old = g_mode; g_mode = mode; return old; }
 
 int or_set_clipper(const char *path, int kind) {
   void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -879,7 +896,13 @@ int or_step(OrFloes *F, const OrParams *P, int32_t *inter_off, double *inter, in
     }
     if (!PERIODIC) {                                            // :150-172
       Vec bx(4), by(4);
-      for (int k = 0; k < 4; ++k) { bx[k] = c2b[2 * k]; by[k] = c2b[2 * k + 1]; }
+      {
+        const int start = (g_mode >> 8) & 3, rev = (g_mode >> 10) & 1;
+        for (int k = 0; k < 4; ++k) {
+          const int q = (start + (rev ? 4 - k : k)) & 3;
+          bx[k] = c2b[2 * q]; by[k] = c2b[2 * q + 1];
+        }
+      }
       Body fb = {P->fb_Xi, P->fb_Yi, P->fb_Ui, P->fb_Vi, P->fb_ksi_ice, P->fb_h, P->fb_area};
       if (!floe_interactions(c1x, c1y, b1, bx, by, fb, true, c2b, PERIODIC, P->Modulus, P->dt, P->mu, P->nu, rows)) {
 #pragma omp atomic write

@@ -48,6 +48,12 @@ typedef struct {
  *   host_clip_batch (tests/hostsim/libvatti_host.so)                                kind = 1 */
 int or_set_clipper(const char *path, int kind);
 
+/* Definitions used where the reference leaves a MathWorks builtin unspecified; returns the previous mode.
+ *   bit 0: libm sin/cos/atan2 instead of or_math.h; bit 1: Monte-Carlo means summed left to right instead of
+ *   the 256-partial fold; bits 8-9 / bit 10: start vertex / reversed direction of the domain-box ring of the
+ *   'dif' clip (floe_interactions.m:31-32).  0 = what the device path reproduces bit for bit. */
+int or_set_mode(int mode);
+
 /* One timestep.  Updates the floes in place.  Contact rows (floe_interactions_all.m:136,167,198) are
  * returned as CSR: floe i owns rows inter_off[i]..inter_off[i+1] of inter (7 doubles each,
  * [partner(1-based; Inf = wall), Fx, Fy, Px, Py, torque, overlap]).  Candidate pairs of the

@@ -80,6 +80,7 @@ def lib():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
     L = ctypes.CDLL(path)
     L.or_set_clipper.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.or_set_mode.argtypes = [ctypes.c_int]
     L.or_step.argtypes = [ctypes.POINTER(CFloes), ctypes.POINTER(CParams), _ip, _dp, ctypes.c_int64,
                           _ip, _ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _ip, ctypes.c_int32]
     L.or_ring_area.restype = ctypes.c_double
@@ -111,6 +112,31 @@ def lib():
     assert rc == 0
     _lib = L
     return L
+
+
+MODE_DEVICE_DEFINED = 0      # or_math.h trig, 256-partial Monte-Carlo fold: what the device reproduces bit for bit
+MODE_LIBM, MODE_SEQSUM = 1, 2
+MODE_INDEPENDENT = MODE_LIBM | MODE_SEQSUM   # host libm + left-to-right means: nothing shared with the kernels
+
+
+def wall_order(start, reverse):
+    """mode bits for the start vertex / direction of the domain-box ring (floe_interactions.m:31-32)."""
+    return ((start & 3) << 8) | ((1 if reverse else 0) << 10)
+
+
+class mode:
+    """with oracle.mode(oracle.MODE_INDEPENDENT): ...  -- the oracle's definitions for the enclosed steps."""
+
+    def __init__(self, m):
+        self.m = int(m)
+
+    def __enter__(self):
+        self.old = lib().or_set_mode(self.m)
+        return self
+
+    def __exit__(self, *a):
+        lib().or_set_mode(self.old)
+        return False
 
 
 def _p(a, t=_dp):
