@@ -39,7 +39,10 @@ enum {
   SZ_ERR_WORKSPACE = -5, /* a device-side list outgrew every workspace tier (never silent) */
   SZ_ERR_STATE = -6,     /* call out of order (e.g. szStep before szFloesUpload) */
   SZ_ERR_PEER = -7,      /* sharded step: another rank reported an error in its segment header */
-  SZ_SHARD_RESIZE = 1    /* sharded step, not an error: a segment has more contact rows than rows_max; exchange again */
+  SZ_SHARD_RESIZE = 1,   /* sharded step, not an error: a segment has more contact rows than rows_max; exchange again */
+  SZ_STEP_NEEDS_MC = 2   /* szStep, not an error: floes whose ocean/wind forcing is due have an empty Monte-Carlo mask
+                            (calc_trajectory.m:100-110 draws new points with rand); NOTHING of the floe array was
+                            changed; fetch them with szMcEmptyDownload, regenerate on the host, szFloesUpdate, step again */
 };
 
 /* per-clip status, one per pair (what the mex would have done for that call) */
@@ -182,11 +185,39 @@ enum {
   SZ_SYNC_ALL = 3
 };
 
+/* field groups of szFloesUpdate / szFloesFetch */
+enum {
+  SZ_F_STATE = 1,   /* every per-floe scalar field, alive, StressCount, Stress, strain, collision_force/torque, OverlapArea */
+  SZ_F_RING = 2,    /* c0 and c_alpha (same number of vertices as uploaded; a ring that changes length: szFloesResync) */
+  SZ_F_STRESSH = 4, /* StressH */
+  SZ_F_MC = 8,      /* the Monte-Carlo fields X, Y, A */
+  SZ_F_ALL = 15
+};
+
 /* Copies the whole struct array to the GPU (replaces any previous one).  The state then lives on the
  * device across szStep calls (dirty-field download only when MATLAB needs it). */
 int szFloesUpload(szContext *ctx, const szFloeState *host);
-/* One timestep on the device-resident floes. */
+/* SURVEY.md 8(f)2 -- synchronisation after MATLAB-side edits without moving the 0.5 GB of histories again.
+ *
+ * szFloesUpdate / szFloesFetch move the field groups `what` (SZ_F_*) of the listed floes (floe numbers, 1-based, as in
+ * interactions(:,1)) from / into `host`, the caller's image of the WHOLE array (same n and ring layout as the resident
+ * one; only the rows of the listed floes are read / written; a null pointer skips that field).  One packed transfer
+ * per group, whatever the number of floes.  Typical use: regenerated Monte-Carlo points (SZ_F_MC, after
+ * SZ_STEP_NEEDS_MC), velocities or thicknesses edited by a MATLAB-side process (SZ_F_STATE), the stress history of
+ * the floes a process is about to reshape (Fetch SZ_F_STRESSH: frac_corner.m:104,157 and Fuse_Floes.m:60-66 scale it).
+ *
+ * szFloesResync replaces the resident array by `host` (any n, any ring layout: floes added, removed, reshaped by
+ * FloeSimplify / fracture / corners / ridging, Subzero.m:169-217,317-372) like szFloesUpload, except that the stress
+ * history and the Monte-Carlo points of new floe k are copied ON THE DEVICE from floe src[k] (1-based) of the previous
+ * array when src[k] > 0; host->StressH / mcX / mcY / mcA are read only at the rows with src[k] == 0 (floes the
+ * MATLAB-side code created or changed).  src == NULL is szFloesUpload.  List capacities grown by earlier steps stay. */
+int szFloesUpdate(szContext *ctx, const szFloeState *host, const int32_t *ids, int32_t nids, int what);
+int szFloesFetch(szContext *ctx, szFloeState *host, const int32_t *ids, int32_t nids, int what);
+int szFloesResync(szContext *ctx, const szFloeState *host, const int32_t *src);
+/* One timestep on the device-resident floes.  SZ_OK, an error, or SZ_STEP_NEEDS_MC (nothing changed; see above). */
 int szStep(szContext *ctx, const szStepParams *params, szStepStats *stats);
+/* floes (1-based, ascending) for which the last szStep returned SZ_STEP_NEEDS_MC */
+int szMcEmptyDownload(szContext *ctx, int32_t *ids, int64_t cap, int64_t *count);
 int szFloesDownload(szContext *ctx, szFloeState *host, int what);
 /* Floe(i).interactions of the last step for the n real floes, CSR: 7 doubles per row
  * [partner (1-based; Inf = boundary), Fx, Fy, Px, Py, torque, overlap], row order of the reference. */
@@ -195,6 +226,13 @@ int szInteractionsDownload(szContext *ctx, int32_t *inter_off, double *inter, in
  * extended list, in the reference's order; wall candidates excluded. */
 int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t cap, int64_t *npairs,
                     int32_t *n_ext);
+
+/* The ghost floes of the last step (floe_interactions_all.m:16-66) in the order of the extended list: ghost g is
+ * Floe(n + g) there (g = 1..nghost).  src = the real floe whose ring and state it copies, parent = the entry of the
+ * extended list it was made from (a real floe or an X ghost, :36,:57), Xi / Yi = its translated position -- what the
+ * ridging / rafting tail needs to index Floe(a(jj,1)) over the extended list (:305-330,:385-458).  Any pointer may be
+ * NULL. */
+int szGhostsDownload(szContext *ctx, int32_t *src, int32_t *parent, double *Xi, double *Yi, int64_t cap, int64_t *nghost);
 
 /* ---- multi-GPU: the step with its dominant stage (the per-pair narrow-phase) sharded over ranks ----------
  * One process per GPU, every rank holds the full floe array (szFloesUpload of the same data on each) and

@@ -76,6 +76,17 @@ class StepStats(ctypes.Structure):
 
 
 SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3
+F_STATE, F_RING, F_STRESSH, F_MC, F_ALL = 1, 2, 4, 8, 15
+SZ_STEP_NEEDS_MC = 2
+
+
+class NeedsMc(SubzeroError):
+    """szStep changed nothing: the forcing of these floes (1-based) is due and their Monte-Carlo mask is empty
+    (calc_trajectory.m:100-110 draws new points with rand).  Regenerate them, `update(ids, F_MC)`, step again."""
+
+    def __init__(self, ids):
+        SubzeroError.__init__(self, "floes %s need new Monte-Carlo points" % (list(ids),))
+        self.ids = np.asarray(ids, np.int32)
 
 
 def pack_floes(S):
@@ -134,6 +145,7 @@ EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
     "szClipBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
+    "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -171,6 +183,11 @@ def load():
     L.szFloesDownload.argtypes = [_vp, ctypes.POINTER(FloeStateC), ctypes.c_int]
     L.szInteractionsDownload.argtypes = [_vp, _ip, _dp, ctypes.c_int64]
     L.szPairsDownload.argtypes = [_vp, _ip, _ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _ip]
+    L.szFloesUpdate.argtypes = [_vp, ctypes.POINTER(FloeStateC), _ip, ctypes.c_int32, ctypes.c_int]
+    L.szFloesFetch.argtypes = [_vp, ctypes.POINTER(FloeStateC), _ip, ctypes.c_int32, ctypes.c_int]
+    L.szFloesResync.argtypes = [_vp, ctypes.POINTER(FloeStateC), _ip]
+    L.szMcEmptyDownload.argtypes = [_vp, _ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    L.szGhostsDownload.argtypes = [_vp, _ip, _ip, _dp, _dp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.szDeviceAlloc.argtypes = [_vp, ctypes.POINTER(_vp), ctypes.c_int64]
     L.szDeviceFree.argtypes = [_vp, _vp]
     L.szCopyToDevice.argtypes = [_vp, _vp, _vp, ctypes.c_int64]
@@ -273,8 +290,54 @@ class FloeInteractions:
     def step(self, params):
         cp = self._packer.pack(params)
         st = StepStats()
-        self.ctx.check(self.ctx.L.szStep(self.ctx.h, ctypes.byref(cp), ctypes.byref(st)), "szStep")
+        rc = self.ctx.L.szStep(self.ctx.h, ctypes.byref(cp), ctypes.byref(st))
+        if rc == SZ_STEP_NEEDS_MC:
+            raise NeedsMc(self.mc_empty())
+        self.ctx.check(rc, "szStep")
         return st
+
+    def mc_empty(self):
+        """Floes (1-based) the last step asked new Monte-Carlo points for."""
+        ids = np.zeros(max(self.floes.n, 1), np.int32)
+        cnt = ctypes.c_int64()
+        self.ctx.check(self.ctx.L.szMcEmptyDownload(self.ctx.h, ids.ctypes.data_as(_ip), len(ids), ctypes.byref(cnt)),
+                       "szMcEmptyDownload")
+        return ids[:cnt.value].copy()
+
+    def update(self, ids, what):
+        """Field groups `what` (F_*) of the floes `ids` (1-based) from the host arrays to the GPU."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        self.ctx.check(self.ctx.L.szFloesUpdate(self.ctx.h, ctypes.byref(self._c), ids.ctypes.data_as(_ip), len(ids), what),
+                       "szFloesUpdate")
+
+    def fetch(self, ids, what):
+        """... and from the GPU into the host arrays."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        self.ctx.check(self.ctx.L.szFloesFetch(self.ctx.h, ctypes.byref(self._c), ids.ctypes.data_as(_ip), len(ids), what),
+                       "szFloesFetch")
+        return self.floes
+
+    def resync(self, floes, src):
+        """Replace the resident array by `floes` (any size / ring layout); new floe k keeps the device-resident stress
+        history and Monte-Carlo points of old floe src[k] (1-based), 0 = read them from `floes`."""
+        c = pack_floes(floes)
+        src = np.ascontiguousarray(src, np.int32)
+        if len(src) != floes.n:
+            raise SubzeroError("resync: src must name a predecessor (or 0) for every floe")
+        self.ctx.check(self.ctx.L.szFloesResync(self.ctx.h, ctypes.byref(c), src.ctypes.data_as(_ip)), "szFloesResync")
+        self.floes, self._c = floes, c
+        self._packer = ParamPacker()
+
+    def ghosts(self):
+        """(src, parent, Xi, Yi) of the ghost floes of the last step; ghost g is Floe(n + g + 1) of the extended list."""
+        cap = 3 * self.floes.n + 8
+        src = np.zeros(cap, np.int32); par = np.zeros(cap, np.int32); x = np.zeros(cap); y = np.zeros(cap)
+        cnt = ctypes.c_int64()
+        self.ctx.check(self.ctx.L.szGhostsDownload(self.ctx.h, src.ctypes.data_as(_ip), par.ctypes.data_as(_ip),
+                                                   x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), cap, ctypes.byref(cnt)),
+                       "szGhostsDownload")
+        g = cnt.value
+        return src[:g].copy(), par[:g].copy(), x[:g].copy(), y[:g].copy()
 
     def download(self, what=SYNC_DYNAMIC):
         self.ctx.check(self.ctx.L.szFloesDownload(self.ctx.h, ctypes.byref(self._c), what), "szFloesDownload")

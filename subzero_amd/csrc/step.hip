@@ -16,6 +16,7 @@
 // phase, and the counters at the end, each published by k_publish into a pinned host buffer (buffers are grow-only,
 // owned by the context).  No CPU fallback exists: every failure is an error code.
 #include <stdlib.h>
+#include <algorithm>
 #include "context.hpp"
 #if defined(SZ_PHASE_PROFILE)
 // Diagnostic build only (make EXTRA=-DSZ_PHASE_PROFILE): wall-clock time of the parts of the contact model per
@@ -64,51 +65,7 @@ extern "C" int szDebugPhases(unsigned long long *out26, int reset) {
 }
 #endif
 
-using namespace szs;
-
-struct StepState {
-  Floes F;            // device pointers
-  Work W;             // device pointers
-  std::vector<DevBuf> bufs;
-  int n = 0, nb = 0, n_stress = 0, n_mc = 0, nverts = 0;
-  int pot_cap = 32;
-  // ocean grids on the device
-  DevBuf oXo, oYo, oU, oV, oWu, oWv;
-  int nxo = 0, nyo = 0;
-  double xo_max = 0, xo_min = 0, yo_max = 0, yo_min = 0; // extent of the uploaded grid axes
-  bool have_ocean = false;
-  // grow-only per-step buffers
-  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
-  DevBuf scratch, rows;
-  DevBuf cell_cnt, cell_off, cell_fill, cell_item;
-  DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
-  std::vector<long long> hdr;     // segment headers of all ranks (szStepShardFinish)
-  long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
-  int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
-  int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
-  double rmax_max = 0;
-  Params P;                       // parameters of the step in flight
-  unsigned long long *c = nullptr; // host copy of the device counters (pinned; k_publish writes it)
-  unsigned long long *c_dev = nullptr; // the same buffer as the device sees it
-  i64 pair_rows_total = 0;        // contact rows of all pairs of the step (bounds the rows of the CSR)
-  unsigned long long bump = 0, zero = 0;
-  i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
-  int N = 0, rank = 0, world = 1;
-  i64 nr = 0;
-  int force_exchange = 0;
-  int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
-  int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
-  int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
-                                  // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
-  int retry_lds_max = 65536;      // ... and what it may grow to while the launch still fits the chip at once (SUBZERO_RETRY_LDS_MAX)
-  int retry_lds = 16384;          // bytes of LDS per pair for that pass when its list is short (SUBZERO_RETRY_LDS, 0: HBM workspace)
-  int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
-  int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
-  i64 last_npairs = 0, last_nrows_real = 0;
-  int last_next = 0;
-  bool stepped = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-};
+#include "step_state.hpp"
 
 namespace {
 
@@ -117,11 +74,15 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 __device__ inline int dev_next(const Work &W) { return (int)W.counters[C_NEXT]; }
 
-__global__ void k_ext_clear(Floes F, Work W) {
+__global__ void k_counters_clear(Floes F, Work W) {
+  int e = threadIdx.x;
+  if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
+}
+__global__ void k_ext_clear(Floes F, Params P, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < W.cap_ext) { ext_clear(e, W); marks_clear(e, F); }
   if (e < F.n) ext_init(e, F, W);
-  if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
+  if (e >= F.nb && e < F.n) mc_precheck(e, F, P, W);
 }
 // ---- exclusive scans: two launches of <= 256 workgroups (one per CU), no spinning --------------------------
 // k_scan_reduce: workgroup b sums its tile of the input -> agg[b]; k_scan_write: workgroup b adds up the
@@ -199,7 +160,7 @@ struct ScanPairs { // pair counts -> pair_base, pair vertex counts -> nv_base
   enum { CH = 2 };
   Work W;
   __device__ int n() const { return dev_next(W); }
-  __device__ long long first(int ch, int k) const { return load(ch, k); }
+  __device__ long long first(int ch, int k) const { if (ch == 0) { Work w = W; pair_room(k, w); } return load(ch, k); }
   __device__ long long load(int ch, int k) const { return ch == 0 ? (long long)W.pair_cnt[k] : (long long)W.pair_nv[k]; }
   __device__ void store(int ch, int k, long long v) const { if (ch == 0) W.pair_base[k] = v; else W.nv_base[k] = v; }
   __device__ void finish(const long long *t) const {
@@ -220,7 +181,7 @@ struct ScanRows {
 struct ScanCells {
   enum { CH = 1 };
   Work W;
-  __device__ int n() const { return W.cells_x * W.cells_y; }
+  __device__ int n() const { return W.lvl_base[W.n_levels]; }
   __device__ long long first(int ch, int k) const { return load(ch, k); }
   __device__ long long load(int, int k) const { return W.cell_cnt[k]; }
   __device__ void store(int, int k, long long v) const { W.cell_off[k] = (int)v; }
@@ -245,7 +206,7 @@ __global__ void k_broad(int lo_is_real, Floes F, Params P, Work W) {
 }
 __global__ void k_cell_clear(Work W) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c <= W.cells_x * W.cells_y) { W.cell_cnt[c] = 0; W.cell_fill[c] = 0; }
+  if (c <= W.lvl_base[W.n_levels]) { W.cell_cnt[c] = 0; W.cell_fill[c] = 0; }
 }
 __global__ void k_cell_count(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,12 +224,14 @@ __global__ void k_broad_scan(Floes F, Params P, Work W) { // thread (i, c9): 9 c
 }
 // 64 floes per workgroup; each thread sorts and filters its candidate list in its own slice of LDS
 // (2 * pot_cap + 1 ints: the odd stride spreads the threads over the banks), or of `spill` when that does not fit
-__global__ void __launch_bounds__(64) k_broad_filter(int lo_is_real, Floes F, Params P, Work W, int *spill) {
+// (`lanes` of the 64 threads work: as many as have room for their slice in 64 KB of LDS at the current capacity)
+__global__ void __launch_bounds__(64) k_broad_filter(int lo_is_real, int lanes, Floes F, Params P, Work W, int *spill) {
   extern __shared__ int filter_lds[];
   int N = dev_next(W);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)threadIdx.x >= lanes) return;
+  int i = blockIdx.x * lanes + threadIdx.x;
   const size_t stride = 2 * (size_t)W.pot_cap + 1;
-  int *tmp = spill ? spill + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
+  int *tmp = spill ? spill + ((size_t)blockIdx.x * lanes + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
   if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
   else { i += F.n; if (i >= N) return; }
   broad_filter(i, F, P, W, tmp);
@@ -282,8 +245,13 @@ __global__ void k_pair_expand(Floes F, Params P, Work W, unsigned long long scra
 }
 // The step's counters for the host, written straight into its pinned buffer (a launch back to back with the kernel
 // before it; a hipMemcpyAsync of 150 bytes costs a copy-engine start of ~6 us in the middle of the step)
-__global__ void k_publish(const unsigned long long *counters, unsigned long long *host_copy) {
-  if (threadIdx.x < (unsigned)C_COUNT) host_copy[threadIdx.x] = counters[threadIdx.x];
+// (reset_next >= 0: the counters are then set up for the next step, with C_NEXT = reset_next, so that it need not
+// start with a launch that clears them)
+__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next) {
+  const unsigned e = threadIdx.x;
+  if (e >= (unsigned)C_COUNT) return;
+  host_copy[e] = counters[e];
+  if (reset_next >= 0 && e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL;
 }
 static_assert(C_COUNT <= 64, "k_publish is launched with one wave");
 // `lanes` of the 64 lanes of each wave carry a pair (the rest stay idle): with only ~4e4 pairs per step the
@@ -350,12 +318,13 @@ __global__ void k_incoming(i64 np, Work W) {
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np) incoming(p, W);
 }
-__global__ void __launch_bounds__(64) k_row_count(Work W, int *spill) { // slices of LDS (or of `spill`) as in k_broad_filter
+__global__ void __launch_bounds__(64) k_row_count(int lanes, Work W, int *spill) { // slices of LDS (or of `spill`) as in k_broad_filter
   extern __shared__ int filter_lds[];
   int N = dev_next(W);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)threadIdx.x >= lanes) return;
+  int i = blockIdx.x * lanes + threadIdx.x;
   const size_t stride = 2 * (size_t)W.pot_cap + 1;
-  int *tmp = spill ? spill + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
+  int *tmp = spill ? spill + ((size_t)blockIdx.x * lanes + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
   if (i < N) row_count(i, W, tmp);
 }
 __global__ void k_row_fill(Floes F, Params P, Work W) {
@@ -483,17 +452,6 @@ __global__ void k_force_import(int first, int count, int cnt_max, Floes F, const
   if (k >= count) return;
   F.FxOA[first + k] = src[k]; F.FyOA[first + k] = src[cnt_max + k]; F.torqueOA[first + k] = src[2 * (size_t)cnt_max + k];
 }
-// running sums of the stress history, once after upload
-__global__ void k_stress_sum(Floes F) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F.n) return;
-  for (int q = 0; q < 4; ++q) {
-    double s = 0;
-    for (int z = 0; z < F.n_stress; ++z) s += F.StressH[((size_t)i * F.n_stress + z) * 4 + q];
-    F.StressSum[4 * i + q] = s;
-  }
-}
-
 // both launches of a scan over at most `bound` elements (the device-side count may be smaller)
 template <class Job>
 static void launch_scan(hipStream_t st, long long *agg, i64 bound, const Job &job) {
@@ -505,57 +463,27 @@ static void launch_scan(hipStream_t st, long long *agg, i64 bound, const Job &jo
   hipLaunchKernelGGL(k_scan_reduce<Job>, dim3(blocks), dim3(1024), 0, st, job, tile, agg);
   hipLaunchKernelGGL(k_scan_write<Job>, dim3(blocks), dim3(1024), 0, st, job, tile, (const long long *)agg);
 }
-inline dim3 grid_for(i64 n, int block) { return dim3((unsigned)((n + block - 1) / block > 0 ? (n + block - 1) / block : 1)); }
-
-template <class T>
-int dev_alloc(szContext *ctx, StepState *S, T *&ptr, size_t count) {
-  S->bufs.emplace_back();
-  DevBuf &b = S->bufs.back();
-  int rc = sz_reserve(ctx, b, count * sizeof(T) + 64);
-  if (rc) return rc;
-  ptr = (T *)b.p;
-  return SZ_OK;
-}
-template <class T>
-int dev_put(szContext *ctx, StepState *S, T *&ptr, const T *src, size_t count) {
-  int rc = dev_alloc(ctx, S, ptr, count);
-  if (rc) return rc;
-  if (count) SZ_HIP(ctx, hipMemcpy(ptr, src, count * sizeof(T), hipMemcpyHostToDevice));
-  return SZ_OK;
-}
-
 } // namespace
 
-void sz_step_destroy(szContext *ctx) {
-  StepState *S = ctx->step;
-  if (!S) return;
-  for (DevBuf &b : S->bufs) sz_release(b);
-  DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
-                    &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item, &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill};
-  for (DevBuf *b : more) sz_release(*b);
-  for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
-  if (S->c) (void)hipHostFree(S->c);
-  delete S;
-  ctx->step = nullptr;
+// k_broad_filter / k_row_count give each working thread 2 * pot_cap + 1 ints of LDS: as many threads per workgroup
+// as fit 64 KB, or slices of HBM (`spill`, `slices` of them) when not even one fits
+static int filter_launch_shape(szContext *ctx, StepState *S, i64 slices, int &lanes, size_t &lds, int *&spill) {
+  const size_t per_thread = (2 * (size_t)S->W.pot_cap + 1) * 4;
+  spill = nullptr;
+  lanes = (int)(((size_t)64 << 10) / per_thread);
+  if (lanes > 64) lanes = 64;
+  if (lanes < 1) {
+    int rc = sz_reserve(ctx, S->filter_spill, (size_t)slices * per_thread);
+    if (rc) return rc;
+    spill = (int *)S->filter_spill.p; lanes = 64; lds = 0;
+    return SZ_OK;
+  }
+  lds = (size_t)lanes * per_thread;
+  return SZ_OK;
 }
 
-extern "C" {
-
-int szFloesUpload(szContext *ctx, const szFloeState *h) {
-  if (!ctx || !h) return SZ_ERR_BAD_ARG;
-  if (h->n <= 0 || h->nb < 0 || h->nb > h->n || h->n_stress <= 0 || h->n_mc <= 0 || !h->vert_off)
-    return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFloesUpload: bad sizes");
-  SZ_HIP(ctx, hipSetDevice(ctx->device));
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  sz_step_destroy(ctx);
-  StepState *S = new StepState();
-  ctx->step = S;
-  for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
-  { int rc0 = dev_alloc(ctx, S, S->scan_agg, 512); if (rc0) return rc0; }
-  SZ_HIP(ctx, hipHostMalloc((void **)&S->c, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
-  memset(S->c, 0, C_COUNT * sizeof(unsigned long long));
-  SZ_HIP(ctx, hipHostGetDevicePointer((void **)&S->c_dev, S->c, 0));
+// tuning knobs (environment) and kernel attributes of a fresh StepState
+int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
@@ -565,51 +493,17 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   if (const char *v = getenv("SUBZERO_RETRY_LDS_MAX")) { int b = atoi(v); if (b >= 0 && b <= 64 * 1024) S->retry_lds_max = b; }
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
+  if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   (void)hipFuncSetAttribute((const void *)k_narrow_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const int n = h->n;
-  const int nv = h->vert_off[n];
-  S->n = n; S->nb = h->nb; S->n_stress = h->n_stress; S->n_mc = h->n_mc; S->nverts = nv;
-  S->bufs.reserve(128);
-  Floes &F = S->F;
-  F.n = n; F.nb = h->nb; F.n_stress = h->n_stress; F.n_mc = h->n_mc;
-  int rc;
-#define PUT(field, count) if ((rc = dev_put(ctx, S, F.field, h->field, (size_t)(count)))) return rc;
-  PUT(Xi, n) PUT(Yi, n) PUT(alpha_i, n) PUT(Ui, n) PUT(Vi, n) PUT(ksi_ice, n)
-  PUT(h, n) PUT(area, n) PUT(mass, n) PUT(inertia_moment, n) PUT(rmax, n)
-  PUT(dXi_p, n) PUT(dYi_p, n) PUT(dUi_p, n) PUT(dVi_p, n) PUT(dalpha_i_p, n) PUT(dksi_ice_p, n)
-  PUT(FxOA, n) PUT(FyOA, n) PUT(torqueOA, n)
-  PUT(alive, n) PUT(vert_off, n + 1)
-  PUT(c0x, nv) PUT(c0y, nv) PUT(cax, nv) PUT(cay, nv)
-  PUT(StressH, (size_t)n * h->n_stress * 4) PUT(StressCount, n) PUT(Stress, 4 * (size_t)n) PUT(strain, 4 * (size_t)n)
-  PUT(mcX, (size_t)n * h->n_mc) PUT(mcY, (size_t)n * h->n_mc) PUT(mcA, (size_t)n * h->n_mc)
-  F.mc_si = h->n_mc; F.mc_sq = 1; // [floe][point]: the forcing kernel reads one floe's points with one wave
-  PUT(collision_force, 2 * (size_t)n) PUT(collision_torque, n) PUT(OverlapArea, n)
-#undef PUT
-  if ((rc = dev_alloc(ctx, S, F.kill, 4 * (size_t)n))) return rc;
-  if ((rc = dev_alloc(ctx, S, F.transfer, 4 * (size_t)n))) return rc;
-  if ((rc = dev_alloc(ctx, S, F.StressSum, 4 * (size_t)n))) return rc;
-  Work &W = S->W;
-  memset(&W, 0, sizeof(W));
-  const size_t cap = 4 * (size_t)n;
-  W.cap_ext = (int)cap; W.pot_cap = S->pot_cap;
-#define NEW(field, count) if ((rc = dev_alloc(ctx, S, W.field, (size_t)(count)))) return rc;
-  NEW(ext_src, cap) NEW(ext_num, cap) NEW(ext_parent, cap) NEW(xg_of, cap) NEW(yg_of, cap) NEW(ext_nv, cap)
-  NEW(ext_x, cap) NEW(ext_y, cap) NEW(flag, cap) NEW(scan, cap) NEW(counters, C_COUNT)
-  NEW(pot_cnt, cap) NEW(pot_list, cap * W.pot_cap)
-  NEW(pair_cnt, cap) NEW(pair_nv, cap) NEW(pair_base, cap + 1) NEW(nv_base, cap + 1)
-  NEW(inc_cnt, cap) NEW(inc_list, cap * W.pot_cap)
-  NEW(row_cnt, cap) NEW(row_off, cap + 1) NEW(cf_ext, 2 * cap) NEW(ct_ext, cap) NEW(ov_ext, cap) NEW(tmax, cap)
-  NEW(st_ext, 3 * (size_t)n) NEW(st_flag, n)
-#undef NEW
-  for (int i = 0; i < n; ++i) if (h->rmax[i] > S->rmax_max) S->rmax_max = h->rmax[i];
-  hipLaunchKernelGGL(k_stress_sum, grid_for(n, 256), dim3(256), 0, ctx->stream, F);
-  SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFuncSetAttribute((const void *)k_broad_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  (void)hipFuncSetAttribute((const void *)k_row_count, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   return SZ_OK;
 }
+
+extern "C" {
 
 // ---- the step in three parts, so that the narrow-phase can be sharded over GPUs ----------------------
 // front : ghosts, grid, broad-phase, flat pair list, per-pair buffers      (every rank, identical results)
@@ -660,50 +554,62 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   W.g_rows = nullptr;
 
   SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
-  hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, W);
-  if (P.PERIODIC) {
-    for (int dim = 0; dim < 2; ++dim) {
-      int bound = (dim == 0) ? n : 2 * n;
-      launch_scan(st, S->scan_agg, bound, ScanGhost{dim, F, P, W});   // flags, slots and the ghosts themselves
-    }
-  }
-  // uniform grid over [-L - cs, L + cs]^2, cell edge cs = 2 max(rmax); positions outside clamp to the border
-  {
-    double cs = 2 * S->rmax_max;
-    if (!(cs > 0)) cs = 1;
-    W.cell_size = cs; W.cell_x0 = -P.Lx - cs; W.cell_y0 = -P.Ly - cs;
-    double nx = (2 * P.Lx + 2 * cs) / cs + 1, ny = (2 * P.Ly + 2 * cs) / cs + 1;
-    W.cells_x = (nx > 2048 || !(nx > 0)) ? 2048 : (int)nx;
-    W.cells_y = (ny > 2048 || !(ny > 0)) ? 2048 : (int)ny;
-    const size_t nc = (size_t)W.cells_x * W.cells_y + 1;
-    if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
-        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, (size_t)cap * sizeof(CellItem)))) return rc;
-    W.cell_item = (CellItem *)S->cell_item.p;
-    W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
-    hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
-    hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
-    launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
-    hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
-  }
-  hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, F, P, W);
-  {
-    const size_t per_thread = (2 * (size_t)W.pot_cap + 1) * 4, lds = 64 * per_thread;
-    int *spill = nullptr;
-    if (lds > 64 * 1024) {   // very long candidate lists: the slices live in HBM instead
-      if ((rc = sz_reserve(ctx, S->filter_spill, (size_t)(3 * (i64)n + 64) * per_thread))) return rc;
-      spill = (int *)S->filter_spill.p;
-    }
-    hipLaunchKernelGGL(k_broad_filter, grid_for(n, 64), dim3(64), spill ? 0 : lds, st, 1, F, P, W, spill);
-    if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, 64), dim3(64), spill ? 0 : lds, st, 0, F, P, W, spill);
-  }
-  launch_scan(st, S->scan_agg, cap, ScanPairs{W});
-  SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
   unsigned long long *c = S->c;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
-  SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipStreamSynchronize(st));
-  if (c[C_ERR_POT]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "broad-phase: %llu floe(s) have more than %d candidates", c[C_ERR_POT], W.pot_cap);
+  S->mc_empty.clear();
+  for (int attempt = 0;; ++attempt) {
+    if (attempt > 0 || !S->counters_clean) hipLaunchKernelGGL(k_counters_clear, dim3(1), dim3(64), 0, st, F, W);
+    S->counters_clean = false;
+    hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
+    if (P.PERIODIC) {
+      for (int dim = 0; dim < 2; ++dim) {
+        int bound = (dim == 0) ? n : 2 * n;
+        launch_scan(st, S->scan_agg, bound, ScanGhost{dim, F, P, W});   // flags, slots and the ghosts themselves
+      }
+    }
+    // hierarchy of uniform grids (step_core.hpp grid_levels); positions outside clamp to the border cells
+    {
+      grid_levels(S->rmax_max, S->rmax_p90, P.Lx, P.Ly, W);
+      const size_t nc = (size_t)W.lvl_base[W.n_levels] + 1;
+      if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
+          (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, (size_t)cap * sizeof(CellItem)))) return rc;
+      W.cell_item = (CellItem *)S->cell_item.p;
+      W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
+      hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
+      hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
+      launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
+      hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
+    }
+    hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, F, P, W);
+    {
+      int lanes; size_t lds; int *spill = nullptr;
+      if ((rc = filter_launch_shape(ctx, S, 3 * (i64)n + 64, lanes, lds, spill))) return rc;
+      hipLaunchKernelGGL(k_broad_filter, grid_for(n, lanes), dim3(64), lds, st, 1, lanes, F, P, W, spill);
+      if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, lanes), dim3(64), lds, st, 0, lanes, F, P, W, spill);
+    }
+    launch_scan(st, S->scan_agg, cap, ScanPairs{W});
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipStreamSynchronize(st));
+    if (c[C_NEED_MC]) {   // nothing of the floe array has been touched yet: the caller regenerates the points and steps again
+      const size_t k = (size_t)c[C_NEED_MC];
+      S->mc_empty.resize(k);
+      SZ_HIP(ctx, hipMemcpy(S->mc_empty.data(), W.mc_list, k * 4, hipMemcpyDeviceToHost));
+      std::sort(S->mc_empty.begin(), S->mc_empty.end());
+      sz_fail(ctx, SZ_STEP_NEEDS_MC, "szStep: %zu floe(s) need new Monte-Carlo points (calc_trajectory.m:100-110); nothing was changed", k);
+      return SZ_STEP_NEEDS_MC;
+    }
+    if (!c[C_ERR_POT]) break;
+    // a candidate list or a mirror list would not fit: grow both to the size this step asks for and run the front again
+    // (the capacity is kept for the following steps)
+    int want = S->pot_cap * 2;
+    while ((unsigned long long)want < c[C_NEED_POT]) want *= 2;
+    if (attempt >= 6 || (size_t)cap * want * 8 > ((size_t)16 << 30))
+      return sz_fail(ctx, SZ_ERR_WORKSPACE, "broad-phase: a floe has %llu candidates; lists of that size are not supported", c[C_NEED_POT]);
+    S->pot_cap = want;
+    if ((rc = bind_lists(ctx, S))) return rc;
+  }
   const i64 np = (i64)c[C_NPAIRS], nvt = (i64)c[C_NVTOT];
   S->np = np; S->nvt = nvt; S->N = (int)c[C_NEXT]; S->retried = 0;
 
@@ -756,7 +662,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
@@ -791,7 +697,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     else
       hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -823,13 +729,9 @@ static int step_back_a(szContext *ctx, StepState *S) {
   int rc;
   if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
   {
-    const size_t per_thread = (2 * (size_t)W.pot_cap + 1) * 4, lds = 64 * per_thread;
-    int *spill = nullptr;
-    if (lds > 64 * 1024) {
-      if ((rc = sz_reserve(ctx, S->filter_spill, (size_t)((i64)cap + 64) * per_thread))) return rc;
-      spill = (int *)S->filter_spill.p;
-    }
-    hipLaunchKernelGGL(k_row_count, grid_for(cap, 64), dim3(64), spill ? 0 : lds, st, W, spill);
+    int lanes; size_t lds; int *spill = nullptr;
+    if ((rc = filter_launch_shape(ctx, S, (i64)cap + 64, lanes, lds, spill))) return rc;
+    hipLaunchKernelGGL(k_row_count, grid_for(cap, lanes), dim3(64), lds, st, lanes, W, spill);
   }
   launch_scan(st, S->scan_agg, cap, ScanRows{W});
   // No host round trip here: every contact row of a pair appears at most twice in the CSR (once for each floe
@@ -856,9 +758,10 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const unsigned long long *)W.counters, S->c_dev);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
+  S->counters_clean = true;
   S->nr = (i64)c[C_NROWS];
   if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
   if (c[C_ERR_MC])
@@ -1024,71 +927,6 @@ int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats) {
   SZ_HIP(ctx, hipGetLastError());
   S->force_exchange = 0;
   return step_back_b(ctx, S, stats);
-}
-
-int szFloesDownload(szContext *ctx, szFloeState *h, int what) {
-  if (!ctx || !h) return SZ_ERR_BAD_ARG;
-  StepState *S = ctx->step;
-  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szFloesDownload: no floes uploaded");
-  if (h->n != S->n) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFloesDownload: n mismatch");
-  SZ_HIP(ctx, hipSetDevice(ctx->device));
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const Floes &F = S->F;
-  const size_t n = (size_t)S->n, nv = (size_t)S->nverts;
-#define GET(field, count) if (h->field) SZ_HIP(ctx, hipMemcpy(h->field, F.field, (size_t)(count) * sizeof(*h->field), hipMemcpyDeviceToHost));
-  if (what & SZ_SYNC_DYNAMIC) {
-    GET(Xi, n) GET(Yi, n) GET(alpha_i, n) GET(Ui, n) GET(Vi, n) GET(ksi_ice, n)
-    GET(h, n) GET(area, n) GET(mass, n) GET(inertia_moment, n) GET(rmax, n)
-    GET(dXi_p, n) GET(dYi_p, n) GET(dUi_p, n) GET(dVi_p, n) GET(dalpha_i_p, n) GET(dksi_ice_p, n)
-    GET(FxOA, n) GET(FyOA, n) GET(torqueOA, n) GET(alive, n)
-    GET(cax, nv) GET(cay, nv)
-    GET(StressCount, n) GET(Stress, 4 * n) GET(strain, 4 * n)
-    GET(collision_force, 2 * n) GET(collision_torque, n) GET(OverlapArea, n)
-    GET(kill, 4 * n) GET(transfer, 4 * n)
-  }
-  if (what & SZ_SYNC_STRESSH) { GET(StressH, n * S->n_stress * 4) }
-#undef GET
-  return SZ_OK;
-}
-
-int szInteractionsDownload(szContext *ctx, int32_t *inter_off, double *inter, int64_t cap_rows) {
-  if (!ctx || !inter_off) return SZ_ERR_BAD_ARG;
-  StepState *S = ctx->step;
-  if (!S || !S->stepped) return sz_fail(ctx, SZ_ERR_STATE, "szInteractionsDownload: no step taken");
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const int n = S->n;
-  std::vector<i64> off((size_t)n + 1);
-  SZ_HIP(ctx, hipMemcpy(off.data(), S->W.row_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
-  for (int i = 0; i <= n; ++i) inter_off[i] = (int32_t)off[i];
-  if (off[n] > cap_rows) return sz_fail(ctx, SZ_ERR_CAPACITY, "szInteractionsDownload: %lld rows, capacity %lld", (long long)off[n], (long long)cap_rows);
-  if (off[n] > 0) {
-    if (!inter) return SZ_ERR_BAD_ARG;
-    SZ_HIP(ctx, hipMemcpy(inter, S->W.rows, (size_t)off[n] * 56, hipMemcpyDeviceToHost));
-  }
-  return SZ_OK;
-}
-
-int szPairsDownload(szContext *ctx, int32_t *pair_i, int32_t *pair_j, int64_t cap, int64_t *npairs, int32_t *n_ext) {
-  if (!ctx || !npairs || !n_ext) return SZ_ERR_BAD_ARG;
-  StepState *S = ctx->step;
-  if (!S || !S->stepped) return sz_fail(ctx, SZ_ERR_STATE, "szPairsDownload: no step taken");
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const i64 np = S->last_npairs;
-  std::vector<int> pi((size_t)np + 1), pj((size_t)np + 1);
-  if (np) {
-    SZ_HIP(ctx, hipMemcpy(pi.data(), S->W.pair_i, (size_t)np * 4, hipMemcpyDeviceToHost));
-    SZ_HIP(ctx, hipMemcpy(pj.data(), S->W.pair_j, (size_t)np * 4, hipMemcpyDeviceToHost));
-  }
-  int64_t k = 0;
-  for (i64 p = 0; p < np; ++p) {
-    if (pj[p] == WALL) continue;
-    if (k < cap) { pair_i[k] = pi[p] + 1; pair_j[k] = pj[p] + 1; }
-    ++k;
-  }
-  *npairs = k;
-  *n_ext = S->last_next;
-  if (k > cap) return sz_fail(ctx, SZ_ERR_CAPACITY, "szPairsDownload: %lld pairs, capacity %lld", (long long)k, (long long)cap);
-  return SZ_OK;
 }
 
 } // extern "C"

@@ -42,7 +42,7 @@ struct Floes {
   long long mc_si, mc_sq;
   double *collision_force, *collision_torque, *OverlapArea;
   int *kill, *transfer; // capacity 4 * n (extended list)
-  double *StressSum;    // [floe][4] running sum of the StressH slots (device only)
+  double *StressSum;    // [floe][8] sum of the StressH slots as an unevaluated pair hi[4], lo[4] (device only; stress_sum_*)
 };
 
 struct Params {
@@ -60,7 +60,7 @@ struct Params {
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -100,11 +100,20 @@ struct Work {
   double *rows; i64 cap_rows;   // 7 doubles per row
   double *cf_ext, *ct_ext, *ov_ext; // per ext floe: sum Fx,Fy (2), sum torque, OverlapArea
   int *tmax;                    // cap_ext: transfer(kill(i)) = i resolution
-  // uniform grid over the extended list for the broad-phase (cell edge >= 2 * max rmax)
-  double cell_size, cell_x0, cell_y0;
-  int cells_x, cells_y;
-  int *cell_cnt, *cell_off, *cell_fill;              // [cells_x * cells_y (+1)]
+  // Hierarchy of uniform grids over the extended list for the broad-phase.  Level k holds the floes with
+  // lvl_r[k-1] < rmax <= lvl_r[k] in cells of edge lvl_cs[k] = 2 * lvl_r[k], so that any partner at level b >= the
+  // level of floe i lies in the 3 x 3 cells of level b around i (rmax_i + rmax_j <= 2 * lvl_r[b]).  A field of
+  // similar floes has one level; one floe 20 times the others gets a coarse level of its own instead of setting the
+  // cell size for everybody.  The cells of all levels share one CSR (cell index = lvl_base[k] + cy * lvl_cx[k] + cx).
+  enum { MAX_LEVELS = 8 };
+  int n_levels;
+  double lvl_r[MAX_LEVELS], lvl_cs[MAX_LEVELS], lvl_x0[MAX_LEVELS], lvl_y0[MAX_LEVELS];
+  int lvl_cx[MAX_LEVELS], lvl_cy[MAX_LEVELS], lvl_base[MAX_LEVELS + 1];
+  int *cell_cnt, *cell_off, *cell_fill;              // [lvl_base[n_levels] (+1)]
   struct CellItem *cell_item;                        // the floes of all cells, in cell order (cap_ext)
+  int *inc_pre;                                      // [cap_ext] candidate pairs that name the floe as partner (bounds inc_cnt)
+  int *mc_cnt;                                       // [n] points inside the floe's Monte-Carlo mask (sum(A), calc_trajectory.m:100)
+  int *mc_list; int mc_list_cap;                     // floes whose forcing is due with an empty mask (1-based), C_NEED_MC of them
   // calc_trajectory values handed from integrate_pre to forcing / integrate_post (per real floe)
   double *st_ext; // [3 n] external force x, y and torque after the limiter (:42-46)
   int *st_flag;   // ST_GO | ST_FORCE
@@ -124,10 +133,14 @@ SZ_HD int iabs(int v) { return v < 0 ? -v : v; }
 __device__ inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ inline int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 __device__ inline int atomic_max(int *p, int v) { return atomicMax(p, v); }
+__device__ inline unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { return atomicMax(p, v); }
+__device__ inline void atomic_inc_noret(int *p) { (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 inline int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
 inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
+inline void atomic_inc_noret(int *p) { ++*p; }
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -137,9 +150,29 @@ SZ_HD void ext_init(int i, const Floes &F, Work &W) { // i < n
   W.ext_src[i] = i; W.ext_x[i] = F.Xi[i]; W.ext_y[i] = F.Yi[i]; W.ext_num[i] = i + 1;
   W.ext_nv[i] = F.vert_off[i + 1] - F.vert_off[i];
 }
+// calc_trajectory.m:94-110: a floe whose forcing is due this step (doInt.flag, or thinner than 0.1 m after the
+// thinning of :76-80) and whose Monte-Carlo mask is empty gets new points from MATLAB's rand.  The step must not
+// guess them: such floes are listed BEFORE anything of the floe array is changed, szStep returns
+// SZ_STEP_NEEDS_MC, the caller regenerates (szFloesUpdate) and steps again.  (alive is the value at the start of
+// the step: a floe that leaves the box in this very step, :152-155, is listed although the reference would skip it.)
+SZ_HD void mc_precheck(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
+  if (!F.alive[i] || F.Xi[i] != F.Xi[i] || W.mc_cnt[i] != 0) return;
+  double hh = F.h[i];
+  if (hh > 10) hh = 10;
+  const double h_new = hh - P.HFo * P.dt / hh;
+  if (!(P.doInt || h_new < 0.1)) return;
+  unsigned long long k = atomic_add(&W.counters[C_NEED_MC], 1ULL);
+  if (k < (unsigned long long)W.mc_list_cap) W.mc_list[k] = i + 1;
+}
+SZ_HD void mc_count(int i, const Floes &F, Work &W) { // i < n
+  int c = 0;
+  const unsigned char *A = F.mcA + i * F.mc_si;
+  for (int q = 0; q < F.n_mc; ++q) c += A[q * F.mc_sq] ? 1 : 0;
+  W.mc_cnt[i] = c;
+}
 SZ_HD void ext_clear(int e, Work &W) { // e < cap_ext
   W.xg_of[e] = -1; W.yg_of[e] = -1; W.pot_cnt[e] = 0; W.inc_cnt[e] = 0; W.tmax[e] = 0;
-  W.pair_cnt[e] = 0; W.pair_nv[e] = 0; W.row_cnt[e] = 0;
+  W.pair_cnt[e] = 0; W.pair_nv[e] = 0; W.row_cnt[e] = 0; W.inc_pre[e] = 0;
   W.cf_ext[2 * e] = 0; W.cf_ext[2 * e + 1] = 0; W.ct_ext[e] = 0; W.ov_ext[e] = 0;
 }
 SZ_HD void marks_clear(int e, const Floes &F) { F.kill[e] = 0; F.transfer[e] = 0; } // e < 4 n (:123)
@@ -219,50 +252,112 @@ SZ_HD int cell_coord(double v, double v0, double cs, int ncell) {
   if (t >= (double)(ncell - 1)) return ncell - 1;
   return (int)t;
 }
-SZ_HD int cell_of(int e, const Work &W) {
-  return cell_coord(W.ext_y[e], W.cell_y0, W.cell_size, W.cells_y) * W.cells_x +
-         cell_coord(W.ext_x[e], W.cell_x0, W.cell_size, W.cells_x);
+SZ_HD int level_of(double r, const Work &W) {
+  int k = 0;
+  while (k + 1 < W.n_levels && r > W.lvl_r[k]) ++k;
+  return k;
 }
-// only live floes enter the grid (a dead floe is never a candidate, :101,:103); each item carries its
-// position and radius so that a cell is one contiguous stream of independent loads
+SZ_HD int cell_at(int level, double x, double y, const Work &W) {
+  return W.lvl_base[level] + cell_coord(y, W.lvl_y0[level], W.lvl_cs[level], W.lvl_cy[level]) * W.lvl_cx[level] +
+         cell_coord(x, W.lvl_x0[level], W.lvl_cs[level], W.lvl_cx[level]);
+}
+// Levels for a field whose candidate floes have radii up to r_max, 90 % of them up to r_p90: the base level takes
+// everything up to min(r_max, 1.5 r_p90) (one level when the sizes are alike), every further level doubles the radius,
+// the top level is open-ended.  Grids span [-L - cs, L + cs] (ghosts lie up to one radius outside the box).
+SZ_HD void grid_levels(double r_max, double r_p90, double Lx, double Ly, Work &W) {
+  if (!(r_max > 0)) r_max = 0.5;
+  double r0 = 1.5 * r_p90;
+  if (!(r0 > 0) || r0 > r_max) r0 = r_max;
+  const int top = (int)Work::MAX_LEVELS - 1;
+  double rt = r0;
+  for (int k = 0; k < top; ++k) rt *= 2;
+  if (rt < r_max) r0 = r0 * (r_max / rt);          // at most MAX_LEVELS levels: stretch the base instead
+  int nl = 0, base = 0;
+  double r = r0;
+  for (;;) {
+    const bool last = (r >= r_max) || nl == top;
+    const double R = last ? (r > r_max ? r : r_max) : r;
+    const double cs = 2 * R;
+    W.lvl_r[nl] = R; W.lvl_cs[nl] = cs; W.lvl_x0[nl] = -Lx - cs; W.lvl_y0[nl] = -Ly - cs;
+    const double nx = (2 * Lx + 2 * cs) / cs + 1, ny = (2 * Ly + 2 * cs) / cs + 1;
+    W.lvl_cx[nl] = (nx > 2048 || !(nx > 0)) ? 2048 : (int)nx;
+    W.lvl_cy[nl] = (ny > 2048 || !(ny > 0)) ? 2048 : (int)ny;
+    W.lvl_base[nl] = base;
+    base += W.lvl_cx[nl] * W.lvl_cy[nl];
+    ++nl;
+    if (last) break;
+    r *= 2;
+  }
+  W.n_levels = nl; W.lvl_base[nl] = base;
+  for (int k = nl; k < (int)Work::MAX_LEVELS; ++k) { W.lvl_r[k] = W.lvl_r[nl - 1]; W.lvl_cs[k] = 0; W.lvl_cx[k] = W.lvl_cy[k] = 0; W.lvl_base[k + 1] = base; W.lvl_x0[k] = W.lvl_y0[k] = 0; }
+}
+SZ_HD int cell_of(int e, const Floes &F, const Work &W) {
+  return cell_at(level_of(F.rmax[W.ext_src[e]], W), W.ext_x[e], W.ext_y[e], W);
+}
+// only live floes that can be a candidate enter the grid (a dead floe never is, :101,:103; floes 1..Nb neither,
+// since j > i >= 1 + Nb); each item carries its position and radius so that a cell is one contiguous stream of
+// independent loads
+SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && s >= F.nb; }
 SZ_HD void cell_count(int e, const Floes &F, Work &W) {
-  if (F.alive[W.ext_src[e]]) atomic_add(&W.cell_cnt[cell_of(e, W)], 1);
+  if (in_grid(e, F, W)) atomic_add(&W.cell_cnt[cell_of(e, F, W)], 1);
 }
 SZ_HD void cell_fill(int e, const Floes &F, Work &W) {
   const int s = W.ext_src[e];
-  if (!F.alive[s]) return;
-  int c = cell_of(e, W);
+  if (!in_grid(e, F, W)) return;
+  int c = cell_of(e, F, W);
   int k = W.cell_off[c] + atomic_add(&W.cell_fill[c], 1);
   CellItem it; it.x = W.ext_x[e]; it.y = W.ext_y[e]; it.r = F.rmax[s]; it.e = e; it.pad = 0;
   W.cell_item[k] = it;
 }
-// broad_scan: thread (i, c9) tests floe i against the items of ONE of its 3 x 3 cells and appends the hits to
-// i's list (unordered, one atomic per hit; nine short loops run side by side -- a thread per row of three cells was
-// measured slower at 1e4 floes, where this stage is latency-bound).  broad_filter: thread i sorts its list by j and
-// applies the `mems` filter in order (:93-99, :103, :113); real floes first, ghosts afterwards (they read their
-// root's list).
+// one more candidate of extended floe `owner`; the count keeps running past the capacity so that the host learns how
+// much room the lists need (step_front grows them and runs the front stages again)
+SZ_HD void pot_append(int owner, int partner, Work &W) {
+  int k = atomic_add(&W.pot_cnt[owner], 1);
+  if (k < W.pot_cap) W.pot_list[(size_t)owner * W.pot_cap + k] = partner + 1;
+}
+// broad_scan: thread (i, c9) tests floe i against the items of ONE of its 3 x 3 cells -- at its own level and at
+// every coarser one -- and appends the hits (unordered, one atomic per hit; nine short loops run side by side -- a
+// thread per row of three cells was measured slower at 1e4 floes, where this stage is latency-bound).  A pair of
+// floes of one level is found from both sides and kept by the lower index; a pair across levels is found from the
+// finer side only, which appends to whichever of the two has the lower index.  broad_filter: thread i sorts its list
+// by j and applies the `mems` filter in order (:93-99, :103, :113); real floes first, ghosts afterwards (they read
+// their root's list).
 SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Work &W) {
   (void)N;
   const int si = W.ext_src[i];
   const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
   if (!(F.alive[si] && !(xi != xi) && P.COLLISION)) return;
-  const int gx = cell_coord(xi, W.cell_x0, W.cell_size, W.cells_x) + (c9 % 3) - 1;
-  const int gy = cell_coord(yi, W.cell_y0, W.cell_size, W.cells_y) + (c9 / 3) - 1;
-  if (gx < 0 || gx >= W.cells_x || gy < 0 || gy >= W.cells_y) return;
-  const int c = gy * W.cells_x + gx;
-  int *mine = W.pot_list + (size_t)i * W.pot_cap;
-  for (int q = W.cell_off[c]; q < W.cell_off[c + 1]; ++q) {
-    const CellItem it = W.cell_item[q];
-    const int j = it.e;
-    if (j <= i) continue;
-    double dx = xi - it.x, dy = yi - it.y;
-    double R = ri + it.r;
-    double d2 = dx * dx + dy * dy;
-    if (d2 > R * R * 1.000001) continue;
-    if (!(::sqrt(d2) < R)) continue;      // :103
-    int k = atomic_add(&W.pot_cnt[i], 1);
-    if (k >= W.pot_cap) { atomic_add(&W.counters[C_ERR_POT], 1ULL); return; }
-    mine[k] = j + 1;
+  const int own = level_of(ri, W);
+  for (int b = own; b < W.n_levels; ++b) {
+    const int gx = cell_coord(xi, W.lvl_x0[b], W.lvl_cs[b], W.lvl_cx[b]) + (c9 % 3) - 1;
+    const int gy = cell_coord(yi, W.lvl_y0[b], W.lvl_cs[b], W.lvl_cy[b]) + (c9 / 3) - 1;
+    if (gx < 0 || gx >= W.lvl_cx[b] || gy < 0 || gy >= W.lvl_cy[b]) continue;
+    const int c = W.lvl_base[b] + gy * W.lvl_cx[b] + gx;
+    for (int q = W.cell_off[c]; q < W.cell_off[c + 1]; ++q) {
+      const CellItem it = W.cell_item[q];
+      const int j = it.e;
+      if (b == own ? j <= i : j == i) continue;
+      double dx = xi - it.x, dy = yi - it.y;
+      double R = ri + it.r;
+      double d2 = dx * dx + dy * dy;
+      if (d2 > R * R * 1.000001) continue;
+      if (!(::sqrt(d2) < R)) continue;      // :103 (the expression is symmetric in i and j up to the sign of dx, dy)
+      if (j > i) pot_append(i, j, W); else pot_append(j, i, W);
+    }
+  }
+}
+// ascending order in place (Shell sort, Ciura's gaps: n^1.3 for the few long lists, the plain insertion sort for the
+// short ones the fields are full of)
+SZ_HD void sort_ascending(int *v, int n) {
+  const int gaps[8] = {701, 301, 132, 57, 23, 10, 4, 1};
+  for (int g = 0; g < 8; ++g) {
+    const int gap = gaps[g];
+    if (gap >= n && gap > 1) continue;
+    for (int a = gap; a < n; ++a) {
+      int x = v[a], b = a;
+      while (b >= gap && v[b - gap] > x) { v[b] = v[b - gap]; b -= gap; }
+      v[b] = x;
+    }
   }
 }
 // tmp: 2 * pot_cap ints of fast private memory (a slice of LDS on the GPU): the list is sorted and filtered
@@ -270,14 +365,14 @@ SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Wor
 SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W, int *tmp) {
   int *mine = W.pot_list + (size_t)i * W.pot_cap;
   int cnt = W.pot_cnt[i];
-  if (cnt > W.pot_cap) cnt = W.pot_cap;
+  if (cnt > W.pot_cap) {                   // the list is incomplete: the host grows the lists and runs the front again
+    atomic_add(&W.counters[C_ERR_POT], 1ULL);
+    atomic_max(&W.counters[C_NEED_POT], (unsigned long long)cnt);
+    cnt = W.pot_cap;
+  }
   int *num = tmp + W.pot_cap;              // ext_num of the entries of tmp
   for (int a = 0; a < cnt; ++a) tmp[a] = mine[a];
-  for (int a = 1; a < cnt; ++a) {          // ascending j
-    int v = tmp[a], b = a;
-    while (b > 0 && tmp[b - 1] > v) { tmp[b] = tmp[b - 1]; --b; }
-    tmp[b] = v;
-  }
+  sort_ascending(tmp, cnt);                // ascending j
   for (int a = 0; a < cnt; ++a) num[a] = W.ext_num[tmp[a] - 1];
   const int *init = nullptr; int ninit = 0;
   if (W.ext_num[i] < 0) {
@@ -288,7 +383,8 @@ SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W, int *tm
   const double ri = F.rmax[W.ext_src[i]];
   const double lim = szc::mind(2 * P.Lx, 2 * P.Ly);
   int kept = 0;
-  for (int a = 0; a < cnt; ++a) {
+  if (!P.PERIODIC) kept = cnt;             // no ghosts: every FloeNum is its own, nothing is ever in `mems` twice (:113)
+  for (int a = kept; a < cnt; ++a) {
     const int j = tmp[a] - 1;
     const int key = iabs(num[a]);
     bool member = false;
@@ -315,10 +411,21 @@ SZ_HD void pair_count(int i, int N, const Floes &F, const Params &P, Work &W) { 
     const int ni = W.ext_nv[i];
     cnt = W.pot_cnt[i];
     const int *mine = W.pot_list + (size_t)i * W.pot_cap;
-    for (int q = 0; q < cnt; ++q) nv += ni + W.ext_nv[mine[q] - 1];
+    for (int q = 0; q < cnt; ++q) {
+      nv += ni + W.ext_nv[mine[q] - 1];
+      atomic_inc_noret(&W.inc_pre[mine[q] - 1]);   // an upper bound of the partner's mirror list (:187-214), see pair_room
+    }
     if (has_wall_pair(i, N, F, P)) { ++cnt; nv += ni + 4; }
   }
   W.pair_cnt[i] = cnt; W.pair_nv[i] = nv;
+}
+// (after every pair_count) the mirror list of floe e cannot outgrow its capacity later in the step -- after
+// calc_trajectory has begun to change the floes -- if the candidate pairs naming e fit it now
+SZ_HD void pair_room(int e, Work &W) {
+  if (W.inc_pre[e] > W.pot_cap) {
+    atomic_add(&W.counters[C_ERR_POT], 1ULL);
+    atomic_max(&W.counters[C_NEED_POT], (unsigned long long)W.inc_pre[e]);
+  }
 }
 SZ_HD void pair_expand(int i, int N, const Floes &F, const Params &P, Work &W) { // after scans
   if (i < F.nb) return;
@@ -826,6 +933,40 @@ SZ_HD void axis_extent(const double *a, int n, double &mx, double &mn) {
   mx = a[0]; mn = a[0];
   for (int k = 1; k < n; ++k) { mx = szc::maxd(mx, a[k]); mn = szc::mind(mn, a[k]); }
 }
+// mean(StressH,3) (calc_trajectory.m:20) without reading the 32 KB history of a floe every step: the sum of the
+// slots is carried as an unevaluated pair hi + lo (|lo| <= ulp(hi)/2) and every replacement of a slot is applied
+// with error-free transformations (Knuth's TwoSum), so hi + lo stays equal to the exact sum of the current slots to
+// ~1e-32 relative for any number of steps -- no drift, and nothing left behind when a large entry rotates out.
+// hi is then that exact sum correctly rounded: closer to the true mean than the left-to-right sum of 1000 terms
+// the reference evaluates (whose own rounding is what separates the two, <= 1.2e-16 * sum|slots|).
+// (needs IEEE arithmetic as written: the library is built with -ffp-contract=off and without fast-math)
+SZ_HD void two_sum(double a, double b, double &s, double &e) {
+  s = a + b;
+  const double bb = s - a;
+  e = (a - (s - bb)) + (b - bb);
+}
+SZ_HD void stress_sum_add(double &hi, double &lo, double v) {
+  double s, e;
+  two_sum(hi, v, s, e);
+  lo += e;
+  two_sum(s, lo, hi, lo);
+}
+SZ_HD void stress_sum_replace(double &hi, double &lo, double old, double now) {
+  double a, e1, b, e2;
+  two_sum(hi, -old, a, e1);
+  two_sum(a, now, b, e2);
+  lo += e1 + e2;
+  two_sum(b, lo, hi, lo);
+}
+// the pair for the history as uploaded: slots added in order (stress_sum_add keeps the sum exact)
+SZ_HD void stress_sum_init(int i, const Floes &F) {
+  for (int q = 0; q < 4; ++q) {
+    double hi = 0, lo = 0;
+    for (int z = 0; z < F.n_stress; ++z) stress_sum_add(hi, lo, F.StressH[((size_t)i * F.n_stress + z) * 4 + q]);
+    F.StressSum[8 * i + q] = hi; F.StressSum[8 * i + 4 + q] = lo;
+  }
+}
+
 SZ_HD void integrate_pre(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
   W.st_flag[i] = 0;
   // ghost sums first (:242-245): the X ghost, then the Y ghost, of this floe; then the floe's own (:262-263)
@@ -903,9 +1044,10 @@ SZ_HD void integrate_pre(int i, const Floes &F, const Params &P, Work &W) { // n
   for (int q = 0; q < 4; ++q) {
     double old = SH[(size_t)(scount - 1) * 4 + q];
     SH[(size_t)(scount - 1) * 4 + q] = S[q];                     // :18 / :26
-    double sum = F.StressSum[4 * i + q] - old + S[q];
-    F.StressSum[4 * i + q] = sum;
-    F.Stress[4 * i + q] = sum / Nz;                              // :20 mean(StressH,3) as a running sum
+    double hi = F.StressSum[8 * i + q], lo = F.StressSum[8 * i + 4 + q];
+    stress_sum_replace(hi, lo, old, S[q]);
+    F.StressSum[8 * i + q] = hi; F.StressSum[8 * i + 4 + q] = lo;
+    F.Stress[4 * i + q] = hi / Nz;                               // :20 mean(StressH,3)
   }
   F.StressCount[i] = scount + 1;
   F.h[i] = h_new; F.mass[i] = floe_mass; F.inertia_moment[i] = floe_inertia; F.alive[i] = alive;

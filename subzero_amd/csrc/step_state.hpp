@@ -1,0 +1,100 @@
+// step_state.hpp -- the device-resident Floe struct array of one context and everything a timestep keeps between
+// its stages (shared by step.hip: the step itself, and sync.hip: upload / download / partial synchronisation).
+#pragma once
+#include <stdlib.h>
+#include <algorithm>
+#include "context.hpp"
+#include "step_core.hpp"
+
+using namespace szs;
+
+struct StepState {
+  Floes F;            // device pointers
+  Work W;             // device pointers
+  std::vector<DevBuf> bufs;
+  int n = 0, nb = 0, n_stress = 0, n_mc = 0, nverts = 0;
+  int pot_cap = 32;               // candidates / mirrored pairs per floe the lists hold; grows when a step needs more (sticky)
+  DevBuf pot_list, inc_list;      // [cap_ext * pot_cap] each
+  DevBuf stage_d, stage_i, stage_ids; // packed transfers of szFloesUpdate / szFloesFetch
+  std::vector<double> h_rmax;     // host copies of rmax (sizes the grids) and of the ring layout (checked by szFloesUpdate)
+  std::vector<int> h_vert_off;
+  std::vector<int> mc_empty;      // floes (1-based) the last szStep asked new Monte-Carlo points for (SZ_STEP_NEEDS_MC)
+  // ocean grids on the device
+  DevBuf oXo, oYo, oU, oV, oWu, oWv;
+  int nxo = 0, nyo = 0;
+  double xo_max = 0, xo_min = 0, yo_max = 0, yo_min = 0; // extent of the uploaded grid axes
+  bool have_ocean = false;
+  // grow-only per-step buffers
+  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
+  DevBuf scratch, rows;
+  DevBuf cell_cnt, cell_off, cell_fill, cell_item;
+  DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
+  std::vector<long long> hdr;     // segment headers of all ranks (szStepShardFinish)
+  long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
+  int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
+  int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
+  double rmax_max = 0, rmax_p90 = 0; // over the floes that can be candidates (i >= Nb)
+  Params P;                       // parameters of the step in flight
+  unsigned long long *c = nullptr; // host copy of the device counters (pinned; k_publish writes it)
+  unsigned long long *c_dev = nullptr; // the same buffer as the device sees it
+  i64 pair_rows_total = 0;        // contact rows of all pairs of the step (bounds the rows of the CSR)
+  unsigned long long bump = 0, zero = 0;
+  i64 np = 0, nvt = 0, retried = 0, pair_rows_local = 0, seg_lo = 0, seg_hi = 0;
+  int N = 0, rank = 0, world = 1;
+  i64 nr = 0;
+  int force_exchange = 0;
+  int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
+  int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
+  int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
+                                  // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
+  int retry_lds_max = 65536;      // ... and what it may grow to while the launch still fits the chip at once (SUBZERO_RETRY_LDS_MAX)
+  int retry_lds = 16384;          // bytes of LDS per pair for that pass when its list is short (SUBZERO_RETRY_LDS, 0: HBM workspace)
+  int narrow_lanes = 64;          // pairs per wave in k_narrow (tuning knob, SUBZERO_NARROW_LANES)
+  int narrow_lds = 0;             // bytes of LDS per lane for the sweep workspace (SUBZERO_NARROW_LDS)
+  i64 last_npairs = 0, last_nrows_real = 0;
+  int last_next = 0;
+  bool stepped = false;
+  bool counters_clean = false;    // the last step ended by resetting the device counters (k_publish with reset)
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+
+inline dim3 grid_for(i64 n, int block) { return dim3((unsigned)((n + block - 1) / block > 0 ? (n + block - 1) / block : 1)); }
+
+template <class T>
+inline int dev_alloc(szContext *ctx, StepState *S, T *&ptr, size_t count) {
+  S->bufs.emplace_back();
+  DevBuf &b = S->bufs.back();
+  int rc = sz_reserve(ctx, b, count * sizeof(T) + 64);
+  if (rc) return rc;
+  ptr = (T *)b.p;
+  return SZ_OK;
+}
+template <class T>
+inline int dev_put(szContext *ctx, StepState *S, T *&ptr, const T *src, size_t count) {
+  int rc = dev_alloc(ctx, S, ptr, count);
+  if (rc) return rc;
+  if (count) SZ_HIP(ctx, hipMemcpy(ptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return SZ_OK;
+}
+
+
+// largest and 90th-percentile bounding radius of the floes that can be candidates (i >= Nb): they size the grids
+inline void rmax_stats(StepState *S, const double *rmax) {
+  std::vector<double> r(rmax + S->nb, rmax + S->n);
+  S->rmax_max = 0; S->rmax_p90 = 0;
+  if (r.empty()) return;
+  for (double v : r) if (v > S->rmax_max) S->rmax_max = v;
+  const size_t k = (size_t)(0.9 * (double)(r.size() - 1));
+  std::nth_element(r.begin(), r.begin() + k, r.end());
+  S->rmax_p90 = r[k];
+}
+// candidate and mirror lists at the current capacity
+inline int bind_lists(szContext *ctx, StepState *S) {
+  Work &W = S->W;
+  int rc;
+  const size_t bytes = (size_t)W.cap_ext * S->pot_cap * 4;
+  if ((rc = sz_reserve(ctx, S->pot_list, bytes)) || (rc = sz_reserve(ctx, S->inc_list, bytes))) return rc;
+  W.pot_list = (int *)S->pot_list.p; W.inc_list = (int *)S->inc_list.p; W.pot_cap = S->pot_cap;
+  return SZ_OK;
+}

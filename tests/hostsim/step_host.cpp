@@ -43,11 +43,16 @@ static long long g_prune_runs[2];
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 using namespace szs;
 
 static int g_narrow_mode = 2;
+static int g_keep_sums = 0;
+static std::vector<double> g_sums;
+static const void *g_sums_for = nullptr;
+extern "C" void host_keep_stress_sums(int on) { g_keep_sums = on; if (!on) g_sums_for = nullptr; }
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
 extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
 extern "C" void host_set_trim(int on) { g_trim_off = !on; }
@@ -72,6 +77,20 @@ extern "C" void host_phase_times(unsigned long long *out) { phase_mark(0); for (
 extern "C" void host_trim_counts(long long *before, long long *after) { *before = g_trim_before; *after = g_trim_after; }
 extern "C" void host_bail_sites(long long *out) { for (int i = 0; i < 64; ++i) out[i] = g_bail_sites[i]; }
 extern "C" void host_fast_counts(long long *hits, long long *bails) { *hits = g_fast_hits; *bails = g_fast_bails; }
+
+// the stress-sum pair (step_core.hpp) on a stream of values: hi after the init and after every replacement
+extern "C" void host_stress_sum_trace(const double *vals, int nslots, int nsteps, double *hi_out) {
+  std::vector<double> slot(vals, vals + nslots);
+  double hi = 0, lo = 0;
+  for (int z = 0; z < nslots; ++z) stress_sum_add(hi, lo, slot[z]);
+  hi_out[0] = hi;
+  for (int k = 0; k < nsteps; ++k) {
+    const int z = k % nslots;
+    stress_sum_replace(hi, lo, slot[z], vals[nslots + k]);
+    slot[z] = vals[nslots + k];
+    hi_out[k + 1] = hi;
+  }
+}
 
 namespace {
 
@@ -136,13 +155,15 @@ struct Sim {
     F.collision_force = hf->collision_force; F.collision_torque = hf->collision_torque; F.OverlapArea = hf->OverlapArea;
     F.kill = hf->kill; F.transfer = hf->transfer;
     n = F.n;
-    F.StressSum = alloc<double>(pool, (size_t)n * 4);
-    for (int i = 0; i < n; ++i)
-      for (int q = 0; q < 4; ++q) {
-        double s = 0;
-        for (int z = 0; z < F.n_stress; ++z) s += F.StressH[((size_t)i * F.n_stress + z) * 4 + q];
-        F.StressSum[4 * i + q] = s;
-      }
+    // The sums of the stress history are device-only state that lives across steps on the GPU; here they are kept
+    // between calls while the caller steps the same arrays (g_keep_sums), else rebuilt from the history as at upload.
+    if (!(g_keep_sums && g_sums_for == (const void *)hf->StressH && (int)(g_sums.size() / 8) == n)) {
+      g_sums.assign((size_t)n * 8, 0.0);
+      F.StressSum = g_sums.data();
+      for (int i = 0; i < n; ++i) stress_sum_init(i, F);
+      g_sums_for = (const void *)hf->StressH;
+    }
+    F.StressSum = g_sums.data();
     P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
     P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
     memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
@@ -162,6 +183,8 @@ struct Sim {
     W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
     W.counters = alloc<unsigned long long>(pool, C_COUNT);
     W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
+    W.inc_pre = alloc<int>(pool, cap); W.mc_cnt = alloc<int>(pool, n); W.mc_list = alloc<int>(pool, n); W.mc_list_cap = n;
+    for (int i = 0; i < n; ++i) mc_count(i, F, W);
     W.pair_cnt = alloc<int>(pool, cap); W.pair_nv = alloc<i64>(pool, cap);
     W.pair_base = alloc<i64>(pool, cap + 1); W.nv_base = alloc<i64>(pool, cap + 1);
     W.inc_cnt = alloc<int>(pool, cap); W.inc_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
@@ -171,9 +194,29 @@ struct Sim {
     W.st_ext = alloc<double>(pool, 3 * (size_t)n); W.st_flag = alloc<int>(pool, n);
   }
 
+  std::vector<int> mc_empty;
   int front(bool all_pairs_broad) {
+    for (int attempt = 0;; ++attempt) {
+      int rc = front_once(all_pairs_broad);
+      if (rc != -7 || all_pairs_broad || attempt >= 6) return rc;
+      // as step_front does: grow the candidate / mirror lists to what this step asks for and run the front again
+      int want = W.pot_cap * 2;
+      while ((unsigned long long)want < W.counters[C_NEED_POT]) want *= 2;
+      W.pot_cap = want;
+      W.pot_list = alloc<int>(pool, (size_t)cap * W.pot_cap); W.inc_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
+      ++grown;
+    }
+  }
+  int grown = 0;
+  int front_once(bool all_pairs_broad) {
+    for (int k = 0; k < C_COUNT; ++k) if (k != C_SCR_BUMP) W.counters[k] = 0;
     for (int e = 0; e < cap; ++e) { ext_clear(e, W); marks_clear(e, F); }
     for (int i = 0; i < n; ++i) ext_init(i, F, W);
+    for (int i = F.nb; i < n; ++i) mc_precheck(i, F, P, W);
+    if (W.counters[C_NEED_MC]) {
+      mc_empty.assign(W.mc_list, W.mc_list + W.counters[C_NEED_MC]);
+      return 2;
+    }
     N = n;
     if (P.PERIODIC) {
       for (int dim = 0; dim < 2; ++dim) {
@@ -188,15 +231,16 @@ struct Sim {
       for (int i = F.nb; i < n; ++i) broad(i, N, F, P, W);     // reals first: ghosts read their lists
       for (int i = n; i < N; ++i) broad(i, N, F, P, W);
     } else {
-      double rm = 0;
-      for (int i = 0; i < n; ++i) rm = szc::maxd(rm, F.rmax[i]);
-      W.cell_size = 2 * rm;
-      W.cell_x0 = -P.Lx - W.cell_size; W.cell_y0 = -P.Ly - W.cell_size;
-      W.cells_x = (int)((2 * P.Lx + 2 * W.cell_size) / W.cell_size) + 1;
-      W.cells_y = (int)((2 * P.Ly + 2 * W.cell_size) / W.cell_size) + 1;
-      if (W.cells_x > 2048) W.cells_x = 2048;
-      if (W.cells_y > 2048) W.cells_y = 2048;
-      const int nc = W.cells_x * W.cells_y;
+      std::vector<double> r(F.rmax + F.nb, F.rmax + n);
+      double rm = 0, p90 = 0;
+      if (!r.empty()) {
+        for (double v : r) rm = szc::maxd(rm, v);
+        const size_t k = (size_t)(0.9 * (double)(r.size() - 1));
+        std::nth_element(r.begin(), r.begin() + k, r.end());
+        p90 = r[k];
+      }
+      grid_levels(rm, p90, P.Lx, P.Ly, W);
+      const int nc = W.lvl_base[W.n_levels];
       W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
       W.cell_item = alloc<CellItem>(pool, cap);
       for (int e = 0; e < N; ++e) cell_count(e, F, W);
@@ -212,6 +256,8 @@ struct Sim {
     }
     if (W.counters[C_ERR_POT]) return -7;
     for (int i = 0; i < N; ++i) pair_count(i, N, F, P, W);
+    for (int e = 0; e < N; ++e) pair_room(e, W);
+    if (W.counters[C_ERR_POT]) return -7;
     np = 0; nvt = 0;
     for (int i = 0; i < N; ++i) { W.pair_base[i] = np; W.nv_base[i] = nvt; np += W.pair_cnt[i]; nvt += W.pair_nv[i]; }
     W.pair_base[N] = np; W.nv_base[N] = nvt;
@@ -324,13 +370,16 @@ struct Sim {
   }
 };
 
+int g_last_grown = 0, g_last_pot_cap = 0, g_last_levels = 0;
+std::vector<int> g_last_mc_empty;
 Sim g_sim; // the sharded entry points keep their state between calls, as the GPU context does
 
 } // namespace
 
 extern "C" {
 
-// returns 0, or: -1 output capacity, -5 workspace, -7 candidate-list overflow, -8 clip error, -9 MC regen.
+// returns 0, or: -1 output capacity, -5 workspace, -7 candidate-list overflow, -8 clip error; 2 = floes need new
+// Monte-Carlo points (nothing changed; host_last_mc_empty lists them), as szStep's SZ_STEP_NEEDS_MC.
 // pot_cap < 0 selects the all-pairs broad-phase with capacity -pot_cap.
 int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, int64_t inter_cap,
               int32_t *pair_i, int32_t *pair_j, int64_t pair_cap, int64_t *npairs_out, int32_t *n_ext,
@@ -338,11 +387,22 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
   Sim s;
   s.bind(hf, hp, pot_cap);
   int rc;
-  if ((rc = s.front(pot_cap < 0))) return rc;
+  rc = s.front(pot_cap < 0);
+  g_last_grown = s.grown; g_last_pot_cap = s.W.pot_cap; g_last_levels = s.W.n_levels; g_last_mc_empty = s.mc_empty;
+  if (rc) return rc;
   if ((rc = s.narrow_range(0, s.np))) return rc;
   *retried = s.retried;
   if ((rc = s.back())) return rc;
   return s.outputs(inter_off, inter, inter_cap, pair_i, pair_j, pair_cap, npairs_out, n_ext);
+}
+
+// what the last host_step did about capacities: [times the lists grew, final capacity, grid levels, floes needing new MC points]
+void host_last_front(int *out4) { out4[0] = g_last_grown; out4[1] = g_last_pot_cap; out4[2] = g_last_levels; out4[3] = (int)g_last_mc_empty.size(); }
+int host_last_mc_empty(int *ids, int cap) {
+  int n = (int)g_last_mc_empty.size();
+  std::sort(g_last_mc_empty.begin(), g_last_mc_empty.end());
+  for (int k = 0; k < n && k < cap; ++k) ids[k] = g_last_mc_empty[k];
+  return n;
 }
 
 // ---- sharded form, mirroring szStepShardBegin / Export / Finish ----

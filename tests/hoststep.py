@@ -29,6 +29,27 @@ def lib():
     return L
 
 
+class NeedsMc(Exception):
+    """The step changed nothing: these floes (1-based) are due for forcing with an empty Monte-Carlo mask."""
+
+    def __init__(self, ids):
+        Exception.__init__(self, "floes %s need new Monte-Carlo points" % (list(ids),))
+        self.ids = np.asarray(ids, np.int32)
+
+
+def last_front():
+    """(times the candidate lists grew, their final capacity, grid levels) of the last `step`."""
+    out = (ctypes.c_int * 4)()
+    lib().host_last_front(out)
+    return out[0], out[1], out[2]
+
+
+def last_mc_empty():
+    ids = np.zeros(1 << 16, np.int32)
+    n = lib().host_last_mc_empty(orc._p(ids, orc._ip), len(ids))
+    return ids[:n].copy()
+
+
 def step(S, P, pot_cap=32):
     L = lib()
     cf, cp = orc.pack_floes(S), orc.pack_params(P)
@@ -40,6 +61,8 @@ def step(S, P, pot_cap=32):
     rc = L.host_step(ctypes.byref(cf), ctypes.byref(cp), orc._p(inter_off, orc._ip), orc._p(inter), cap_rows,
                      orc._p(pi, orc._ip), orc._p(pj, orc._ip), cap_pairs, ctypes.byref(npairs), ctypes.byref(next_),
                      pot_cap, ctypes.byref(retried))
+    if rc == 2:
+        raise NeedsMc(last_mc_empty())
     if rc != 0:
         raise RuntimeError("host_step failed: %d" % rc)
     r = orc.StepResult()
@@ -104,3 +127,35 @@ def trim_counts():
 def set_prune(on):
     """Crossings of long rings skip runs of edges that InterX's first sign test is certain to reject; on by default."""
     lib().host_set_prune(int(on))
+
+
+def keep_stress_sums(on):
+    """The running sums of the stress history are device-only state; on the GPU they live from upload to upload.  With
+    this on, successive `step` calls on the same arrays keep them too (off: rebuilt from StressH every call)."""
+    lib().host_keep_stress_sums(int(on))
+
+
+def stress_bound(A, rtol=1e-10):
+    """|Stress(device) - Stress(oracle)| allowed per component: rtol relative to the value plus the rounding of the
+    reference's own left-to-right mean over the history (<= 1.2e-16 * sum|slots|; the device carries the exact sum)."""
+    return rtol * np.abs(A.Stress) + 1.2e-16 * np.abs(A.StressH).sum(1)
+
+
+def check_stress(A, B, tag=""):
+    """Stress of the device state B against the oracle state A (history bit-identical, mean within stress_bound)."""
+    assert np.array_equal(A.StressH, B.StressH), tag + " StressH"
+    d = np.abs(A.Stress - B.Stress)
+    lim = stress_bound(A)
+    assert (d <= lim).all(), "%s Stress: worst excess %.3e (value %.3e)" % (tag, float((d - lim).max()), float(np.abs(A.Stress).max()))
+
+
+def stress_sum_trace(vals, nslots):
+    """High word of the stress-sum pair after initialising it with vals[:nslots] and after each replacement of slot
+    k % nslots by vals[nslots + k] (the device functions of step_core.hpp, host build)."""
+    vals = np.ascontiguousarray(vals, np.float64)
+    nsteps = len(vals) - nslots
+    out = np.zeros(nsteps + 1)
+    L = lib()
+    L.host_stress_sum_trace.argtypes = [orc._dp, ctypes.c_int, ctypes.c_int, orc._dp]
+    L.host_stress_sum_trace(orc._p(vals), nslots, nsteps, orc._p(out))
+    return out

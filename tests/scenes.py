@@ -100,6 +100,32 @@ def baseline_config(name):
     return S, P
 
 
+def nares_full():
+    """The stand-in for BASELINE configs[4] at the size SURVEY 8(d).5 prescribes: 1e4 Voronoi floes in the
+    2e5 x 1e6 m channel (initialize_boundaries.m:14-16), 12 static concave islands (Nb) with outlines of the
+    reference's FloeShapes.mat, wind V = -10 m/s."""
+    return nares_standin(n=11500, nb=12, seed=5)   # 10204 floes remain around the islands
+
+
+def ghost_list(S, P):
+    """floe_interactions_all.m:16-66 in plain loops: (src, parent, x, y) of the ghost floes in the order the reference
+    appends them (1-based floe numbers over the extended list), for checking szGhostsDownload."""
+    Lx, Ly = P.c2_boundary[0].max(), P.c2_boundary[1].max()
+    ext = [(i, S.Xi[i], S.Yi[i]) for i in range(S.n)]
+    out = []
+    for dim, L in ((0, Lx), (1, Ly)):
+        for e in range(len(ext)):
+            i, x, y = ext[e]
+            a, b = S.vert_off[i], S.vert_off[i + 1]
+            m = np.abs((S.cax[a:b] + x) if dim == 0 else (S.cay[a:b] + y)).max()
+            if S.alive[i] and m > L:
+                gx = x - 2 * Lx * np.sign(x) if dim == 0 else x
+                gy = y - 2 * Ly * np.sign(y) if dim == 1 else y
+                ext.append((i, gx, gy))
+                out.append((i + 1, e + 1, gx, gy))
+    return out
+
+
 def nares_standin(n=260, nb=3, seed=5):
     """BASELINE configs[4] at test size (the real case's files are absent from the reference checkout):
     a 2e5 x 1e6 m walled channel, `nb` static floes with outlines of the reference's FloeShapes.mat first in the
@@ -194,3 +220,29 @@ def edge_cases(periodic=False):
     P = synth.StepParams(dt=10, periodic=periodic, height=0.8)
     P.Modulus = 5e7
     return S, P
+
+
+def big_among_small(n=3000, ratio=20.0, periodic=False, seed=31, centre=(0.0, 0.0), sides=48, n_stress=4, n_mc=200):
+    """One floe `ratio` times the median radius in a pack of small ones: a `sides`-gon replaces the
+    Voronoi cells under it and overlaps the ring of cells around it a little, so it has far more than 32 candidate
+    partners and contacts.  With `periodic` and an off-centre position the big floe reaches across the box edge and
+    gets a ghost."""
+    S0 = synth.voronoi_field(n, 1.0, seed=seed, vel_seed=seed + 1, vel_sigma=0.1, n_stress=n_stress, n_mc=n_mc)
+    R = ratio * float(np.median(S0.rmax))
+    c = np.asarray(centre, float)
+    polys = []
+    for i in range(S0.n):
+        x, y = S0.ring(i)
+        if np.hypot(S0.Xi[i] - c[0], S0.Yi[i] - c[1]) > R * 0.985:
+            polys.append(np.stack([x[:-1], y[:-1]], 1))
+    ang = -np.linspace(0, 2 * np.pi, sides, endpoint=False) + 0.1
+    big = np.stack([R * np.cos(ang), R * np.sin(ang)], 1) + c
+    # the big floe sits in the middle of the array: it is both an `i` with many j > i and a `j` of many i < j
+    k = len(polys) // 2
+    polys = polys[:k] + [big] + polys[k:]
+    S = synth.build_state(polys, height=0.25, seed=seed + 7, n_stress=n_stress, n_mc=n_mc)
+    vr = np.random.default_rng(seed + 2)
+    S.Ui[:] = vr.normal(0, 0.1, S.n); S.Vi[:] = vr.normal(0, 0.1, S.n)
+    P = synth.StepParams(dt=10, periodic=periodic)
+    P.Modulus = synth.reference_modulus(S)
+    return S, P, k

@@ -122,7 +122,8 @@ def test_full_size_parity_with_the_oracle(ctx):
         sim.download(capi.SYNC_ALL)
         off, rows = sim.interactions()
         assert np.array_equal(ra.inter_off, off) and np.array_equal(ra.inter, rows), "step %d" % it
-        assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
+        assert hoststep.compare_states(A, G) == [], "step %d" % it
+        hoststep.check_stress(A, G, "step %d" % it)
     assert len(rows) > 20000
 
 
@@ -146,5 +147,6 @@ def test_evolved_field_parity_with_the_oracle(ctx):
         sim.download(capi.SYNC_ALL)
         off, rows = sim.interactions()
         assert np.array_equal(ra.inter_off, off) and np.array_equal(ra.inter, rows), "step %d" % it
-        assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "Stress")] == [], "step %d" % it
+        assert hoststep.compare_states(A, G) == [], "step %d" % it
+        hoststep.check_stress(A, G, "step %d" % it)
     assert len(rows) > 500 and retried > 2000
