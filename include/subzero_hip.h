@@ -92,6 +92,18 @@ int szClipBatch(szContext *ctx, int npairs,
                 int32_t *ring_off, int64_t ring_cap,
                 int32_t *pair_ring_off, int32_t *status);
 
+/* The same with several contours per operand, as the mex accepts them (a struct ARRAY Subj / Clip: every element
+ * is one contour, mexclipper.cpp:44-62, all handed to AddPaths :291-297).  Pair p's subject is the rings
+ * a_pair_off[p] .. a_pair_off[p+1], ring r the vertices a_ring_off[r] .. a_ring_off[r+1] of (ax, ay); the clip likewise.
+ * (polyclip.m:72 never passes more than one contour; the form exists because the reference's gateway does.) */
+int szClipPathsBatch(szContext *ctx, int npairs,
+                     const int64_t *ax, const int64_t *ay, const int32_t *a_ring_off, const int32_t *a_pair_off,
+                     const int64_t *bx, const int64_t *by, const int32_t *b_ring_off, const int32_t *b_pair_off,
+                     int method, int subj_fill, int clip_fill,
+                     int64_t *outx, int64_t *outy, int64_t out_cap,
+                     int32_t *ring_off, int64_t ring_cap,
+                     int32_t *pair_ring_off, int32_t *status);
+
 /* polyclip.m:63-80 in one call: doubles in (metres), x2^32 fixed-point conversion with MATLAB int64()
  * semantics (round half away from zero, saturating), clip, back to doubles (/2^32). Same layout. */
 int szPolyclipBatch(szContext *ctx, int npairs,

@@ -143,7 +143,7 @@ class ParamPacker:
 # every symbol include/subzero_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
-    "szClipBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
+    "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
@@ -172,6 +172,9 @@ def load():
     L.szClipBatch.argtypes = [_vp, ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p,
                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
+    L.szClipPathsBatch.argtypes = [_vp, ctypes.c_int, _i64p, _i64p, _i32p, _i32p, _i64p, _i64p, _i32p, _i32p,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
     L.szPolyclipBatch.argtypes = [_vp, ctypes.c_int, _f64p, _f64p, _i32p, _f64p, _f64p, _i32p,
                                   ctypes.c_int,
                                   _f64p, _f64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
@@ -251,6 +254,23 @@ class Context:
                 cap_v *= 4; cap_r *= 4
                 continue
             self.check(rc, "szClipBatch")
+            return ox, oy, roff, proff, st[:n]
+
+    def clip_paths_batch(self, ax, ay, a_ring_off, a_pair_off, bx, by, b_ring_off, b_pair_off, method, subj_fill=0, clip_fill=0):
+        """clip_batch with several contours per operand (ring CSR + pair -> ring range CSR)."""
+        n = len(a_pair_off) - 1
+        total = int(len(ax) + len(bx))
+        cap_v, cap_r = 2 * total + 64 * n + 64, total + 8 * n + 8
+        while True:
+            ox = np.zeros(cap_v, np.int64); oy = np.zeros(cap_v, np.int64)
+            roff = np.zeros(cap_r + 1, np.int32); proff = np.zeros(n + 1, np.int32)
+            st = np.zeros(max(n, 1), np.int32)
+            rc = self.L.szClipPathsBatch(self.h, n, ax, ay, a_ring_off, a_pair_off, bx, by, b_ring_off, b_pair_off,
+                                         method, subj_fill, clip_fill, ox, oy, cap_v, roff, cap_r, proff, st)
+            if rc == SZ_ERR_CAPACITY:
+                cap_v *= 4; cap_r *= 4
+                continue
+            self.check(rc, "szClipPathsBatch")
             return ox, oy, roff, proff, st[:n]
 
     def polyclip_batch(self, ax, ay, aoff, bx, by, boff, method):

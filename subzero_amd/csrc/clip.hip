@@ -42,6 +42,14 @@ struct RingF64 {
   __device__ Pt operator()(int i) const { Pt p; p.x = to_fixed(x[i]); p.y = to_fixed(y[i]); return p; }
 };
 
+// several rings per operand (szClipPathsBatch): rings ring0 .. ring0 + n of a ring CSR over the vertex pool
+struct PathsI64 {
+  const i64 *x, *y; const int *ring_off; int ring0, n;
+  __device__ int count() const { return n; }
+  __device__ int len(int k) const { return ring_off[ring0 + k + 1] - ring_off[ring0 + k]; }
+  __device__ RingI64 ring(int k) const { const int v = ring_off[ring0 + k]; RingI64 r = {x + v, y + v}; return r; }
+};
+
 struct SlotSink {
   i64 *ox, *oy;
   int *roff;
@@ -61,6 +69,7 @@ struct ClipArgs {
   int nlist;
   const i64 *ax, *ay; const int *aoff;
   const i64 *bx, *by; const int *boff;
+  const int *aring, *bring;     // when non-null: aoff / boff give RING ranges per pair and these the vertex range of each ring
   const double *fax, *fay, *fbx, *fby; // when non-null the inputs are doubles (polyclip form)
   int method, fill_s, fill_c;
   int mult;
@@ -81,6 +90,11 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
   int p = a.list ? a.list[t] : t;
   int a0 = a.aoff[p], na = a.aoff[p + 1] - a0;
   int b0 = a.boff[p], nb = a.boff[p + 1] - b0;
+  const int ra0 = a0, nra = na, rb0 = b0, nrb = nb;   // (ring ranges when the operands have several contours)
+  if (a.aring) {
+    a0 = a.aring[ra0]; na = a.aring[ra0 + nra] - a0;
+    b0 = a.bring[rb0]; nb = a.bring[rb0 + nrb] - b0;
+  }
   i64 nv = (i64)(na + nb) * a.mult;
   i64 wbytes = (i64)szv::WS_PER_VERTEX * nv + szv::WS_PER_CLIP;
   i64 cv = slot_verts(nv), cr = slot_rings(nv);
@@ -107,7 +121,10 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
   sink.ox = a.ovx + voff; sink.oy = a.ovy + voff; sink.roff = a.oroff + roff;
   sink.cap_v = (int)cv; sink.cap_r = (int)cr; sink.nv = 0; sink.nr = 0;
   sink.roff[0] = 0;
-  if (a.fax) {
+  if (a.aring) {
+    PathsI64 pa = {a.ax, a.ay, a.aring, ra0, nra}, pb = {a.bx, a.by, a.bring, rb0, nrb};
+    st = szv::clip_paths(a.ws + woff, (int)nv, pa, pb, a.method, a.fill_s, a.fill_c, sink);
+  } else if (a.fax) {
     RingF64 ra = {a.fax + a0, a.fay + a0}, rb = {a.fbx + b0, a.fby + b0};
     st = szv::clip_rings(a.ws + woff, (int)nv, ra, na, rb, nb, a.method, a.fill_s, a.fill_c, sink);
   } else {
@@ -321,6 +338,46 @@ int szClipBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay
   a.method = method; a.fill_s = subj_fill; a.fill_c = clip_fill;
   if ((rc = run(ctx, a, nullptr))) return rc;
   return gather<int64_t>(ctx, a, outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);
+}
+
+int szClipPathsBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay, const int32_t *a_ring_off,
+                     const int32_t *a_pair_off, const int64_t *bx, const int64_t *by, const int32_t *b_ring_off,
+                     const int32_t *b_pair_off, int method, int subj_fill, int clip_fill, int64_t *outx, int64_t *outy,
+                     int64_t out_cap, int32_t *ring_off, int64_t ring_cap, int32_t *pair_ring_off, int32_t *status) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  if (npairs < 0 || !a_ring_off || !a_pair_off || !b_ring_off || !b_pair_off || !ring_off || !pair_ring_off || (npairs && !status))
+    return sz_fail(ctx, SZ_ERR_BAD_ARG, "szClipPathsBatch: null argument");
+  if (!valid_op(method, subj_fill, clip_fill)) {
+    for (int p = 0; p < npairs; ++p) status[p] = SZ_CLIP_BAD_ARG;
+    for (int p = 0; p <= npairs; ++p) pair_ring_off[p] = 0;
+    ring_off[0] = 0;
+    return SZ_OK;
+  }
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  const int nra = a_pair_off[npairs], nrb = b_pair_off[npairs];
+  const i64 ta = a_ring_off[nra], tb = b_ring_off[nrb];
+  int rc;
+  DevBuf d_aring, d_bring;   // (rare call: its two extra index arrays are not kept in the context)
+  if ((rc = upload(ctx, ctx->in_ax, ax, (size_t)ta)) || (rc = upload(ctx, ctx->in_ay, ay, (size_t)ta)) ||
+      (rc = upload(ctx, ctx->in_aoff, a_pair_off, (size_t)npairs + 1)) || (rc = upload(ctx, ctx->in_bx, bx, (size_t)tb)) ||
+      (rc = upload(ctx, ctx->in_by, by, (size_t)tb)) || (rc = upload(ctx, ctx->in_boff, b_pair_off, (size_t)npairs + 1)) ||
+      (rc = upload(ctx, d_aring, a_ring_off, (size_t)nra + 1)) || (rc = upload(ctx, d_bring, b_ring_off, (size_t)nrb + 1))) {
+    sz_release(d_aring); sz_release(d_bring);
+    return rc;
+  }
+  ClipArgs a;
+  memset(&a, 0, sizeof(a));
+  if (!(rc = prepare(ctx, npairs, ta + tb, a))) {
+    a.ax = (const i64 *)ctx->in_ax.p; a.ay = (const i64 *)ctx->in_ay.p; a.aoff = (const int *)ctx->in_aoff.p;
+    a.bx = (const i64 *)ctx->in_bx.p; a.by = (const i64 *)ctx->in_by.p; a.boff = (const int *)ctx->in_boff.p;
+    a.aring = (const int *)d_aring.p; a.bring = (const int *)d_bring.p;
+    a.method = method; a.fill_s = subj_fill; a.fill_c = clip_fill;
+    if (!(rc = run(ctx, a, nullptr)))
+      rc = gather<int64_t>(ctx, a, outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  sz_release(d_aring); sz_release(d_bring);
+  return rc;
 }
 
 int szPolyclipBatch(szContext *ctx, int npairs, const double *ax, const double *ay, const int32_t *aoff,

@@ -1781,6 +1781,24 @@ SZ_HD int clip_rings_t(void *workspace, const Caps &caps, const RingA &a, int na
   if (!s.write(sink)) return ST_OUT_CAPACITY;
   return ST_OK;
 }
+// The same with several rings per operand (mexclipper.cpp:291-297: AddPaths(subj), AddPaths(clip), every contour of a
+// struct array).  PathsA / PathsB: .count() rings, .len(k) vertices of ring k, .ring(k) -> callable (int) -> Pt.
+template <class PathsA, class PathsB, class Sink>
+SZ_HD int clip_paths(void *workspace, int cap_nv, const PathsA &A, const PathsB &B, int op, int fill_subject, int fill_clip, Sink &sink) {
+  if (op < 0 || op > 3 || fill_subject < 0 || fill_subject > 3 || fill_clip < 0 || fill_clip > 3) return ST_BAD_ARG;
+  int total = 0;
+  for (int k = 0; k < A.count(); ++k) total += A.len(k);
+  for (int k = 0; k < B.count(); ++k) total += B.len(k);
+  if (cap_nv < total) return ST_WORKSPACE;
+  Sweep s;
+  s.bind_caps(workspace, caps_for(cap_nv));
+  s.op = op; s.fill_s = fill_subject; s.fill_c = fill_clip;
+  for (int k = 0; k < A.count(); ++k) { s.add_ring(A.ring(k), A.len(k), KIND_SUBJECT); if (s.err) return s.err; }
+  for (int k = 0; k < B.count(); ++k) { s.add_ring(B.ring(k), B.len(k), KIND_CLIP); if (s.err) return s.err; }
+  if (!s.run()) return s.err ? s.err : ST_CLIP_ERROR;
+  if (!s.write(sink)) return ST_OUT_CAPACITY;
+  return ST_OK;
+}
 template <class RingA, class RingB, class Sink>
 SZ_HD int clip_rings(void *workspace, int cap_nv, const RingA &a, int na, const RingB &b, int nb, int op,
                      int fill_subject, int fill_clip, Sink &sink) {

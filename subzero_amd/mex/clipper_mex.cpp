@@ -1,11 +1,13 @@
 // clipper_mex.cpp -- drop-in replacement of the reference's `clipper` mex (private/mexclipper.cpp:83-305)
-// on top of libsubzero_hip.so.  NOT compiled in this repository's CI: it needs MATLAB's mex.h, which the
-// build image does not have.  Build on a MATLAB host with
+// on top of libsubzero_hip.so.  Build on a MATLAB host with
 //   mex -R2017b clipper_mex.cpp -output clipper -I<repo>/include -L<repo>/subzero_amd/csrc -lsubzero_hip
-// and put the result on the path before the reference's private/clipper.mexa64.
+// and put the result on the path before the reference's private/clipper.mexa64.  (This repository has no MATLAB:
+// tests/mexstub/ is a working test double of the mx* / mex* calls used here; tests/test_mex_*.py compile this file
+// against it and drive it.)
 //
 // Same three call forms and the same error texts as the reference gateway:
-//   out = clipper(Subj, Clip, method [, subjFill, clipFill])   -> szClipBatch   (mexclipper.cpp:204-305)
+//   out = clipper(Subj, Clip, method [, subjFill, clipFill])   -> szClipPathsBatch (mexclipper.cpp:204-305; Subj / Clip
+//                                                                 may be struct ARRAYS: one contour per element, :44-62)
 //   cw  = clipper(P)                                           -> szOrientation (mexclipper.cpp:134-145)
 //   out = clipper(Subj, delta, 's'|'r'|'m' [, info])           -> not on the hot path; raises an error
 // Subj / Clip: struct arrays with int64 column fields x, y (mexclipper.cpp:28-41); out: 1xK struct array
@@ -18,58 +20,75 @@
 static szContext *g_ctx = nullptr;
 static void at_exit(void) { if (g_ctx) { szDestroy(g_ctx); g_ctx = nullptr; } }
 
-static void read_rings(const mxArray *p, std::vector<int64_t> &x, std::vector<int64_t> &y, int &nrings) {
+// every element of the struct array is one contour (mexclipper.cpp:13-62); off = vertex range of each
+static void read_rings(const mxArray *p, std::vector<int64_t> &x, std::vector<int64_t> &y, std::vector<int32_t> &off) {
   if (!mxIsStruct(p)) mexErrMsgTxt("Input needs to be structure.");
   if (!mxGetM(p) || !mxGetN(p)) mexErrMsgTxt("Empty structure.");
   int ix = mxGetFieldNumber(p, "x"), iy = mxGetFieldNumber(p, "y");
   if (ix == -1) mexErrMsgTxt("Input structure must contain a field 'x'.");
   if (iy == -1) mexErrMsgTxt("Input structure must contain a field 'y'.");
-  nrings = (int)mxGetNumberOfElements(p);
-  if (nrings != 1) mexErrMsgTxt("Only single polygon clippings are allowed in the current code"); // polyclip.m:72
-  const mxArray *fx = mxGetFieldByNumber(p, 0, ix), *fy = mxGetFieldByNumber(p, 0, iy);
-  if (!mxIsInt64(fx)) mexErrMsgTxt("Structure field 'x' must be of type INT64.");
-  if (!mxIsInt64(fy)) mexErrMsgTxt("Structure field 'y' must be of type INT64.");
-  size_t n = mxGetNumberOfElements(fx);
-  if (n != mxGetNumberOfElements(fy)) mexErrMsgTxt("Structure fields x and y must be the same length.");
-  const int64_t *px = (const int64_t *)mxGetData(fx), *py = (const int64_t *)mxGetData(fy);
-  x.assign(px, px + n); y.assign(py, py + n);
+  const size_t nrings = mxGetNumberOfElements(p);
+  x.clear(); y.clear(); off.assign(1, 0);
+  for (size_t r = 0; r < nrings; ++r) {
+    const mxArray *fx = mxGetFieldByNumber(p, r, ix), *fy = mxGetFieldByNumber(p, r, iy);
+    if (!fx || !mxIsInt64(fx)) mexErrMsgTxt("Structure field 'x' must be of type INT64.");
+    if (!fy || !mxIsInt64(fy)) mexErrMsgTxt("Structure field 'y' must be of type INT64.");
+    size_t n = mxGetNumberOfElements(fx);
+    if (n != mxGetNumberOfElements(fy)) mexErrMsgTxt("Structure fields x and y must be the same length.");
+    const int64_t *px = (const int64_t *)mxGetData(fx), *py = (const int64_t *)mxGetData(fy);
+    x.insert(x.end(), px, px + n); y.insert(y.end(), py, py + n);
+    off.push_back((int32_t)x.size());
+  }
+}
+static void need_context() {
+  if (g_ctx) return;
+  if (szCreate(&g_ctx, 0) != SZ_OK) mexErrMsgTxt("subzero_hip: no usable gfx950 GPU (there is no CPU fallback).");
+  mexAtExit(at_exit);
 }
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   if (nrhs == 0) { mexPrintf("OutPol = clipper(RefPol, ClipPol, Method, [RefF], [ClipF]);  (MI355X build)\n"); return; }
   if (nlhs != 1) mexErrMsgTxt("One output required.");
-  if (!g_ctx) {
-    if (szCreate(&g_ctx, 0) != SZ_OK) mexErrMsgTxt("subzero_hip: no usable gfx950 GPU (there is no CPU fallback).");
-    mexAtExit(at_exit);
-  }
   std::vector<int64_t> sx, sy, cx, cy;
-  int ns = 0, nc = 0;
-  if (nrhs == 1) { // orientation
-    read_rings(prhs[0], sx, sy, ns);
-    int o = 0;
-    szOrientation(sx.data(), sy.data(), (int)sx.size(), &o);
-    plhs[0] = mxCreateLogicalMatrix(1, 1);
-    *mxGetLogicals(plhs[0]) = (o != 0);
+  std::vector<int32_t> soff, coff;
+  if (nrhs == 1) { // orientation of every contour (mexclipper.cpp:134-145): host arithmetic, no GPU needed
+    read_rings(prhs[0], sx, sy, soff);
+    const size_t nr = soff.size() - 1;
+    plhs[0] = mxCreateDoubleMatrix(nr, 1, mxREAL);      // (a double column of 0 / 1, as the reference returns)
+    for (size_t r = 0; r < nr; ++r) {
+      int o = 0;
+      szOrientation(sx.data() + soff[r], sy.data() + soff[r], soff[r + 1] - soff[r], &o);
+      mxGetPr(plhs[0])[r] = (double)(o != 0);
+    }
     return;
   }
-  if (nrhs < 3) mexErrMsgTxt("1-5 inputs required.");
-  if (!mxIsStruct(prhs[1])) mexErrMsgTxt("offset mode (clipper(P, delta, type)) is not provided by the MI355X build");
+  // offset mode (mexclipper.cpp:146-203: clipper(P, delta [, 's'|'r'|'m' [, info]]); nothing in the reference calls it)
+  if (nrhs == 2 || (nrhs >= 3 && nrhs <= 4 && mxIsChar(prhs[2])))
+    mexErrMsgTxt("clipper: the offset form clipper(P, delta, type) is not provided by the MI355X build (no caller in SubZero)");
   if (!mxIsDouble(prhs[2]) || mxGetM(prhs[2]) != 1 || mxGetN(prhs[2]) != 1) mexErrMsgTxt("Third input must be scalar.");
+  if (!mxIsStruct(prhs[1])) mexErrMsgTxt("clipper: the offset form clipper(P, delta, type) is not provided by the MI355X build (no caller in SubZero)");
   int method = (int)mxGetScalar(prhs[2]);
   if (method < 0 || method > 3) mexErrMsgTxt("Third input must be 0, 1, 2, or 3.");
   int sf = 0, cf = 0;
-  if (nrhs >= 4) { sf = (int)mxGetScalar(prhs[3]); if (sf < 0 || sf > 3) mexErrMsgTxt("Fourth input must be 0, 1, 2, or 3."); }
-  if (nrhs >= 5) { cf = (int)mxGetScalar(prhs[4]); if (cf < 0 || cf > 3) mexErrMsgTxt("Fifth input must be 0, 1, 2, or 3."); }
-  read_rings(prhs[0], sx, sy, ns);
-  read_rings(prhs[1], cx, cy, nc);
-  int32_t aoff[2] = {0, (int32_t)sx.size()}, boff[2] = {0, (int32_t)cx.size()};
+  if (nrhs >= 4) {
+    if (!mxIsDouble(prhs[3]) || mxGetM(prhs[3]) != 1 || mxGetN(prhs[3]) != 1) mexErrMsgTxt("Fourth input must be scalar if specified.");
+    sf = (int)mxGetScalar(prhs[3]); if (sf < 0 || sf > 3) mexErrMsgTxt("Fourth input must be 0, 1, 2, or 3.");
+  }
+  if (nrhs >= 5) {
+    if (!mxIsDouble(prhs[4]) || mxGetM(prhs[4]) != 1 || mxGetN(prhs[4]) != 1) mexErrMsgTxt("Fifth input must be scalar if specified.");
+    cf = (int)mxGetScalar(prhs[4]); if (cf < 0 || cf > 3) mexErrMsgTxt("Fifth input must be 0, 1, 2, or 3.");
+  }
+  read_rings(prhs[0], sx, sy, soff);
+  read_rings(prhs[1], cx, cy, coff);
+  need_context();                     // (every argument error above is raised without touching the GPU)
+  int32_t apair[2] = {0, (int32_t)soff.size() - 1}, bpair[2] = {0, (int32_t)coff.size() - 1};
   int64_t cap = 4 * (int64_t)(sx.size() + cx.size()) + 64;
   for (;;) {
     std::vector<int64_t> ox(cap), oy(cap);
     std::vector<int32_t> roff(cap + 1);
     int32_t proff[2], status = 0;
-    int rc = szClipBatch(g_ctx, 1, sx.data(), sy.data(), aoff, cx.data(), cy.data(), boff, method, sf, cf,
-                         ox.data(), oy.data(), cap, roff.data(), cap, proff, &status);
+    int rc = szClipPathsBatch(g_ctx, 1, sx.data(), sy.data(), soff.data(), apair, cx.data(), cy.data(), coff.data(), bpair,
+                              method, sf, cf, ox.data(), oy.data(), cap, roff.data(), cap, proff, &status);
     if (rc == SZ_ERR_CAPACITY) { cap *= 4; continue; }
     if (rc != SZ_OK) mexErrMsgTxt(szLastError(g_ctx));
     if (status != SZ_CLIP_OK) mexErrMsgTxt("Clipper Error.");

@@ -432,3 +432,30 @@ def run_gpu(ctx, ps, method, fill_s=0, fill_c=0):
     ax, ay, aoff, bx, by, boff = ps.arrays()
     ox, oy, roff, proff, st = ctx.clip_batch(ax, ay, aoff, bx, by, boff, method, fill_s, fill_c)
     return ClipResult(ox, oy, roff, proff, st)
+
+
+def rings_of(res, p):
+    return res.rings(p)
+
+
+def run_ref_paths(subj, clip, method, fill_s=0, fill_c=0):
+    """One clip with several contours per operand through the reference's own Clipper (oracle/_ref: ref_clip takes
+    ring sets, as mexclipper.cpp:291-297 hands them to AddPaths).  -> list of int64 (n, 2) rings in solution order."""
+    L = ref_lib()
+    L.ref_clip.argtypes = [_i64p, _i64p, _i32p, ctypes.c_int, _i64p, _i64p, _i32p, ctypes.c_int, ctypes.c_int,
+                           ctypes.c_int, ctypes.c_int, _i64p, _i64p, ctypes.c_int, _i32p, ctypes.c_int,
+                           ctypes.POINTER(ctypes.c_int32)]
+
+    def pack(rs):
+        off = np.zeros(len(rs) + 1, np.int32)
+        for k, r in enumerate(rs):
+            off[k + 1] = off[k] + len(r)
+        v = np.concatenate(rs).astype(np.int64)
+        return np.ascontiguousarray(v[:, 0]), np.ascontiguousarray(v[:, 1]), off
+    sx, sy, soff = pack(subj); cx, cy, coff = pack(clip)
+    cap = 16 * (len(sx) + len(cx)) + 256
+    ox = np.zeros(cap, np.int64); oy = np.zeros(cap, np.int64); ooff = np.zeros(cap + 1, np.int32)
+    nr = ctypes.c_int32()
+    rc = L.ref_clip(sx, sy, soff, len(subj), cx, cy, coff, len(clip), method, fill_s, fill_c, ox, oy, cap, ooff, cap, ctypes.byref(nr))
+    assert rc == 0, rc
+    return [np.stack([ox[ooff[r]:ooff[r + 1]], oy[ooff[r]:ooff[r + 1]]], 1) for r in range(nr.value)]

@@ -1,0 +1,173 @@
+"""The MATLAB gateways driven end to end on the GPU through the test double of the MEX API (tests/mexstub/,
+tests/mexharness.py): what a MATLAB session would see from subzero_step / clipper, checked against the oracle and the
+reference's own Clipper."""
+import numpy as np
+import pytest
+
+import clipgen as g
+import hoststep
+import mexharness as mx
+import oracle
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stepgw():
+    gw = mx.Gateway("subzero_step_mex.cpp", "subzero_step")
+    yield gw
+    gw.call(0, mx.string("close"))
+
+
+@pytest.fixture(scope="module")
+def clipper():
+    return mx.Gateway("clipper_mex.cpp", "clipper")
+
+
+def gw_step(gw, F, P, nlhs=5):
+    out = gw.call(nlhs, mx.string("step"), F, *mx.step_args(P))
+    return out
+
+
+def test_step_gateway_matches_the_oracle_and_keeps_the_history_on_the_device(stepgw):
+    S, P = scenes.pack(120, periodic=True, n_stress=5, n_mc=120)
+    P.set_reference_ocean()
+    S.Xi += 250.0                                     # ghosts from the first step on
+    A, G = S.copy(), S.copy()
+    F, = stepgw.call(1, mx.string("upload"), mx.floe_struct(G), mx.scalar(0))
+    for it in range(8):
+        P.doInt = int(it % 4 == 0)
+        want_ghosts = scenes.ghost_list(A, P)
+        ra = oracle.step(A, P, threads=8)
+        F, kill, transfer, ghosts, need = gw_step(stepgw, F, P)
+        assert mx.numel(need) == 0
+        inter = mx.read_floes(F, G)
+        for i in range(S.n):
+            want = ra.inter[ra.inter_off[i]:ra.inter_off[i + 1]]
+            assert inter[i].shape == ((len(want), 7) if len(want) else (0, 0)) and np.array_equal(inter[i].reshape(-1, 7), want), (it, i)
+        bad = [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "kill", "transfer")]
+        assert bad == [], (it, bad)
+        k = mx.to_numpy(kill).ravel(); t = mx.to_numpy(transfer).ravel()
+        assert len(k) == ra.n_ext and np.array_equal(k, A.kill[:ra.n_ext]) and np.array_equal(t, A.transfer[:ra.n_ext])
+        gs = [mx.to_numpy(mx.get_field(ghosts, 0, f)).ravel() for f in ("src", "parent", "Xi", "Yi")]
+        assert [tuple(v) for v in zip(*[x.tolist() for x in gs])] == want_ghosts and len(want_ghosts) > 5
+    # Stress followed the reference although StressH never travelled; the host copy of the history is stale by design
+    assert np.abs(A.Stress).max() > 0 and np.abs(G.StressH).max() == 0
+    # 'upload' of the stale array is refused; 'fetch' brings the history, then it matches
+    with pytest.raises(mx.MexError) as e:
+        stepgw.call(1, mx.string("upload"), F, mx.scalar(0))
+    assert "newer stress history" in str(e.value)
+    F, = stepgw.call(1, mx.string("fetch"), F, mx.row(np.arange(1, S.n + 1)), mx.string("h"))
+    mx.read_floes(F, G, bulk=True)
+    hoststep.check_stress(A, G, "after fetch")
+    # a MATLAB-side change: two floes die and are removed (floe_interactions_all.m:12-13), one floe gets a kick
+    keep = [i for i in range(S.n) if i not in (3, 77)]
+    A2 = sub_state(A, keep); G2 = sub_state(G, keep)
+    F2 = mx.floe_struct(G2)
+    for k, i in enumerate(keep):
+        mx.set_field(F2, k, "gpuIndex", mx.scalar(i + 1))
+        mx.set_field(F2, k, "StressH", mx.numeric(np.zeros((2, 2, 5))))     # stale on purpose: the device's history must win
+    F2, = stepgw.call(1, mx.string("resync"), F2, mx.scalar(0))
+    for it in range(8, 13):
+        P.doInt = int(it % 4 == 0)
+        oracle.step(A2, P, threads=8)
+        F2, = gw_step(stepgw, F2, P, nlhs=1)
+    F2, = stepgw.call(1, mx.string("fetch"), F2, mx.row(np.arange(1, len(keep) + 1)), mx.string("h"))
+    mx.read_floes(F2, G2, bulk=True)
+    assert [b for b in hoststep.compare_states(A2, G2) if b[0] not in ("kill", "transfer")] == []
+    hoststep.check_stress(A2, G2, "after resync")
+
+
+def sub_state(S, keep):
+    from subzero_amd import synth
+    vo = np.zeros(len(keep) + 1, np.int32)
+    for k, i in enumerate(keep):
+        vo[k + 1] = vo[k] + S.vert_off[i + 1] - S.vert_off[i]
+    T = synth.FloeState(len(keep), vo, S.nb, S.n_stress, S.n_mc)
+    for f in synth.FloeState.ARRAYS:
+        if f in ("vert_off", "kill", "transfer"):
+            continue
+        a = getattr(S, f)
+        if f in ("c0x", "c0y", "cax", "cay"):
+            for k, i in enumerate(keep):
+                getattr(T, f)[vo[k]:vo[k + 1]] = a[S.vert_off[i]:S.vert_off[i + 1]]
+        else:
+            getattr(T, f)[...] = a[keep]
+    return T
+
+
+def test_step_gateway_reports_floes_that_need_new_monte_carlo_points(stepgw):
+    S, P = scenes.pack(40, periodic=False, n_stress=3, n_mc=60)
+    S.mcA[11] = 0
+    A, G = S.copy(), S.copy()
+    stepgw.call(0, mx.string("close"))
+    F, = stepgw.call(1, mx.string("upload"), mx.floe_struct(G), mx.scalar(0))
+    P.doInt = 1
+    F1, kill, transfer, ghosts, need = gw_step(stepgw, F, P)
+    assert mx.to_numpy(need).ravel().tolist() == [12.0]
+    H = G.copy(); mx.read_floes(F1, H)
+    assert hoststep.compare_states(G, H) == []            # nothing changed
+    rng = np.random.default_rng(3)
+    a, b = S.vert_off[11], S.vert_off[12]
+    from subzero_amd import synth
+    X = G.rmax[11] * (2 * rng.random(G.n_mc) - 1); Y = G.rmax[11] * (2 * rng.random(G.n_mc) - 1)
+    inside = synth._inpolygon(X, Y, G.cax[a:b], G.cay[a:b])
+    for T in (A, G):
+        T.mcX[11], T.mcY[11], T.mcA[11] = X, Y, inside
+    F = mx.floe_struct(G)
+    stepgw.call(0, mx.string("update"), F, mx.row([12]), mx.string("m"))
+    ra = oracle.step(A, P, threads=4)
+    F, kill, transfer, ghosts, need = gw_step(stepgw, F, P)
+    assert mx.numel(need) == 0
+    mx.read_floes(F, G)
+    assert [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "kill", "transfer")] == []
+
+
+def test_clipper_gateway_boolean_mode_against_the_reference_build(clipper):
+    if g.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    ps = g.shape_pairs(40, seed=8)
+    for method in range(4):
+        ref = g.run_ref(ps, method)
+        ax, ay, aoff, bx, by, boff = ps.arrays()
+        for p in range(len(ps)):
+            a = np.stack([ax[aoff[p]:aoff[p + 1]], ay[aoff[p]:aoff[p + 1]]], 1)
+            b = np.stack([bx[boff[p]:boff[p + 1]], by[boff[p]:boff[p + 1]]], 1)
+
+            def ring(v):
+                s = mx.struct(1, ["x", "y"])
+                mx.set_field(s, 0, "x", mx.numeric(v[:, 0], "int64")); mx.set_field(s, 0, "y", mx.numeric(v[:, 1], "int64"))
+                return s
+            out, = clipper.call(1, ring(a), ring(b), mx.scalar(method))
+            rings = [np.stack([mx.to_numpy(mx.get_field(out, r, "x")).ravel(), mx.to_numpy(mx.get_field(out, r, "y")).ravel()], 1)
+                     for r in range(mx.numel(out))]
+            want = g.rings_of(ref, p)
+            assert len(rings) == len(want), (method, p)
+            for r, w in zip(rings, want):
+                assert r.dtype == np.float64 and np.array_equal(r, w.astype(np.float64)), (method, p)
+
+
+def test_clipper_gateway_takes_several_contours_per_operand(clipper):
+    if g.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    # subject: two disjoint squares + a hole-like inner ring; clip: two overlapping rings -- every fill rule and operation
+    S32 = 1 << 32
+    sq = lambda x0, y0, s: np.array([[x0, y0], [x0 + s, y0], [x0 + s, y0 + s], [x0, y0 + s]], np.int64) * S32
+    subj = [sq(0, 0, 10), sq(20, 0, 10), sq(2, 2, 4)[::-1]]
+    clip = [sq(5, -3, 8), sq(8, 3, 16)]
+    for method in range(4):
+        for sf in range(4):
+            for cf in (0, 1):
+                want = g.run_ref_paths(subj, clip, method, sf, cf)
+                def rings(vs):
+                    s = mx.struct(len(vs), ["x", "y"])
+                    for k, v in enumerate(vs):
+                        mx.set_field(s, k, "x", mx.numeric(v[:, 0], "int64")); mx.set_field(s, k, "y", mx.numeric(v[:, 1], "int64"))
+                    return s
+                out, = clipper.call(1, rings(subj), rings(clip), mx.scalar(method), mx.scalar(sf), mx.scalar(cf))
+                got = [np.stack([mx.to_numpy(mx.get_field(out, r, "x")).ravel(), mx.to_numpy(mx.get_field(out, r, "y")).ravel()], 1).astype(np.int64)
+                       for r in range(mx.numel(out))]
+                assert len(got) == len(want), (method, sf, cf)
+                for r, w in zip(got, want):
+                    assert np.array_equal(r, w), (method, sf, cf)

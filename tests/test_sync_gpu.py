@@ -161,6 +161,7 @@ def test_one_floe_twenty_times_the_median_grows_the_lists(ctx, periodic):
 
 def test_ghosts_for_the_matlab_tail(ctx):
     S, P = scenes.pack(300, periodic=True)
+    S.Xi += 300.0; S.Yi += 200.0                    # the pack reaches across the east and north edges: ghosts from the first step on
     A, G = S.copy(), S.copy()
     sim = capi.FloeInteractions(ctx, G)
     for it in range(4):
