@@ -68,22 +68,28 @@ SZ_HD_NOINLINE int clip_fixed(void *ws, int cap_nv, const i64 *ax, const i64 *ay
   return szv::clip_rings(ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
 }
 
-// The same sweep with its Wide records in the lane's slice of the dynamic LDS: lane t's workspace starts at byte
-// t * lds_stride (launch contract of k_narrow_lds).  The address is formed here from the LDS symbol, so that the
-// compiler emits ds_ instructions for the whole sweep (a generic pointer to the same bytes gives flat_ accesses).
-SZ_HD_NOINLINE int clip_fixed_lds(void *host_ws, int lds_stride, int cap_nv, const i64 *ax, const i64 *ay, int na, const i64 *bx,
+// A pointer the caller vouches to be LDS.  The kernels hand their lanes' blocks of the dynamic LDS down as ordinary
+// pointers; telling the compiler what they are lets it emit ds_ instructions (LDS latency, no flat address check)
+// without a non-kernel function ever naming an `extern __shared__` array itself.  That matters: a function that does
+// is lowered through a per-kernel offset table indexed by an implicit kernel-id register as soon as two kernels of
+// the module can reach such functions, and the 32-vertex second pass of round 1 -- the second kernel to do so -- was
+// the one that faulted ("the k_narrow_convex_big fault").  No callee re-derives a block from the
+// launch geometry any more, so there is no unchecked launch contract either.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SZ_ASSUME_LDS(ptr) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)(ptr)))
+#else
+#define SZ_ASSUME_LDS(ptr) ((void)(ptr))
+#endif
+
+// The same sweep with its Wide records in the lane's slice of LDS (`lds_ws`, handed down by k_narrow_lds; on the host
+// build a plain buffer stands in for it).
+SZ_HD_NOINLINE int clip_fixed_lds(void *lds_ws, int cap_nv, const i64 *ax, const i64 *ay, int na, const i64 *bx,
                                   const i64 *by, int nb, int op, RegionSink *sink) {
   FixedRing a = {ax, ay}, b = {bx, by};
   sink->nv = 0; sink->nr = 0;
   if (sink->ox != nullptr) sink->roff[0] = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
-  void *ws = sz_dynamic_lds + (size_t)threadIdx.x * (size_t)lds_stride;
-  (void)host_ws;
-#else
-  void *ws = host_ws; (void)lds_stride;
-#endif
-  return szv::clip_rings(ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
+  SZ_ASSUME_LDS(lds_ws);
+  return szv::clip_rings_lds(lds_ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
 }
 
 // compact-record form (inlined: the workspace pointer then stays provably in LDS for the GPU compiler)
@@ -116,13 +122,7 @@ SZ_HD_NOINLINE int clip_in_block(Blk *blk, void *deque_mem, int shifted, double 
                                  RegionSink *sink) {
   sink->nv = 0; sink->nr = 0;
   if (sink->ox != nullptr) sink->roff[0] = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  // Launch contract of the kernels that call this (k_narrow_convex*): the block of lane t is at byte
-  // t * sizeof(Blk) of the dynamic LDS.  Re-deriving it here (instead of using the generic pointer, which is
-  // the same address) lets the compiler prove the accesses are LDS and emit ds_ instead of flat_ instructions.
-  extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
-  blk = (Blk *)(sz_dynamic_lds + (size_t)threadIdx.x * sizeof(Blk));
-#endif
+  SZ_ASSUME_LDS(blk);   // the lane's block of the kernel's dynamic LDS (k_narrow_convex / k_narrow_convex_big)
   szx::FastWsT<Blk> fw = {blk, (Pt *)deque_mem, 24};
   szx::VertsMetres verts = {shifted, sx, sy};
   return szx::clip_monotone(fw, verts, na, nb, *sink);
@@ -139,13 +139,12 @@ struct ClipWide {
 // k_narrow_lds: each clip takes the lane's slice of LDS when its (trimmed) rings fit it, the pair's HBM slice
 // otherwise -- or when the records of the clip outgrow the slice after all
 struct ClipWideLds {
-  void *host_ws; int lds_stride, lds_ws_bytes, cap_nv;    // the slice's stride / what of it the sweep may use; cap_nv: what the HBM slice holds
+  void *host_ws; void *lds_ws; int lds_ws_bytes, cap_nv;    // HBM slice / the lane's slice of LDS and what of it the sweep may use; cap_nv: what the HBM slice holds
   // the sweep's part of the slice, free between two clips (device only)
   SZ_HD double *idle(int &bytes) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) char sz_dynamic_lds[];
     bytes = lds_ws_bytes;
-    return (double *)(sz_dynamic_lds + (size_t)threadIdx.x * (size_t)lds_stride);
+    return (double *)lds_ws;
 #else
     bytes = 0; return nullptr;
 #endif
@@ -160,7 +159,7 @@ struct ClipWideLds {
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
     const int lc = lds_cap();
     if (na + nb <= lc) {
-      int st = clip_fixed_lds(host_ws, lds_stride, lc, ax, ay, na, bx, by, nb, op, sink);
+      int st = clip_fixed_lds(lds_ws, lc, ax, ay, na, bx, by, nb, op, sink);
       if (st != szv::ST_WORKSPACE || lc >= cap_nv) return st;
     }
     return clip_fixed(host_ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
@@ -175,7 +174,8 @@ struct ClipCompact {
   }
   SZ_HD bool fits(int nv) const { return nv <= szv::COMPACT_MAX_NV; }
 };
-enum { ST_DEFER = 101 };  // "redo this pair with the general sweep" (the fast path does not cover it)
+enum { ST_DEFER = 101,      // "redo this pair with the general sweep" (the fast path does not cover it)
+       ST_DEFER_BIG = 102 }; // "... with the fast path on the larger block": the rings are only too long for this one
 
 // ---- rings in metres: c_alpha + (Xi, Yi), optionally closed by one more vertex (:62-67) ----
 struct RingD {
@@ -867,7 +867,7 @@ SZ_HD bool well_inside_box(const Box &b, const double *c2b) {
 // Both parts with Wide records in the pair's HBM slice (the general path).
 SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
                        const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out, int lds_stride = 0, int lds_ws_bytes = 0) {
+                       PairScratch &S, PairOut &out, void *lds_ws = nullptr, int lds_ws_bytes = 0) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   {
     Box b1, b2;
@@ -880,8 +880,12 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
     }
   }
   int nreg = 0;
-  if (lds_stride > 0) {   // the sweep workspace of this lane is its slice of LDS (k_narrow_lds)
-    ViaArrays<ClipWideLds> clip = {{S.ws, lds_stride, lds_ws_bytes, S.cap_nv}};
+  if (lds_ws != nullptr) {   // the sweep workspace of this lane is its slice of LDS (k_narrow_lds)
+#if defined(__HIP_DEVICE_COMPILE__)
+    ViaArrays<ClipWideLds> clip = {{S.ws, lds_ws, lds_ws_bytes, S.cap_nv}};
+#else
+    ViaArrays<ClipWideLds> clip = {{S.ws, S.ws, lds_ws_bytes, S.cap_nv}};   // (no LDS on the host: the pair's own workspace stands in)
+#endif
     int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
     if (st != szv::ST_OK) return st;
     return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
@@ -921,7 +925,8 @@ SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &rin
       ring_box(ring1, b1); ring_box(ring2, b2);
       if (boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
     }
-    return ST_DEFER;
+    return ((int)Blk::NV < (int)szx::FastBlockBig::NV && n1 <= (int)szx::FastBlockBig::NV && n2 <= (int)szx::FastBlockBig::NV && n1 >= 1 && n2 >= 1)
+               ? (int)ST_DEFER_BIG : (int)ST_DEFER;
   }
   // (the sweep converts with to_fixed_in_range: coordinates must be finite and, with the <= 1 m shift of the
   // second clip, within its range -- anything else, e.g. a NaN floe, goes to the general sweep)

@@ -84,6 +84,8 @@ struct FastBlockT {
 };
 typedef FastBlockT<16> FastBlock;      // the step's fast pass: 64 lanes x 616 B of LDS per wave (four waves per CU); longer rings take the general sweep
 static_assert(sizeof(FastBlock) == 616 && (sizeof(FastBlock) / 8) % 2 == 1, "FastBlock layout changed: keep the size 8 x odd");
+typedef FastBlockT<32> FastBlockBig;   // second pass over the pairs whose rings have 17-32 vertices: 1128 B per lane, a few lanes per wave
+static_assert(sizeof(FastBlockBig) == 1128 && (sizeof(FastBlockBig) / 8) % 2 == 1, "FastBlockBig layout changed: keep the size 8 x odd");
 
 // MATLAB int64(v * 2^32): round half away from zero, saturating, NaN -> 0 (polyclip.m:63-66)
 SZ_HD i64 to_fixed(double v) {

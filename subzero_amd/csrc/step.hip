@@ -284,6 +284,18 @@ __global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int 
   if (t < count) narrow_convex(first + t, (const int *)nullptr, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
 }
 
+// Second fast pass: the pairs the first one found too long for its 16-vertex blocks but not for 32-vertex ones (many-
+// sided and mildly evolved floes), a few lanes per wave (1128 B of LDS each).  What it does not cover joins the list of
+// the general kernel.
+#define CONVEX_BIG_STRIDE 1128
+static_assert(CONVEX_BIG_STRIDE % 16 == 8 && CONVEX_BIG_STRIDE == sizeof(szx::FastBlockBig), "lane stride must be 8 x odd and hold a FastBlockBig");
+__global__ void __launch_bounds__(64) k_narrow_convex_big(i64 count, const int *list, int lanes, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)threadIdx.x >= lanes) return;
+  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (t < count) narrow_convex(t, list, F, P, W, (szx::FastBlockBig *)(smem + (size_t)threadIdx.x * CONVEX_BIG_STRIDE));
+}
+
 // Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
 // 64-lane workgroup per CU (64 x 2344 B = 146.5 KB of the 160 KB); the lane stride is 8 x odd bytes so that
 // the same field of neighbouring lanes falls into different banks.  k_narrow_a: first clip of every pair;
@@ -497,6 +509,8 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   (void)hipFuncSetAttribute((const void *)k_narrow_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)k_narrow_convex_big, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CONVEX_BIG_STRIDE);
+  if (const char *v = getenv("SUBZERO_BIG_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->big_lanes = l; }
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)k_broad_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute((const void *)k_row_count, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -620,6 +634,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
       (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
       (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
       (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
+      (rc = sz_reserve(ctx, S->big_list, npa * 4)) ||
       (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
       (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
   const i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -629,6 +644,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
   W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
   W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
   W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
+  W.big_list = (int *)S->big_list.p;
   W.pair_rowoff = (i64 *)S->pair_rowoff.p;
   W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
   W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
@@ -665,6 +681,22 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (convex && c[C_BIG] > 0) {
+    // rings of 17-32 vertices: the fast path again, on the larger block; its leftovers join the general kernel's list
+    const i64 nb = (i64)c[C_BIG];
+    if (S->big_lanes > 0) {
+      const int L = S->big_lanes;
+      hipLaunchKernelGGL(k_narrow_convex_big, grid_for(nb, L), dim3(64), (size_t)L * CONVEX_BIG_STRIDE, st, nb, (const int *)S->big_list.p, L, F, P, W);
+    } else {   // (pass switched off: straight to the general kernel, through the same list mechanics)
+      SZ_HIP(ctx, hipMemcpyAsync((int *)S->retry_list.p + c[C_RETRY], S->big_list.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
+      S->bump = c[C_RETRY] + (unsigned long long)nb;
+      SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->bump, 8, hipMemcpyHostToDevice, st));
+    }
+    SZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipStreamSynchronize(st));
+  }
   int mult = fast ? 0 : 1; // what the fast path could not hold starts at the 1x tier of the general path
   while (c[C_RETRY] > 0) {
     mult = mult ? mult * 8 : 1;

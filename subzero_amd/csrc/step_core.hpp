@@ -60,7 +60,7 @@ struct Params {
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -91,6 +91,7 @@ struct Work {
   int *pair_mult;               // [cap_pairs] capacity tier used
   int *pair_nrows, *pair_status, *pair_flag; // flag: 1 sentinel +Inf, 2 sentinel -Inf, 4 contributes rows
   int *retry_list;
+  int *big_list;                // pairs the first pass hands to the fast path on the 32-vertex block (C_BIG of them)
   int *touch_list;              // pairs whose first clip found overlap regions (two-stage fast path)
   int *pair_nreg;               // regions of the first clip
   // mirrored rows
@@ -574,9 +575,14 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
                                 P.mu, P.nu, S, out, fast_blk);
   else
     st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
-                           P.mu, P.nu, S, out, (LDS_WS && fast_ws) ? fast_ws_bytes : 0, lds_ws_bytes);
+                           P.mu, P.nu, S, out, (LDS_WS && fast_ws) ? fast_ws : nullptr, lds_ws_bytes);
   SZC_PHASE(0);
   W.pair_status[p] = st;
+  if (st == szc::ST_DEFER_BIG) {
+    unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL);
+    W.big_list[k] = (int)p;
+    return;
+  }
   if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY || st == szc::ST_DEFER) {
     unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
     W.retry_list[k] = (int)p;

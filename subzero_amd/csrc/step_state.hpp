@@ -25,7 +25,7 @@ struct StepState {
   double xo_max = 0, xo_min = 0, yo_max = 0, yo_min = 0; // extent of the uploaded grid axes
   bool have_ocean = false;
   // grow-only per-step buffers
-  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy;
+  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy, big_list;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_item;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
@@ -45,6 +45,7 @@ struct StepState {
   int force_exchange = 0;
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
+  int big_lanes = 16;             // pairs per wave of the second fast pass (32-vertex blocks, SUBZERO_BIG_LANES; 0: no such pass)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
                                   // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
   int retry_lds_max = 65536;      // ... and what it may grow to while the launch still fits the chip at once (SUBZERO_RETRY_LDS_MAX)

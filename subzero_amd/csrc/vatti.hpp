@@ -109,6 +109,9 @@ struct Records {
 };
 typedef Records<int, int> Wide;
 typedef Records<signed char, signed char> Compact; // at most 127 entries per list, even-odd fill only
+// Wide records again under a name of their own: the sweep instantiated on it is a separate set of functions, so a
+// caller that keeps the workspace in LDS gets its own copy, specialised for ds_ addressing (contact.hpp clip_fixed_lds)
+struct WideLds : Records<int, int> {};
 
 // ---- numeric kernels ----------------------------------------------------------------------
 
@@ -1804,6 +1807,12 @@ SZ_HD int clip_rings(void *workspace, int cap_nv, const RingA &a, int na, const 
                      int fill_subject, int fill_clip, Sink &sink) {
   if (cap_nv < na + nb) return ST_WORKSPACE;
   return clip_rings_t<Wide>(workspace, caps_for(cap_nv), a, na, b, nb, op, fill_subject, fill_clip, sink);
+}
+template <class RingA, class RingB, class Sink>
+SZ_HD int clip_rings_lds(void *workspace, int cap_nv, const RingA &a, int na, const RingB &b, int nb, int op,
+                         int fill_subject, int fill_clip, Sink &sink) {
+  if (cap_nv < na + nb) return ST_WORKSPACE;
+  return clip_rings_t<WideLds>(workspace, caps_for(cap_nv), a, na, b, nb, op, fill_subject, fill_clip, sink);
 }
 // The compact tier: even-odd fill, at most COMPACT_MAX_NV input vertices, workspace_bytes_compact() bytes.
 template <class RingA, class RingB, class Sink>

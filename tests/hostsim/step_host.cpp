@@ -49,6 +49,8 @@ static long long g_prune_runs[2];
 using namespace szs;
 
 static int g_narrow_mode = 2;
+static long long g_big_pairs = 0;
+extern "C" long long host_big_pairs(void) { return g_big_pairs; }
 static int g_keep_sums = 0;
 static std::vector<double> g_sums;
 static const void *g_sums_for = nullptr;
@@ -265,7 +267,7 @@ struct Sim {
     W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
     W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
     W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
-    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1);
+    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1);
     W.touch_list = alloc<int>(pool, np + 1); W.pair_nreg = alloc<int>(pool, np + 1);
     for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
     i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -293,6 +295,11 @@ struct Sim {
         if (g_narrow_mode == 2) narrow_convex(p, nullptr, F, P, W, &blk);
         else narrow(p, nullptr, 1, F, P, W);
       }
+      // second fast pass on the 32-vertex block, as step_narrow does
+      szx::FastBlockBig big;
+      std::vector<int> bl(W.big_list, W.big_list + W.counters[C_BIG]);
+      g_big_pairs += (long long)bl.size();
+      for (size_t t = 0; t < bl.size(); ++t) narrow_convex((i64)t, bl.data(), F, P, W, &big);
     }
     retried = (i64)W.counters[C_RETRY];
     int mult = (g_narrow_mode != 0) ? 0 : 1;   // the fast path's leftovers start at the 1x general tier

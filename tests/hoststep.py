@@ -159,3 +159,9 @@ def stress_sum_trace(vals, nslots):
     L.host_stress_sum_trace.argtypes = [orc._dp, ctypes.c_int, ctypes.c_int, orc._dp]
     L.host_stress_sum_trace(orc._p(vals), nslots, nsteps, orc._p(out))
     return out
+
+
+def big_pairs():
+    """Pairs handed to the second fast pass (32-vertex blocks) so far."""
+    lib().host_big_pairs.restype = ctypes.c_longlong
+    return int(lib().host_big_pairs())
