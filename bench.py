@@ -32,11 +32,14 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_workload(n_floes, seed=4, box_scale=1.0):
+def build_workload(n_floes, seed=4, Lx=1e5, Ly=1e5):
     from subzero_amd import synth
-    L = 1e5 * box_scale
-    S = synth.voronoi_field(n_floes, 1.0, Lx=L, Ly=L, seed=seed, vel_seed=2, vel_sigma=0.1)
-    P = synth.StepParams(dt=10.0, Lx=L, Ly=L, periodic=True)
+    S = synth.voronoi_field(n_floes, 1.0, Lx=Lx, Ly=Ly, seed=seed, vel_seed=2, vel_sigma=0.1)
+    P = synth.StepParams(dt=10.0, Lx=Lx, Ly=Ly, periodic=True)
+    if Lx > 2e5 or Ly > 2e5:      # the ocean / wind grid covers the box with the reference's margin (initialize_ocean.m: 4 x the box)
+        P.Xo = np.arange(-Lx - 3e5, Lx + 3e5 + 1, 1e4); P.Yo = np.arange(-Ly - 3e5, Ly + 3e5 + 1, 1e4)
+        shape = (len(P.Yo), len(P.Xo))
+        P.Uocn = np.zeros(shape); P.Vocn = np.zeros(shape); P.Uwind = np.zeros(shape); P.Vwind = np.zeros(shape)
     P.Modulus = synth.reference_modulus(S)
     return S, P
 

@@ -293,6 +293,42 @@ int64_t szShardForcingBytes(szContext *ctx, int world);
 int szStepShardForcing(szContext *ctx, void *d_send);
 int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats);
 
+/* ---- multi-GPU, spatial partition (BASELINE north_star): floes owned by x-strips of the domain, one
+ * neighbour exchange of halo floes per step --------------------------------------------------------------------
+ * Every rank uploads the same array (szFloesUpload) and keeps it at its global size and index; after szSpatialInit
+ * only the floes whose centroid lies in the rank's strip [edges[rank], edges[rank+1]) are its own: it alone
+ * integrates them, and their stress history and Monte-Carlo points are current nowhere else.  Per step:
+ *
+ *   szSpatialPack   (periodic, d_left, d_right, caps, &info)   my floes within `halo` of each edge (26 scalars + ring:
+ *                                                               208 + 16 nv bytes each) and the floes whose centroid
+ *                                                               left the strip (whole state), into two device buffers
+ *                                                               of szSpatialMessageBytes(caps) bytes
+ *   [caller: send d_left to the left neighbour and d_right to the right one, receive theirs: RCCL send/recv over
+ *    xGMI (torch.distributed batch_isend_irecv), strips form a ring when the domain is periodic]
+ *   szSpatialUnpack (d_from_left, d_from_right, caps, &info)    (NULL for a side without neighbour)
+ *   szStep          (params, stats)                             the unchanged step on what the rank now knows
+ *
+ * Results for owned floes (state, contact rows, kill / transfer) are bit-identical to the single-GPU step; a pair
+ * between floes of two ranks is evaluated by both.  Partner numbers of GHOST floes in the contact rows are local to
+ * the rank (its ghost list: szGhostsDownload); real partners carry their global number.  halo >= 2 x (2 max rmax)
+ * and every strip at least as wide as the halo (szSpatialInit checks both).  info.overflow = 1: a message did not fit
+ * its capacities (info.need_* tell what the edge needs): repeat Pack / exchange / Unpack with larger buffers before
+ * szStep -- nothing has been lost, Pack can be called again. */
+typedef struct szSpatialInfo {
+  int64_t left_records, left_doubles, left_migrants;
+  int64_t right_records, right_doubles, right_migrants;
+  int64_t need_records, need_doubles, need_migrants;
+  int64_t n_owned, n_present;    /* after Unpack: floes this rank integrates / knows this step */
+  int32_t overflow, has_left, has_right, reserved;
+} szSpatialInfo;
+int szSpatialInit(szContext *ctx, int rank, int world, const double *edges, double halo);
+int64_t szSpatialMessageBytes(szContext *ctx, int64_t cap_records, int64_t cap_doubles, int64_t cap_migrants);
+int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int64_t cap_records, int64_t cap_doubles,
+                  int64_t cap_migrants, szSpatialInfo *info);
+int szSpatialUnpack(szContext *ctx, const void *d_from_left, const void *d_from_right, int64_t cap_records,
+                    int64_t cap_doubles, int64_t cap_migrants, szSpatialInfo *info);
+int szSpatialOwned(szContext *ctx, uint8_t *owned);   /* owned[i] = 1: this rank integrates floe i (n bytes) */
+
 /* clipper(P) orientation mode (mexclipper.cpp:134-145): 1 if Area(P) >= 0 else 0.  Host arithmetic
  * on n vertices (an O(n) sum; there is nothing to accelerate). */
 int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation);

@@ -146,6 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
+    "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",

@@ -112,6 +112,9 @@ struct Work {
   int lvl_cx[MAX_LEVELS], lvl_cy[MAX_LEVELS], lvl_base[MAX_LEVELS + 1];
   int *cell_cnt, *cell_off, *cell_fill;              // [lvl_base[n_levels] (+1)]
   struct CellItem *cell_item;                        // the floes of all cells, in cell order (cap_ext)
+  // Spatially sharded step (multi-GPU, spatial.hip): every rank keeps the arrays at their global size and index, but
+  // only the floes of its strip (owned) and the halo it received this step are current (present).  null = all floes.
+  const unsigned char *present, *owned;
   int *inc_pre;                                      // [cap_ext] candidate pairs that name the floe as partner (bounds inc_cnt)
   int *mc_cnt;                                       // [n] points inside the floe's Monte-Carlo mask (sum(A), calc_trajectory.m:100)
   int *mc_list; int mc_list_cap;                     // floes whose forcing is due with an empty mask (1-based), C_NEED_MC of them
@@ -126,6 +129,8 @@ struct Work {
 // per-pair scratch slice: linear bound so that offsets follow from prefix sums (see carve())
 enum { SCR_PER_V = 704, SCR_PER_PAIR = 4096 };
 
+SZ_HD bool is_present(int s, const Work &W) { return !W.present || W.present[s] != 0; }
+SZ_HD bool is_owned(int s, const Work &W) { return !W.owned || W.owned[s] != 0; }
 SZ_HD double sgn(double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); }
 SZ_HD double absd(double v) { return v < 0 ? -v : v; }
 SZ_HD int iabs(int v) { return v < 0 ? -v : v; }
@@ -157,7 +162,7 @@ SZ_HD void ext_init(int i, const Floes &F, Work &W) { // i < n
 // SZ_STEP_NEEDS_MC, the caller regenerates (szFloesUpdate) and steps again.  (alive is the value at the start of
 // the step: a floe that leaves the box in this very step, :152-155, is listed although the reference would skip it.)
 SZ_HD void mc_precheck(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
-  if (!F.alive[i] || F.Xi[i] != F.Xi[i] || W.mc_cnt[i] != 0) return;
+  if (!F.alive[i] || F.Xi[i] != F.Xi[i] || W.mc_cnt[i] != 0 || !is_owned(i, W)) return;
   double hh = F.h[i];
   if (hh > 10) hh = 10;
   const double h_new = hh - P.HFo * P.dt / hh;
@@ -180,6 +185,7 @@ SZ_HD void marks_clear(int e, const Floes &F) { F.kill[e] = 0; F.transfer[e] = 0
 // flag[e] = alive and the translated ring reaches beyond the box in dimension dim (:31,:52)
 SZ_HD void ghost_flag(int e, int dim, const Floes &F, const Params &P, Work &W) {
   int s = W.ext_src[e], v0 = F.vert_off[s], nv = F.vert_off[s + 1] - v0;
+  if (!is_present(s, W)) { W.flag[e] = 0; return; }   // (sharded step: not a floe this rank knows this step)
   // no vertex is farther from the floe position than rmax (initialize_floe_values.m:26 defines it so, and the
   // rotation of c0 into c_alpha keeps the distances): a floe well inside the box needs no look at its ring
   // (the 1e-9 relative margin is far above the rounding of the rotated ring and of the sums below)
@@ -298,7 +304,7 @@ SZ_HD int cell_of(int e, const Floes &F, const Work &W) {
 // only live floes that can be a candidate enter the grid (a dead floe never is, :101,:103; floes 1..Nb neither,
 // since j > i >= 1 + Nb); each item carries its position and radius so that a cell is one contiguous stream of
 // independent loads
-SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && s >= F.nb; }
+SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && s >= F.nb && is_present(s, W); }
 SZ_HD void cell_count(int e, const Floes &F, Work &W) {
   if (in_grid(e, F, W)) atomic_add(&W.cell_cnt[cell_of(e, F, W)], 1);
 }
@@ -327,7 +333,7 @@ SZ_HD void broad_scan(int i, int c9, int N, const Floes &F, const Params &P, Wor
   (void)N;
   const int si = W.ext_src[i];
   const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
-  if (!(F.alive[si] && !(xi != xi) && P.COLLISION)) return;
+  if (!(F.alive[si] && !(xi != xi) && P.COLLISION && is_present(si, W))) return;
   const int own = level_of(ri, W);
   for (int b = own; b < W.n_levels; ++b) {
     const int gx = cell_coord(xi, W.lvl_x0[b], W.lvl_cs[b], W.lvl_cx[b]) + (c9 % 3) - 1;
@@ -404,19 +410,26 @@ SZ_HD void broad_filter(int i, const Floes &F, const Params &P, Work &W, int *tm
 // ---------------------------------------------------------------------------------------------
 // flat pair list
 // ---------------------------------------------------------------------------------------------
-SZ_HD bool has_wall_pair(int i, int N, const Floes &F, const Params &P) { return !P.PERIODIC && i >= F.nb && i < N; }
+SZ_HD bool has_wall_pair(int i, int N, const Floes &F, const Params &P, const Work &W) {
+  return !P.PERIODIC && i >= F.nb && i < N && is_present(W.ext_src[i], W) && is_owned(W.ext_src[i], W);
+}
+// (sharded step) a candidate pair is evaluated by the ranks that integrate one of its two floes -- both of them when
+// the floes belong to different ranks: same inputs, same arithmetic, same rows on both sides, nothing to send back
+SZ_HD bool pair_relevant(int i, int j, const Work &W) { return !W.owned || W.owned[W.ext_src[i]] || W.owned[W.ext_src[j]]; }
 
 SZ_HD void pair_count(int i, int N, const Floes &F, const Params &P, Work &W) { // i < N
   int cnt = 0; i64 nv = 0;
   if (i >= F.nb) {
     const int ni = W.ext_nv[i];
-    cnt = W.pot_cnt[i];
+    const int all = W.pot_cnt[i];
     const int *mine = W.pot_list + (size_t)i * W.pot_cap;
-    for (int q = 0; q < cnt; ++q) {
+    for (int q = 0; q < all; ++q) {
+      if (!pair_relevant(i, mine[q] - 1, W)) continue;
+      ++cnt;
       nv += ni + W.ext_nv[mine[q] - 1];
       atomic_inc_noret(&W.inc_pre[mine[q] - 1]);   // an upper bound of the partner's mirror list (:187-214), see pair_room
     }
-    if (has_wall_pair(i, N, F, P)) { ++cnt; nv += ni + 4; }
+    if (has_wall_pair(i, N, F, P, W)) { ++cnt; nv += ni + 4; }
   }
   W.pair_cnt[i] = cnt; W.pair_nv[i] = nv;
 }
@@ -433,13 +446,15 @@ SZ_HD void pair_expand(int i, int N, const Floes &F, const Params &P, Work &W) {
   i64 p = W.pair_base[i], nvo = W.nv_base[i];
   const int ni = W.ext_nv[i];
   const int *mine = W.pot_list + (size_t)i * W.pot_cap;
-  for (int q = 0; q < W.pot_cnt[i]; ++q, ++p) {
-    if (p >= W.cap_pairs) return;
+  for (int q = 0; q < W.pot_cnt[i]; ++q) {
     int j = mine[q] - 1;
+    if (!pair_relevant(i, j, W)) continue;
+    if (p >= W.cap_pairs) return;
     W.pair_i[p] = i; W.pair_j[p] = j; W.pair_nvoff[p] = nvo;
     nvo += ni + W.ext_nv[j];
+    ++p;
   }
-  if (has_wall_pair(i, N, F, P) && p < W.cap_pairs) {
+  if (has_wall_pair(i, N, F, P, W) && p < W.cap_pairs) {
     W.pair_i[p] = i; W.pair_j[p] = WALL; W.pair_nvoff[p] = nvo;
   }
 }
@@ -798,7 +813,7 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
   W.ov_ext[i] = ov;
   W.cf_ext[2 * i] = sfx; W.cf_ext[2 * i + 1] = sfy; W.ct_ext[i] = stq;
   // floe centre outside the box (:152-155)
-  if (!P.PERIODIC && i >= F.nb && i < N0) {
+  if (!P.PERIODIC && i >= F.nb && i < N0 && is_present(i, W) && is_owned(i, W)) {
     const double *c = P.c2_boundary;
     // inpolygon of one point against the 5-point closed box, inpolygon.m:150-224
     double mnx = c[0], mxx = c[0], mny = c[1], mxy = c[1];
@@ -975,6 +990,7 @@ SZ_HD void stress_sum_init(int i, const Floes &F) {
 
 SZ_HD void integrate_pre(int i, const Floes &F, const Params &P, Work &W) { // nb <= i < n
   W.st_flag[i] = 0;
+  if (!is_owned(i, W)) return;   // (sharded step: another rank integrates this floe)
   // ghost sums first (:242-245): the X ghost, then the Y ghost, of this floe; then the floe's own (:262-263)
   double cfx = 0, cfy = 0, ctq = 0;
   if (P.PERIODIC) {

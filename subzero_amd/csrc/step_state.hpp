@@ -34,6 +34,13 @@ struct StepState {
   int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
   double rmax_max = 0, rmax_p90 = 0; // over the floes that can be candidates (i >= Nb)
+  double rmax_max_all = 0;           // over all floes (the reach of the spatially sharded step)
+  // spatially sharded step (spatial.hip)
+  int sp_rank = 0, sp_world = 1;
+  double sp_halo = 0;
+  std::vector<double> sp_edges;
+  DevBuf sp_masks, sp_edges_dev, sp_counts;   // present[n] then owned[n]; strip edges; two counters
+  long long *sp_hdr = nullptr;                // pinned: the headers of the two messages a Pack produced
   Params P;                       // parameters of the step in flight
   unsigned long long *c = nullptr; // host copy of the device counters (pinned; k_publish writes it)
   unsigned long long *c_dev = nullptr; // the same buffer as the device sees it
@@ -83,7 +90,8 @@ inline int dev_put(szContext *ctx, StepState *S, T *&ptr, const T *src, size_t c
 // largest and 90th-percentile bounding radius of the floes that can be candidates (i >= Nb): they size the grids
 inline void rmax_stats(StepState *S, const double *rmax) {
   std::vector<double> r(rmax + S->nb, rmax + S->n);
-  S->rmax_max = 0; S->rmax_p90 = 0;
+  S->rmax_max = 0; S->rmax_p90 = 0; S->rmax_max_all = 0;
+  for (int i = 0; i < S->n; ++i) if (rmax[i] > S->rmax_max_all) S->rmax_max_all = rmax[i];
   if (r.empty()) return;
   for (double v : r) if (v > S->rmax_max) S->rmax_max = v;
   const size_t k = (size_t)(0.9 * (double)(r.size() - 1));

@@ -94,10 +94,11 @@ void destroy_state(StepState *S) {
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
                     &S->retry_copy, &S->big_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
                     &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->pot_list, &S->inc_list,
-                    &S->stage_d, &S->stage_i, &S->stage_ids};
+                    &S->stage_d, &S->stage_i, &S->stage_ids, &S->sp_masks, &S->sp_edges_dev, &S->sp_counts};
   for (DevBuf *b : more) sz_release(*b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   if (S->c) (void)hipHostFree(S->c);
+  if (S->sp_hdr) (void)hipHostFree(S->sp_hdr);
   delete S;
 }
 

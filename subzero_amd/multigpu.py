@@ -179,61 +179,274 @@ class ShardedInteractions:
         return st
 
 
+# =====================================================================================================================
+# Spatial partition (BASELINE north_star): floes owned by x-strips, one neighbour exchange per step.
+# The design and the proof sketch of its exactness are in subzero_amd/csrc/spatial_core.hpp.
+# =====================================================================================================================
+class SpatialInfo(ctypes.Structure):
+    """szSpatialInfo"""
+    _fields_ = [(k, ctypes.c_int64) for k in ("left_records", "left_doubles", "left_migrants", "right_records",
+                                              "right_doubles", "right_migrants", "need_records", "need_doubles",
+                                              "need_migrants", "n_owned", "n_present")] + \
+               [(k, ctypes.c_int32) for k in ("overflow", "has_left", "has_right", "reserved")]
+
+
+def strip_edges(floes, world, Lx, halo=None):
+    """Edges of `world` x-strips over [-Lx, Lx]: floe-count quantiles of the centroids, moved onto multiples of the
+    broad-phase bin (2 max rmax) and kept at least `halo` (default 2 x reach = 4 max rmax) wide.  Every rank computes
+    the same edges from the same uploaded array."""
+    rmax = float(np.max(floes.rmax))
+    bin_ = 2 * rmax
+    halo = 4 * rmax if halo is None else halo
+    x = np.sort(floes.Xi[np.isfinite(floes.Xi) & (floes.alive > 0)])
+    edges = [-float(Lx)]
+    for k in range(1, world):
+        q = x[min(len(x) - 1, (len(x) * k) // world)] if len(x) else -Lx + 2 * Lx * k / world
+        e = -Lx + round((q + Lx) / bin_) * bin_
+        edges.append(float(min(max(e, edges[-1] + halo), Lx - (world - k) * halo)))
+    edges.append(float(Lx))
+    if world > 1 and min(np.diff(edges)) < halo:
+        raise ValueError("the domain is too narrow for %d strips with a %.0f m halo (use fewer ranks)" % (world, halo))
+    return np.asarray(edges, np.float64), float(halo)
+
+
+class GpuSpatialBackend:
+    """One GPU of the spatially sharded job: szContext, device-resident array, torch CUDA tensors as messages."""
+
+    def __init__(self, floes, local_rank, rank, world, edges, halo):
+        import torch
+        from . import capi
+        self.torch, self.capi = torch, capi
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self.ctx = capi.Context(local_rank)
+        self.sim = capi.FloeInteractions(self.ctx, floes)
+        L = self.ctx.L
+        L.szSpatialInit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_double]
+        L.szSpatialMessageBytes.restype = ctypes.c_int64
+        L.szSpatialMessageBytes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+        L.szSpatialPack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(SpatialInfo)]
+        L.szSpatialUnpack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_int64, ctypes.POINTER(SpatialInfo)]
+        L.szSpatialOwned.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8)]
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx.check(L.szSetStream(self.ctx.h, ctypes.c_void_p(self.stream.cuda_stream)), "szSetStream")
+        e = np.ascontiguousarray(edges, np.float64)
+        self.ctx.check(L.szSpatialInit(self.ctx.h, rank, world, e.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), halo), "szSpatialInit")
+        self._bufs = {}
+
+    def message_bytes(self, caps):
+        return int(self.ctx.L.szSpatialMessageBytes(self.ctx.h, *caps))
+
+    def buffer(self, name, nbytes):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < nbytes:
+            b = self.torch.zeros(int(nbytes * 1.25) + 256, dtype=self.torch.uint8, device=self.device)
+            self._bufs[name] = b
+        return b[:nbytes]
+
+    def stream_scope(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def pack(self, periodic, left, right, caps):
+        info = SpatialInfo()
+        self.ctx.check(self.ctx.L.szSpatialPack(self.ctx.h, int(periodic), ctypes.c_void_p(left.data_ptr()),
+                                                ctypes.c_void_p(right.data_ptr()), caps[0], caps[1], caps[2], ctypes.byref(info)),
+                       "szSpatialPack")
+        return info
+
+    def unpack(self, from_left, from_right, caps):
+        info = SpatialInfo()
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        self.ctx.check(self.ctx.L.szSpatialUnpack(self.ctx.h, p(from_left), p(from_right), caps[0], caps[1], caps[2],
+                                                  ctypes.byref(info)), "szSpatialUnpack")
+        return info
+
+    def step(self, P):
+        return self.sim.step(P)
+
+    def header(self, t):
+        """(records, doubles, migrants, status) of a received message header (a 64-byte device tensor)."""
+        h = t.view(self.torch.int64).cpu().numpy()
+        return int(h[0]), int(h[1]), int(h[2]), int(h[3])
+
+    def bulk_row(self):
+        S = self.sim.floes
+        return ((S.n_stress * 32 + S.n_mc * 17 + 7) // 8) * 8
+
+    def owned(self):
+        m = np.zeros(self.sim.floes.n, np.uint8)
+        self.ctx.check(self.ctx.L.szSpatialOwned(self.ctx.h, m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "szSpatialOwned")
+        return m.astype(bool)
+
+    def close(self):
+        self.ctx.close()
+
+
+class SpatialInteractions:
+    """floe_interactions_all over `world` ranks, each owning the floes of one x-strip; `step` is called by every rank
+    with the same P.  Per step: pack -> exchange with the two neighbours (a ring when periodic) -> unpack -> step.
+    The exchange is two grouped rounds of send / recv: the 64-byte headers (what each message holds), then exactly
+    the used part of the three arrays of each message (record offsets, record doubles, bulk rows of floes that
+    changed strip) -- nothing is sized by guesswork, nothing is padded on the wire."""
+
+    def __init__(self, backend, rank, world, n_floes, n_vertices, group=None):
+        import torch.distributed as dist
+        self.dist, self.be, self.rank, self.world, self.group = dist, backend, rank, world, group
+        # local capacities of the message buffers: every floe could be in a message; a few dozen change strip at most
+        self.caps = (int(n_floes), int(47 * n_floes + 2 * n_vertices), int(max(64, n_floes // 16)))
+        self.exchanges = 0
+        self.bytes_sent = 0
+        self.last = None
+
+    def _views(self, buf, caps, bulk_row):
+        """(header, record offsets, doubles, bulk) sub-tensors of a message buffer (layout of spatial_core.hpp sp_msg_view)."""
+        o_rec = 64
+        o_dbl = o_rec + ((4 * caps[0] + 7) // 8) * 8
+        o_bulk = o_dbl + 8 * caps[1]
+        return buf[:64], buf[o_rec:o_dbl], buf[o_dbl:o_bulk], buf[o_bulk:o_bulk + caps[2] * bulk_row]
+
+    def _round(self, ops):
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def step(self, P):
+        be, dist = self.be, self.dist
+        if self.world == 1:
+            return be.step(P)
+        left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        with be.stream_scope():
+            caps = self.caps
+            nbytes = be.message_bytes(caps)
+            bufs = {k: be.buffer(k, nbytes) for k in ("send_left", "send_right", "from_left", "from_right")}
+            sent = be.pack(P.PERIODIC, bufs["send_left"], bufs["send_right"], caps)
+            if sent.overflow:
+                raise RuntimeError("spatial exchange: %d floes changed strip in one step (capacity %d)" % (sent.need_migrants, caps[2]))
+            hl, hr = bool(sent.has_left), bool(sent.has_right)
+            bulk_row = be.bulk_row()
+            v = {k: self._views(b, caps, bulk_row) for k, b in bufs.items()}
+            # round 1: headers (tags name the direction of travel: on a ring of two both neighbours are the same peer)
+            ops = []
+            if hl: ops.append(dist.P2POp(dist.isend, v["send_left"][0], left, self.group, tag=1))
+            if hr: ops.append(dist.P2POp(dist.isend, v["send_right"][0], right, self.group, tag=2))
+            if hr: ops.append(dist.P2POp(dist.irecv, v["from_right"][0], right, self.group, tag=1))
+            if hl: ops.append(dist.P2POp(dist.irecv, v["from_left"][0], left, self.group, tag=2))
+            self._round(ops)
+            hdr = {k: be.header(v[k][0]) for k in ("from_left", "from_right") if (hl if k == "from_left" else hr)}
+            for k, h in hdr.items():
+                if h[0] > caps[0] or h[1] > caps[1] or h[2] > caps[2]:
+                    raise RuntimeError("spatial exchange: the neighbour's message does not fit the local buffers")
+            # round 2: the used part of each array
+            ops = []
+            def parts(key, n_rec, n_dbl, n_migr):
+                _, rec, dbl, bulk = v[key]
+                out = []
+                if n_rec: out += [rec[:4 * n_rec], dbl[:8 * n_dbl]]
+                if n_migr: out.append(bulk[:n_migr * bulk_row])
+                return out
+            if hl:
+                for t in parts("send_left", sent.left_records, sent.left_doubles, sent.left_migrants):
+                    ops.append(dist.P2POp(dist.isend, t, left, self.group, tag=1)); self.bytes_sent += t.numel()
+            if hr:
+                for t in parts("send_right", sent.right_records, sent.right_doubles, sent.right_migrants):
+                    ops.append(dist.P2POp(dist.isend, t, right, self.group, tag=2)); self.bytes_sent += t.numel()
+            if hr:
+                for t in parts("from_right", *hdr["from_right"][:3]):
+                    ops.append(dist.P2POp(dist.irecv, t, right, self.group, tag=1))
+            if hl:
+                for t in parts("from_left", *hdr["from_left"][:3]):
+                    ops.append(dist.P2POp(dist.irecv, t, left, self.group, tag=2))
+            self._round(ops)
+            self.exchanges += 1
+            got = be.unpack(bufs["from_left"] if hl else None, bufs["from_right"] if hr else None, caps)
+            self.last = (sent, got)
+            return be.step(P)
+
+
+def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
+    """`steps` timed steps of the spatially sharded job on the field S; -> (seconds: max over ranks, stats)."""
+    from . import capi
+    Lx = float(P.c2_boundary[0].max())
+    edges, halo = strip_edges(S, world, Lx)
+    be = GpuSpatialBackend(S, local_rank, rank, world, edges, halo)
+    sim = SpatialInteractions(be, rank, world, S.n, int(S.vert_off[-1]))
+    it = 0
+    for _ in range(warmup):
+        P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    narrow_ms = 0.0; pairs = 0; pair_bytes = 0.0
+    for _ in range(steps):
+        P.doInt = int(it % 10 == 0)
+        st = sim.step(P); it += 1
+        narrow_ms += st.narrow_ms; pairs += st.n_pairs
+        pair_bytes += 16.0 * st.pair_vertices + 112.0 * st.n_pairs + 56.0 * st.pair_rows
+    torch.cuda.synchronize(); dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # collisions of the last step (calc_collisionNum.m:6) over the floes each rank owns, summed over the ranks
+    off, rows = be.sim.interactions()
+    mine = be.owned()
+    keep = np.repeat(mine, np.diff(off))
+    cnt = torch.tensor([capi.collision_count(rows[keep]), float(pairs), float(mine.sum()), float(sim.last[1].n_present if sim.last else S.n),
+                        float(sim.bytes_sent / max(sim.exchanges, 1))], dtype=torch.float64, device=be.device)
+    tot = cnt.clone(); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    stats = {"collisions_last_step": float(tot[0]), "pairs_evaluated": float(tot[1]), "owned_floes_rank0": int(cnt[2]),
+             "present_floes_max": int(mx[3]), "bytes_sent_per_rank_step_max": float(mx[4]),
+             "narrow_ms": narrow_ms / max(steps, 1), "pair_bytes": pair_bytes / max(steps, 1), "halo_m": halo,
+             "strip_edges_m": [float(e) for e in edges]}
+    be.close()
+    return float(el.item()), stats
+
+
 def bench_main(args, rank, local_rank, world):
-    """bench.py for --gpus > 1 (launched by torch.distributed.run, one rank per GPU)."""
+    """bench.py for --gpus > 1 (launched by torch.distributed.run, one rank per GPU): the spatial partition.
+    `value` is the WEAK-scaling figure (args.floes floes per GPU: the one-GPU field repeated `world` times along x, one
+    strip per GPU); the same line carries a STRONG-scaling run of the one-GPU field cut into `world` strips."""
     import torch
     import torch.distributed as dist
-    from . import capi
     import bench as bench_mod
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    # weak scaling: `floes` per GPU; the box grows with sqrt(world) so that the floe density (and the work per
-    # candidate pair) stays that of the one-GPU workload.  Same seeds on every rank: identical arrays.
-    S, P = bench_mod.build_workload(args.floes * world, box_scale=float(np.sqrt(world)))
-    be = GpuBackend(S, local_rank)
-    sim = ShardedInteractions(be, rank, world)
-    it = 0
-    for _ in range(args.warmup):
-        P.doInt = int(it % 10 == 0); sim.step(P); it += 1
-    dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    narrow_ms = 0.0; pairs = 0; rows = 0; seg_pairs = 0; pair_bytes = 0.0
-    for _ in range(args.steps):
-        P.doInt = int(it % 10 == 0)
-        st = sim.step(P); it += 1
-        narrow_ms += st.narrow_ms; pairs += st.n_pairs; rows += st.n_rows
-        ns = sim.last_info.seg_hi - sim.last_info.seg_lo
-        seg_pairs += ns
-        share = ns / max(st.n_pairs, 1)
-        pair_bytes += share * (16.0 * st.pair_vertices + 112.0 * st.n_pairs) + 56.0 * st.pair_rows
-    torch.cuda.synchronize(); dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
-    off, inter = be.sim.interactions()
     k = args.steps
+    # weak: same seeds on every rank -> identical arrays; box 2e5 * world x 2e5 m
+    S, P = bench_mod.build_workload(args.floes * world, Lx=1e5 * world, Ly=1e5)
+    el, st = _spatial_run(S, P, rank, local_rank, world, k, args.warmup, torch, dist)
+    strong = None
+    try:
+        S1, P1 = bench_mod.build_workload(args.floes)
+        el1, st1 = _spatial_run(S1, P1, rank, local_rank, world, k, args.warmup, torch, dist)
+        strong = {"value": S1.n * k / el1, "unit": "floe-timesteps/s", "floes": int(S1.n), "ms_per_step": el1 / k * 1e3,
+                  "timesteps_per_s": k / el1, "present_floes_max": st1["present_floes_max"], "halo_m": st1["halo_m"],
+                  "bytes_sent_per_rank_step_max": st1["bytes_sent_per_rank_step_max"]}
+    except ValueError as e:        # strips narrower than the halo: this field cannot be cut that finely
+        strong = {"value": None, "note": str(e)}
     if rank == 0:
-        achieved = (pair_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
+        achieved = st["pair_bytes"] / (st["narrow_ms"] * 1e-3) / 1e9 if st["narrow_ms"] > 0 else 0.0
         out = {
             "metric": "floe-timesteps/sec", "value": S.n * k / el, "unit": "floe-timesteps/s",
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64+int64", "data": "synthetic",
-            "config": {"workload": "pack%d: %d Voronoi floes (%d per GPU), concentration 1.0, periodic +-%.3g m box, "
+            "config": {"workload": "pack%d: %d Voronoi floes (%d per GPU), concentration 1.0, periodic +-%.3g x +-1e5 m box, "
                                    "dt=10 s, collisions + ocean drag (forcing refreshed every 10th step)"
-                                   % (S.n, S.n, args.floes, 1e5 * np.sqrt(world)),
+                                   % (S.n, S.n, args.floes, 1e5 * world),
                        "floes": int(S.n), "floes_per_gpu": int(args.floes),
-                       "parallelism": "%d GPUs: narrow-phase sharded over the pair list, 1 RCCL all-gather/step, "
-                                      "other stages replicated" % world},
+                       "parallelism": "%d GPUs: floes owned by x-strips, one RCCL send/recv of halo floes with each neighbour per step "
+                                      "(ring), border pairs evaluated on both sides" % world},
             "timesteps_per_s": k / el,
-            "contact_pairs_per_s": capi.collision_count(inter) * k / el,
-            "candidate_pairs_per_s": pairs / el,
-            "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (rank 0's segment of the pair list)",
+            "contact_pairs_per_s": st["collisions_last_step"] * k / el,
+            "candidate_pairs_evaluated_per_s": st["pairs_evaluated"] / el,
+            "spatial": {k2: st[k2] for k2 in ("owned_floes_rank0", "present_floes_max", "bytes_sent_per_rank_step_max", "halo_m")},
+            "strong_scaling": strong,
+            "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (rank 0's pairs)",
                          "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
+                         "kernel_ms": st["narrow_ms"], "algorithmic_bytes_per_launch": st["pair_bytes"]},
         }
         print(json.dumps(out), flush=True)
-    be.close()
     dist.destroy_process_group()

@@ -40,6 +40,7 @@ static long long g_prune_runs[2];
 #define SZC_PRUNE_PROBE(skipped) (++g_prune_runs[(skipped)])
 #define SZC_TRIM_OFF g_trim_off
 #include "../../subzero_amd/csrc/step_core.hpp"
+#include "../../subzero_amd/csrc/spatial_core.hpp"
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,6 +49,12 @@ static long long g_prune_runs[2];
 
 using namespace szs;
 
+// spatially sharded step (spatial_core.hpp): the masks and the strips live across the calls of one rank's process
+static bool g_sp_active = false;
+static std::vector<unsigned char> g_sp_masks;     // present[n] then owned[n]
+static std::vector<double> g_sp_edges;
+static int g_sp_rank = 0, g_sp_world = 1;
+static double g_sp_halo = 0;
 static int g_narrow_mode = 2;
 static long long g_big_pairs = 0;
 extern "C" long long host_big_pairs(void) { return g_big_pairs; }
@@ -144,6 +151,10 @@ struct Sim {
 
   void bind(HFloes *hf, const HParams *hp, int pot_cap) {
     pool.clear();
+    bind_floes(hf);
+    bind_rest(hp, pot_cap);
+  }
+  void bind_floes(HFloes *hf) {
     F.n = hf->n; F.nb = hf->nb; F.n_stress = hf->n_stress; F.n_mc = hf->n_mc;
     F.Xi = hf->Xi; F.Yi = hf->Yi; F.alpha_i = hf->alpha_i; F.Ui = hf->Ui; F.Vi = hf->Vi; F.ksi_ice = hf->ksi_ice;
     F.h = hf->h; F.area = hf->area; F.mass = hf->mass; F.inertia_moment = hf->inertia_moment; F.rmax = hf->rmax;
@@ -166,6 +177,8 @@ struct Sim {
       g_sums_for = (const void *)hf->StressH;
     }
     F.StressSum = g_sums.data();
+  }
+  void bind_rest(const HParams *hp, int pot_cap) {
     P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
     P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
     memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
@@ -194,6 +207,7 @@ struct Sim {
     W.cf_ext = alloc<double>(pool, 2 * (size_t)cap); W.ct_ext = alloc<double>(pool, cap); W.ov_ext = alloc<double>(pool, cap);
     W.tmax = alloc<int>(pool, cap);
     W.st_ext = alloc<double>(pool, 3 * (size_t)n); W.st_flag = alloc<int>(pool, n);
+    if (g_sp_active) { W.present = g_sp_masks.data(); W.owned = g_sp_masks.data() + n; }
   }
 
   std::vector<int> mc_empty;
@@ -378,7 +392,8 @@ struct Sim {
 };
 
 int g_last_grown = 0, g_last_pot_cap = 0, g_last_levels = 0;
-std::vector<int> g_last_mc_empty;
+std::vector<int> g_last_mc_empty, g_last_ghost_src, g_last_ghost_parent;
+std::vector<double> g_last_ghost_x, g_last_ghost_y;
 Sim g_sim; // the sharded entry points keep their state between calls, as the GPU context does
 
 } // namespace
@@ -397,6 +412,8 @@ int host_step(HFloes *hf, const HParams *hp, int32_t *inter_off, double *inter, 
   rc = s.front(pot_cap < 0);
   g_last_grown = s.grown; g_last_pot_cap = s.W.pot_cap; g_last_levels = s.W.n_levels; g_last_mc_empty = s.mc_empty;
   if (rc) return rc;
+  g_last_ghost_src.assign(s.W.ext_src + s.n, s.W.ext_src + s.N); g_last_ghost_parent.assign(s.W.ext_parent + s.n, s.W.ext_parent + s.N);
+  g_last_ghost_x.assign(s.W.ext_x + s.n, s.W.ext_x + s.N); g_last_ghost_y.assign(s.W.ext_y + s.n, s.W.ext_y + s.N);
   if ((rc = s.narrow_range(0, s.np))) return rc;
   *retried = s.retried;
   if ((rc = s.back())) return rc;
@@ -411,6 +428,107 @@ int host_last_mc_empty(int *ids, int cap) {
   for (int k = 0; k < n && k < cap; ++k) ids[k] = g_last_mc_empty[k];
   return n;
 }
+
+// the ghost list of the last host_step (as szGhostsDownload): 1-based src / parent, positions
+int host_last_ghosts(int *src, int *parent, double *x, double *y, int cap) {
+  const int g = (int)g_last_ghost_src.size();
+  for (int k = 0; k < g && k < cap; ++k) { src[k] = g_last_ghost_src[k] + 1; parent[k] = g_last_ghost_parent[k] + 1; x[k] = g_last_ghost_x[k]; y[k] = g_last_ghost_y[k]; }
+  return g;
+}
+
+// ---- spatially sharded form, mirroring szSpatialInit / Pack / Unpack (then host_step as usual) ----
+int host_spatial_init(HFloes *hf, int rank, int world, const double *edges, double halo) {
+  const int n = hf->n;
+  double rm = 0;
+  for (int i = 0; i < n; ++i) rm = szc::maxd(rm, hf->rmax[i]);
+  if (!(halo > 0)) halo = 4 * rm;          // 2 x reach, reach = 2 max rmax
+  if (halo < 4 * rm) return -2;
+  if (world > 1) for (int r = 0; r < world; ++r) if (edges[r + 1] - edges[r] < halo) return -2;
+  g_sp_rank = rank; g_sp_world = world; g_sp_halo = halo;
+  g_sp_edges.assign(edges, edges + world + 1);
+  g_sp_masks.assign(2 * (size_t)n, 0);
+  for (int i = 0; i < n; ++i) {
+    const double x = hf->Xi[i];
+    const bool mine = sp_strip_of(x, edges, world) == rank || (x != x && rank == 0);
+    g_sp_masks[i] = mine; g_sp_masks[(size_t)n + i] = mine;
+  }
+  g_sp_active = true;
+  return 0;
+}
+void host_spatial_off(void) { g_sp_active = false; }
+void host_spatial_pause(int paused) { g_sp_active = !paused && !g_sp_masks.empty(); }   // (a test's single-process reference step runs unmasked)
+int64_t host_spatial_message_bytes(HFloes *hf, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr) {
+  return (int64_t)sp_msg_bytes(cap_rec, cap_dbl, cap_migr, sp_bulk_row(hf->n_stress, hf->n_mc));
+}
+static SpatialGeom host_geom(int periodic) {
+  SpatialGeom g;
+  g.rank = g_sp_rank; g.world = g_sp_world; g.periodic = periodic;
+  g.lo = g_sp_edges[g_sp_rank]; g.hi = g_sp_edges[g_sp_rank + 1]; g.halo = g_sp_halo;
+  g.has_left = g_sp_world > 1 && (periodic || g_sp_rank > 0);
+  g.has_right = g_sp_world > 1 && (periodic || g_sp_rank < g_sp_world - 1);
+  return g;
+}
+// info: [left rec, dbl, migr, right rec, dbl, migr, need rec, dbl, migr, overflow, has_left, has_right, n_owned, n_present]
+int host_spatial_pack(HFloes *hf, int periodic, void *left, void *right, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr, int64_t *info) {
+  Sim &s = g_sim;
+  s.bind_floes(hf);
+  std::vector<int> mc((size_t)hf->n);
+  s.W.mc_cnt = mc.data();
+  for (int i = 0; i < hf->n; ++i) mc_count(i, s.F, s.W);
+  const size_t row = sp_bulk_row(hf->n_stress, hf->n_mc);
+  SpatialMsg l = sp_msg_view((char *)left, cap_rec, cap_dbl, cap_migr, row), r = sp_msg_view((char *)right, cap_rec, cap_dbl, cap_migr, row);
+  for (int k = 0; k < SP_HDR; ++k) { l.hdr[k] = 0; r.hdr[k] = 0; }
+  const SpatialGeom g = host_geom(periodic);
+  unsigned char *present = g_sp_masks.data(), *owned = present + hf->n;
+  for (int i = hf->n - 1; i >= 0; --i) sp_classify(i, s.F, s.W, g, g_sp_edges.data(), present, owned, l, r);   // any order
+  sp_seal(l); sp_seal(r);
+  SpatialMsg *ms[2] = {&l, &r};
+  for (int side = 0; side < 2; ++side) {
+    SpatialMsg &m = *ms[side];
+    for (long long k = 0; k < m.hdr[0]; ++k) {
+      const double *rec = m.dbl + m.rec_off[k];
+      if (rec[1] == 0.0) continue;
+      char *rowp = m.bulk + (long long)rec[3] * m.bulk_row;
+      for (size_t w = 0; w < (size_t)m.bulk_row / 8; ++w) sp_bulk_word((int)rec[0], w, true, s.F, rowp, s.W);
+    }
+  }
+  info[0] = l.hdr[0]; info[1] = l.hdr[1]; info[2] = l.hdr[2]; info[3] = r.hdr[0]; info[4] = r.hdr[1]; info[5] = r.hdr[2];
+  info[6] = std::max(l.hdr[4], r.hdr[4]); info[7] = std::max(l.hdr[5], r.hdr[5]); info[8] = std::max(l.hdr[6], r.hdr[6]);
+  info[9] = (l.hdr[3] != SP_OK || r.hdr[3] != SP_OK) ? 1 : 0; info[10] = g.has_left; info[11] = g.has_right;
+  s.W.mc_cnt = nullptr;
+  return 0;
+}
+int host_spatial_unpack(HFloes *hf, const void *left, const void *right, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr, int64_t *info) {
+  Sim &s = g_sim;
+  s.bind_floes(hf);
+  std::vector<int> mc((size_t)hf->n);
+  s.W.mc_cnt = mc.data();
+  const size_t row = sp_bulk_row(hf->n_stress, hf->n_mc);
+  unsigned char *present = g_sp_masks.data(), *owned = present + hf->n;
+  const void *bufs[2] = {left, right};
+  for (int k = 0; k < 14; ++k) info[k] = 0;
+  for (int side = 0; side < 2; ++side) {
+    if (!bufs[side]) continue;
+    SpatialMsg m = sp_msg_view((char *)bufs[side], cap_rec, cap_dbl, cap_migr, row);
+    info[6] = std::max<int64_t>(info[6], m.hdr[4]); info[7] = std::max<int64_t>(info[7], m.hdr[5]); info[8] = std::max<int64_t>(info[8], m.hdr[6]);
+    if (m.hdr[3] != SP_OK) { info[9] = 1; continue; }
+    info[3 * side] = m.hdr[0]; info[3 * side + 1] = m.hdr[1]; info[3 * side + 2] = m.hdr[2];
+    for (long long k = m.hdr[0] - 1; k >= 0; --k) {                     // any order
+      const double *rec = m.dbl + m.rec_off[k];
+      const int i = (int)rec[0];
+      const bool was_owned = owned[i] != 0;
+      sp_take(k, s.F, s.W, m, present, owned);
+      if (rec[1] != 0.0 && !was_owned) {
+        char *rowp = m.bulk + (long long)rec[3] * m.bulk_row;
+        for (size_t w = 0; w < (size_t)m.bulk_row / 8; ++w) sp_bulk_word(i, w, false, s.F, rowp, s.W);
+      }
+    }
+  }
+  for (int i = 0; i < hf->n; ++i) { info[12] += owned[i]; info[13] += present[i]; }
+  s.W.mc_cnt = nullptr;
+  return 0;
+}
+void host_spatial_owned(unsigned char *out, int n) { for (int i = 0; i < n; ++i) out[i] = g_sp_masks[(size_t)n + i]; }
 
 // ---- sharded form, mirroring szStepShardBegin / Export / Finish ----
 int64_t host_shard_segment_bytes(int64_t seg_max, int64_t rows_max) { return (int64_t)seg_bytes_for(seg_max, rows_max); }

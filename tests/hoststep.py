@@ -165,3 +165,13 @@ def big_pairs():
     """Pairs handed to the second fast pass (32-vertex blocks) so far."""
     lib().host_big_pairs.restype = ctypes.c_longlong
     return int(lib().host_big_pairs())
+
+
+def last_ghosts():
+    """(src, parent, x, y) of the ghost floes of the last `step` (1-based numbers over the extended list)."""
+    cap = 1 << 16
+    src = np.zeros(cap, np.int32); par = np.zeros(cap, np.int32); x = np.zeros(cap); y = np.zeros(cap)
+    L = lib()
+    L.host_last_ghosts.argtypes = [orc._ip, orc._ip, orc._dp, orc._dp, ctypes.c_int]
+    g = L.host_last_ghosts(orc._p(src, orc._ip), orc._p(par, orc._ip), orc._p(x), orc._p(y), cap)
+    return src[:g].copy(), par[:g].copy(), x[:g].copy(), y[:g].copy()

@@ -1,0 +1,120 @@
+"""The spatially partitioned step on the GPU through the C ABI (szSpatialInit / Pack / Unpack + szStep): two and three
+ranks emulated on the one card of the test box -- one context and one device-resident array per rank, the neighbour
+messages copied between their device buffers as RCCL send / recv would deliver them (exactly the used parts, after the
+headers) -- against the single-GPU step and the oracle.  The orchestration over torch.distributed is exercised under
+gloo in tests/test_spatial_cpu.py and, here, with a one-rank RCCL group."""
+import numpy as np
+import pytest
+
+import hoststep
+import oracle
+import scenes
+from subzero_amd import capi, multigpu
+
+pytestmark = pytest.mark.gpu
+
+
+class Rank:
+    def __init__(self, S, rank, world, edges, halo):
+        self.S = S.copy()
+        self.be = multigpu.GpuSpatialBackend(self.S, 0, rank, world, edges, halo)
+        self.caps = (S.n, 47 * S.n + 2 * int(S.vert_off[-1]), max(64, S.n // 16))
+        nbytes = self.be.message_bytes(self.caps)
+        self.buf = {k: self.be.buffer(k, nbytes) for k in ("send_left", "send_right", "from_left", "from_right")}
+        self.rank, self.world = rank, world
+
+    def views(self, key):
+        caps, row = self.caps, self.be.bulk_row()
+        o_rec = 64; o_dbl = o_rec + ((4 * caps[0] + 7) // 8) * 8; o_bulk = o_dbl + 8 * caps[1]
+        b = self.buf[key]
+        return b[:64], b[o_rec:o_dbl], b[o_dbl:o_bulk], b[o_bulk:o_bulk + caps[2] * row]
+
+
+def deliver(src, skey, dst, dkey):
+    """What the two rounds of send / recv move: the header, then the used part of each array."""
+    hs, rs, ds, bs = src.views(skey); hd, rd, dd, bd = dst.views(dkey)
+    hd.copy_(hs)
+    n_rec, n_dbl, n_migr, status = src.be.header(hs)
+    assert status == 0
+    row = src.be.bulk_row()
+    rd[:4 * n_rec].copy_(rs[:4 * n_rec]); dd[:8 * n_dbl].copy_(ds[:8 * n_dbl]); bd[:n_migr * row].copy_(bs[:n_migr * row])
+    return 64 + 4 * n_rec + 8 * n_dbl + n_migr * row, n_migr
+
+
+@pytest.mark.parametrize("world,periodic", [(2, True), (3, True), (2, False)])
+def test_emulated_ranks_match_the_oracle(world, periodic):
+    import torch
+    n = 2700 if world == 3 else 1800
+    S, P = scenes.pack(n, periodic=periodic, n_stress=6, n_mc=80)
+    P.set_reference_ocean()
+    S.Ui += 45.0 if periodic else 12.0
+    A = S.copy()
+    edges, halo = multigpu.strip_edges(S, world, float(P.c2_boundary[0].max()))
+    ranks = [Rank(S, r, world, edges, halo) for r in range(world)]
+    moved = 0; wire = 0; present_max = 0
+    for it in range(8):
+        P.doInt = int(it % 4 == 0)
+        ra = oracle.step(A, P, threads=16)
+        infos = []
+        for R in ranks:
+            with R.be.stream_scope():
+                infos.append(R.be.pack(P.PERIODIC, R.buf["send_left"], R.buf["send_right"], R.caps))
+        torch.cuda.synchronize()
+        for R, sent in zip(ranks, infos):
+            assert not sent.overflow
+            if sent.has_left:
+                b, m = deliver(R, "send_left", ranks[(R.rank - 1) % world], "from_right"); wire += b; moved += m
+            if sent.has_right:
+                b, m = deliver(R, "send_right", ranks[(R.rank + 1) % world], "from_left"); wire += b; moved += m
+        torch.cuda.synchronize()
+        own = np.zeros(S.n, int)
+        for R, sent in zip(ranks, infos):
+            with R.be.stream_scope():
+                got = R.be.unpack(R.buf["from_left"] if sent.has_left else None, R.buf["from_right"] if sent.has_right else None, R.caps)
+                present_max = max(present_max, int(got.n_present))
+                R.be.step(P)
+            G = R.be.sim.download(capi.SYNC_ALL)
+            off, rows = R.be.sim.interactions()
+            mine = R.be.owned()
+            own += mine
+            ids = np.nonzero(mine)[0]
+            for f in hoststep.STATE_FIELDS:
+                if f in ("kill", "transfer", "cax", "cay"):
+                    continue
+                a, b = np.asarray(getattr(A, f))[ids], np.asarray(getattr(G, f))[ids]
+                assert ((a == b) | (np.isnan(a.astype(float)) & np.isnan(b.astype(float)))).all(), "step %d rank %d: %s" % (it, R.rank, f)
+            d = np.abs(A.Stress[ids] - G.Stress[ids])
+            assert (d <= hoststep.stress_bound(A)[ids]).all()
+            for i in ids[::7]:        # contact rows of every 7th owned floe (real partners by number; ghost partners are numbered per rank)
+                a = ra.inter[ra.inter_off[i]:ra.inter_off[i + 1]]; b = rows[off[i]:off[i + 1]]
+                assert a.shape == b.shape and np.array_equal(a[:, 1:], b[:, 1:]), (it, R.rank, i)
+                real = a[:, 0] <= S.n
+                assert np.array_equal(a[real, 0], b[real, 0])
+        assert (own == 1).all(), "step %d: ownership is not a partition" % it
+    assert moved > 0 and present_max < S.n
+    print("spatial x%d: %.1f KB on the wire per rank and step, most floes present on a rank %d of %d"
+          % (world, wire / 8 / world / 1024, present_max, S.n))
+    for R in ranks:
+        R.be.close()
+
+
+def test_orchestration_with_a_one_rank_rccl_group():
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        S, P = scenes.pack(300, periodic=True, n_stress=4, n_mc=60)
+        A = S.copy()
+        edges, halo = multigpu.strip_edges(S, 1, float(P.c2_boundary[0].max()))
+        be = multigpu.GpuSpatialBackend(S, 0, 0, 1, edges, halo)
+        sim = multigpu.SpatialInteractions(be, 0, 1, S.n, int(S.vert_off[-1]))
+        for it in range(4):
+            P.doInt = int(it == 0)
+            oracle.step(A, P, threads=4); sim.step(P)
+        G = be.sim.download(capi.SYNC_ALL)
+        assert hoststep.compare_states(A, G) == [] and be.owned().all()
+        be.close()
+    finally:
+        dist.destroy_process_group()
