@@ -708,6 +708,9 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
   int np = crossings_any(c1, c2, S.px, S.py, S.cap_p, lay_x, lay_y);                   // :70
   SZC_PHASE(4);
   if (np < 0) return szv::ST_WORKSPACE;
+#if defined(SZ_ABLATE) && SZ_ABLATE == 3
+  out.has_sentinel = 1; out.sentinel = (double)np * 0; return szv::ST_OK;   // diagnostic build: stop after InterX
+#endif
   if (np < 2 || is_inf(overlap0) || nreg == 0) {                                       // :71-74
     out.has_sentinel = 1;
     out.sentinel = overlap0;
@@ -775,6 +778,9 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
     // :140-155 shift ring 1 by the unit direction and clip again
     const bool shifted = !(dl < 0.1);
     if (!shifted) { fdx = 0; fdy = 0; }
+#if defined(SZ_ABLATE) && SZ_ABLATE == 4
+    { if (out.nrows >= S.cap_rows) return szv::ST_OUT_CAPACITY; double *row = S.rows + 5 * out.nrows; row[0] = fdx; row[1] = fdy; row[2] = pcx; row[3] = pcy; row[4] = Ar; ++out.nrows; continue; }   // diagnostic build: no second clip
+#endif
     RegionSink s2 = {S.r2x, S.r2y, S.r2off, S.cap_v, S.cap_r, 0, 0};
     SZC_PHASE(6);
     st = clip.second(c1, shifted, fdx, fdy, c2, op, S, &s2);
@@ -948,11 +954,17 @@ SZ_HD int pair_contact_fast(const RingD &ring1, const Body &f1, const RingD &rin
   }
   if (!in_range) return ST_DEFER;
   if (boxes_apart(b1, b2)) { no_contact(out); return szv::ST_OK; }
+#if defined(SZ_ABLATE) && SZ_ABLATE == 1
+  no_contact(out); return szv::ST_OK;      // diagnostic build: stop after staging
+#endif
   RingL l1 = {blk->v.m.x[0], blk->v.m.y[0], n1, 0}, l2 = {blk->v.m.x[1], blk->v.m.y[1], n2, 0};
   InBlock<Blk> clip = {blk, S.ws};
   int nreg = 0;
   int st = pair_clip1(l1, l2, false, S, clip, nreg);
   if (st != szv::ST_OK) return st;
+#if defined(SZ_ABLATE) && SZ_ABLATE == 2
+  no_contact(out); return szv::ST_OK;      // diagnostic build: stop after the first clip
+#endif
   return pair_finish(l1, f1, l2, f2, false, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
 }
 

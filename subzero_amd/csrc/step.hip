@@ -277,10 +277,12 @@ __global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, i
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
 #define CONVEX_STRIDE 616
 static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
-__global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
+// (dev_count: the pair count where the host does not know it yet -- the speculative step launches for a capacity)
+__global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, const unsigned long long *dev_count, int lanes, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)threadIdx.x >= lanes) return;
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
+  if (dev_count && t >= (i64)*dev_count) return;
   if (t < count) narrow_convex(first + t, (const int *)nullptr, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
 }
 
@@ -505,6 +507,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_RETRY_LDS_MAX")) { int b = atoi(v); if (b >= 0 && b <= 64 * 1024) S->retry_lds_max = b; }
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
+  if (const char *v = getenv("SUBZERO_SPECULATE")) S->no_speculation = atoi(v) == 0;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -523,7 +526,8 @@ extern "C" {
 // front : ghosts, grid, broad-phase, flat pair list, per-pair buffers      (every rank, identical results)
 // narrow: pair_contact on the pairs [lo, hi) + capacity-tier retries       (one segment per rank)
 // back  : mirror lists, contact rows, sums, calc_trajectory                (every rank, identical results)
-static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
+enum { STEP_RETRY_EXACT = 1000 };   // internal: the speculative step did not fit its capacities; run it again the exact way
+static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool speculative = false) {
   hipStream_t st = ctx->stream;
   int rc;
   // ocean / wind grids: uploaded on the first step and whenever the forcing is refreshed
@@ -603,6 +607,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     launch_scan(st, S->scan_agg, cap, ScanPairs{W});
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
+    if (speculative) break;   // no read-back here: the counts are checked with those of the narrow phase (step_narrow)
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
@@ -624,7 +629,8 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp) {
     S->pot_cap = want;
     if ((rc = bind_lists(ctx, S))) return rc;
   }
-  const i64 np = (i64)c[C_NPAIRS], nvt = (i64)c[C_NVTOT];
+  S->speculating = speculative;
+  const i64 np = speculative ? S->spec_np : (i64)c[C_NPAIRS], nvt = speculative ? S->spec_nvt : (i64)c[C_NVTOT];
   S->np = np; S->nvt = nvt; S->N = (int)c[C_NEXT]; S->retried = 0;
 
   // per-pair buffers and scratch, sized for this step (grow-only)
@@ -665,8 +671,10 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
       // one wave per SIMD is all this kernel can use (it is bound by the path of its longest lane): as few pairs
       // per wave as still give every one of the 1024 SIMDs at most one wave -- fewer lanes, less divergence
       int L = S->convex_lanes;
-      if (L == 0) { const i64 want = (hi - lo + 1023) / 1024; L = (int)(want < 16 ? 16 : want > 64 ? 64 : want); }
-      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo, L, F, P, W);
+      const i64 expect = S->speculating ? S->last_npairs : hi - lo;   // (speculative step: the launch covers a capacity, the pairs are about last step's)
+      if (L == 0) { const i64 want = (expect + 1023) / 1024; L = (int)(want < 16 ? 16 : want > 64 ? 64 : want); }
+      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo,
+                         S->speculating ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr, L, F, P, W);
     } else if (fast) {
       const int L = S->fast_lanes;
       const size_t lds = (size_t)L * FAST_WS_STRIDE;
@@ -681,6 +689,15 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (S->speculating) {
+    // The front stages ran without a read-back, for capacities taken from the last step.  Nothing of the floe array
+    // has been changed so far (the narrow phase writes its own buffers only), so whatever does not fit is simply done
+    // again the exact way.
+    S->speculating = false;
+    if (c[C_NEED_MC] || c[C_ERR_POT] || (i64)c[C_NPAIRS] > S->spec_np || (i64)c[C_NVTOT] > S->spec_nvt || c[C_ERR_ARENA])
+      return STEP_RETRY_EXACT;
+    S->np = (i64)c[C_NPAIRS]; S->nvt = (i64)c[C_NVTOT]; S->N = (int)c[C_NEXT];
+  }
   if (convex && c[C_BIG] > 0) {
     // rings of 17-32 vertices: the fast path again, on the larger block; its leftovers join the general kernel's list
     const i64 nb = (i64)c[C_BIG];
@@ -812,6 +829,11 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   return SZ_OK;
 }
 
+// capacities of the next speculative step: this step's counts and a margin
+static void spec_caps(StepState *S) {
+  S->spec_np = S->np + S->np / 4 + 1024;
+  S->spec_nvt = S->nvt + S->nvt / 4 + 16384;
+}
 static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
   int rc;
   if ((rc = step_back_a(ctx, S))) return rc;
@@ -825,9 +847,25 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStep: no floes uploaded");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
+  // Steady state: the front stages and the narrow phase are queued back to back, sized by the last step's counts plus
+  // a margin, and validated at the one read-back after the narrow phase (one host round trip fewer per step).
+  if (S->spec_np > 0 && !S->no_speculation && S->convex_fast && !S->fast_path) {
+    if ((rc = step_front(ctx, S, hp, true))) return rc;
+    rc = step_narrow(ctx, S, 0, S->spec_np);
+    if (rc != STEP_RETRY_EXACT) {
+      if (rc) return rc;
+      rc = step_back(ctx, S, stats);
+      if (!rc) spec_caps(S);
+      return rc;
+    }
+    S->counters_clean = false;
+    ++S->spec_misses;
+  }
   if ((rc = step_front(ctx, S, hp))) return rc;
   if ((rc = step_narrow(ctx, S, 0, S->np))) return rc;
-  return step_back(ctx, S, stats);
+  rc = step_back(ctx, S, stats);
+  if (!rc) spec_caps(S);
+  return rc;
 }
 
 // ---- sharded form: Begin (front + my segment of the narrow-phase) / Export / Finish (import all + back) ----

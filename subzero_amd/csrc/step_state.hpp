@@ -62,6 +62,8 @@ struct StepState {
   i64 last_npairs = 0, last_nrows_real = 0;
   int last_next = 0;
   bool stepped = false;
+  bool speculating = false, no_speculation = false;   // szStep queues front + narrow phase without the read-back in between
+  i64 spec_np = 0, spec_nvt = 0, spec_misses = 0;     // ... sized by these capacities (0: no previous step to size from)
   bool counters_clean = false;    // the last step ended by resetting the device counters (k_publish with reset)
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
