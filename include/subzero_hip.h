@@ -293,6 +293,15 @@ int64_t szShardForcingBytes(szContext *ctx, int world);
 int szStepShardForcing(szContext *ctx, void *d_send);
 int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats);
 
+/* ---- calc_eulerian_data.m:1-192 on the device-resident floes -----------------------------------
+ * Mass-weighted averages of the floe fields over the Nx x Ny grid of the domain box; floe-cell overlaps are clipped on
+ * the GPU (ring against rectangle).  out: 18 fields of Ny x Nx doubles each, MATLAB column-major (element (jj, ii) at
+ * jj + Ny * ii, jj counted from the top row as calc_eulerian_data.m:75 flips y), in the order
+ *   u v du dv stress stressxx stressyx stressxy stressyy strainux strainvx strainuy strainvy c Over Mtot area h
+ * (the fields of the struct the reference returns).  Nb must be 0: cells with topography subtracted (:10-24,:139-141)
+ * are not provided.  kernel_ms (may be NULL): HIP-event time of the cell kernel. */
+int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const double *c2_boundary, int periodic, double *out, double *kernel_ms);
+
 /* ---- multi-GPU, spatial partition (BASELINE north_star): floes owned by x-strips of the domain, one
  * neighbour exchange of halo floes per step --------------------------------------------------------------------
  * Every rank uploads the same array (szFloesUpload) and keeps it at its global size and index; after szSpatialInit

@@ -1026,3 +1026,150 @@ int or_step(OrFloes *F, const OrParams *P, int32_t *inter_off, double *inter, in
 }
 
 } // extern "C"
+
+// =================================================================================================
+// calc_eulerian_data.m:1-192.  area(intersect(box, poly)) is a MathWorks polyshape operation; by its
+// definition: the ring cut down to the rectangle, half-plane by half-plane (x >= xl, x <= xh, y >= yl, y <= yh), and
+// the |shoelace| of the result relative to its first vertex.  Written here with explicit vertex lists per stage (the
+// device streams the same stages without buffers); tests pin it against the reference Clipper's 'int' of the same
+// ring and rectangle.  Nb > 0 (boundaries subtracted from the box, :10-24,:139-141) is not restated: returns -3.
+namespace {
+void clip_half_plane(const Vec &xi, const Vec &yi, int k, double bound, Vec &xo, Vec &yo) {
+  xo.clear(); yo.clear();
+  const size_t n = xi.size();
+  if (n == 0) return;
+  auto inside = [&](double x, double y) { return k == 0 ? x >= bound : k == 1 ? x <= bound : k == 2 ? y >= bound : y <= bound; };
+  // edges in the order v0->v1, v1->v2, ..., v(n-1)->v0: the first vertex is emitted last
+  for (size_t q = 0; q < n; ++q) {
+    const double ax = xi[q], ay = yi[q], bx = xi[(q + 1) % n], by = yi[(q + 1) % n];
+    const bool ia = inside(ax, ay), ib = inside(bx, by);
+    if (ia != ib) {
+      double x, y;
+      if (k < 2) { double t = (bound - ax) / (bx - ax); x = bound; y = ay + t * (by - ay); }
+      else { double t = (bound - ay) / (by - ay); y = bound; x = ax + t * (bx - ax); }
+      xo.push_back(x); yo.push_back(y);
+    }
+    if (ib) { xo.push_back(bx); yo.push_back(by); }
+  }
+}
+double ring_box_area(const Vec &x, const Vec &y, double xl, double xh, double yl, double yh) {
+  Vec ax = x, ay = y, bx, by;
+  const double bounds[4] = {xl, xh, yl, yh};
+  for (int k = 0; k < 4; ++k) { clip_half_plane(ax, ay, k, bounds[k], bx, by); ax.swap(bx); ay.swap(by); }
+  const int n = (int)ax.size();
+  if (n == 0) return 0.0;
+  double s = 0;
+  for (int i = 0; i < n; ++i) {   // every vertex after the first against its predecessor, then the closing edge
+    const int p = i, c = (i + 1) % n;
+    const double px = ax[p] - ax[0], py = ay[p] - ay[0], cx = ax[c] - ax[0], cy = ay[c] - ay[0];
+    s += px * cy - cx * py;
+  }
+  return fabs(0.5 * s);
+}
+} // namespace
+
+extern "C" double or_ring_box_area(const double *x, const double *y, int n, double xl, double xh, double yl, double yh) {
+  return ring_box_area(Vec(x, x + n), Vec(y, y + n), xl, xh, yl, yh);
+}
+
+// out: 18 fields of Ny x Nx (MATLAB column-major: element (jj, ii) at jj + Ny * ii), in the order
+// u v du dv stress stressxx stressyx stressxy stressyy strainux strainvx strainuy strainvy c Over Mtot area h
+extern "C" int or_eulerian(const OrFloes *F, int Nx, int Ny, int Nb, const double *c2b, int PERIODIC, double *out) {
+  if (Nb > 0) return -3;
+  const int N0 = F->n;
+  double Lx = c2b[0], Ly = c2b[1], xmin = c2b[0], ymin = c2b[1];
+  for (int k = 1; k < 5; ++k) { Lx = std::max(Lx, c2b[2 * k]); Ly = std::max(Ly, c2b[2 * k + 1]); xmin = std::min(xmin, c2b[2 * k]); ymin = std::min(ymin, c2b[2 * k + 1]); }
+  struct Ent { int src; double x, y; };
+  std::vector<Ent> E;
+  for (int i = 0; i < N0; ++i) if (F->alive[i]) { Ent e = {i, F->Xi[i], F->Yi[i]}; E.push_back(e); }   // :7-8
+  auto sgn = [](double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+  auto extent = [&](const Ent &e, int dim) {
+    int v0 = F->vert_off[e.src], nv = F->vert_off[e.src + 1] - v0;
+    double m = 0;
+    for (int k = 0; k < nv; ++k) m = std::max(m, fabs(dim == 0 ? F->cax[v0 + k] + e.x : F->cay[v0 + k] + e.y));
+    return m;
+  };
+  if (PERIODIC && !E.empty()) {
+    const int n1 = (int)E.size();
+    for (int i = 0; i < n1; ++i)                                             // :41-50
+      if (extent(E[i], 0) > Lx) { Ent g = E[i]; g.x = E[i].x - 2 * Lx * sgn(E[i].x); E.push_back(g); }
+    // :58-67 -- as shipped the test reads `poly`, which still holds the LAST floe of the first loop: every live entry
+    // (or none) gets a Y image
+    const bool all = extent(E[n1 - 1], 1) > Ly;
+    const int n2 = (int)E.size();
+    if (all) for (int i = 0; i < n2; ++i) { Ent g = E[i]; g.y = E[i].y - 2 * Ly * sgn(E[i].y); E.push_back(g); }
+  }
+  const int M = (int)E.size();
+  Vec xg(Nx + 1), yg(Ny + 1);
+  const double stepx = (Lx - xmin) / Nx, stepy = (Ly - ymin) / Ny;
+  for (int k = 0; k <= Nx; ++k) xg[k] = xmin + k * stepx;                  // :73 (colon operator: start + k * step)
+  for (int k = 0; k <= Ny; ++k) yg[Ny - k] = ymin + k * stepy;             // :74-75 fliplr
+  xg[Nx] = Lx; yg[0] = Ly;                                                 // (the colon operator ends on the upper limit)
+  const double dx = fabs(xg[1] - xg[0]), dy = fabs(yg[1] - yg[0]);
+  const double r_max = sqrt((dx / 2) * (dx / 2) + (dy / 2) * (dy / 2));
+  const size_t cells = (size_t)Nx * Ny;
+  for (size_t k = 0; k < 18 * cells; ++k) out[k] = 0.0;
+  auto nz = [](double v) { return v != v ? 0.0 : v; };
+  for (int ii = 0; ii < Nx; ++ii) {
+    for (int jj = 0; jj < Ny; ++jj) {
+      const double xc = 0.5 * (xg[ii] + xg[ii + 1]), yc = 0.5 * (yg[jj] + yg[jj + 1]);
+      std::vector<int> live;
+      double Mpre = 0;
+      for (int e = 0; e < M; ++e) {                                        // :122-128
+        double ddx = xc - E[e].x, ddy = yc - E[e].y;
+        double pint = sqrt(ddx * ddx + ddy * ddy) - (F->rmax[E[e].src] + r_max);
+        if (pint < 0) { live.push_back(e); Mpre += F->mass[E[e].src]; }
+      }
+      if (!(Mpre > 0)) continue;                                           // :136-137
+      const double xl = xg[ii], xh = xg[ii + 1], yh = yg[jj], yl = yg[jj + 1];
+      double bxs[4] = {xl, xl, xh, xh}, bys[4] = {yh, yl, yl, yh};         // :140 bound
+      const double abox = ring_area(bxs, bys, 4);
+      std::vector<int> fn; Vec Aover;
+      for (size_t q = 0; q < live.size(); ++q) {
+        const Ent &en = E[live[q]];
+        int v0 = F->vert_off[en.src], nv = F->vert_off[en.src + 1] - v0;
+        if (nv > 1 && F->cax[v0] == F->cax[v0 + nv - 1] && F->cay[v0] == F->cay[v0 + nv - 1]) --nv;   // polyshape drops the closing copy
+        Vec rx(nv), ry(nv);
+        for (int k = 0; k < nv; ++k) { rx[k] = F->cax[v0 + k] + en.x; ry[k] = F->cay[v0 + k] + en.y; }
+        double a = ring_box_area(rx, ry, xl, xh, yl, yh);
+        if (a != 0) { fn.push_back(live[q]); Aover.push_back(a); }          // :150-151
+      }
+      double Mtot = 0, Atot = 0;
+      for (size_t q = 0; q < fn.size(); ++q) {
+        const int s = E[fn[q]].src;
+        Mtot += nz(F->mass[s]) * Aover[q] / nz(F->area[s]);                 // :153
+        Atot += Aover[q];
+      }
+      const size_t at = (size_t)jj + (size_t)Ny * ii;
+      out[13 * cells + at] = Atot / abox;                                   // c
+      if (!(Mtot > 0)) continue;
+      double sOver = 0;
+      for (size_t q = 0; q < fn.size(); ++q) sOver += F->OverlapArea[E[fn[q]].src];
+      out[14 * cells + at] = sOver / (double)fn.size();
+      out[15 * cells + at] = Mtot;
+      out[16 * cells + at] = Atot;
+      auto wavg = [&](const double *field, int stride, int comp) {
+        double s = 0;
+        for (size_t q = 0; q < fn.size(); ++q) {
+          const int src = E[fn[q]].src;
+          s += nz(field[(size_t)stride * src + comp]) * nz(F->mass[src]) * Aover[q] / nz(F->area[src]);
+        }
+        return s / Mtot;
+      };
+      out[17 * cells + at] = wavg(F->h, 1, 0);
+      out[0 * cells + at] = wavg(F->Ui, 1, 0); out[1 * cells + at] = wavg(F->Vi, 1, 0);
+      out[2 * cells + at] = wavg(F->dUi_p, 1, 0); out[3 * cells + at] = wavg(F->dVi_p, 1, 0);
+      // Stress(1,1) Stress(1,2) Stress(2,1) Stress(2,2) of the column-major 2 x 2: elements 0, 2, 1, 3
+      const double sxx = wavg(F->Stress, 4, 0), syx = wavg(F->Stress, 4, 2), sxy = wavg(F->Stress, 4, 1), syy = wavg(F->Stress, 4, 3);
+      out[5 * cells + at] = sxx; out[6 * cells + at] = syx; out[7 * cells + at] = sxy; out[8 * cells + at] = syy;
+      out[9 * cells + at] = wavg(F->strain, 4, 0); out[10 * cells + at] = wavg(F->strain, 4, 2);
+      out[11 * cells + at] = wavg(F->strain, 4, 1); out[12 * cells + at] = wavg(F->strain, 4, 3);
+      // max(eig([sxx syx; sxy syy])): the larger root of the characteristic polynomial
+      const double tr = 0.5 * (sxx + syy), df = 0.5 * (sxx - syy);
+      double ev = tr + sqrt(df * df + syx * sxy);
+      if (fabs(ev) > 1e8) ev = 0;
+      out[4 * cells + at] = ev;
+    }
+  }
+  return 0;
+}

@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
+    "szEulerianData", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -348,6 +348,19 @@ class FloeInteractions:
         self.ctx.check(self.ctx.L.szFloesResync(self.ctx.h, ctypes.byref(c), src.ctypes.data_as(_ip)), "szFloesResync")
         self.floes, self._c = floes, c
         self._packer = ParamPacker()
+
+    EULERIAN_FIELDS = ["u", "v", "du", "dv", "stress", "stressxx", "stressyx", "stressxy", "stressyy", "strainux", "strainvx",
+                       "strainuy", "strainvy", "c", "Over", "Mtot", "area", "h"]
+
+    def eulerian_data(self, Nx, Ny, Nb, c2_boundary, periodic):
+        """calc_eulerian_data.m on the device-resident floes -> ({field: (Ny, Nx) array}, kernel ms)."""
+        cb = np.ascontiguousarray(np.asarray(c2_boundary, np.float64).T.ravel())
+        out = np.zeros((18, Nx, Ny))        # [field][ii][jj]: column-major Ny x Nx per field
+        ms = ctypes.c_double()
+        self.ctx.L.szEulerianData.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp]
+        self.ctx.check(self.ctx.L.szEulerianData(self.ctx.h, Nx, Ny, Nb, cb.ctypes.data_as(_dp), int(periodic),
+                                                 out.ctypes.data_as(_dp), ctypes.byref(ms)), "szEulerianData")
+        return {k: out[q].T.copy() for q, k in enumerate(self.EULERIAN_FIELDS)}, ms.value
 
     def ghosts(self):
         """(src, parent, Xi, Yi) of the ghost floes of the last step; ghost g is Floe(n + g + 1) of the extended list."""

@@ -200,3 +200,28 @@ def floe_interactions(c1, s1, c2, s2, boundary, c2_boundary, periodic, modulus, 
     if n < 0:
         raise RuntimeError("or_floe_interactions failed: %d" % n)
     return f[:n], pc[:n], ov[:n]
+
+
+EULERIAN_FIELDS = ["u", "v", "du", "dv", "stress", "stressxx", "stressyx", "stressxy", "stressyy", "strainux", "strainvx",
+                   "strainuy", "strainvy", "c", "Over", "Mtot", "area", "h"]
+
+
+def eulerian_data(S, Nx, Ny, Nb, c2_boundary, periodic):
+    """calc_eulerian_data.m restated (oracle): {field: (Ny, Nx) array}."""
+    L = lib()
+    cb = np.ascontiguousarray(np.asarray(c2_boundary, np.float64).T.ravel())
+    out = np.zeros((18, Nx, Ny))
+    L.or_eulerian.argtypes = [ctypes.POINTER(CFloes), ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp]
+    cf = pack_floes(S)
+    rc = L.or_eulerian(ctypes.byref(cf), Nx, Ny, Nb, _p(cb), int(periodic), _p(out))
+    if rc != 0:
+        raise RuntimeError("or_eulerian failed: %d" % rc)
+    return {k: out[q].T.copy() for q, k in enumerate(EULERIAN_FIELDS)}
+
+
+def ring_box_area(x, y, xl, xh, yl, yh):
+    L = lib()
+    L.or_ring_box_area.restype = ctypes.c_double
+    L.or_ring_box_area.argtypes = [_dp, _dp, ctypes.c_int] + [ctypes.c_double] * 4
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    return L.or_ring_box_area(_p(x), _p(y), len(x), xl, xh, yl, yh)
