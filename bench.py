@@ -11,8 +11,10 @@ One JSON line on stdout (rank 0).  `value` is floe-timesteps/s with all inputs r
                  pair) priced by the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per ring vertex of both rings +
                  2 x 56 B of body scalars + 56 B per contact row) over its HIP-event duration, against the
                  8 TB/s HBM3E peak.  The kernel is bound by the issue rate and latency of divergent int64/FP64
-                 code (one pair per lane), not by HBM: the fraction is reported as computed.  `traffic` is the
-                 PMC figure of profiles/r01_pmc_narrow.json (same command under rocprofv3 --pmc).
+                 code (one pair per lane), not by HBM: the fraction is reported as computed ("limiter" says so).
+                 `traffic` is the PMC figure of THIS round's profile of the same command
+                 (profiles/r02_pmc_narrow.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes); null
+                 when that file is absent -- a bench run cannot collect PMC counters by itself.
   cpu_baseline : the CPU oracle (C++ restatement of the MATLAB path around the reference's own Clipper)
                  on the host cores, a bounded sample of the same workload.  TEST INFRASTRUCTURE timed as a
                  baseline only; the product path never calls it.
@@ -128,15 +130,20 @@ def main():
 
     off, inter = sim.interactions()
     collisions = capi.collision_count(inter)
+    if np.isinf(inter[:, 0]).any():
+        raise SystemExit("bench: boundary rows in a periodic workload")
+    # calc_collisionNum.m:6 summed over the timed steps: without boundary rows every collision is two rows
+    collisions_timed = rows / 2.0
     sim.download(capi.SYNC_ALL)
 
     k = args.steps
     achieved = (pair_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_narrow.json")
+    traffic = traffic_src = None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_narrow.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/r02_pmc_narrow.json"
         except Exception:
             traffic = None
     out = {
@@ -148,13 +155,14 @@ def main():
                                "collisions + ocean drag (forcing refreshed every 10th step)" % (S.n, S.n),
                    "floes": int(S.n), "floes_per_gpu": int(S.n), "parallelism": "1 GPU"},
         "timesteps_per_s": k / el,
-        "contact_pairs_per_s": collisions * k / el,
+        "contact_pairs_per_s": collisions_timed / el,
         "candidate_pairs_per_s": pairs / el,
         "contact_rows_last_step": int(len(inter)), "collisions_last_step": collisions,
         "device_ms_per_step": dev_ms / k,
         "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (pair interaction: clip + contact force, first pass over all pairs)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "limiter": "issue rate and latency of divergent int64/FP64 code (one pair per lane), not HBM",
                      "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
     }
     if not args.no_cpu_baseline:

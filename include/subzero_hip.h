@@ -302,6 +302,22 @@ int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats);
  * are not provided.  kernel_ms (may be NULL): HIP-event time of the cell kernel. */
 int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const double *c2_boundary, int periodic, double *out, double *kernel_ms);
 
+/* ---- corner grinding, the per-vertex decision: Physical_Processes/corners.m:13-92 ---------------
+ * Call after a step, for the floes the driver selected (Subzero.m:339-348: Floe(~keep)); ids[q] is the 1-based number
+ * of the q-th of them in the floe array, in ascending order as Floe(~keep) lists them.  For each, from the contact
+ * rows of that step and the positions after it:
+ *   count[q]   number of vertices considered (0: not eligible -- q < Nb, as the loop of :55 starts at 1+Nb of the
+ *              SUBSET, or no contact row, :56)
+ *   angles     interior angles in degrees (polygon_operations/polyangles.m), count[q] values from angles[offsets[q]]
+ *   da         1 where the vertex lies in a partner's outline / outside c2_boundary or is nearest to a contact point
+ *              (:72-88), at the same offsets
+ * The caller completes :70-71,91 with its own random stream, in the order of q over the eligible floes:
+ *   Anorm = 180 - 360/count;  grind = (rand(count,1) > angles/Anorm) & da;  sum(grind) > 1 -> frac_corner (MATLAB side).
+ * offsets[nsub+1] is filled from the stored outline lengths; cap = room of angles / da in vertices (SZ_ERR_CAPACITY when
+ * short).  n_ext (may be NULL): length of the extended list Floe0 the partner numbers were resolved in. */
+int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, int Nb, const double *c2_boundary, int32_t *offsets, int32_t *count,
+                       double *angles, uint8_t *da, int64_t cap, int32_t *n_ext, double *kernel_ms);
+
 /* ---- multi-GPU, spatial partition (BASELINE north_star): floes owned by x-strips of the domain, one
  * neighbour exchange of halo floes per step --------------------------------------------------------------------
  * Every rank uploads the same array (szFloesUpload) and keeps it at its global size and index; after szSpatialInit

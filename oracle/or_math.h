@@ -12,6 +12,7 @@
  */
 #ifndef OR_MATH_H
 #define OR_MATH_H
+#include <math.h>   /* sqrt only */
 
 static inline double orm_abs(double v) { return v < 0 ? -v : v; }
 
@@ -132,6 +133,14 @@ static inline double orm_atan2(double y, double x) {
   double z = orm_atan_pos(ay / ax);
   if (x < 0) z = pi - (z - pi_lo);
   return y < 0 ? -z : z;
+}
+
+/* real part of acos(a) for any real a (MATLAB's acos is complex outside [-1, 1]: real part 0 or pi) */
+static inline double orm_acos_real(double a) {
+  if (a != a) return a;
+  if (a >= 1.0) return 0.0;
+  if (a <= -1.0) return 3.14159265358979311600e+00;
+  return orm_atan2(sqrt((1.0 - a) * (1.0 + a)), a);
 }
 
 #endif /* OR_MATH_H */

@@ -1173,3 +1173,145 @@ extern "C" int or_eulerian(const OrFloes *F, int Nx, int Ny, int Nb, const doubl
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Corner grinding up to the `grind` decision: Physical_Processes/corners.m:13-92 with
+// polygon_operations/polyangles.m:1-173.  The uniform draws of :71 belong to the caller (the selection of Subzero.m:
+// 339-348 and `break1` are applied in the tests with numpy's generator on both sides).  polyshape(...).Vertices is taken
+// as the stored outline without its closing copy (floe outlines come out of polyshape: clockwise, no repeats; dupgone
+// of polyangles.m:162-173 then removes nothing).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+double t_acos_real(double a) {
+  if (g_mode & 1) { if (a != a) return a; return a >= 1 ? 0.0 : (a <= -1 ? M_PI : acos(a)); }
+  return orm_acos_real(a);
+}
+
+// polyangles.m:136-159
+void pa_polyedge(double x1, double y1, double x2, double y2, double w[3]) {
+  if (x1 == x2) { w[1] = 0; w[0] = -1 / x1; w[2] = 1; }
+  else if (y1 == y2) { w[0] = 0; w[1] = -1 / y1; w[2] = 1; }
+  else if (x1 == y1 && x2 == y2) { w[0] = 1; w[1] = 1; w[2] = 0; }
+  else {
+    w[0] = (y1 - y2) / (x1 * (y2 - y1) - y1 * (x2 - x1) + EPS);
+    w[1] = -w[0] * (x2 - x1) / (y2 - y1);
+    w[2] = 1;
+  }
+}
+
+// polyangles.m:13-54 for a ring given without its closing copy
+Vec polyangles(const Vec &x, const Vec &y) {
+  const int n = (int)x.size();
+  Vec ang(n);
+  if (n == 0) return ang;
+  Vec cx = x, cy = y;                                  // :21-24 close the polygon
+  cx.push_back(x[0]); cy.push_back(y[0]);
+  Vec dx(n), dy(n);                                    // :27 d = diff(xy)
+  for (int k = 0; k < n; ++k) { dx[k] = cx[k + 1] - cx[k]; dy[k] = cy[k + 1] - cy[k]; }
+  Vec raw(n);
+  for (int k = 0; k < n; ++k) {
+    const int k2 = (k + 1) % n;                        // :29 v2 = [d(2:end,:); d(1,:)]
+    const double v1x = -dx[k], v1y = -dy[k], v2x = dx[k2], v2y = dy[k2];
+    const double dot = v1x * v2x + v1y * v2y;          // :30
+    double m1 = sqrt(v1x * v1x + v1y * v1y), m2 = sqrt(v2x * v2x + v2y * v2y);
+    if (m1 == 0) m1 = EPS;                             // :37-38
+    if (m2 == 0) m2 = EPS;
+    raw[k] = t_acos_real(dot / m1 / m2) * 180 / M_PI;  // :39
+  }
+  for (int k = 0; k < n; ++k) ang[(k + 1) % n] = raw[k];   // :44 circshift
+  // :57-133 convex_angle_test; sgn(1) = 1
+  const double L = 1e25;
+  for (int k = 1; k < n; ++k) {                        // k = 2 : length(xy) - 1, 1-based
+    const double fx = cx[k - 1], fy = cy[k - 1], sx = cx[k], sy = cy[k], tx = cx[k + 1], ty = cy[k + 1];
+    double w[3];
+    pa_polyedge(fx, fy, sx, sy, w);
+    const double ddx = sx - fx, ddy = sy - fy;
+    double e[3] = {0, 0, 1};
+    if (ddx <= 0 && ddy >= 0) { e[0] = L; e[1] = L; }
+    else if (ddx <= 0 && ddy <= 0) { e[0] = -L; e[1] = L; }
+    else if (ddx >= 0 && ddy <= 0) { e[0] = -L; e[1] = -L; }
+    else { e[0] = L; e[1] = -L; }
+    const double vp = w[0] * e[0] + w[1] * e[1] + w[2] * e[2];
+    const double s = vp > 0 ? 1.0 : (vp < 0 ? -1.0 : vp);
+    for (int q = 0; q < 3; ++q) w[q] = s * w[q];
+    if (w[0] * tx + w[1] * ty + w[2] < 0) ang[k] = 360 - ang[k];   // :53-54,130-132
+  }
+  return ang;
+}
+
+} // namespace
+
+extern "C" void or_polyangles(const double *x, const double *y, int n, double *out) {
+  Vec a = polyangles(Vec(x, x + n), Vec(y, y + n));
+  for (int k = 0; k < n; ++k) out[k] = a[k];
+}
+
+// ids[q]: 1-based floe numbers of Floe(~keep); inter_off / inter: the floes' contact rows (7 columns, CSR), as the step
+// left them.  offsets[nsub + 1], count[nsub], angles / da at the offsets (stored outline lengths back to back).
+extern "C" int or_corner_candidates(const OrFloes *F, const int *inter_off, const double *inter, const int *ids, int nsub, int Nb,
+                                    const double *c2b, int *offsets, int *count, double *angles, uint8_t *da, int *n_ext) {
+  const int n = F->n;
+  double Lx = c2b[0], Ly = c2b[1];
+  for (int k = 1; k < 5; ++k) { Lx = std::max(Lx, c2b[2 * k]); Ly = std::max(Ly, c2b[2 * k + 1]); }
+  struct Ent { int src; double x, y; int alive; };
+  std::vector<Ent> E;
+  for (int i = 0; i < n; ++i) { Ent e = {i, F->Xi[i], F->Yi[i], F->alive[i]}; E.push_back(e); }
+  auto sgn = [](double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+  auto extent = [&](const Ent &e, int dim) {
+    int v0 = F->vert_off[e.src], nv = F->vert_off[e.src + 1] - v0;
+    double m = 0;
+    for (int k = 0; k < nv; ++k) m = std::max(m, fabs(dim == 0 ? F->cax[v0 + k] + e.x : F->cay[v0 + k] + e.y));
+    return m;
+  };
+  for (int i = 0; i < n; ++i)                                                   // :21-30
+    if (E[i].alive && extent(E[i], 0) > Lx) { Ent g = E[i]; g.x = E[i].x - 2 * Lx * sgn(E[i].x); E.push_back(g); }
+  const int n2 = (int)E.size();
+  for (int i = 0; i < n2; ++i)                                                  // :38-47
+    if (E[i].alive && extent(E[i], 1) > Ly) { Ent g = E[i]; g.y = E[i].y - 2 * Ly * sgn(E[i].y); E.push_back(g); }
+  const int N0 = (int)E.size();                                                 // :52
+  if (n_ext) *n_ext = N0;
+  Vec bx(5), by(5);
+  for (int k = 0; k < 5; ++k) { bx[k] = c2b[2 * k]; by[k] = c2b[2 * k + 1]; }
+  int at = 0;
+  for (int q = 0; q < nsub; ++q) {
+    const int i = ids[q] - 1;
+    const int v0 = F->vert_off[i], nvs = F->vert_off[i + 1] - v0;
+    offsets[q] = at; at += nvs;
+    count[q] = 0;
+    const int r0 = inter_off[i], r1 = inter_off[i + 1];
+    if (q < Nb || r1 == r0) continue;                                           // :55-56
+    int nv = nvs;
+    if (nv > 1 && F->cax[v0] == F->cax[v0 + nv - 1] && F->cay[v0] == F->cay[v0 + nv - 1]) --nv;   // :66-68
+    Vec px(F->cax + v0, F->cax + v0 + nv), py(F->cay + v0, F->cay + v0 + nv);
+    Vec ang = polyangles(px, py);                                               // :69
+    Vec tx(nv), ty(nv);                                                         // :64 polytrue
+    for (int k = 0; k < nv; ++k) { tx[k] = px[k] + F->Xi[i]; ty[k] = py[k] + F->Yi[i]; }
+    std::vector<int> in(nv, 0), flag(nv, 0);
+    bool bnd = false;
+    for (int r = r0; r < r1; ++r) {
+      const double partner = inter[7 * r];
+      if (std::isinf(partner)) { bnd = true; continue; }                        // :75-76
+      if (!(partner <= N0)) continue;                                           // :77
+      const Ent &e = E[(int)partner - 1];
+      const int p0 = F->vert_off[e.src], pn = F->vert_off[e.src + 1] - p0;
+      Vec cx(pn), cy(pn);
+      for (int k = 0; k < pn; ++k) { cx[k] = F->cax[p0 + k] + e.x; cy[k] = F->cay[p0 + k] + e.y; }   // :79
+      for (int k = 0; k < nv; ++k) in[k] += inpolygon1(tx[k], ty[k], cx, cy) ? 1 : 0;               // :80-81
+      // :60-61,73,88 the vertex nearest to the contact point
+      int best = 0; double bd = 0;
+      for (int k = 0; k < nv; ++k) {
+        const double ddx = tx[k] - inter[7 * r + 3], ddy = ty[k] - inter[7 * r + 4];
+        const double d = ddx * ddx + ddy * ddy;
+        if (k == 0 || d < bd) { bd = d; best = k; }
+      }
+      flag[best] = 1;
+    }
+    if (bnd) for (int k = 0; k < nv; ++k) in[k] += inpolygon1(tx[k], ty[k], bx, by) ? 0 : 1;        // :83-86
+    for (int k = 0; k < nv; ++k) if (in[k] > 0) flag[k] = 1;                   // :87
+    count[q] = nv;
+    for (int k = 0; k < nv; ++k) { angles[offsets[q] + k] = ang[k]; da[offsets[q] + k] = (uint8_t)flag[k]; }
+  }
+  offsets[nsub] = at;
+  return 0;
+}

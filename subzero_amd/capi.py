@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szEulerianData", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
+    "szEulerianData", "szCornerCandidates", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -361,6 +361,26 @@ class FloeInteractions:
         self.ctx.check(self.ctx.L.szEulerianData(self.ctx.h, Nx, Ny, Nb, cb.ctypes.data_as(_dp), int(periodic),
                                                  out.ctypes.data_as(_dp), ctypes.byref(ms)), "szEulerianData")
         return {k: out[q].T.copy() for q, k in enumerate(self.EULERIAN_FIELDS)}, ms.value
+
+    def corner_candidates(self, ids, Nb, c2_boundary):
+        """corners.m:13-92 for the floes ids (1-based, in Floe(~keep) order) on the contact rows of the last step ->
+        (offsets, count, angles, da, N0, kernel ms); see include/subzero_hip.h szCornerCandidates."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        nsub = len(ids)
+        vo = self.floes.vert_off
+        total = int(sum(int(vo[i]) - int(vo[i - 1]) for i in ids if 1 <= i <= self.floes.n))
+        offsets = np.zeros(nsub + 1, np.int32); count = np.zeros(max(nsub, 1), np.int32)
+        ang = np.zeros(total + 1); da = np.zeros(total + 1, np.uint8)
+        n_ext = ctypes.c_int32(); ms = ctypes.c_double()
+        cb = np.ascontiguousarray(np.asarray(c2_boundary, np.float64).T.ravel())
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        self.ctx.L.szCornerCandidates.argtypes = [_vp, _ip, ctypes.c_int, ctypes.c_int, _dp, _ip, _ip, _dp, u8, ctypes.c_int64,
+                                                  _ip, _dp]
+        self.ctx.check(self.ctx.L.szCornerCandidates(self.ctx.h, ids.ctypes.data_as(_ip), nsub, int(Nb), cb.ctypes.data_as(_dp),
+                                                     offsets.ctypes.data_as(_ip), count.ctypes.data_as(_ip), ang.ctypes.data_as(_dp),
+                                                     da.ctypes.data_as(u8), total, ctypes.byref(n_ext), ctypes.byref(ms)),
+                       "szCornerCandidates")
+        return offsets, count[:nsub], ang[:total], da[:total], n_ext.value, ms.value
 
     def ghosts(self):
         """(src, parent, Xi, Yi) of the ghost floes of the last step; ghost g is Floe(n + g + 1) of the extended list."""

@@ -131,4 +131,12 @@ SZ_HD double atan2(double y, double x) {
   return y < 0 ? -z : z;
 }
 
+// real(acos(a)) for any real a (MATLAB returns a complex value outside [-1, 1]; its real part is 0 or pi)
+SZ_HD double acos_real(double a) {
+  if (a != a) return a;
+  if (a >= 1.0) return 0.0;
+  if (a <= -1.0) return 3.14159265358979311600e+00;
+  return atan2(::sqrt((1.0 - a) * (1.0 + a)), a);
+}
+
 } // namespace szm

@@ -440,12 +440,14 @@ def bench_main(args, rank, local_rank, world):
                                       "(ring), border pairs evaluated on both sides" % world},
             "timesteps_per_s": k / el,
             "contact_pairs_per_s": st["collisions_last_step"] * k / el,
+            "contact_pairs_basis": "collisions of the last timed step (owned floes, summed over ranks) x steps / time",
             "candidate_pairs_evaluated_per_s": st["pairs_evaluated"] / el,
             "spatial": {k2: st[k2] for k2 in ("owned_floes_rank0", "present_floes_max", "bytes_sent_per_rank_step_max", "halo_m")},
             "strong_scaling": strong,
             "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (rank 0's pairs)",
                          "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None,
+                         "limiter": "issue rate and latency of divergent int64/FP64 code (one pair per lane), not HBM",
                          "kernel_ms": st["narrow_ms"], "algorithmic_bytes_per_launch": st["pair_bytes"]},
         }
         print(json.dumps(out), flush=True)

@@ -225,3 +225,38 @@ def ring_box_area(x, y, xl, xh, yl, yh):
     L.or_ring_box_area.argtypes = [_dp, _dp, ctypes.c_int] + [ctypes.c_double] * 4
     x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
     return L.or_ring_box_area(_p(x), _p(y), len(x), xl, xh, yl, yh)
+
+
+def polyangles(x, y):
+    """polygon_operations/polyangles.m for a clockwise ring given without its closing copy (degrees)."""
+    L = lib()
+    L.or_polyangles.argtypes = [_dp, _dp, ctypes.c_int, _dp]
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    out = np.zeros(len(x))
+    L.or_polyangles(_p(x), _p(y), len(x), _p(out))
+    return out
+
+
+def corner_candidates(S, inter_off, inter, ids, Nb, c2_boundary):
+    """corners.m:13-92 restated (oracle) for the floes ids (1-based, Floe(~keep) order) ->
+    (offsets, count, angles, da, N0)."""
+    L = lib()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    L.or_corner_candidates.argtypes = [ctypes.POINTER(CFloes), ip, _dp, ip, ctypes.c_int, ctypes.c_int, _dp, ip, ip, _dp,
+                                       ctypes.POINTER(ctypes.c_uint8), ip]
+    cb = np.ascontiguousarray(np.asarray(c2_boundary, np.float64).T.ravel())
+    ids = np.ascontiguousarray(ids, np.int32)
+    off = np.ascontiguousarray(inter_off, np.int32)
+    rows = np.ascontiguousarray(inter, np.float64).reshape(-1, 7) if len(inter) else np.zeros((1, 7))
+    nsub = len(ids)
+    total = int(sum(S.vert_off[i] - S.vert_off[i - 1] for i in ids))
+    offsets = np.zeros(nsub + 1, np.int32); count = np.zeros(max(nsub, 1), np.int32)
+    ang = np.zeros(total + 1); da = np.zeros(total + 1, np.uint8)
+    n_ext = ctypes.c_int32()
+    cf = pack_floes(S)
+    rc = L.or_corner_candidates(ctypes.byref(cf), off.ctypes.data_as(ip), _p(rows), ids.ctypes.data_as(ip), nsub, Nb, _p(cb),
+                                offsets.ctypes.data_as(ip), count.ctypes.data_as(ip), _p(ang),
+                                da.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(n_ext))
+    if rc != 0:
+        raise RuntimeError("or_corner_candidates failed: %d" % rc)
+    return offsets, count[:nsub], ang[:total], da[:total], n_ext.value

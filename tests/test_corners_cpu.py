@@ -1,0 +1,124 @@
+"""Corner grinding up to the `grind` decision (corners.m:13-92, polyangles.m): the oracle's restatement
+against known answers and against an independent numpy evaluation, and the host-side selection rule."""
+import numpy as np
+
+import oracle
+import scenes
+from subzero_amd import corners
+
+
+def test_polyangles_known_answers():
+    # clockwise square, clockwise regular polygons: every interior angle 180 - 360/n
+    sq = np.array([[0, 0], [0, 2], [2, 2], [2, 0]], float)
+    assert np.allclose(oracle.polyangles(sq[:, 0], sq[:, 1]), 90.0, atol=1e-12)
+    for n in (3, 5, 8, 13):
+        t = -2 * np.pi * np.arange(n) / n + 0.3
+        a = oracle.polyangles(7 * np.cos(t) + 1.5, 7 * np.sin(t) - 2.5)
+        assert np.allclose(a, 180.0 - 360.0 / n, atol=1e-10), (n, a)
+    # an L (clockwise from its lower-left corner): one reflex corner of 270 degrees
+    Lx = np.array([0, 0, 1, 1, 3, 3], float); Ly = np.array([0, 3, 3, 1, 1, 0], float)
+    a = oracle.polyangles(Lx, Ly)
+    assert np.allclose(a, [90, 90, 90, 270, 90, 90], atol=1e-10), a
+    assert abs(a.sum() - 180.0 * (len(a) - 2)) < 1e-9
+    # the routine's own assumption: the first vertex counts as convex whatever it is (polyangles.m:91)
+    a = oracle.polyangles(np.roll(Lx, -3), np.roll(Ly, -3))
+    assert abs(a[0] - 90.0) < 1e-10
+
+
+def test_polyangles_libm_mode_agrees():
+    rng = np.random.default_rng(5)
+    t = -np.sort(rng.uniform(0, 2 * np.pi, 11))
+    r = 30 + rng.uniform(-8, 8, 11)                       # star-shaped: simple, with reflex corners
+    k = int(np.argmax(r)); t = np.roll(t, -k); r = np.roll(r, -k)   # (start on a convex vertex: polyangles.m:91)
+    x, y = r * np.cos(t), r * np.sin(t)
+    a = oracle.polyangles(x, y)
+    with oracle.mode(oracle.MODE_LIBM):
+        b = oracle.polyangles(x, y)
+    assert np.abs(a - b).max() < 1e-11 and abs(a.sum() - 180.0 * 9) < 1e-8 and (a > 180).any()
+
+
+def _ray_inside(px, py, rx, ry):
+    """even-odd ray casting, written independently of inpolygon.m (vertices exactly on an edge are not exercised)"""
+    inside = False
+    n = len(rx)
+    for k in range(n):
+        xa, ya, xb, yb = rx[k], ry[k], rx[(k + 1) % n], ry[(k + 1) % n]
+        if (ya > py) != (yb > py) and px < (xb - xa) * (py - ya) / (yb - ya) + xa:
+            inside = not inside
+    return inside
+
+
+def _colliding(periodic):
+    S, P = scenes.pack(300, periodic=periodic)
+    P.set_reference_ocean()
+    S.Xi += 300.0
+    r = None
+    for it in range(6):
+        P.doInt = int(it % 5 == 0)
+        r = oracle.step(S, P, threads=8)
+    return S, P, r
+
+
+def test_candidates_against_an_independent_evaluation():
+    for periodic in (True, False):
+        S, P, r = _colliding(periodic)
+        ids = np.arange(1, S.n + 1, 3, dtype=np.int32)
+        off, cnt, ang, da, N0 = oracle.corner_candidates(S, r.inter_off, r.inter, ids, 0, P.c2_boundary)
+        assert N0 >= S.n and (N0 > S.n or not periodic)   # (corners.m makes images whatever PERIODIC says)
+        checked = flagged = 0
+        for q, fid in enumerate(ids):
+            i = fid - 1
+            rows = r.inter[r.inter_off[i]:r.inter_off[i + 1]]
+            if len(rows) == 0:
+                assert cnt[q] == 0
+                continue
+            v0, v1 = S.vert_off[i], S.vert_off[i + 1] - 1          # stored rings carry their closing copy
+            assert cnt[q] == v1 - v0
+            x, y = S.cax[v0:v1] + S.Xi[i], S.cay[v0:v1] + S.Yi[i]
+            want = np.zeros(v1 - v0, bool)
+            for row in rows:
+                if np.isinf(row[0]):
+                    c = np.asarray(P.c2_boundary)
+                    want |= ~((x >= c[0].min()) & (x <= c[0].max()) & (y >= c[1].min()) & (y <= c[1].max()))
+                    continue
+                if row[0] > S.n:
+                    continue                                      # images: covered by the GPU-vs-oracle test
+                j = int(row[0]) - 1
+                w0, w1 = S.vert_off[j], S.vert_off[j + 1] - 1
+                rx, ry = S.cax[w0:w1] + S.Xi[j], S.cay[w0:w1] + S.Yi[j]
+                want |= np.array([_ray_inside(a, b, rx, ry) for a, b in zip(x, y)])
+                want[np.argmin((x - row[3]) ** 2 + (y - row[4]) ** 2)] = True
+            got = da[off[q]:off[q] + cnt[q]] != 0
+            if any(row[0] > S.n and not np.isinf(row[0]) for row in rows):
+                assert not (want & ~got).any()                    # the images can only add flags
+            else:
+                assert np.array_equal(want, got), (fid, want, got)
+                checked += 1
+            flagged += got.sum()
+            a = ang[off[q]:off[q] + cnt[q]]
+            assert abs(a.sum() - 180.0 * (cnt[q] - 2)) < 1e-7      # interior angles of a simple polygon
+        assert checked > 20 and flagged > 20
+
+
+def test_selection_rule_and_grind_flags():
+    rng = np.random.default_rng(11)
+    N, Nb = 50, 3
+    u = rng.uniform(size=N)
+    area = rng.uniform(1e6, 2e6, N); over = area * rng.uniform(0, 0.3, N)
+    keep = corners.keep_mask(u, over, area, Nb)
+    assert keep[:Nb].all()
+    for k in range(Nb, N):
+        assert keep[k] == (u[k] > 0.7 and not over[k] / area[k] > 0.15)
+    keep2 = corners.keep_mask(u, over, area, Nb, min_floe_size=1.5e6)
+    assert keep2[area < 1.5e6].all()
+    # grind: two floes, the second not eligible
+    offsets = np.array([0, 5, 9]); count = np.array([4, 0])
+    angles = np.array([90.0, 60.0, 120.0, 90.0, 0.0, 0, 0, 0, 0]); da = np.array([1, 1, 0, 1, 0, 0, 0, 0, 0], np.uint8)
+    assert corners.draws_needed(count) == 4
+    anorm = 180.0 - 360.0 / 4
+    draws = np.array([0.99, 0.5, 0.99, 0.999999])
+    grind, frac = corners.grind_flags(offsets, count, angles, da, draws)
+    assert list(grind[:4]) == [bool(0.99 > 90 / anorm), False, False, bool(0.999999 > 90 / anorm)]
+    assert list(frac) == [False, False]
+    grind, frac = corners.grind_flags(offsets, count, np.array([30.0, 30, 30, 30, 0, 0, 0, 0, 0]), da, draws)
+    assert list(grind[:4]) == [True, True, False, True] and list(frac) == [True, False]
