@@ -27,6 +27,13 @@
 //       reference's lines :102-109 for those floes, subzero_step('update', Floe, needMC, 'm') and call 'step' again.
 //   Floe = subzero_step('fetch', Floe, ids, what)     what: any of 's' state, 'r' c0 / c_alpha, 'h' StressH, 'm' X, Y, A
 //   subzero_step('update', Floe, ids, what)           the same groups from Floe(ids) to the device (same ring lengths)
+//   C = subzero_step('corners', ids, Nb, c2_boundary)
+//       after a 'step': the per-vertex part of corners.m:13-92 for the floes Floe(ids) (ids = find(~keep), Subzero.m:
+//       341-348).  C(q).angles: interior angles (polyangles.m), C(q).da: the contact / inside flags of :72-88; both []
+//       for a floe the loop of :55-56 skips.  The caller draws `rand(n,1) > C(q).angles/Anorm` and calls frac_corner as
+//       before.
+//   eul = subzero_step('eulerian', Nx, Ny, Nb, c2_boundary, PERIODIC)
+//       calc_eulerian_data.m:1-192 on the resident floes: the struct of Ny x Nx fields the reference returns (Nb = 0).
 //   subzero_step('close')
 // The struct <-> struct-of-arrays marshalling below is the only work done on the MATLAB thread.
 #include "mex.h"
@@ -307,6 +314,46 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (what & SZ_F_RING) unpack_rings(plhs[0], g_soa, ids.data(), (int)ids.size(), true);
     unpack_bulk(plhs[0], g_soa, ids.data(), (int)ids.size(), (what & SZ_F_STRESSH) != 0, (what & SZ_F_MC) != 0);
     if ((what & SZ_F_STRESSH) && (int)ids.size() == n) g_history_ahead = false;
+    return;
+  }
+  if (!strcmp(cmd, "corners")) {
+    if (nrhs < 4) mexErrMsgTxt("C = subzero_step('corners', ids, Nb, c2_boundary)");
+    const std::vector<int32_t> ids = parse_ids(prhs[1], n);
+    const int nsub = (int)ids.size();
+    const double *cb = doubles(prhs[3], 10, "c2_boundary", -1);
+    int64_t cap = 0;
+    for (int q = 0; q < nsub; ++q) cap += g_soa.vert_off[ids[q]] - g_soa.vert_off[ids[q] - 1];
+    std::vector<int32_t> off((size_t)nsub + 1), cnt((size_t)nsub + 1);
+    std::vector<double> ang((size_t)cap + 1);
+    std::vector<uint8_t> da((size_t)cap + 1);
+    check(szCornerCandidates(g_ctx, ids.data(), nsub, (int)mxGetScalar(prhs[2]), cb, off.data(), cnt.data(), ang.data(), da.data(), cap, nullptr, nullptr));
+    const char *names[] = {"angles", "da"};
+    plhs[0] = mxCreateStructMatrix(1, (size_t)nsub, 2, names);
+    for (int q = 0; q < nsub; ++q) {
+      const int m = cnt[q];
+      mxArray *a = mxCreateDoubleMatrix((size_t)m, m ? 1 : 0, mxREAL), *d = mxCreateDoubleMatrix((size_t)m, m ? 1 : 0, mxREAL);
+      for (int k = 0; k < m; ++k) { mxGetPr(a)[k] = ang[(size_t)off[q] + k]; mxGetPr(d)[k] = da[(size_t)off[q] + k]; }
+      mxSetFieldByNumber(plhs[0], (size_t)q, 0, a);
+      mxSetFieldByNumber(plhs[0], (size_t)q, 1, d);
+    }
+    return;
+  }
+  if (!strcmp(cmd, "eulerian")) {
+    if (nrhs < 6) mexErrMsgTxt("eul = subzero_step('eulerian', Nx, Ny, Nb, c2_boundary, PERIODIC)");
+    const int Nx = (int)mxGetScalar(prhs[1]), Ny = (int)mxGetScalar(prhs[2]);
+    if (Nx < 1 || Ny < 1) mexErrMsgTxt("subzero_step('eulerian'): Nx, Ny must be positive");
+    const double *cb = doubles(prhs[4], 10, "c2_boundary", -1);
+    const size_t cells = (size_t)Nx * Ny;
+    std::vector<double> out(18 * cells);
+    check(szEulerianData(g_ctx, Nx, Ny, (int)mxGetScalar(prhs[3]), cb, mxGetScalar(prhs[5]) != 0, out.data(), nullptr));
+    const char *names[] = {"u", "v", "du", "dv", "stress", "stressxx", "stressyx", "stressxy", "stressyy", "strainux", "strainvx",
+                           "strainuy", "strainvy", "c", "Over", "Mtot", "area", "h"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 18, names);
+    for (int f = 0; f < 18; ++f) {
+      mxArray *a = mxCreateDoubleMatrix((size_t)Ny, (size_t)Nx, mxREAL);
+      memcpy(mxGetPr(a), out.data() + (size_t)f * cells, cells * 8);
+      mxSetFieldByNumber(plhs[0], 0, f, a);
+    }
     return;
   }
   if (strcmp(cmd, "step")) mexErrMsgTxt("subzero_step: unknown command");

@@ -171,3 +171,35 @@ def test_clipper_gateway_takes_several_contours_per_operand(clipper):
                 assert len(got) == len(want), (method, sf, cf)
                 for r, w in zip(got, want):
                     assert np.array_equal(r, w), (method, sf, cf)
+
+
+def test_step_gateway_corners_and_eulerian_commands(stepgw):
+    """'corners' (corners.m:13-92 per vertex) and 'eulerian' (calc_eulerian_data.m) as a MATLAB session sees them."""
+    S, P = scenes.pack(150, periodic=True, n_stress=5, n_mc=120)
+    P.set_reference_ocean()
+    S.Xi += 250.0
+    A, G = S.copy(), S.copy()
+    F, = stepgw.call(1, mx.string("upload"), mx.floe_struct(G), mx.scalar(0))
+    for it in range(6):
+        P.doInt = int(it % 4 == 0)
+        ra = oracle.step(A, P, threads=8)
+        F, kill, transfer, ghosts, need = gw_step(stepgw, F, P)
+    mx.read_floes(F, G)
+    ids = np.arange(2, S.n + 1, 2)
+    cb = mx.numeric(np.asarray(P.c2_boundary, float))
+    C, = stepgw.call(1, mx.string("corners"), mx.row(ids), mx.scalar(3), cb)
+    off, cnt, ang, da, N0 = oracle.corner_candidates(A, ra.inter_off, ra.inter, ids.astype(np.int32), 3, P.c2_boundary)
+    assert mx.numel(C) == len(ids) and (cnt > 0).sum() > 10 and (cnt[:3] == 0).all()
+    for q in range(len(ids)):
+        a = mx.to_numpy(mx.get_field(C, q, "angles")).ravel(); d = mx.to_numpy(mx.get_field(C, q, "da")).ravel()
+        assert len(a) == cnt[q] == len(d)
+        assert np.array_equal(a, ang[off[q]:off[q] + cnt[q]]) and np.array_equal(d, da[off[q]:off[q] + cnt[q]].astype(float))
+    E, = stepgw.call(1, mx.string("eulerian"), mx.scalar(6), mx.scalar(4), mx.scalar(0), cb, mx.scalar(1))
+    hoststep.check_stress(A, G)
+    A.Stress[:] = G.Stress
+    want = oracle.eulerian_data(A, 6, 4, 0, P.c2_boundary, True)
+    for k in oracle.EULERIAN_FIELDS:
+        got = mx.to_numpy(mx.get_field(E, 0, k))
+        assert got.shape == (4, 6) and np.array_equal(got, want[k]), k
+    with pytest.raises(mx.MexError):
+        stepgw.call(1, mx.string("corners"), mx.row([S.n + 1]), mx.scalar(0), cb)
