@@ -85,6 +85,37 @@ def cpu_baseline(S, P, budget_s=12.0):
                       "then 1 timestep on 1 thread, %.1f s" % (steps, S.n, threads, el, el1)}
 
 
+def clip_kernel_line(ctx, with_cpu, n_pairs=20000, cpu_pairs=3000):
+    """Kernel-level clips/s of the B1 surface (szClipBatch's kernel, inputs resident in HBM) on pairs of the
+    reference's own floe outlines (test/test_conservation/FloeShapes.mat, decoded in tests/golden/): the workload of
+    BASELINE.md's Clipper probe (real outlines paired and partially overlapped, intersection), next to the reference
+    Clipper build on one host core over a bounded sample of the same pairs."""
+    import clipgen
+    ps = clipgen.shape_pairs(n_pairs, seed=2)
+    ax, ay, aoff, bx, by, boff = ps.arrays()
+    d = [ctx.to_device(v) for v in (ax, ay, aoff, bx, by, boff)]
+    ms = []
+    for it in range(4):
+        st = ctx.clip_batch_device(len(ps), *d, len(ax), len(bx), 1)
+        if it:
+            ms.append(st.kernel_ms)
+    for v in d:
+        ctx.free(v)
+    k_ms = sum(ms) / len(ms)
+    out = {"workload": "%d pairs of FloeShapes.mat outlines, partially overlapped, intersection (polyclip 'int')" % n_pairs,
+           "pairs": int(st.pairs), "mean_input_vertices_per_pair": st.input_vertices / max(st.pairs, 1),
+           "kernel_ms": k_ms, "clips_per_s": st.pairs / (k_ms * 1e-3), "rings_out": int(st.rings_out),
+           "redone_at_a_larger_workspace": int(st.retried), "failed": int(st.failed),
+           # 16 B per input vertex + 16 B per output vertex (DESIGN.md section 4)
+           "algorithmic_GBps": 16.0 * (st.input_vertices + st.vertices_out) / (k_ms * 1e-3) / 1e9}
+    if with_cpu and clipgen.ref_lib() is not None:
+        sub = clipgen.shape_pairs(cpu_pairs, seed=2)
+        t0 = time.time(); clipgen.run_ref(sub, 1); el = time.time() - t0
+        out["cpu_reference"] = {"clips_per_s": cpu_pairs / el, "cores": 1, "kind": "reference",
+                                "sample": "the reference Clipper build (oracle/_ref) on the first %d of the same pairs, %.2f s" % (cpu_pairs, el)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--floes", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clip-line", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +199,8 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, P)
+    if not args.no_clip_line:
+        out["clip_kernel"] = clip_kernel_line(ctx, not args.no_cpu_baseline)
     ctx.close()
     print(json.dumps(out), flush=True)
 

@@ -318,6 +318,17 @@ int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const double *c2_boun
 int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, int Nb, const double *c2_boundary, int32_t *offsets, int32_t *count,
                        double *angles, uint8_t *da, int64_t cap, int32_t *n_ext, double *kernel_ms);
 
+/* ---- fracture, the deformation step: Physical_Processes/fracture_floe.m:14-52 ------------------
+ * Call after a step, for the floes about to be fractured (fracture.m:51-55; ids 1-based).  Each is pushed by the
+ * partner of its largest contact overlap: polyclip 'int' -> centroid and p_poly_dist of the overlap region -> partner
+ * moved along the contact force -> polyclip 'dif' (both clips on the GPU).  changed[s] = 1 when fracture_floe.m:44-50
+ * replaces the floe's outline: then Xi / Yi / area [s] hold the new centroid and area and cx / cy [ring_off[s] ..
+ * ring_off[s+1]) the new c_alpha (open ring, as polyclip returns it); otherwise the floe is left as it is.  The device
+ * copy of the floes is NOT modified: the Voronoi tessellation that follows (:54-124, rand / polybnd_voronoi / new
+ * floes) stays on the MATLAB side and the array comes back through szFloesResync.  cap: room of cx / cy. */
+int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, int32_t *changed, double *Xi, double *Yi, double *area,
+                     int32_t *ring_off, double *cx, double *cy, int64_t cap);
+
 /* ---- multi-GPU, spatial partition (BASELINE north_star): floes owned by x-strips of the domain, one
  * neighbour exchange of halo floes per step --------------------------------------------------------------------
  * Every rank uploads the same array (szFloesUpload) and keeps it at its global size and index; after szSpatialInit

@@ -1315,3 +1315,62 @@ extern "C" int or_corner_candidates(const OrFloes *F, const int *inter_off, cons
   offsets[nsub] = at;
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// fracture_floe.m:14-52 -- the deformation a floe receives from the partner of its largest overlap before it is
+// tessellated.  ids: 1-based floes (fracture.m:51-55); inter_off / inter: the contact rows of the step.
+// out: changed[s]; Xi / Yi / area [s]; new c_alpha rings back to back (ring_off[nsel + 1]).
+// ---------------------------------------------------------------------------------------------
+extern "C" int or_fracture_deform(const OrFloes *F, const int *inter_off, const double *inter, const int *ids, int nsel, int *changed,
+                                  double *Xi, double *Yi, double *area, int *ring_off, double *cx, double *cy, int cap) {
+  int at = 0;
+  ring_off[0] = 0;
+  for (int s = 0; s < nsel; ++s) {
+    const int i = ids[s] - 1;
+    changed[s] = 0; Xi[s] = Yi[s] = area[s] = 0;
+    ring_off[s + 1] = at;
+    // :16-22 rows with a finite partner; [~,k] = max(a(:,7))
+    int k = -1;
+    for (int r = inter_off[i]; r < inter_off[i + 1]; ++r) {
+      if (std::isinf(inter[7 * r])) continue;
+      if (k < 0 || inter[7 * r + 6] > inter[7 * k + 6]) k = r;
+    }
+    if (k < 0) continue;
+    const int v0 = F->vert_off[i], nv = F->vert_off[i + 1] - v0;
+    Vec X1(nv), Y1(nv);
+    for (int q = 0; q < nv; ++q) { X1[q] = F->cax[v0 + q] + F->Xi[i]; Y1[q] = F->cay[v0 + q] + F->Yi[i]; }   // :23-24
+    const double clip = inter[7 * k];
+    if (!(clip < F->n + 1)) continue;                                       // :26
+    const int j = (int)clip - 1;
+    const int w0 = F->vert_off[j], nw = F->vert_off[j + 1] - w0;
+    Vec X2(nw), Y2(nw);
+    for (int q = 0; q < nw; ++q) { X2[q] = F->cax[w0 + q] + F->Xi[j]; Y2[q] = F->cay[w0 + q] + F->Yi[j]; }   // :27-28
+    bool ok = true;
+    std::vector<Ring> reg = polyclip(X1, Y1, X2, Y2, 1, ok);                // :29 'int'
+    if (!ok) return -4;
+    if (reg.empty()) continue;                                              // :31
+    const Ring &t = reg[0];                                                 // :32
+    double xm, ym;
+    ring_centroid(t.x.data(), t.y.data(), (int)t.x.size(), xm, ym);         // :33
+    Vec d;
+    p_poly_dist(Vec(1, xm), Vec(1, ym), t.x, t.y, d);                       // :34
+    const double fx = inter[7 * k + 1], fy = inter[7 * k + 2];
+    const double Fn = sqrt(fx * fx + fy * fy);                              // :35 vecnorm
+    const double xs = fx * fabs(d[0]) / 2 / Fn, ys = fy * fabs(d[0]) / 2 / Fn;   // :36-37
+    for (int q = 0; q < nw; ++q) { X2[q] = X2[q] + xs; Y2[q] = Y2[q] + ys; }      // :38
+    reg = polyclip(X1, Y1, X2, Y2, 0, ok);                                  // :39 'dif'
+    if (!ok) return -4;
+    if (reg.empty()) continue;                                              // :40
+    const Ring &u = reg[0];                                                 // :41
+    const int m = (int)u.x.size();
+    const double Anew = polyarea(u.x.data(), u.y.data(), m);                // :42
+    if (!(Anew / F->area[i] > 0.9)) continue;                               // :43
+    ring_centroid(u.x.data(), u.y.data(), m, xm, ym);                       // :44
+    if (at + m > cap) return -2;
+    changed[s] = 1; Xi[s] = xm; Yi[s] = ym; area[s] = Anew;                 // :45-46
+    for (int q = 0; q < m; ++q) { cx[at + q] = u.x[q] - xm; cy[at + q] = u.y[q] - ym; }   // :47
+    at += m;
+    ring_off[s + 1] = at;
+  }
+  return 0;
+}

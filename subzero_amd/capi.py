@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szEulerianData", "szCornerCandidates", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
+    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -381,6 +381,22 @@ class FloeInteractions:
                                                      da.ctypes.data_as(u8), total, ctypes.byref(n_ext), ctypes.byref(ms)),
                        "szCornerCandidates")
         return offsets, count[:nsub], ang[:total], da[:total], n_ext.value, ms.value
+
+    def fracture_deform(self, ids):
+        """fracture_floe.m:14-52 for the floes ids (1-based) on the contact rows of the last step ->
+        (changed, Xi, Yi, area, rings): rings[s] = new c_alpha (2 x m, open) where changed[s]."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        nsel = len(ids)
+        changed = np.zeros(max(nsel, 1), np.int32); X = np.zeros(max(nsel, 1)); Y = np.zeros(max(nsel, 1)); A = np.zeros(max(nsel, 1))
+        roff = np.zeros(nsel + 1, np.int32)
+        cap = 4 * int(self.floes.vert_off[-1]) + 64 * nsel + 64
+        cx = np.zeros(cap); cy = np.zeros(cap)
+        self.ctx.L.szFractureDeform.argtypes = [_vp, _ip, ctypes.c_int, _ip, _dp, _dp, _dp, _ip, _dp, _dp, ctypes.c_int64]
+        self.ctx.check(self.ctx.L.szFractureDeform(self.ctx.h, ids.ctypes.data_as(_ip), nsel, changed.ctypes.data_as(_ip), X.ctypes.data_as(_dp),
+                                                   Y.ctypes.data_as(_dp), A.ctypes.data_as(_dp), roff.ctypes.data_as(_ip), cx.ctypes.data_as(_dp),
+                                                   cy.ctypes.data_as(_dp), cap), "szFractureDeform")
+        rings = [np.stack([cx[roff[s]:roff[s + 1]], cy[roff[s]:roff[s + 1]]]) for s in range(nsel)]
+        return changed[:nsel], X[:nsel], Y[:nsel], A[:nsel], rings
 
     def ghosts(self):
         """(src, parent, Xi, Yi) of the ghost floes of the last step; ghost g is Floe(n + g + 1) of the extended list."""

@@ -8,8 +8,9 @@
 //  * pairs whose lists outgrow their slice (only heavily self-intersecting input does) are appended to
 //    a retry list with one wave-aggregated atomic and re-run at 8x / 64x capacity -- on the GPU.
 //    There is no CPU fallback anywhere in this file.
-#include "context.hpp"
-#include "vatti.hpp"
+#include "clip_batch.hpp"
+
+using szb::ClipArgs;
 
 namespace {
 
@@ -63,25 +64,6 @@ struct SlotSink {
   __device__ bool ring_end() { ++nr; roff[nr] = nv; return true; }
 };
 
-struct ClipArgs {
-  int npairs;
-  const int *list; // null: all pairs, closed-form slots; else: pairs to re-run, bump-allocated slots
-  int nlist;
-  const i64 *ax, *ay; const int *aoff;
-  const i64 *bx, *by; const int *boff;
-  const int *aring, *bring;     // when non-null: aoff / boff give RING ranges per pair and these the vertex range of each ring
-  const double *fax, *fay, *fbx, *fby; // when non-null the inputs are doubles (polyclip form)
-  int method, fill_s, fill_c;
-  int mult;
-  char *ws; i64 ws_cap;         // workspace arena
-  i64 *ovx, *ovy; i64 ov_cap;   // result vertices
-  int *oroff; i64 or_cap;       // result ring offsets (local to the pair's vertex slot)
-  i64 *ov_base, *or_base;       // per pair: where its slots start
-  int *nrings, *status;
-  int *retry; int retry_cap;    // pairs to re-run with a larger workspace
-  unsigned long long *counters; // [0] retry count, [1] ws bump, [2] ov bump, [3] or bump,
-                                // [4] rings out, [5] verts out, [6] failed, [7] arena exhausted
-};
 
 __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,8 +131,10 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
   }
 }
 
+} // namespace
+
 // Sizes and (re)allocates the context's clip buffers for a batch; fills the common ClipArgs fields.
-int prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
+int szb::prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
   i64 ws_main = (i64)szv::WS_PER_VERTEX * total + (i64)szv::WS_PER_CLIP * npairs;
   i64 ov_main = 2 * total + 8 * (i64)npairs;
   i64 or_main = total + 5 * (i64)npairs;
@@ -186,7 +170,7 @@ int prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
 }
 
 // Runs the main pass and the retry tiers.  On return the per-pair arrays on the device are final.
-int run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
+int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
   if (a.npairs == 0) {
     if (stats) memset(stats, 0, sizeof(*stats));
     return SZ_OK;
@@ -239,6 +223,11 @@ int run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
   }
   return SZ_OK;
 }
+
+namespace {
+
+using szb::prepare;
+using szb::run;
 
 template <class T>
 int upload(szContext *ctx, DevBuf &b, const T *src, size_t n) {

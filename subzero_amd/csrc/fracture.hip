@@ -1,0 +1,196 @@
+// fracture.hip -- szFractureDeform: the "slight permanent deformation" a floe receives when it fractures
+// (Physical_Processes/fracture_floe.m:14-52), on the device-resident floes and contact rows.
+//
+// For every listed floe: the contact row of largest overlap among its floe partners (:17-23), the overlap region
+// polyclip(floe, partner, 'int') (:30), the partner pushed into the floe by half the distance from the region's
+// centroid to its outline, along the contact force (:33-39), and the floe cut back by polyclip(floe, partner, 'dif')
+// (:40); when more than 90 % of the floe is left, its first piece becomes the floe's new outline, centroid and area
+// (:43-50).  Both clips are launches of the batched clip kernel (clip.hip) on operands put together on the device;
+// the few scalars in between are one thread per floe.  The Voronoi tessellation that follows (:54-124: rand,
+// polybnd_voronoi, polyshape intersections, new floes) reshapes the floe array and stays on the MATLAB side.
+//
+// centroid(polyshape(X,Y)) and polyarea are restated as in contact.hpp (shoelace relative to the first vertex;
+// polyarea.m's own expression); p_poly_dist is dist_to_ring.
+#include "step_state.hpp"
+#include "clip_batch.hpp"
+
+namespace {
+
+struct Pick { int partner; int pad; double fx, fy; };   // partner: 0-based floe, -1 none
+
+// :14-27  row of largest overlap among the rows with a finite partner; partner must be a real floe (:26)
+__global__ void k_frac_pick(Floes F, Work W, const int *ids, int nsel, Pick *pick) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsel) return;
+  const int i = ids[s] - 1;
+  Pick p; p.partner = -1; p.pad = 0; p.fx = p.fy = 0;
+  bool have = false;
+  double best = 0, clip = 0;
+  for (i64 r = W.row_off[i]; r < W.row_off[i + 1]; ++r) {
+    const double *row = W.rows + 7 * r;
+    if (szc::is_inf(row[0])) continue;                        // :19-21
+    if (!have || row[6] > best) { have = true; best = row[6]; clip = row[0]; p.fx = row[1]; p.fy = row[2]; }   // [~,k] = max(a(:,7)): the first of equals
+  }
+  if (have && clip < (double)(F.n + 1) && clip >= 1) p.partner = (int)clip - 1;   // :26 (ghost partners: no deformation)
+  pick[s] = p;
+}
+
+// operands of the clips: ring of the floe (c_alpha + position, as stored: closed) and of its partner, in metres
+__global__ void k_frac_rings(Floes F, const int *ids, int nsel, const Pick *pick, const int *aoff, const int *boff,
+                             double *ax, double *ay, double *bx, double *by) {
+  int s = blockIdx.x;
+  if (s >= nsel) return;
+  const int i = ids[s] - 1, j = pick[s].partner;
+  const int v0 = F.vert_off[i], nv = F.vert_off[i + 1] - v0;
+  for (int k = threadIdx.x; k < nv; k += blockDim.x) { ax[aoff[s] + k] = F.cax[v0 + k] + F.Xi[i]; ay[aoff[s] + k] = F.cay[v0 + k] + F.Yi[i]; }
+  if (j < 0) return;
+  const int w0 = F.vert_off[j], nw = F.vert_off[j + 1] - w0;
+  for (int k = threadIdx.x; k < nw; k += blockDim.x) { bx[boff[s] + k] = F.cax[w0 + k] + F.Xi[j]; by[boff[s] + k] = F.cay[w0 + k] + F.Yi[j]; }
+}
+
+// a result ring of the clip kernel as dist_to_ring reads it (closed by its first vertex, p_poly_dist.m:133-141)
+struct OutRing {
+  const i64 *x, *y; int n;
+  __device__ int len() const { return n + 1; }
+  __device__ double X(int k) const { return szc::from_fixed(x[k >= n ? 0 : k]); }
+  __device__ double Y(int k) const { return szc::from_fixed(y[k >= n ? 0 : k]); }
+};
+
+// :31-39  first region of the overlap -> centroid, distance to its outline, the partner's ring moved along the force
+__global__ void k_frac_shift(szb::ClipArgs a, int nsel, const Pick *pick, const int *boff, double *bx, double *by, int *stage) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsel) return;
+  stage[s] = 0;
+  if (pick[s].partner < 0) return;
+  if (a.status[s] != szv::ST_OK) { stage[s] = -1; return; }                          // the mex would have raised "Clipper Error."
+  if (a.nrings[s] < 1) return;                                                       // :31 XInew empty
+  const int *ro = a.oroff + a.or_base[s];
+  const i64 *rx = a.ovx + a.ov_base[s] + ro[0], *ry = a.ovy + a.ov_base[s] + ro[0];
+  const int n = ro[1] - ro[0];
+  double xm, ym;
+  szc::region_centroid(rx, ry, n, xm, ym);                                // :32
+  OutRing ring = {rx, ry, n};
+  const double d = szc::dist_to_ring(xm, ym, ring);                        // :33 (|d_min1|)
+  const double fx = pick[s].fx, fy = pick[s].fy;
+  const double Fn = ::sqrt(fx * fx + fy * fy);                              // :34 vecnorm
+  const double xs = fx * d / 2 / Fn, ys = fy * d / 2 / Fn;                  // :35-36
+  const int nb = boff[s + 1] - boff[s];
+  for (int k = 0; k < nb; ++k) { bx[boff[s] + k] = bx[boff[s] + k] + xs; by[boff[s] + k] = by[boff[s] + k] + ys; }   // :37
+  stage[s] = 1;
+}
+
+// :41-50  first piece of the difference: kept when it holds more than 90 % of the floe's area
+__global__ void k_frac_finish(szb::ClipArgs a, Floes F, const int *ids, int nsel, const int *stage, const int *ooff, int *changed,
+                              double *nXi, double *nYi, double *narea, int *nlen, double *ox, double *oy) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsel) return;
+  changed[s] = 0; nlen[s] = 0;
+  if (stage[s] < 0 || (stage[s] > 0 && a.status[s] != szv::ST_OK)) { changed[s] = -2; return; }
+  if (!stage[s] || a.nrings[s] < 1) return;
+  const int *ro = a.oroff + a.or_base[s];
+  const i64 *rx = a.ovx + a.ov_base[s] + ro[0], *ry = a.ovy + a.ov_base[s] + ro[0];
+  const int n = ro[1] - ro[0];
+  const double Anew = szc::region_polyarea(rx, ry, n);                     // :43
+  if (!(Anew / F.area[ids[s] - 1] > 0.9)) return;                          // :44
+  if (n > ooff[s + 1] - ooff[s]) { changed[s] = -1; return; }              // (cannot happen: the slot holds 2 (na + nb) + 8 vertices)
+  double xm, ym;
+  szc::region_centroid(rx, ry, n, xm, ym);                                // :45
+  nXi[s] = xm; nYi[s] = ym; narea[s] = Anew;                               // :46-47
+  for (int k = 0; k < n; ++k) { ox[ooff[s] + k] = szc::from_fixed(rx[k]) - xm; oy[ooff[s] + k] = szc::from_fixed(ry[k]) - ym; }   // :48
+  nlen[s] = n; changed[s] = 1;
+}
+
+template <class T>
+int fetch(szContext *ctx, std::vector<T> &h, const void *d, size_t n) {
+  h.resize(n ? n : 1);
+  if (n) SZ_HIP(ctx, hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  return SZ_OK;
+}
+
+} // namespace
+
+extern "C" int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, int32_t *changed, double *Xi, double *Yi, double *area,
+                                int32_t *ring_off, double *cx, double *cy, int64_t cap) {
+  if (!ctx || nsel < 0 || !ring_off || (nsel > 0 && (!ids || !changed || !Xi || !Yi || !area))) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S || !S->stepped) return sz_fail(ctx, SZ_ERR_STATE, "szFractureDeform: no step taken (the contact rows of a step are the input)");
+  ring_off[0] = 0;
+  if (nsel == 0) return SZ_OK;
+  const int n = S->n;
+  for (int s = 0; s < nsel; ++s)
+    if (ids[s] < 1 || ids[s] > n) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFractureDeform: ids[%d] = %d outside 1..%d", s, (int)ids[s], n);
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc = SZ_OK;
+  DevBuf d_ids, d_pick, d_aoff, d_boff, d_stage, d_ooff, d_chg, d_sc, d_len, d_ox, d_oy;
+  auto cleanup = [&]() { sz_release(d_ids); sz_release(d_pick); sz_release(d_aoff); sz_release(d_boff); sz_release(d_stage); sz_release(d_ooff);
+                         sz_release(d_chg); sz_release(d_sc); sz_release(d_len); sz_release(d_ox); sz_release(d_oy); };
+#define FR_TRY(expr) do { if ((rc = (expr))) { cleanup(); return rc; } } while (0)
+#define FR_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szFractureDeform: %s", hipGetErrorString(e_)); } } while (0)
+  FR_TRY(sz_reserve(ctx, d_ids, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_pick, (size_t)nsel * sizeof(Pick)));
+  FR_HIP(hipMemcpyAsync(d_ids.p, ids, (size_t)nsel * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_frac_pick, grid_for(nsel, 64), dim3(64), 0, st, S->F, S->W, (const int *)d_ids.p, nsel, (Pick *)d_pick.p);
+  std::vector<Pick> pick((size_t)nsel);
+  FR_HIP(hipMemcpyAsync(pick.data(), d_pick.p, (size_t)nsel * sizeof(Pick), hipMemcpyDeviceToHost, st));
+  FR_HIP(hipStreamSynchronize(st));
+  // operand layout: the floe's stored ring, its partner's stored ring (none: empty)
+  std::vector<int> aoff((size_t)nsel + 1, 0), boff((size_t)nsel + 1, 0), ooff((size_t)nsel + 1, 0);
+  for (int s = 0; s < nsel; ++s) {
+    const int na = S->h_vert_off[ids[s]] - S->h_vert_off[ids[s] - 1];
+    const int nb = pick[s].partner >= 0 ? S->h_vert_off[pick[s].partner + 1] - S->h_vert_off[pick[s].partner] : 0;
+    aoff[s + 1] = aoff[s] + na; boff[s + 1] = boff[s] + nb;
+    ooff[s + 1] = ooff[s] + (nb ? 2 * (na + nb) + 8 : 0);
+  }
+  const i64 ta = aoff[nsel], tb = boff[nsel], to = ooff[nsel];
+  FR_TRY(sz_reserve(ctx, d_aoff, (size_t)(nsel + 1) * 4)); FR_TRY(sz_reserve(ctx, d_boff, (size_t)(nsel + 1) * 4)); FR_TRY(sz_reserve(ctx, d_ooff, (size_t)(nsel + 1) * 4));
+  FR_TRY(sz_reserve(ctx, ctx->in_fax, (size_t)ta * 8 + 16)); FR_TRY(sz_reserve(ctx, ctx->in_fay, (size_t)ta * 8 + 16));
+  FR_TRY(sz_reserve(ctx, ctx->in_fbx, (size_t)tb * 8 + 16)); FR_TRY(sz_reserve(ctx, ctx->in_fby, (size_t)tb * 8 + 16));
+  FR_TRY(sz_reserve(ctx, d_stage, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_chg, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_len, (size_t)nsel * 4));
+  FR_TRY(sz_reserve(ctx, d_sc, (size_t)nsel * 24)); FR_TRY(sz_reserve(ctx, d_ox, (size_t)to * 8 + 16)); FR_TRY(sz_reserve(ctx, d_oy, (size_t)to * 8 + 16));
+  FR_HIP(hipMemcpyAsync(d_aoff.p, aoff.data(), (size_t)(nsel + 1) * 4, hipMemcpyHostToDevice, st));
+  FR_HIP(hipMemcpyAsync(d_boff.p, boff.data(), (size_t)(nsel + 1) * 4, hipMemcpyHostToDevice, st));
+  FR_HIP(hipMemcpyAsync(d_ooff.p, ooff.data(), (size_t)(nsel + 1) * 4, hipMemcpyHostToDevice, st));
+  double *ax = (double *)ctx->in_fax.p, *ay = (double *)ctx->in_fay.p, *bx = (double *)ctx->in_fbx.p, *by = (double *)ctx->in_fby.p;
+  hipLaunchKernelGGL(k_frac_rings, dim3((unsigned)nsel), dim3(64), 0, st, S->F, (const int *)d_ids.p, nsel, (const Pick *)d_pick.p,
+                     (const int *)d_aoff.p, (const int *)d_boff.p, ax, ay, bx, by);
+  FR_HIP(hipGetLastError());
+  // the two clips; a floe without a partner is an empty second operand: the clip of it is skipped by its stage flag
+  szb::ClipArgs a;
+  memset(&a, 0, sizeof(a));
+  FR_TRY(szb::prepare(ctx, nsel, ta + tb, a));
+  a.fax = ax; a.fay = ay; a.fbx = bx; a.fby = by; a.aoff = (const int *)d_aoff.p; a.boff = (const int *)d_boff.p;
+  a.method = SZ_CLIP_INTERSECTION; a.fill_s = SZ_FILL_EVENODD; a.fill_c = SZ_FILL_EVENODD;
+  FR_TRY(szb::run(ctx, a, nullptr));
+  hipLaunchKernelGGL(k_frac_shift, grid_for(nsel, 64), dim3(64), 0, st, a, nsel, (const Pick *)d_pick.p, (const int *)d_boff.p, bx, by, (int *)d_stage.p);
+  FR_HIP(hipGetLastError());
+  szb::ClipArgs b;
+  memset(&b, 0, sizeof(b));
+  FR_TRY(szb::prepare(ctx, nsel, ta + tb, b));
+  b.fax = ax; b.fay = ay; b.fbx = bx; b.fby = by; b.aoff = (const int *)d_aoff.p; b.boff = (const int *)d_boff.p;
+  b.method = SZ_CLIP_DIFFERENCE; b.fill_s = SZ_FILL_EVENODD; b.fill_c = SZ_FILL_EVENODD;
+  FR_TRY(szb::run(ctx, b, nullptr));
+  double *sc = (double *)d_sc.p;
+  hipLaunchKernelGGL(k_frac_finish, grid_for(nsel, 64), dim3(64), 0, st, b, S->F, (const int *)d_ids.p, nsel, (const int *)d_stage.p, (const int *)d_ooff.p,
+                     (int *)d_chg.p, sc, sc + nsel, sc + 2 * (size_t)nsel, (int *)d_len.p, (double *)d_ox.p, (double *)d_oy.p);
+  FR_HIP(hipGetLastError());
+  std::vector<int> chg, len;
+  std::vector<double> scal, hx, hy;
+  FR_TRY(fetch(ctx, chg, d_chg.p, (size_t)nsel)); FR_TRY(fetch(ctx, len, d_len.p, (size_t)nsel)); FR_TRY(fetch(ctx, scal, d_sc.p, (size_t)3 * nsel));
+  FR_TRY(fetch(ctx, hx, d_ox.p, (size_t)to)); FR_TRY(fetch(ctx, hy, d_oy.p, (size_t)to));
+  FR_HIP(hipStreamSynchronize(st));
+  cleanup();
+  int64_t at = 0;
+  for (int s = 0; s < nsel; ++s) {
+    if (chg[s] < 0) return sz_fail(ctx, SZ_ERR_WORKSPACE, "szFractureDeform: the piece of floe %d outgrew its slot", (int)ids[s]);
+    if (chg[s] == -2) return sz_fail(ctx, SZ_ERR_HIP, "szFractureDeform: floe %d: the reference's \"Clipper Error.\" condition", (int)ids[s]);
+    changed[s] = chg[s];
+    Xi[s] = chg[s] ? scal[s] : 0; Yi[s] = chg[s] ? scal[(size_t)nsel + s] : 0; area[s] = chg[s] ? scal[2 * (size_t)nsel + s] : 0;
+    if (chg[s]) {
+      if (at + len[s] > cap || !cx || !cy) return sz_fail(ctx, SZ_ERR_CAPACITY, "szFractureDeform: %lld vertices or more, capacity %lld", (long long)(at + len[s]), (long long)cap);
+      for (int k = 0; k < len[s]; ++k) { cx[at + k] = hx[(size_t)ooff[s] + k]; cy[at + k] = hy[(size_t)ooff[s] + k]; }
+      at += len[s];
+    }
+    ring_off[s + 1] = (int32_t)at;
+  }
+  return SZ_OK;
+}

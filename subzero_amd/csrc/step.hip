@@ -67,6 +67,15 @@ extern "C" int szDebugPhases(unsigned long long *out26, int reset) {
 
 #include "step_state.hpp"
 
+#if defined(SZ_WAVE_CYCLES)
+// Diagnostic build only (make EXTRA=-DSZ_WAVE_CYCLES): wall-clock ticks (100 MHz) of every wave of the last fast-pass
+// launch, read with szDebugWaveCycles.  Not in the product build.
+__device__ unsigned long long sz_wave_cycles[1 << 17];
+extern "C" int szDebugWaveCycles(unsigned long long *out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_wave_cycles), sizeof(unsigned long long) * (size_t)(n < (1 << 17) ? n : (1 << 17))) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
@@ -278,12 +287,21 @@ __global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, i
 #define CONVEX_STRIDE 616
 static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
 // (dev_count: the pair count where the host does not know it yet -- the speculative step launches for a capacity)
-__global__ void __launch_bounds__(64) k_narrow_convex(i64 first, i64 count, const unsigned long long *dev_count, int lanes, Floes F, Params P, Work W) {
+#ifndef SZ_CONVEX_WAVES_ATTR
+#define SZ_CONVEX_WAVES_ATTR
+#endif
+__global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 first, i64 count, const unsigned long long *dev_count, int lanes, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)threadIdx.x >= lanes) return;
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   if (dev_count && t >= (i64)*dev_count) return;
+#if defined(SZ_WAVE_CYCLES)
+  const unsigned long long t0 = wall_clock64();
+#endif
   if (t < count) narrow_convex(first + t, (const int *)nullptr, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
+#if defined(SZ_WAVE_CYCLES)
+  if (threadIdx.x == 0 && blockIdx.x < (1u << 17)) sz_wave_cycles[blockIdx.x] = wall_clock64() - t0;
+#endif
 }
 
 // Second fast pass: the pairs the first one found too long for its 16-vertex blocks but not for 32-vertex ones (many-

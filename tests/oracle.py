@@ -173,6 +173,11 @@ def ring_area(x, y):
     return lib().or_ring_area(_p(x), _p(y), len(x))
 
 
+def polyarea(x, y):
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    return lib().or_polyarea(_p(x), _p(y), len(x))
+
+
 def ring_centroid(x, y):
     x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
     cx, cy = ctypes.c_double(), ctypes.c_double()
@@ -260,3 +265,25 @@ def corner_candidates(S, inter_off, inter, ids, Nb, c2_boundary):
     if rc != 0:
         raise RuntimeError("or_corner_candidates failed: %d" % rc)
     return offsets, count[:nsub], ang[:total], da[:total], n_ext.value
+
+
+def fracture_deform(S, inter_off, inter, ids):
+    """fracture_floe.m:14-52 restated (oracle) -> (changed, Xi, Yi, area, rings)."""
+    L = lib()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    L.or_fracture_deform.argtypes = [ctypes.POINTER(CFloes), ip, _dp, ip, ctypes.c_int, ip, _dp, _dp, _dp, ip, _dp, _dp, ctypes.c_int]
+    ids = np.ascontiguousarray(ids, np.int32)
+    off = np.ascontiguousarray(inter_off, np.int32)
+    rows = np.ascontiguousarray(inter, np.float64).reshape(-1, 7) if len(inter) else np.zeros((1, 7))
+    nsel = len(ids)
+    changed = np.zeros(max(nsel, 1), np.int32); X = np.zeros(max(nsel, 1)); Y = np.zeros(max(nsel, 1)); A = np.zeros(max(nsel, 1))
+    roff = np.zeros(nsel + 1, np.int32)
+    cap = 4 * int(S.vert_off[-1]) + 64 * nsel + 64
+    cx = np.zeros(cap); cy = np.zeros(cap)
+    cf = pack_floes(S)
+    rc = L.or_fracture_deform(ctypes.byref(cf), off.ctypes.data_as(ip), _p(rows), ids.ctypes.data_as(ip), nsel, changed.ctypes.data_as(ip),
+                              _p(X), _p(Y), _p(A), roff.ctypes.data_as(ip), _p(cx), _p(cy), cap)
+    if rc != 0:
+        raise RuntimeError("or_fracture_deform failed: %d" % rc)
+    rings = [np.stack([cx[roff[s]:roff[s + 1]], cy[roff[s]:roff[s + 1]]]) for s in range(nsel)]
+    return changed[:nsel], X[:nsel], Y[:nsel], A[:nsel], rings
