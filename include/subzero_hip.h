@@ -329,6 +329,11 @@ int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, int Nb, con
 int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, int32_t *changed, double *Xi, double *Yi, double *area,
                      int32_t *ring_off, double *cx, double *cy, int64_t cap);
 
+/* polygon_operations/FloeSimplify.m:14-34: for each listed floe the floes it may touch -- alive, centres more than 1 m
+ * apart and closer than the sum of the rmax -- as 1-based floe numbers in ascending order (CSR: off[nsel + 1], list).
+ * Reads the resident positions; the caller takes c_alpha, Ui ... of those floes from its own array. */
+int szPotentialInteractions(szContext *ctx, const int32_t *ids, int nsel, int32_t *off, int32_t *list, int64_t cap);
+
 /* ---- multi-GPU, spatial partition (BASELINE north_star): floes owned by x-strips of the domain, one
  * neighbour exchange of halo floes per step --------------------------------------------------------------------
  * Every rank uploads the same array (szFloesUpload) and keeps it at its global size and index; after szSpatialInit

@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
+    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szPotentialInteractions", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -397,6 +397,22 @@ class FloeInteractions:
                                                    cy.ctypes.data_as(_dp), cap), "szFractureDeform")
         rings = [np.stack([cx[roff[s]:roff[s + 1]], cy[roff[s]:roff[s + 1]]]) for s in range(nsel)]
         return changed[:nsel], X[:nsel], Y[:nsel], A[:nsel], rings
+
+    def potential_interactions(self, ids):
+        """FloeSimplify.m:14-34 for the floes ids (1-based): list of arrays of 1-based partner numbers, ascending."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        nsel = len(ids)
+        off = np.zeros(nsel + 1, np.int32)
+        cap = 64 * nsel + 64
+        self.ctx.L.szPotentialInteractions.argtypes = [_vp, _ip, ctypes.c_int, _ip, _ip, ctypes.c_int64]
+        while True:
+            lst = np.zeros(cap, np.int32)
+            rc = self.ctx.L.szPotentialInteractions(self.ctx.h, ids.ctypes.data_as(_ip), nsel, off.ctypes.data_as(_ip), lst.ctypes.data_as(_ip), cap)
+            if rc == SZ_ERR_CAPACITY:
+                cap *= 4
+                continue
+            self.ctx.check(rc, "szPotentialInteractions")
+            return [lst[off[s]:off[s + 1]].copy() for s in range(nsel)]
 
     def ghosts(self):
         """(src, parent, Xi, Yi) of the ghost floes of the last step; ghost g is Floe(n + g + 1) of the extended list."""

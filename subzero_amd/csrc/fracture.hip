@@ -194,3 +194,71 @@ extern "C" int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, in
   }
   return SZ_OK;
 }
+
+// ---- FloeSimplify.m:14-34: the floes a floe may touch, by bounding circles, in ascending floe number ---------------
+namespace {
+__global__ void __launch_bounds__(64) k_potential(Floes F, const int *ids, int nsel, int cap_each, int *cnt, int *list) {
+  const int s = blockIdx.x;
+  if (s >= nsel) return;
+  const int i = ids[s] - 1, lane = threadIdx.x;
+  const double xi = F.Xi[i], yi = F.Yi[i], ri = F.rmax[i];
+  int kept = 0;
+  for (int base = 0; base < F.n; base += 64) {
+    const int j = base + lane;
+    bool hit = false;
+    if (j < F.n && F.alive[j]) {
+      const double dx = xi - F.Xi[j], dy = yi - F.Yi[j];
+      const double d = ::sqrt(dx * dx + dy * dy);                 // :21
+      hit = d > 1 && d < (ri + F.rmax[j]);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int at = kept + __popcll(m & ((1ULL << lane) - 1ULL));
+      if (at < cap_each) list[(size_t)s * cap_each + at] = j + 1;
+    }
+    kept += __popcll(m);
+  }
+  if (lane == 0) cnt[s] = kept;
+}
+} // namespace
+
+extern "C" int szPotentialInteractions(szContext *ctx, const int32_t *ids, int nsel, int32_t *off, int32_t *list, int64_t cap) {
+  if (!ctx || nsel < 0 || !off || (nsel > 0 && !ids)) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szPotentialInteractions: no floes uploaded");
+  off[0] = 0;
+  if (nsel == 0) return SZ_OK;
+  for (int s = 0; s < nsel; ++s)
+    if (ids[s] < 1 || ids[s] > S->n) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szPotentialInteractions: ids[%d] = %d outside 1..%d", s, (int)ids[s], S->n);
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int cap_each = 64, rc;
+  DevBuf d_ids, d_cnt, d_list;
+  auto cleanup = [&]() { sz_release(d_ids); sz_release(d_cnt); sz_release(d_list); };
+  if ((rc = sz_reserve(ctx, d_ids, (size_t)nsel * 4)) || (rc = sz_reserve(ctx, d_cnt, (size_t)nsel * 4))) { cleanup(); return rc; }
+  std::vector<int> cnt((size_t)nsel), h;
+  for (;;) {      // (a floe with more neighbours than the room per floe: once more with what it needs)
+    if ((rc = sz_reserve(ctx, d_list, (size_t)nsel * cap_each * 4))) { cleanup(); return rc; }
+    hipError_t e = hipMemcpyAsync(d_ids.p, ids, (size_t)nsel * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_potential, dim3((unsigned)nsel), dim3(64), 0, st, S->F, (const int *)d_ids.p, nsel, cap_each, (int *)d_cnt.p, (int *)d_list.p); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)nsel * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szPotentialInteractions: %s", hipGetErrorString(e)); }
+    int most = 0;
+    for (int s = 0; s < nsel; ++s) most = cnt[s] > most ? cnt[s] : most;
+    if (most <= cap_each) break;
+    cap_each = most;
+  }
+  h.resize((size_t)nsel * cap_each);
+  hipError_t e = hipMemcpy(h.data(), d_list.p, h.size() * 4, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return sz_fail(ctx, SZ_ERR_HIP, "szPotentialInteractions: %s", hipGetErrorString(e));
+  int64_t at = 0;
+  for (int s = 0; s < nsel; ++s) {
+    if (at + cnt[s] > cap || (cnt[s] && !list)) return sz_fail(ctx, SZ_ERR_CAPACITY, "szPotentialInteractions: %lld entries or more, capacity %lld", (long long)(at + cnt[s]), (long long)cap);
+    for (int k = 0; k < cnt[s]; ++k) list[at + k] = h[(size_t)s * cap_each + k];
+    at += cnt[s];
+    off[s + 1] = (int32_t)at;
+  }
+  return SZ_OK;
+}

@@ -34,6 +34,11 @@
 //       before.
 //   eul = subzero_step('eulerian', Nx, Ny, Nb, c2_boundary, PERIODIC)
 //       calc_eulerian_data.m:1-192 on the resident floes: the struct of Ny x Nx fields the reference returns (Nb = 0).
+//   D = subzero_step('deform', ids)
+//       after a 'step': fracture_floe.m:14-52 for Floe(ids).  D(q).changed; when 1, D(q).Xi / Yi / area / c_alpha are
+//       the values :46-48 assign (c_alpha 2 x m, open).  The resident floes are not modified.
+//   Pt = subzero_step('potential', ids)
+//       FloeSimplify.m:14-34: Pt(q).floeNum = the floes Floe(ids(q)) may touch (row vector, ascending).
 //   subzero_step('close')
 // The struct <-> struct-of-arrays marshalling below is the only work done on the MATLAB thread.
 #include "mex.h"
@@ -335,6 +340,52 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       for (int k = 0; k < m; ++k) { mxGetPr(a)[k] = ang[(size_t)off[q] + k]; mxGetPr(d)[k] = da[(size_t)off[q] + k]; }
       mxSetFieldByNumber(plhs[0], (size_t)q, 0, a);
       mxSetFieldByNumber(plhs[0], (size_t)q, 1, d);
+    }
+    return;
+  }
+  if (!strcmp(cmd, "deform")) {
+    if (nrhs < 2) mexErrMsgTxt("D = subzero_step('deform', ids)");
+    const std::vector<int32_t> ids = parse_ids(prhs[1], n);
+    const int nsel = (int)ids.size();
+    std::vector<int32_t> chg((size_t)nsel + 1), roff((size_t)nsel + 1);
+    std::vector<double> X((size_t)nsel + 1), Y((size_t)nsel + 1), A((size_t)nsel + 1);
+    int64_t cap = 4 * (int64_t)g_soa.vert_off[n] + 64 * (int64_t)nsel + 64;
+    std::vector<double> cx((size_t)cap), cy((size_t)cap);
+    check(szFractureDeform(g_ctx, ids.data(), nsel, chg.data(), X.data(), Y.data(), A.data(), roff.data(), cx.data(), cy.data(), cap));
+    const char *names[] = {"changed", "Xi", "Yi", "area", "c_alpha"};
+    plhs[0] = mxCreateStructMatrix(1, (size_t)nsel, 5, names);
+    for (int q = 0; q < nsel; ++q) {
+      const int m = roff[q + 1] - roff[q];
+      mxSetFieldByNumber(plhs[0], (size_t)q, 0, mxCreateDoubleScalar(chg[q]));
+      mxSetFieldByNumber(plhs[0], (size_t)q, 1, mxCreateDoubleScalar(X[q]));
+      mxSetFieldByNumber(plhs[0], (size_t)q, 2, mxCreateDoubleScalar(Y[q]));
+      mxSetFieldByNumber(plhs[0], (size_t)q, 3, mxCreateDoubleScalar(A[q]));
+      mxArray *c = mxCreateDoubleMatrix(m ? 2 : 0, (size_t)m, mxREAL);
+      for (int k = 0; k < m; ++k) { mxGetPr(c)[2 * k] = cx[(size_t)roff[q] + k]; mxGetPr(c)[2 * k + 1] = cy[(size_t)roff[q] + k]; }
+      mxSetFieldByNumber(plhs[0], (size_t)q, 4, c);
+    }
+    return;
+  }
+  if (!strcmp(cmd, "potential")) {
+    if (nrhs < 2) mexErrMsgTxt("Pt = subzero_step('potential', ids)");
+    const std::vector<int32_t> ids = parse_ids(prhs[1], n);
+    const int nsel = (int)ids.size();
+    std::vector<int32_t> off((size_t)nsel + 1), list;
+    int64_t cap = 64 * (int64_t)nsel + 64;
+    for (;;) {
+      list.resize((size_t)cap);
+      const int rc = szPotentialInteractions(g_ctx, ids.data(), nsel, off.data(), list.data(), cap);
+      if (rc == SZ_ERR_CAPACITY) { cap *= 4; continue; }
+      check(rc);
+      break;
+    }
+    const char *names[] = {"floeNum"};
+    plhs[0] = mxCreateStructMatrix(1, (size_t)nsel, 1, names);
+    for (int q = 0; q < nsel; ++q) {
+      const int m = off[q + 1] - off[q];
+      mxArray *v = mxCreateDoubleMatrix(1, (size_t)m, mxREAL);
+      for (int k = 0; k < m; ++k) mxGetPr(v)[k] = list[(size_t)off[q] + k];
+      mxSetFieldByNumber(plhs[0], (size_t)q, 0, v);
     }
     return;
   }

@@ -54,3 +54,21 @@ def test_fracture_deform_argument_errors(ctx):
         sim.fracture_deform(np.array([0], np.int32))
     out = sim.fracture_deform(np.zeros(0, np.int32))
     assert len(out[0]) == 0
+
+
+def test_potential_interactions_match_floesimplify(ctx):
+    """FloeSimplify.m:14-34 (numpy transcription of the loop as the checker): alive partners, centres more than 1 m
+    apart, bounding circles overlapping, ascending."""
+    S, P = scenes.pack(400, periodic=False)
+    S.alive[7] = 0
+    # one floe as large as a quarter of the domain: far more partners than the first guess of the room per floe
+    S.rmax[11] = 6e4
+    sim = capi.FloeInteractions(ctx, S.copy())
+    ids = np.array([1, 12, 8, 200, 400], np.int32)
+    got = sim.potential_interactions(ids)
+    for s, fid in enumerate(ids):
+        i = fid - 1
+        d = np.sqrt((S.Xi[i] - S.Xi) ** 2 + (S.Yi[i] - S.Yi) ** 2)
+        want = np.nonzero((S.alive != 0) & (d > 1) & (d < S.rmax[i] + S.rmax))[0] + 1
+        assert np.array_equal(got[s], want), fid
+    assert len(got[1]) > 64 and 8 not in got[0].tolist()
