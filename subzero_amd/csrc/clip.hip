@@ -8,6 +8,7 @@
 //  * pairs whose lists outgrow their slice (only heavily self-intersecting input does) are appended to
 //    a retry list with one wave-aggregated atomic and re-run at 8x / 64x capacity -- on the GPU.
 //    There is no CPU fallback anywhere in this file.
+#include <stdlib.h>
 #include "clip_batch.hpp"
 
 using szb::ClipArgs;
@@ -66,7 +67,8 @@ struct SlotSink {
 
 
 __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)threadIdx.x >= a.lanes) return;
+  int t = blockIdx.x * a.lanes + threadIdx.x;
   int n = a.list ? a.nlist : a.npairs;
   if (t >= n) return;
   int p = a.list ? a.list[t] : t;
@@ -169,14 +171,23 @@ int szb::prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
   return SZ_OK;
 }
 
+static int clip_lanes(int npairs) {
+  if (const char *v = getenv("SUBZERO_CLIP_LANES")) { const int l = atoi(v); if (l >= 1 && l <= 64) return l; }
+  const int want = (npairs + 2047) / 2048;
+  return want < 1 ? 1 : want > 64 ? 64 : want;
+}
+
 // Runs the main pass and the retry tiers.  On return the per-pair arrays on the device are final.
 int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
   if (a.npairs == 0) {
     if (stats) memset(stats, 0, sizeof(*stats));
     return SZ_OK;
   }
+  // One sweep per lane, and a wave lasts as long as the sum of its lanes' divergent paths: as few pairs per wave as
+  // still give each of the 1024 SIMDs its two waves (252 VGPRs) -- a batch of 2e4 pairs runs 10 per wave.
+  a.lanes = clip_lanes(a.npairs);
   SZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_clip, dim3((a.npairs + 63) / 64), dim3(64), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_clip, dim3((a.npairs + a.lanes - 1) / a.lanes), dim3(64), 0, ctx->stream, a);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   unsigned long long c[8];
@@ -205,7 +216,8 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
     b.list = (const int *)list2.p;
     b.nlist = nlist;
     b.mult = mult;
-    hipLaunchKernelGGL(k_clip, dim3((nlist + 63) / 64), dim3(64), 0, ctx->stream, b);
+    b.lanes = clip_lanes(nlist);
+    hipLaunchKernelGGL(k_clip, dim3((nlist + b.lanes - 1) / b.lanes), dim3(64), 0, ctx->stream, b);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
     SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -18,6 +18,7 @@ struct ClipArgs {
   const double *fax, *fay, *fbx, *fby; // when non-null the inputs are doubles (polyclip form)
   int method, fill_s, fill_c;
   int mult;
+  int lanes;                    // pairs per 64-lane wave (the rest of the lanes idle: fewer divergent sweeps per wave)
   char *ws; i64 ws_cap;         // workspace arena
   i64 *ovx, *ovy; i64 ov_cap;   // result vertices
   int *oroff; i64 or_cap;       // result ring offsets (local to the pair's vertex slot)

@@ -67,7 +67,7 @@ int szSpatialInit(szContext *ctx, int rank, int world, const double *edges, doub
   S->sp_edges.assign(edges, edges + world + 1);
   const int n = S->n;
   int rc;
-  if ((rc = sz_reserve(ctx, S->sp_masks, 2 * (size_t)n + 64)) || (rc = sz_reserve(ctx, S->sp_edges_dev, ((size_t)world + 1) * 8)) ||
+  if ((rc = sz_reserve(ctx, S->sp_masks, 3 * (size_t)n + 64)) || (rc = sz_reserve(ctx, S->sp_edges_dev, ((size_t)world + 1) * 8)) ||
       (rc = sz_reserve(ctx, S->sp_counts, 64))) return rc;
   // ownership of the uploaded array: the strip of each centroid (every rank was handed the same array)
   std::vector<unsigned char> m(2 * (size_t)n, 0);
@@ -110,6 +110,8 @@ int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int
   SpatialMsg l = sp_msg_view((char *)d_left, cap_rec, cap_dbl, cap_migr, row), r = sp_msg_view((char *)d_right, cap_rec, cap_dbl, cap_migr, row);
   unsigned char *present = (unsigned char *)S->sp_masks.p, *owned = present + S->n;
   const SpatialGeom g = geom_of(S, periodic);
+  // (ownership as it is now: a message that overflows gives it back, so that Pack can be called again with more room)
+  SZ_HIP(ctx, hipMemcpyAsync(owned + S->n, owned, (size_t)S->n, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_sp_header_clear, dim3(1), dim3(64), 0, st, l, r);
   hipLaunchKernelGGL(k_sp_classify, grid_for(S->n, 256), dim3(256), 0, st, S->F, S->W, g, (const double *)S->sp_edges_dev.p, present, owned, l, r);
   long long *hdev = nullptr;
@@ -118,8 +120,10 @@ int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   const long long *h = S->sp_hdr;
-  if (h[2] > 0) hipLaunchKernelGGL(k_sp_bulk, dim3((unsigned)h[0]), dim3(256), 0, st, S->F, S->W, l, 1);
-  if (h[SP_HDR + 2] > 0) hipLaunchKernelGGL(k_sp_bulk, dim3((unsigned)h[SP_HDR]), dim3(256), 0, st, S->F, S->W, r, 1);
+  const bool overflow = h[3] != SP_OK || h[SP_HDR + 3] != SP_OK;
+  if (overflow) SZ_HIP(ctx, hipMemcpyAsync(owned, owned + S->n, (size_t)S->n, hipMemcpyDeviceToDevice, st));   // nothing was handed over
+  if (!overflow && h[2] > 0) hipLaunchKernelGGL(k_sp_bulk, dim3((unsigned)h[0]), dim3(256), 0, st, S->F, S->W, l, 1);
+  if (!overflow && h[SP_HDR + 2] > 0) hipLaunchKernelGGL(k_sp_bulk, dim3((unsigned)h[SP_HDR]), dim3(256), 0, st, S->F, S->W, r, 1);
   SZ_HIP(ctx, hipGetLastError());
   if (ctx->stream == ctx->own_stream) SZ_HIP(ctx, hipStreamSynchronize(st));   // the exchange runs on another stream
   memset(info, 0, sizeof(*info));
@@ -128,7 +132,7 @@ int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int
   info->need_records = h[4] > h[SP_HDR + 4] ? h[4] : h[SP_HDR + 4];
   info->need_doubles = h[5] > h[SP_HDR + 5] ? h[5] : h[SP_HDR + 5];
   info->need_migrants = h[6] > h[SP_HDR + 6] ? h[6] : h[SP_HDR + 6];
-  info->overflow = (h[3] != SP_OK || h[SP_HDR + 3] != SP_OK) ? 1 : 0;
+  info->overflow = overflow ? 1 : 0;
   info->has_left = g.has_left; info->has_right = g.has_right;
   return SZ_OK;
 }

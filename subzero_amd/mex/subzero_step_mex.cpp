@@ -25,7 +25,14 @@
 //       (:305-330,:385-458) indexes them.  needMC: floes whose ocean / wind forcing is due with an empty Monte-Carlo
 //       mask (calc_trajectory.m:100-110 draws new points with rand).  When it is not empty NOTHING was changed: run the
 //       reference's lines :102-109 for those floes, subzero_step('update', Floe, needMC, 'm') and call 'step' again.
-//   Floe = subzero_step('fetch', Floe, ids, what)     what: any of 's' state, 'r' c0 / c_alpha, 'h' StressH, 'm' X, Y, A
+//   [kill, transfer, needMC, dead, ghosts] = subzero_step('advance', floebound, ocean, winds, c2_boundary, dt, HFo, Modulus,
+//                                                          doIntFlag, COLLISION, PERIODIC [, mu, nu])
+//       the same timestep with nothing written back: the MATLAB array goes stale and is brought up to
+//       date with 'fetch' (..., 'sri') at output steps (Subzero.m:220,285) and before MATLAB-side processes.  What the
+//       tail of floe_interactions_all.m acts on every step comes back: kill / transfer (:467-501), the floes that died.
+//       'upload' / 'resync' / 'update' of state refuse a stale array.
+//   Floe = subzero_step('fetch', Floe, ids, what)     what: any of 's' state, 'r' c0 / c_alpha, 'h' StressH, 'm' X, Y, A,
+//                                                     'i' interactions of the last step
 //   subzero_step('update', Floe, ids, what)           the same groups from Floe(ids) to the device (same ring lengths)
 //   C = subzero_step('corners', ids, Nb, c2_boundary)
 //       after a 'step': the per-vertex part of corners.m:13-92 for the floes Floe(ids) (ids = find(~keep), Subzero.m:
@@ -79,6 +86,7 @@ struct Soa {
 Soa g_soa;              // the resident array as the gateway knows it
 bool g_resident = false;
 bool g_history_ahead = false;   // the device has stepped since the host last saw StressH
+bool g_state_ahead = false;     // 'advance' has stepped since the host last saw the dynamic fields and c_alpha
 
 void fail(const char *fmt, ...) {
   char buf[768];
@@ -226,13 +234,14 @@ void unpack_bulk(mxArray *F, const Soa &S, const int32_t *ids, int nids, bool hi
   }
 }
 
+enum { F_INTERACTIONS = 1 << 8 };   // 'i': Floe(ids).interactions of the last step (gateway-level group, not a szFloesFetch one)
 int parse_what(const mxArray *a) {
   char w[16];
-  if (!a || !mxIsChar(a) || mxGetString(a, w, sizeof(w))) fail("subzero_step: `what` must be a short char array of s, r, h, m");
+  if (!a || !mxIsChar(a) || mxGetString(a, w, sizeof(w))) fail("subzero_step: `what` must be a short char array of s, r, h, m, i");
   int what = 0;
   for (const char *p = w; *p; ++p) {
     if (*p == 's') what |= SZ_F_STATE; else if (*p == 'r') what |= SZ_F_RING; else if (*p == 'h') what |= SZ_F_STRESSH;
-    else if (*p == 'm') what |= SZ_F_MC; else fail("subzero_step: unknown field group '%c'", *p);
+    else if (*p == 'm') what |= SZ_F_MC; else if (*p == 'i') what |= F_INTERACTIONS; else fail("subzero_step: unknown field group '%c'", *p);
   }
   return what;
 }
@@ -257,16 +266,78 @@ bool same_floe(const Soa &now, int k, const Soa &was, int g) {
          !memcmp(&now.c0y[now.vert_off[k]], &was.c0y[was.vert_off[g]], (size_t)nv * 8);
 }
 
+
+// Floe(ids).interactions (all floes when ids == nullptr) of the last step: K x 7, column-major, [] when the floe touched nothing
+void put_interactions(mxArray *F, int n, const int32_t *ids, int nids) {
+  std::vector<int32_t> off((size_t)n + 1);
+  int rc = szInteractionsDownload(g_ctx, off.data(), nullptr, 0);     // offsets first: they say how many rows there are
+  if (rc != SZ_OK && rc != SZ_ERR_CAPACITY && rc != SZ_ERR_BAD_ARG) check(rc);
+  std::vector<double> rows((size_t)(off[n] > 0 ? off[n] : 1) * 7);
+  check(szInteractionsDownload(g_ctx, off.data(), rows.data(), (int64_t)(rows.size() / 7)));
+  const int cnt = ids ? nids : n;
+  for (int q = 0; q < cnt; ++q) {
+    const int i = ids ? ids[q] - 1 : q;
+    const int k0 = off[i], K = off[i + 1] - k0;
+    mxArray *in = mxCreateDoubleMatrix(K, K ? 7 : 0, mxREAL);
+    for (int r = 0; r < K; ++r) for (int c = 0; c < 7; ++c) mxGetPr(in)[(size_t)c * K + r] = rows[(size_t)7 * (k0 + r) + c];
+    put_field(F, (size_t)i, "interactions", in);
+  }
+}
+
+// floebound, ocean, winds, c2_boundary, dt, HFo, Modulus, doInt, COLLISION, PERIODIC [, mu, nu] from a[0..]
+void step_params(int na, const mxArray **a, szStepParams &p) {
+  if (na < 10) mexErrMsgTxt("subzero_step: floebound, ocean, winds, c2_boundary, dt, HFo, Modulus, doInt, COLLISION, PERIODIC [, mu, nu] expected");
+  const mxArray *fb = a[0], *oc = a[1], *wi = a[2];
+  memset(&p, 0, sizeof(p));
+  memcpy(p.c2_boundary, doubles(a[3], 10, "c2_boundary", -1), 10 * sizeof(double));
+  p.dt = mxGetScalar(a[4]);
+  { const mxArray *H = a[5]; const size_t m = mxGetNumberOfElements(H); double s = 0; for (size_t k = 0; k < m; ++k) s += mxGetPr(H)[k]; p.HFo = m ? s / (double)m : 0; } // mean(HFo(:)), calc_trajectory.m:5
+  p.Modulus = mxGetScalar(a[6]);
+  p.mu = na > 10 ? mxGetScalar(a[10]) : 0.2; p.nu = na > 11 ? mxGetScalar(a[11]) : 0.3;   // floe_interactions.m:20-21
+  p.doInt = mxGetScalar(a[7]) != 0; p.COLLISION = mxGetScalar(a[8]) != 0; p.PERIODIC = mxGetScalar(a[9]) != 0;
+  p.fb_h = scalar_field(fb, 0, "h"); p.fb_area = scalar_field(fb, 0, "area"); p.fb_Xi = scalar_field(fb, 0, "Xi");
+  p.fb_Yi = scalar_field(fb, 0, "Yi"); p.fb_Ui = scalar_field(fb, 0, "Ui"); p.fb_Vi = scalar_field(fb, 0, "Vi");
+  p.fb_ksi_ice = scalar_field(fb, 0, "ksi_ice");
+  const mxArray *Xo = need_field(oc, 0, "Xo"), *Yo = need_field(oc, 0, "Yo");
+  p.nxo = (int)mxGetNumberOfElements(Xo); p.nyo = (int)mxGetNumberOfElements(Yo);
+  const size_t grid = (size_t)p.nxo * p.nyo;
+  p.Xo = mxGetPr(Xo); p.Yo = mxGetPr(Yo);
+  p.Uocn = doubles(need_field(oc, 0, "Uocn"), grid, "Uocn", -1); p.Vocn = doubles(need_field(oc, 0, "Vocn"), grid, "Vocn", -1);
+  p.Uwind = doubles(need_field(wi, 0, "u"), grid, "u", -1); p.Vwind = doubles(need_field(wi, 0, "v"), grid, "v", -1);
+  p.fCoriolis = scalar_field(oc, 0, "fCoriolis"); p.turn_angle = scalar_field(oc, 0, "turn_angle");
+}
+mxArray *row_of(const std::vector<int32_t> &v, size_t count) {
+  mxArray *a = mxCreateDoubleMatrix(1, count, mxREAL);
+  for (size_t k = 0; k < count; ++k) mxGetPr(a)[k] = v[k];
+  return a;
+}
+mxArray *ghost_struct(int G) {
+  std::vector<int32_t> gs((size_t)G + 1), gp((size_t)G + 1);
+  std::vector<double> gx((size_t)G + 1), gy((size_t)G + 1);
+  int64_t cnt = 0;
+  if (G >= 0) check(szGhostsDownload(g_ctx, gs.data(), gp.data(), gx.data(), gy.data(), G, &cnt));
+  const char *names[] = {"src", "parent", "Xi", "Yi"};
+  mxArray *out = mxCreateStructMatrix(1, 1, 4, names);
+  mxArray *a[4];
+  for (int k = 0; k < 4; ++k) a[k] = mxCreateDoubleMatrix(1, (size_t)cnt, mxREAL);
+  for (int64_t g = 0; g < cnt; ++g) { mxGetPr(a[0])[g] = gs[(size_t)g]; mxGetPr(a[1])[g] = gp[(size_t)g]; mxGetPr(a[2])[g] = gx[(size_t)g]; mxGetPr(a[3])[g] = gy[(size_t)g]; }
+  for (int k = 0; k < 4; ++k) mxSetFieldByNumber(out, 0, k, a[k]);
+  return out;
+}
+
 } // namespace
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgTxt("subzero_step(command, ...)");
   char cmd[16];
   mxGetString(prhs[0], cmd, sizeof(cmd));
-  if (!strcmp(cmd, "close")) { at_exit(); g_resident = false; g_history_ahead = false; g_soa = Soa(); return; }
+  if (!strcmp(cmd, "close")) { at_exit(); g_resident = false; g_history_ahead = false; g_state_ahead = false; g_soa = Soa(); return; }
   const bool upload = !strcmp(cmd, "upload"), resync = !strcmp(cmd, "resync");
   if (upload || resync) {
     if (nrhs < 3) fail("Floe = subzero_step('%s', Floe, Nb)", cmd);
+    if (g_resident && g_state_ahead)
+      fail("subzero_step('%s'): the device has stepped ('advance') since this Floe array was current; "
+           "Floe = subzero_step('fetch', Floe, 1:numel(Floe), 'sr') first", cmd);
     Soa S;
     pack(prhs[1], (int)mxGetScalar(prhs[2]), S);     // argument errors first: they do not need a GPU
     if (!g_ctx) {
@@ -308,17 +379,22 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       Soa S;
       pack(prhs[1], g_soa.nb, S);
       szFloeState s = S.view();
+      if (what & F_INTERACTIONS) mexErrMsgTxt("subzero_step('update'): interactions are a result of 'step', not an input");
+      if (g_state_ahead && (what & (SZ_F_STATE | SZ_F_RING)))
+        mexErrMsgTxt("subzero_step('update'): the device has stepped ('advance') since this Floe array was current; 'fetch' the floes ('sr') before changing and updating them");
       check(szFloesUpdate(g_ctx, &s, ids.data(), (int32_t)ids.size(), what));
       g_soa = S;
       return;
     }
     szFloeState s = g_soa.view();
-    check(szFloesFetch(g_ctx, &s, ids.data(), (int32_t)ids.size(), what));
+    if (what & SZ_F_ALL) check(szFloesFetch(g_ctx, &s, ids.data(), (int32_t)ids.size(), what & SZ_F_ALL));
     plhs[0] = mxDuplicateArray(prhs[1]);
+    if (what & F_INTERACTIONS) put_interactions(plhs[0], n, ids.data(), (int)ids.size());
     if (what & SZ_F_STATE) unpack_state(plhs[0], g_soa, ids.data(), (int)ids.size());
     if (what & SZ_F_RING) unpack_rings(plhs[0], g_soa, ids.data(), (int)ids.size(), true);
     unpack_bulk(plhs[0], g_soa, ids.data(), (int)ids.size(), (what & SZ_F_STRESSH) != 0, (what & SZ_F_MC) != 0);
     if ((what & SZ_F_STRESSH) && (int)ids.size() == n) g_history_ahead = false;
+    if ((what & SZ_F_STATE) && (what & SZ_F_RING) && (int)ids.size() == n) g_state_ahead = false;
     return;
   }
   if (!strcmp(cmd, "corners")) {
@@ -407,28 +483,45 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
     return;
   }
+  if (!strcmp(cmd, "advance")) {
+    // one timestep with NOTHING written back: the state stays on the device; what the MATLAB tail
+    // of floe_interactions_all.m acts on comes back -- kill / transfer (:467-501) and the floes that died
+    szStepParams p;
+    step_params(nrhs - 1, prhs + 1, p);
+    szStepStats stats; memset(&stats, 0, sizeof(stats));
+    const int rc = szStep(g_ctx, &p, &stats);
+    if (rc == SZ_STEP_NEEDS_MC) {
+      std::vector<int32_t> ids((size_t)n);
+      int64_t cnt = 0;
+      check(szMcEmptyDownload(g_ctx, ids.data(), n, &cnt));
+      if (nlhs < 3) mexErrMsgTxt("subzero_step('advance'): floes need new Monte-Carlo points (calc_trajectory.m:100-110); call with three outputs to receive the list");
+      plhs[0] = mxCreateDoubleMatrix(1, 0, mxREAL); plhs[1] = mxCreateDoubleMatrix(1, 0, mxREAL);
+      plhs[2] = row_of(ids, (size_t)cnt);
+      if (nlhs > 3) plhs[3] = mxCreateDoubleMatrix(1, 0, mxREAL);
+      if (nlhs > 4) plhs[4] = ghost_struct(-1);
+      return;
+    }
+    check(rc);
+    g_history_ahead = true; g_state_ahead = true;
+    // only alive / kill / transfer cross PCIe
+    szFloeState s; memset(&s, 0, sizeof(s));
+    s.n = g_soa.n; s.nb = g_soa.nb; s.n_stress = g_soa.n_stress; s.n_mc = g_soa.n_mc;
+    s.alive = g_soa.alive.data(); s.kill = g_soa.kill.data(); s.transfer = g_soa.transfer.data();
+    check(szFloesDownload(g_ctx, &s, SZ_SYNC_DYNAMIC));
+    const int N = (int)stats.n_ext;
+    if (nlhs > 0) plhs[0] = row_of(g_soa.kill, (size_t)N);
+    if (nlhs > 1) plhs[1] = row_of(g_soa.transfer, (size_t)N);
+    if (nlhs > 2) plhs[2] = mxCreateDoubleMatrix(1, 0, mxREAL);
+    if (nlhs > 3) { std::vector<int32_t> dead; for (int i = 0; i < n; ++i) if (!g_soa.alive[i]) dead.push_back(i + 1); plhs[3] = row_of(dead, dead.size()); }
+    if (nlhs > 4) plhs[4] = ghost_struct(N - n);
+    return;
+  }
   if (strcmp(cmd, "step")) mexErrMsgTxt("subzero_step: unknown command");
   if (nrhs < 12) mexErrMsgTxt("subzero_step('step', Floe, floebound, ocean, winds, c2_boundary, dt, HFo, Modulus, doInt, COLLISION, PERIODIC [, mu, nu])");
   if (nlhs < 1) mexErrMsgTxt("subzero_step('step'): at least one output (Floe) required");
   if ((int)mxGetNumberOfElements(prhs[1]) != n) mexErrMsgTxt("subzero_step('step'): Floe has a different length than the resident array ('resync' first)");
-  const mxArray *fb = prhs[2], *oc = prhs[3], *wi = prhs[4];
-  szStepParams p; memset(&p, 0, sizeof(p));
-  memcpy(p.c2_boundary, doubles(prhs[5], 10, "c2_boundary", -1), 10 * sizeof(double));
-  p.dt = mxGetScalar(prhs[6]);
-  { const mxArray *H = prhs[7]; const size_t m = mxGetNumberOfElements(H); double s = 0; for (size_t k = 0; k < m; ++k) s += mxGetPr(H)[k]; p.HFo = m ? s / (double)m : 0; } // mean(HFo(:)), calc_trajectory.m:5
-  p.Modulus = mxGetScalar(prhs[8]);
-  p.mu = nrhs > 12 ? mxGetScalar(prhs[12]) : 0.2; p.nu = nrhs > 13 ? mxGetScalar(prhs[13]) : 0.3;   // floe_interactions.m:20-21
-  p.doInt = mxGetScalar(prhs[9]) != 0; p.COLLISION = mxGetScalar(prhs[10]) != 0; p.PERIODIC = mxGetScalar(prhs[11]) != 0;
-  p.fb_h = scalar_field(fb, 0, "h"); p.fb_area = scalar_field(fb, 0, "area"); p.fb_Xi = scalar_field(fb, 0, "Xi");
-  p.fb_Yi = scalar_field(fb, 0, "Yi"); p.fb_Ui = scalar_field(fb, 0, "Ui"); p.fb_Vi = scalar_field(fb, 0, "Vi");
-  p.fb_ksi_ice = scalar_field(fb, 0, "ksi_ice");
-  const mxArray *Xo = need_field(oc, 0, "Xo"), *Yo = need_field(oc, 0, "Yo");
-  p.nxo = (int)mxGetNumberOfElements(Xo); p.nyo = (int)mxGetNumberOfElements(Yo);
-  const size_t grid = (size_t)p.nxo * p.nyo;
-  p.Xo = mxGetPr(Xo); p.Yo = mxGetPr(Yo);
-  p.Uocn = doubles(need_field(oc, 0, "Uocn"), grid, "Uocn", -1); p.Vocn = doubles(need_field(oc, 0, "Vocn"), grid, "Vocn", -1);
-  p.Uwind = doubles(need_field(wi, 0, "u"), grid, "u", -1); p.Vwind = doubles(need_field(wi, 0, "v"), grid, "v", -1);
-  p.fCoriolis = scalar_field(oc, 0, "fCoriolis"); p.turn_angle = scalar_field(oc, 0, "turn_angle");
+  szStepParams p;
+  step_params(nrhs - 2, prhs + 2, p);
   szStepStats stats; memset(&stats, 0, sizeof(stats));
   const int rc = szStep(g_ctx, &p, &stats);
   if (rc == SZ_STEP_NEEDS_MC) {
@@ -444,7 +537,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     return;
   }
   check(rc);
-  g_history_ahead = true;
+  g_history_ahead = true; g_state_ahead = false;   // (every dynamic field is written back below)
   szFloeState s = g_soa.view();
   check(szFloesDownload(g_ctx, &s, SZ_SYNC_DYNAMIC));
   std::vector<int32_t> off((size_t)n + 1);

@@ -298,6 +298,7 @@ class SpatialInteractions:
         self.caps = (int(n_floes), int(47 * n_floes + 2 * n_vertices), int(max(64, n_floes // 16)))
         self.exchanges = 0
         self.bytes_sent = 0
+        self.regrown = 0
         self.last = None
 
     def _views(self, buf, caps, bulk_row):
@@ -318,12 +319,18 @@ class SpatialInteractions:
             return be.step(P)
         left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
         with be.stream_scope():
-            caps = self.caps
-            nbytes = be.message_bytes(caps)
-            bufs = {k: be.buffer(k, nbytes) for k in ("send_left", "send_right", "from_left", "from_right")}
-            sent = be.pack(P.PERIODIC, bufs["send_left"], bufs["send_right"], caps)
-            if sent.overflow:
-                raise RuntimeError("spatial exchange: %d floes changed strip in one step (capacity %d)" % (sent.need_migrants, caps[2]))
+            # my messages: a message that does not fit (more floes changed strip than there is room for) is packed
+            # again into larger buffers -- nothing has been sent yet, nothing is lost (include/subzero_hip.h)
+            while True:
+                caps = self.caps
+                nbytes = be.message_bytes(caps)
+                bufs = {k: be.buffer(k, nbytes) for k in ("send_left", "send_right", "from_left", "from_right")}
+                sent = be.pack(P.PERIODIC, bufs["send_left"], bufs["send_right"], caps)
+                if not sent.overflow:
+                    break
+                self.caps = (max(caps[0], int(sent.need_records)), max(caps[1], int(sent.need_doubles)),
+                             max(2 * caps[2], int(sent.need_migrants)))
+                self.regrown += 1
             hl, hr = bool(sent.has_left), bool(sent.has_right)
             bulk_row = be.bulk_row()
             v = {k: self._views(b, caps, bulk_row) for k, b in bufs.items()}
@@ -335,9 +342,18 @@ class SpatialInteractions:
             if hl: ops.append(dist.P2POp(dist.irecv, v["from_left"][0], left, self.group, tag=2))
             self._round(ops)
             hdr = {k: be.header(v[k][0]) for k in ("from_left", "from_right") if (hl if k == "from_left" else hr)}
-            for k, h in hdr.items():
-                if h[0] > caps[0] or h[1] > caps[1] or h[2] > caps[2]:
-                    raise RuntimeError("spatial exchange: the neighbour's message does not fit the local buffers")
+            # a neighbour whose message is larger than my buffers (it has grown its own): lay my receive buffers out
+            # for what the headers announce before anything else arrives
+            rcaps = tuple(max([caps[q]] + [h[q] for h in hdr.values()]) for q in range(3))
+            if rcaps != caps:
+                rbytes = be.message_bytes(rcaps)
+                for k in hdr:
+                    head = v[k][0].clone()
+                    bufs[k] = be.buffer(k, rbytes)
+                    v[k] = self._views(bufs[k], rcaps, bulk_row)
+                    v[k][0].copy_(head)
+                self.caps = rcaps
+                self.regrown += 1
             # round 2: the used part of each array
             ops = []
             def parts(key, n_rec, n_dbl, n_migr):
@@ -360,9 +376,15 @@ class SpatialInteractions:
                     ops.append(dist.P2POp(dist.irecv, t, left, self.group, tag=2))
             self._round(ops)
             self.exchanges += 1
-            got = be.unpack(bufs["from_left"] if hl else None, bufs["from_right"] if hr else None, caps)
+            got = be.unpack(bufs["from_left"] if hl else None, bufs["from_right"] if hr else None, rcaps)
             self.last = (sent, got)
             return be.step(P)
+
+    def retry_local(self, P):
+        """After `step` raised capi.NeedsMc (the step changed nothing and is rank-local from here on): the caller has
+        updated the Monte-Carlo points of the listed floes; run the step again without another exchange."""
+        with self.be.stream_scope():
+            return self.be.step(P)
 
 
 def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):

@@ -480,8 +480,10 @@ int host_spatial_pack(HFloes *hf, int periodic, void *left, void *right, int64_t
   for (int k = 0; k < SP_HDR; ++k) { l.hdr[k] = 0; r.hdr[k] = 0; }
   const SpatialGeom g = host_geom(periodic);
   unsigned char *present = g_sp_masks.data(), *owned = present + hf->n;
+  const std::vector<unsigned char> owned_before(owned, owned + hf->n);
   for (int i = hf->n - 1; i >= 0; --i) sp_classify(i, s.F, s.W, g, g_sp_edges.data(), present, owned, l, r);   // any order
   sp_seal(l); sp_seal(r);
+  if (l.hdr[3] != SP_OK || r.hdr[3] != SP_OK) std::copy(owned_before.begin(), owned_before.end(), owned);     // (as szSpatialPack: nothing was handed over)
   SpatialMsg *ms[2] = {&l, &r};
   for (int side = 0; side < 2; ++side) {
     SpatialMsg &m = *ms[side];

@@ -135,7 +135,8 @@ def _worker(rank, world, port, scene, steps, drift, q):
         import scenes
         from subzero_amd import multigpu
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        S, P = getattr(scenes, scene[0])(*scene[1], **scene[2])
+        kw = dict(scene[2]); tiny = kw.pop("tiny_migrant_room", False)
+        S, P = getattr(scenes, scene[0])(*scene[1], **kw)
         P.set_reference_ocean()
         S.Ui += drift                                  # a common drift: floes cross strip edges (and the periodic edge)
         ref = S.copy()
@@ -143,6 +144,8 @@ def _worker(rank, world, port, scene, steps, drift, q):
         edges, halo = multigpu.strip_edges(S, world, Lx)
         be = HostSpatialBackend(S, rank, world, edges, halo)
         sim = multigpu.SpatialInteractions(be, rank, world, S.n, int(S.vert_off[-1]))
+        if tiny:                                       # room for ONE floe changing strip: messages must grow, on both ends
+            sim.caps = (sim.caps[0], sim.caps[1], 1)
         owned0 = be.owned()
         most_present = 0
         for it in range(steps):
@@ -176,10 +179,10 @@ def _worker(rank, world, port, scene, steps, drift, q):
             most_present = max(most_present, int(sim.last[1].n_present))
         moved = int((own != owned0).sum())
         dist.destroy_process_group()
-        q.put((rank, "ok", moved, be.migrants_in, most_present, int(own.sum()), sim.bytes_sent // max(sim.exchanges, 1), len(r1.inter)))
+        q.put((rank, "ok", moved, be.migrants_in, most_present, int(own.sum()), sim.bytes_sent // max(sim.exchanges, 1), len(r1.inter), sim.regrown))
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0, 0, 0, 0, 0))
+        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0, 0, 0, 0, 0, 0))
 
 
 def run(world, scene, steps, drift):
@@ -208,3 +211,10 @@ def test_spatial_step_equals_single_process(world, periodic):
     assert res[0][7] > 100                              # contacts were exercised
     for r in res:
         assert r[4] < total, "a rank held current data for every floe: nothing was sharded"
+
+
+def test_messages_grow_when_more_floes_change_strip_than_fit():
+    """Room for one migrant per message: the sender packs again into larger buffers, the receiver lays its buffers out
+    for what the header announces -- same results, nobody raises, nobody waits for a peer that has left."""
+    res = run(2, ("pack", (1800,), {"periodic": True, "n_stress": 6, "n_mc": 80, "tiny_migrant_room": True}), 6, 90.0)
+    assert sum(r[3] for r in res) > 4 and sum(r[8] for r in res) > 0

@@ -118,3 +118,30 @@ def test_orchestration_with_a_one_rank_rccl_group():
         be.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_a_message_that_overflows_hands_nothing_over():
+    """szSpatialPack with no room for a floe that changed strip: overflow is reported with what the edge needs, the
+    ownership is as it was, and the same call with room succeeds (include/subzero_hip.h: "Pack can be called again")."""
+    S, P = scenes.pack(1800, periodic=True, n_stress=6, n_mc=80)
+    P.set_reference_ocean()
+    S.Ui += 90.0
+    edges, halo = multigpu.strip_edges(S, 2, float(P.c2_boundary[0].max()))
+    R = Rank(S, 0, 2, edges, halo)
+    sent = None
+    for it in range(6):                     # step alone until some of its floes have left the strip
+        P.doInt = 0
+        R.be.step(P)
+    before = R.be.owned()
+    small = (R.caps[0], R.caps[1], 0)
+    nbytes = R.be.message_bytes(R.caps)
+    with R.be.stream_scope():
+        sent = R.be.pack(P.PERIODIC, R.buf["send_left"][:nbytes], R.buf["send_right"][:nbytes], small)
+    assert sent.overflow and sent.need_migrants >= 1
+    assert np.array_equal(R.be.owned(), before)
+    with R.be.stream_scope():
+        sent = R.be.pack(P.PERIODIC, R.buf["send_left"], R.buf["send_right"], R.caps)
+    assert not sent.overflow and sent.left_migrants + sent.right_migrants >= 1
+    after = R.be.owned()
+    assert before.sum() - after.sum() == sent.left_migrants + sent.right_migrants
+    R.be.close()
