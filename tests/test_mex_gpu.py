@@ -233,3 +233,48 @@ def test_step_gateway_deform_and_potential_commands(stepgw):
         d = np.sqrt((A.Xi[i] - A.Xi) ** 2 + (A.Yi[i] - A.Yi) ** 2)
         want = np.nonzero((A.alive != 0) & (d > 1) & (d < A.rmax[i] + A.rmax))[0] + 1
         assert np.array_equal(mx.to_numpy(mx.get_field(Pt, q, "floeNum")).ravel(), want.astype(float))
+
+
+def test_advance_leaves_the_state_on_the_device_until_it_is_fetched(stepgw):
+    """'advance': the timestep with nothing written back.  kill / transfer / dead floes come back every
+    step; the stale MATLAB array is refused by 'upload' / 'resync' / 'update' until 'fetch' has brought it up to date;
+    after the fetch it equals the oracle's array, interactions included."""
+    S, P = scenes.pack(140, periodic=True, n_stress=5, n_mc=120)
+    P.set_reference_ocean()
+    S.Xi += 250.0
+    A, G = S.copy(), S.copy()
+    stepgw.call(0, mx.string("close"))
+    F, = stepgw.call(1, mx.string("upload"), mx.floe_struct(G), mx.scalar(0))
+    for it in range(7):
+        P.doInt = int(it % 4 == 0)
+        ra = oracle.step(A, P, threads=8)
+        kill, transfer, need, dead, ghosts = stepgw.call(5, mx.string("advance"), *mx.step_args(P))
+        assert mx.numel(need) == 0
+        k = mx.to_numpy(kill).ravel(); t = mx.to_numpy(transfer).ravel()
+        assert len(k) == ra.n_ext and np.array_equal(k, A.kill[:ra.n_ext]) and np.array_equal(t, A.transfer[:ra.n_ext])
+        assert np.array_equal(mx.to_numpy(dead).ravel(), np.nonzero(A.alive == 0)[0] + 1.0)
+        assert mx.numel(mx.get_field(ghosts, 0, "src")) == ra.n_ext - S.n
+    # the MATLAB array has not moved
+    assert mx.to_numpy(mx.get_field(F, 0, "Xi")).ravel()[0] == S.Xi[0]
+    for cmd in ("upload", "resync"):
+        with pytest.raises(mx.MexError) as e:
+            stepgw.call(1, mx.string(cmd), F, mx.scalar(0))
+        assert "'advance'" in str(e.value) and "fetch" in str(e.value)
+    with pytest.raises(mx.MexError):
+        stepgw.call(0, mx.string("update"), F, mx.row([1]), mx.string("s"))
+    F, = stepgw.call(1, mx.string("fetch"), F, mx.row(np.arange(1, S.n + 1)), mx.string("sri"))
+    inter = mx.read_floes(F, G)
+    bad = [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "kill", "transfer", "Stress")]
+    assert bad == [], bad
+    assert np.abs(A.Stress - G.Stress).max() <= 1e-10 * max(1.0, np.abs(A.Stress).max())
+    for i in range(S.n):
+        want = ra.inter[ra.inter_off[i]:ra.inter_off[i + 1]]
+        assert np.array_equal(inter[i].reshape(-1, 7), want), i
+    F, = stepgw.call(1, mx.string("resync"), F, mx.scalar(0))        # up to date again: accepted
+    # and the write-back step continues from there
+    P.doInt = 0
+    ra = oracle.step(A, P, threads=8)
+    F, kill, transfer, ghosts, need = gw_step(stepgw, F, P)
+    mx.read_floes(F, G)
+    bad = [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "kill", "transfer", "Stress")]
+    assert bad == [], bad
