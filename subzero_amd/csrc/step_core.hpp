@@ -301,10 +301,10 @@ SZ_HD void grid_levels(double r_max, double r_p90, double Lx, double Ly, Work &W
 SZ_HD int cell_of(int e, const Floes &F, const Work &W) {
   return cell_at(level_of(F.rmax[W.ext_src[e]], W), W.ext_x[e], W.ext_y[e], W);
 }
-// only live floes that can be a candidate enter the grid (a dead floe never is, :101,:103; floes 1..Nb neither,
-// since j > i >= 1 + Nb); each item carries its position and radius so that a cell is one contiguous stream of
-// independent loads
-SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && s >= F.nb && is_present(s, W); }
+// only live floes that can be a candidate enter the grid (a dead floe never is, :101,:103; entries 1..Nb of the list
+// neither, since j > i >= 1 + Nb -- but the GHOST of a boundary floe is an entry beyond N0 and is one, :76-103); each
+// item carries its position and radius so that a cell is one contiguous stream of independent loads
+SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && e >= F.nb && is_present(s, W); }
 SZ_HD void cell_count(int e, const Floes &F, Work &W) {
   if (in_grid(e, F, W)) atomic_add(&W.cell_cnt[cell_of(e, F, W)], 1);
 }

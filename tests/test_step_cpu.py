@@ -129,7 +129,9 @@ def test_baseline_configs_match_oracle(name, steps):
         assert (ra.inter[:, 0] == np.inf).any()        # the moving walls push on the pack
 
 
-@pytest.mark.parametrize("seed", range(2000, 2024))
+# (50239 ... 53828: scenes of the round-2 GPU campaign in which the ghost of a boundary floe -- one of the Nb floes,
+# crossing the periodic edge -- is the partner of a real floe: entries beyond N0 are candidates whatever their source)
+@pytest.mark.parametrize("seed", list(range(2000, 2024)) + [50239, 50249, 50599, 53828])
 def test_random_scenes_match_oracle(seed):
     S, P, steps = scenes.random_scene(seed)
     A, B = S.copy(), S.copy()

@@ -145,7 +145,7 @@ def test_forcing_with_more_points_than_the_kernel_keeps(ctx):
     assert exact
 
 
-@pytest.mark.parametrize("seed", range(3000, 3030))
+@pytest.mark.parametrize("seed", list(range(3000, 3030)) + [50239, 50249, 50599, 53828])   # (+ ghosts of boundary floes as partners)
 def test_random_scenes(ctx, seed):
     # random small scenes (Voronoi packs, concave outlines, many-sided floes; walls or periodic; Nb, forcing)
     S, P, steps = scenes.random_scene(seed)
