@@ -370,6 +370,16 @@ int szSpatialUnpack(szContext *ctx, const void *d_from_left, const void *d_from_
                     int64_t cap_doubles, int64_t cap_migrants, szSpatialInfo *info);
 int szSpatialOwned(szContext *ctx, uint8_t *owned);   /* owned[i] = 1: this rank integrates floe i (n bytes) */
 
+/* clipper(P, delta, type [, info]) offset mode (mexclipper.cpp:146-203): ClipperOffset with AddPaths(P, jt,
+ * etClosedPolygon), Execute(solution, delta).  x / y / ring_off: the nrings contours of P (int64, as the mex reads
+ * them); delta in the same units (+ outset, - inset); join: 0 square ('s'), 1 round ('r'), 2 miter ('m'); info: the
+ * optional fourth argument (ArcTolerance for round, MiterLimit for miter), <= 0 when not given (defaults 0.25, 2).
+ * The raw offset polygons are built on the host (one pass over the vertices, with the host's libm as in the
+ * reference), their clean-up -- the union of self-intersecting polygons -- runs on the GPU.  status: SZ_CLIP_*. */
+int szOffsetPaths(szContext *ctx, const int64_t *x, const int64_t *y, const int32_t *ring_off, int nrings, double delta,
+                  int join, double info, int64_t *outx, int64_t *outy, int64_t out_cap, int32_t *out_ring_off,
+                  int64_t ring_cap, int32_t *nrings_out, int32_t *status);
+
 /* clipper(P) orientation mode (mexclipper.cpp:134-145): 1 if Area(P) >= 0 else 0.  Host arithmetic
  * on n vertices (an O(n) sum; there is nothing to accelerate). */
 int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation);

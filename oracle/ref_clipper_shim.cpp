@@ -10,6 +10,7 @@
 // Method numbering is the mex's (mexclipper.cpp:215-230): 0 Difference, 1 Intersection,
 // 2 Xor, 3 Union; fill types 0 EvenOdd, 1 NonZero, 2 Positive, 3 Negative (:243-287).
 //
+// and of its offset mode (:146-203, ref_offset below).
 // mexclipper.cpp itself cannot be compiled here (needs MATLAB's mex.h).
 #include "clipper.hpp"
 #include <stdint.h>
@@ -102,6 +103,37 @@ int ref_orientation(const int64_t *x, const int64_t *y, int n) {
   Path p((size_t)n);
   for (int i = 0; i < n; ++i) { p[i].X = x[i]; p[i].Y = y[i]; }
   return Orientation(p) ? 1 : 0;
+}
+
+// Offset mode of the mex (mexclipper.cpp:146-203): ClipperOffset co; [ArcTolerance / MiterLimit = info when given];
+// co.AddPaths(subj, jt, etClosedPolygon); co.Execute(solution, delta).  join: 0 square, 1 round, 2 miter (the mex's
+// 's' / 'r' / 'm'); info <= 0: not given (the class defaults: MiterLimit 2, ArcTolerance 0.25).
+// Status as ref_clip (3 = output capacity).
+int ref_offset(const int64_t *sx, const int64_t *sy, const int32_t *soff, int snr, double delta, int join, double info,
+               int64_t *outx, int64_t *outy, int out_cap, int32_t *out_off, int ring_cap, int32_t *out_nrings) {
+  *out_nrings = 0;
+  out_off[0] = 0;
+  if (join < 0 || join > 2) return 2;
+  try {
+    Paths subj = to_paths(sx, sy, soff, snr);
+    Paths solution;
+    ClipperOffset co;
+    if (info > 0 && join == 1) co.ArcTolerance = info;
+    if (info > 0 && join == 2) co.MiterLimit = info;
+    co.AddPaths(subj, join == 0 ? jtSquare : join == 1 ? jtRound : jtMiter, etClosedPolygon);
+    co.Execute(solution, delta);
+    if ((int)solution.size() > ring_cap) return 3;
+    int n = 0;
+    for (size_t i = 0; i < solution.size(); ++i) {
+      if (n + (int)solution[i].size() > out_cap) return 3;
+      for (size_t j = 0; j < solution[i].size(); ++j) { outx[n] = solution[i][j].X; outy[n] = solution[i][j].Y; ++n; }
+      out_off[i + 1] = n;
+    }
+    *out_nrings = (int)solution.size();
+  } catch (...) {
+    return 4;
+  }
+  return 0;
 }
 
 // Batch form for tests and for the cpu_baseline leg of bench.py: single-ring subject and

@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szPotentialInteractions", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
+    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -273,6 +273,30 @@ class Context:
                 continue
             self.check(rc, "szClipPathsBatch")
             return ox, oy, roff, proff, st[:n]
+
+    def offset_paths(self, rings, delta, join, info=0.0):
+        """clipper(P, delta, type [, info]): rings = list of (n, 2) int64 arrays; join 0 square / 1 round / 2 miter.
+        -> list of (m, 2) int64 arrays, as the reference's ClipperOffset returns them."""
+        x = np.ascontiguousarray(np.concatenate([np.asarray(r)[:, 0] for r in rings]) if rings else np.zeros(0), np.int64)
+        y = np.ascontiguousarray(np.concatenate([np.asarray(r)[:, 1] for r in rings]) if rings else np.zeros(0), np.int64)
+        off = np.zeros(len(rings) + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        self.L.szOffsetPaths.argtypes = [_vp, i64p, i64p, _ip, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double, i64p, i64p,
+                                         ctypes.c_int64, _ip, ctypes.c_int64, _ip, _ip]
+        cap = 64 * (len(x) + 16)
+        while True:
+            ox = np.zeros(cap, np.int64); oy = np.zeros(cap, np.int64); roff = np.zeros(cap + 1, np.int32)
+            nr = ctypes.c_int32(); st = ctypes.c_int32()
+            rc = self.L.szOffsetPaths(self.h, x.ctypes.data_as(i64p), y.ctypes.data_as(i64p), off.ctypes.data_as(_ip), len(rings), float(delta),
+                                      int(join), float(info), ox.ctypes.data_as(i64p), oy.ctypes.data_as(i64p), cap, roff.ctypes.data_as(_ip),
+                                      cap, ctypes.byref(nr), ctypes.byref(st))
+            if rc == SZ_ERR_CAPACITY:
+                cap *= 4
+                continue
+            self.check(rc, "szOffsetPaths")
+            if st.value != 0:
+                raise SubzeroError("szOffsetPaths: clip status %d" % st.value)
+            return [np.stack([ox[roff[r]:roff[r + 1]], oy[roff[r]:roff[r + 1]]], 1) for r in range(nr.value)]
 
     def polyclip_batch(self, ax, ay, aoff, bx, by, boff, method):
         n = len(aoff) - 1

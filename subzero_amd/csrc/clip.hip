@@ -9,7 +9,11 @@
 //    a retry list with one wave-aggregated atomic and re-run at 8x / 64x capacity -- on the GPU.
 //    There is no CPU fallback anywhere in this file.
 #include <stdlib.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
 #include "clip_batch.hpp"
+#include "offset.hpp"
 
 using szb::ClipArgs;
 
@@ -51,6 +55,8 @@ struct PathsI64 {
   __device__ int len(int k) const { return ring_off[ring0 + k + 1] - ring_off[ring0 + k]; }
   __device__ RingI64 ring(int k) const { const int v = ring_off[ring0 + k]; RingI64 r = {x + v, y + v}; return r; }
 };
+
+enum { CLIP_OFFSET_OUTSET = 4, CLIP_OFFSET_INSET = 5 };   // ClipArgs::method beyond the four boolean operations
 
 struct SlotSink {
   i64 *ox, *oy;
@@ -105,7 +111,11 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
   sink.ox = a.ovx + voff; sink.oy = a.ovy + voff; sink.roff = a.oroff + roff;
   sink.cap_v = (int)cv; sink.cap_r = (int)cr; sink.nv = 0; sink.nr = 0;
   sink.roff[0] = 0;
-  if (a.aring) {
+  if (a.aring && a.method >= CLIP_OFFSET_OUTSET) {
+    // clean-up of the raw offset polygons (ClipperOffset::Execute); the clip operand only reserves room for the box
+    PathsI64 pa = {a.ax, a.ay, a.aring, ra0, nra};
+    st = szv::offset_cleanup(a.ws + woff, (int)nv, pa, a.method == CLIP_OFFSET_OUTSET, sink);
+  } else if (a.aring) {
     PathsI64 pa = {a.ax, a.ay, a.aring, ra0, nra}, pb = {a.bx, a.by, a.bring, rb0, nrb};
     st = szv::clip_paths(a.ws + woff, (int)nv, pa, pb, a.method, a.fill_s, a.fill_c, sink);
   } else if (a.fax) {
@@ -341,19 +351,11 @@ int szClipBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay
   return gather<int64_t>(ctx, a, outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);
 }
 
-int szClipPathsBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay, const int32_t *a_ring_off,
-                     const int32_t *a_pair_off, const int64_t *bx, const int64_t *by, const int32_t *b_ring_off,
-                     const int32_t *b_pair_off, int method, int subj_fill, int clip_fill, int64_t *outx, int64_t *outy,
-                     int64_t out_cap, int32_t *ring_off, int64_t ring_cap, int32_t *pair_ring_off, int32_t *status) {
-  if (!ctx) return SZ_ERR_BAD_ARG;
-  if (npairs < 0 || !a_ring_off || !a_pair_off || !b_ring_off || !b_pair_off || !ring_off || !pair_ring_off || (npairs && !status))
-    return sz_fail(ctx, SZ_ERR_BAD_ARG, "szClipPathsBatch: null argument");
-  if (!valid_op(method, subj_fill, clip_fill)) {
-    for (int p = 0; p < npairs; ++p) status[p] = SZ_CLIP_BAD_ARG;
-    for (int p = 0; p <= npairs; ++p) pair_ring_off[p] = 0;
-    ring_off[0] = 0;
-    return SZ_OK;
-  }
+// host arrays -> device -> k_clip in its several-contours form -> gather (method may be one of the CLIP_OFFSET_* modes)
+static int clip_paths_host(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay, const int32_t *a_ring_off,
+                           const int32_t *a_pair_off, const int64_t *bx, const int64_t *by, const int32_t *b_ring_off,
+                           const int32_t *b_pair_off, int method, int subj_fill, int clip_fill, int64_t *outx, int64_t *outy,
+                           int64_t out_cap, int32_t *ring_off, int64_t ring_cap, int32_t *pair_ring_off, int32_t *status) {
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   const int nra = a_pair_off[npairs], nrb = b_pair_off[npairs];
   const i64 ta = a_ring_off[nra], tb = b_ring_off[nrb];
@@ -378,6 +380,59 @@ int szClipPathsBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_
   }
   (void)hipStreamSynchronize(ctx->stream);
   sz_release(d_aring); sz_release(d_bring);
+  return rc;
+}
+
+int szClipPathsBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay, const int32_t *a_ring_off,
+                     const int32_t *a_pair_off, const int64_t *bx, const int64_t *by, const int32_t *b_ring_off,
+                     const int32_t *b_pair_off, int method, int subj_fill, int clip_fill, int64_t *outx, int64_t *outy,
+                     int64_t out_cap, int32_t *ring_off, int64_t ring_cap, int32_t *pair_ring_off, int32_t *status) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  if (npairs < 0 || !a_ring_off || !a_pair_off || !b_ring_off || !b_pair_off || !ring_off || !pair_ring_off || (npairs && !status))
+    return sz_fail(ctx, SZ_ERR_BAD_ARG, "szClipPathsBatch: null argument");
+  if (!valid_op(method, subj_fill, clip_fill)) {
+    for (int p = 0; p < npairs; ++p) status[p] = SZ_CLIP_BAD_ARG;
+    for (int p = 0; p <= npairs; ++p) pair_ring_off[p] = 0;
+    ring_off[0] = 0;
+    return SZ_OK;
+  }
+  return clip_paths_host(ctx, npairs, ax, ay, a_ring_off, a_pair_off, bx, by, b_ring_off, b_pair_off, method, subj_fill, clip_fill,
+                         outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);
+}
+
+// ---- offset mode of the mex: clipper(P, delta, type [, info]) (mexclipper.cpp:146-203) ---------------------------
+// ClipperOffset (clipper.cpp:3786-4218) in two parts.  The raw offset polygons -- one pass over the vertices of each
+// contour: unit normals, and per vertex a mitred / squared / rounded join -- are built here on the host with the
+// host's libm, as the reference library does (sin, cos, acos, atan2, tan decide integer roundings: the same libm is
+// what makes the result identical).  Their clean-up -- a union of heavily self-intersecting polygons, which is where
+// the time goes -- is the sweep on the GPU (szv::offset_cleanup).
+int szOffsetPaths(szContext *ctx, const int64_t *x, const int64_t *y, const int32_t *ring_off, int nrings, double delta, int join,
+                  double info, int64_t *outx, int64_t *outy, int64_t out_cap, int32_t *out_ring_off, int64_t ring_cap,
+                  int32_t *nrings_out, int32_t *status) {
+  if (!ctx) return SZ_ERR_BAD_ARG;
+  if (nrings < 0 || !ring_off || !out_ring_off || !nrings_out || !status || join < 0 || join > 2)
+    return sz_fail(ctx, SZ_ERR_BAD_ARG, "szOffsetPaths: bad argument");
+  szo::Offsetter co;
+  if (info > 0 && join == 1) co.ArcTolerance = info;
+  if (info > 0 && join == 2) co.MiterLimit = info;
+  for (int r = 0; r < nrings; ++r) co.add_path(x + ring_off[r], y + ring_off[r], ring_off[r + 1] - ring_off[r]);
+  co.fix_orientations();
+  co.do_offset(delta, join);
+  // the clean-up as one "pair" of the batched clip: subject = the raw offset polygons; for an inset the clip operand
+  // is a placeholder of four vertices that reserves the workspace of the bounding rectangle the sweep adds
+  const bool outset = delta > 0;
+  std::vector<int64_t> sx, sy, cx, cy;
+  std::vector<int32_t> sro(1, 0), cro(1, 0);
+  for (size_t i = 0; i < co.dest.size(); ++i) {
+    for (size_t j = 0; j < co.dest[i].size(); ++j) { sx.push_back(co.dest[i][j].X); sy.push_back(co.dest[i][j].Y); }
+    sro.push_back((int32_t)sx.size());
+  }
+  if (!outset) { cx.assign(4, 0); cy.assign(4, 0); cro.push_back(4); }
+  int32_t spo[2] = {0, (int32_t)sro.size() - 1}, cpo[2] = {0, (int32_t)cro.size() - 1}, proff[2] = {0, 0};
+  sx.push_back(0); sy.push_back(0); cx.push_back(0); cy.push_back(0);   // (never empty pointers)
+  const int rc = clip_paths_host(ctx, 1, sx.data(), sy.data(), sro.data(), spo, cx.data(), cy.data(), cro.data(), cpo,
+                                 outset ? CLIP_OFFSET_OUTSET : CLIP_OFFSET_INSET, 0, 0, outx, outy, out_cap, out_ring_off, ring_cap, proff, status);
+  *nrings_out = proff[1];
   return rc;
 }
 

@@ -336,6 +336,7 @@ struct SweepT {
   int cur_lm; // next local minimum to insert
   int op, fill_s, fill_c;
   int err;
+  int reverse_out;   // Clipper::ReverseSolution (clipper.cpp:1478,1598,3721,3734); only ClipperOffset sets it
 
   SZ_HD void bind(void *buf, int nv) { bind_caps(buf, caps_for(nv)); }
   SZ_HD void bind_caps(void *buf, const Caps &c) {
@@ -353,6 +354,7 @@ struct SweepT {
     ael = sel = NIL;
     cur_lm = 0;
     err = ST_OK;
+    reverse_out = 0;
   }
   SZ_HD void fail(int code) { if (err == ST_OK) err = code; }
 
@@ -1629,13 +1631,13 @@ struct SweepT {
         if (ring_inside(R[r2].pts, R[r1].pts)) {
           R[r2].hole = !R[r1].hole;
           R[r2].first_left = r1;
-          if (R[r2].hole == (ring_area(R[r2].pts) > 0)) reverse_ring(R[r2].pts);
+          if (((R[r2].hole != 0) != (reverse_out != 0)) == (ring_area(R[r2].pts) > 0)) reverse_ring(R[r2].pts);
         } else if (ring_inside(R[r1].pts, R[r2].pts)) {
           R[r2].hole = R[r1].hole;
           R[r1].hole = !R[r2].hole;
           R[r2].first_left = R[r1].first_left;
           R[r1].first_left = r2;
-          if (R[r1].hole == (ring_area(R[r1].pts) > 0)) reverse_ring(R[r1].pts);
+          if (((R[r1].hole != 0) != (reverse_out != 0)) == (ring_area(R[r1].pts) > 0)) reverse_ring(R[r1].pts);
         } else {
           R[r2].hole = R[r1].hole;
           R[r2].first_left = R[r1].first_left;
@@ -1727,7 +1729,7 @@ struct SweepT {
 
     for (int i = 0; i < nR; ++i) {
       if (R[i].pts == NIL) continue;
-      if ((R[i].hole != 0) == (ring_area(R[i].pts) > 0)) reverse_ring(R[i].pts);
+      if (((R[i].hole != 0) != (reverse_out != 0)) == (ring_area(R[i].pts) > 0)) reverse_ring(R[i].pts);
     }
     if (nJ > 0) do_joins();
     if (err) return false;
@@ -1739,14 +1741,16 @@ struct SweepT {
   // Emit the result rings: ring k of the solution starts at pts.prev and walks backwards
   // (clipper.cpp:3199-3217).  sink.ring_begin(), sink.vertex(Pt), sink.ring_end(); each returns
   // false when the caller's buffer is full.
+  // skip_first: the first ring of the solution is left out (ClipperOffset::Execute, clipper.cpp:3913)
   template <class Sink>
-  SZ_HD bool write(Sink &sink) const {
+  SZ_HD bool write(Sink &sink, bool skip_first = false) const {
     for (int i = 0; i < nR; ++i) {
       if (R[i].pts == NIL) continue;
       int p = P[R[i].pts].prev;
       int cnt = 0;
       { int q = p; do { ++cnt; q = P[q].next; } while (q != p); }
       if (cnt < 2) continue;
+      if (skip_first) { skip_first = false; continue; }
       if (!sink.ring_begin()) return false;
       for (int k = 0; k < cnt; ++k) {
         if (!sink.vertex(P[p].pt)) return false;
@@ -1800,6 +1804,58 @@ SZ_HD int clip_paths(void *workspace, int cap_nv, const PathsA &A, const PathsB 
   for (int k = 0; k < B.count(); ++k) { s.add_ring(B.ring(k), B.len(k), KIND_CLIP); if (s.err) return s.err; }
   if (!s.run()) return s.err ? s.err : ST_CLIP_ERROR;
   if (!s.write(sink)) return ST_OUT_CAPACITY;
+  return ST_OK;
+}
+// The clean-up of ClipperOffset::Execute (clipper.cpp:3887-3915) for the raw offset polygons A: their union with
+// positive fill (delta > 0), or -- delta < 0 -- with a rectangle 10 units outside their bounds added, negative fill,
+// reversed output and the first ring of the solution (the rectangle's) dropped.  cap_nv >= total vertices + 4.
+struct BoxRing {
+  Pt p[4];
+  SZ_HD Pt operator()(int i) const { return p[i]; }
+};
+template <class PathsA, class Sink>
+SZ_HD int offset_cleanup(void *workspace, int cap_nv, const PathsA &A, bool outset, Sink &sink) {
+  int total = outset ? 0 : 4;
+  for (int k = 0; k < A.count(); ++k) total += A.len(k);
+  if (cap_nv < total) return ST_WORKSPACE;
+  Sweep s;
+  s.bind_caps(workspace, caps_for(cap_nv));
+  s.op = OP_UNION;
+  s.fill_s = s.fill_c = outset ? FILL_POSITIVE : FILL_NEGATIVE;
+  for (int k = 0; k < A.count(); ++k) { s.add_ring(A.ring(k), A.len(k), KIND_SUBJECT); if (s.err) return s.err; }
+  if (!outset) {
+    // ClipperBase::GetBounds (clipper.cpp:1295-1332) over the bounds of every local minimum
+    i64 left = 0, top = 0, right = 0, bottom = 0;
+    for (int m = 0; m < s.nM; ++m) {
+      const int lb = s.M[m].left;
+      if (m == 0) { left = right = s.E[lb].bot.x; top = bottom = s.E[lb].bot.y; }
+      if (s.E[lb].bot.y > bottom) bottom = s.E[lb].bot.y;
+      for (int side = 0; side < 2; ++side) {
+        int e = side ? s.M[m].right : lb;
+        while (s.E[e].up != NIL) {
+          if (s.E[e].bot.x < left) left = s.E[e].bot.x;
+          if (s.E[e].bot.x > right) right = s.E[e].bot.x;
+          e = s.E[e].up;
+        }
+        if (s.E[e].bot.x < left) left = s.E[e].bot.x;
+        if (s.E[e].bot.x > right) right = s.E[e].bot.x;
+        if (s.E[e].top.x < left) left = s.E[e].top.x;
+        if (s.E[e].top.x > right) right = s.E[e].top.x;
+        if (s.E[e].top.y < top) top = s.E[e].top.y;
+      }
+    }
+    BoxRing box;
+    box.p[0].x = left - 10; box.p[0].y = bottom + 10;
+    box.p[1].x = right + 10; box.p[1].y = bottom + 10;
+    box.p[2].x = right + 10; box.p[2].y = top - 10;
+    box.p[3].x = left - 10; box.p[3].y = top - 10;
+    s.add_ring(box, 4, KIND_SUBJECT);
+    if (s.err) return s.err;
+    s.reverse_out = 1;
+  }
+  if (s.nM == 0) return ST_OK;            // Execute returns false on no input, the solution stays empty: no error in this mode
+  if (!s.run()) return s.err ? s.err : ST_OK;   // (ClipperOffset::Execute ignores the return value of Clipper::Execute)
+  if (!s.write(sink, !outset)) return ST_OUT_CAPACITY;
   return ST_OK;
 }
 template <class RingA, class RingB, class Sink>

@@ -5,11 +5,11 @@
 // tests/mexstub/ is a working test double of the mx* / mex* calls used here; tests/test_mex_*.py compile this file
 // against it and drive it.)
 //
-// Same three call forms and the same error texts as the reference gateway:
+// The reference gateway's three call forms and error texts:
 //   out = clipper(Subj, Clip, method [, subjFill, clipFill])   -> szClipPathsBatch (mexclipper.cpp:204-305; Subj / Clip
 //                                                                 may be struct ARRAYS: one contour per element, :44-62)
 //   cw  = clipper(P)                                           -> szOrientation (mexclipper.cpp:134-145)
-//   out = clipper(Subj, delta, 's'|'r'|'m' [, info])           -> not on the hot path; raises an error
+//   out = clipper(Subj, delta [, 's'|'r'|'m' [, info]])         -> szOffsetPaths (mexclipper.cpp:146-203)
 // Subj / Clip: struct arrays with int64 column fields x, y (mexclipper.cpp:28-41); out: 1xK struct array
 // with double fields x, y holding integer values (mexclipper.cpp:65-81).
 #include "mex.h"
@@ -62,11 +62,58 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
     return;
   }
-  // offset mode (mexclipper.cpp:146-203: clipper(P, delta [, 's'|'r'|'m' [, info]]); nothing in the reference calls it)
-  if (nrhs == 2 || (nrhs >= 3 && nrhs <= 4 && mxIsChar(prhs[2])))
-    mexErrMsgTxt("clipper: the offset form clipper(P, delta, type) is not provided by the MI355X build (no caller in SubZero)");
+  // offset mode (mexclipper.cpp:146-203: clipper(P, delta [, 's'|'r'|'m' [, info]]))
+  if (nrhs == 2 || (nrhs >= 3 && nrhs <= 4 && mxIsChar(prhs[2]))) {
+    if (!mxIsStruct(prhs[0]) || mxGetM(prhs[0]) != 1 || mxGetN(prhs[0]) != 1)
+      mexErrMsgTxt("First input must be a scalar polygon structure (with fields .x and .y).");
+    if (!mxIsDouble(prhs[1]) || mxGetM(prhs[1]) != 1 || mxGetN(prhs[1]) != 1)
+      mexErrMsgTxt("Second input must be either a structure (a second polygon) or a scalar double (outset Delta).");
+    const double delta = mxGetScalar(prhs[1]);
+    double info = 0.0;
+    char type = 'm';
+    if (nrhs >= 3) {
+      char *t = mxArrayToString(prhs[2]);
+      if (!t) mexErrMsgTxt("Unable to access the MiterType string.");
+      type = t[0] >= 'A' && t[0] <= 'Z' ? (char)(t[0] - 'A' + 'a') : t[0];
+      mxFree(t);
+      if (nrhs >= 4) {
+        if (!mxIsDouble(prhs[3]) || mxGetM(prhs[3]) != 1 || mxGetN(prhs[3]) != 1) mexErrMsgTxt("The MITERINFO (fourth argument) must be a scalar double.");
+        info = mxGetScalar(prhs[3]);
+        if (info <= 0.0) mexErrMsgTxt("The MITERINFO must be a positive double.");
+      }
+    }
+    int join;
+    if (type == 'r') { join = 1; if (nrhs < 4) mexErrMsgTxt("The MITERINFO (fourth argument) must specify the arc tolerance for round joints."); }
+    else if (type == 's') { join = 0; info = 0.0; }
+    else if (type == 'm') { join = 2; if (nrhs >= 4 && info < 2.0) mexWarnMsgTxt("MiterLimit below 2.0 is ignored"); }
+    else { join = 2; mexErrMsgTxt("Invalid MiterType string."); }
+    read_rings(prhs[0], sx, sy, soff);
+    need_context();
+    int64_t cap = 64 * (int64_t)(sx.size() + 16);
+    for (;;) {
+      std::vector<int64_t> ox((size_t)cap), oy((size_t)cap);
+      std::vector<int32_t> roff((size_t)cap + 1);
+      int32_t nr = 0, status = 0;
+      const int rc = szOffsetPaths(g_ctx, sx.data(), sy.data(), soff.data(), (int)soff.size() - 1, delta, join, info, ox.data(), oy.data(), cap,
+                                   roff.data(), cap, &nr, &status);
+      if (rc == SZ_ERR_CAPACITY) { cap *= 4; continue; }
+      if (rc != SZ_OK) mexErrMsgTxt(szLastError(g_ctx));
+      if (status != SZ_CLIP_OK) mexErrMsgTxt("Clipper Error.");
+      const char *names[] = {"x", "y"};
+      mwSize dims[2] = {1, (mwSize)nr};
+      plhs[0] = mxCreateStructArray(2, dims, 2, names);
+      for (int r = 0; r < nr; ++r) {
+        const int n = roff[r + 1] - roff[r];
+        mxArray *ax = mxCreateDoubleMatrix(n, 1, mxREAL), *ay = mxCreateDoubleMatrix(n, 1, mxREAL);
+        for (int k = 0; k < n; ++k) { mxGetPr(ax)[k] = (double)ox[roff[r] + k]; mxGetPr(ay)[k] = (double)oy[roff[r] + k]; }
+        mxSetFieldByNumber(plhs[0], r, 0, ax);
+        mxSetFieldByNumber(plhs[0], r, 1, ay);
+      }
+      return;
+    }
+  }
   if (!mxIsDouble(prhs[2]) || mxGetM(prhs[2]) != 1 || mxGetN(prhs[2]) != 1) mexErrMsgTxt("Third input must be scalar.");
-  if (!mxIsStruct(prhs[1])) mexErrMsgTxt("clipper: the offset form clipper(P, delta, type) is not provided by the MI355X build (no caller in SubZero)");
+  if (!mxIsStruct(prhs[1])) mexErrMsgTxt("second input must be a polygon structure.");
   int method = (int)mxGetScalar(prhs[2]);
   if (method < 0 || method > 3) mexErrMsgTxt("Third input must be 0, 1, 2, or 3.");
   int sf = 0, cf = 0;

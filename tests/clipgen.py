@@ -322,7 +322,7 @@ def ref_lib():
 def host_lib():
     path = os.path.join(ROOT, "tests", "hostsim", "libvatti_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "vatti_host.cpp")
-    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("vatti.hpp", "convex.hpp", "trim.hpp")]
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("vatti.hpp", "convex.hpp", "trim.hpp", "offset.hpp")]
     if (not os.path.exists(path)) or os.path.getmtime(path) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
                                src, "-o", path])
@@ -459,3 +459,43 @@ def run_ref_paths(subj, clip, method, fill_s=0, fill_c=0):
     rc = L.ref_clip(sx, sy, soff, len(subj), cx, cy, coff, len(clip), method, fill_s, fill_c, ox, oy, cap, ooff, cap, ctypes.byref(nr))
     assert rc == 0, rc
     return [np.stack([ox[ooff[r]:ooff[r + 1]], oy[ooff[r]:ooff[r + 1]]], 1) for r in range(nr.value)]
+
+
+def run_ref_offset(rings, delta, join, info=0.0):
+    """The reference's ClipperOffset through the mex's glue (oracle/ref_clipper_shim.cpp ref_offset) -> list of rings."""
+    L = ref_lib()
+    L.ref_offset.argtypes = [_i64p, _i64p, _i32p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                             _i64p, _i64p, ctypes.c_int, _i32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
+    x = np.ascontiguousarray(np.concatenate([np.asarray(r)[:, 0] for r in rings]), np.int64)
+    y = np.ascontiguousarray(np.concatenate([np.asarray(r)[:, 1] for r in rings]), np.int64)
+    off = np.zeros(len(rings) + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+    cap = 64 * (len(x) + 16)
+    while True:
+        ox = np.zeros(cap, np.int64); oy = np.zeros(cap, np.int64); roff = np.zeros(cap + 1, np.int32); nr = ctypes.c_int32()
+        rc = L.ref_offset(x, y, off, len(rings), float(delta), int(join), float(info), ox, oy, cap, roff, cap, ctypes.byref(nr))
+        if rc == 3:
+            cap *= 4
+            continue
+        assert rc == 0, rc
+        return [np.stack([ox[roff[r]:roff[r + 1]], oy[roff[r]:roff[r + 1]]], 1) for r in range(nr.value)]
+
+
+def run_host_offset(rings, delta, join, info=0.0):
+    """The library's offset mode with its clean-up sweep on the host (tests/hostsim) -> list of rings."""
+    L = host_lib()
+    L.host_offset.argtypes = [_i64p, _i64p, _i32p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                              _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)]
+    x = np.ascontiguousarray(np.concatenate([np.asarray(r)[:, 0] for r in rings]), np.int64)
+    y = np.ascontiguousarray(np.concatenate([np.asarray(r)[:, 1] for r in rings]), np.int64)
+    off = np.zeros(len(rings) + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+    cap = 64 * (len(x) + 16)
+    while True:
+        ox = np.zeros(cap, np.int64); oy = np.zeros(cap, np.int64); roff = np.zeros(cap + 1, np.int32); nr = ctypes.c_int32()
+        rc = L.host_offset(x, y, off, len(rings), float(delta), int(join), float(info), ox, oy, cap, roff, cap, ctypes.byref(nr))
+        if rc == 3 or rc == 5:      # ST_OUT_CAPACITY / workspace tiers exhausted at this output size
+            cap *= 4
+            if cap > 1 << 28:
+                raise RuntimeError("host_offset: status %d" % rc)
+            continue
+        assert rc == 0, rc
+        return [np.stack([ox[roff[r]:roff[r + 1]], oy[roff[r]:roff[r + 1]]], 1) for r in range(nr.value)]

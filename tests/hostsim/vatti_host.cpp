@@ -117,3 +117,40 @@ extern "C" int host_clip_batch(int npairs,
   }
   return 0;
 }
+
+// ---- the offset mode as the library runs it (offset.hpp on the host + szv::offset_cleanup), with the clean-up on the
+// host instead of the GPU: the CPU suite checks it against the reference's ClipperOffset (oracle/_ref ref_offset)
+#include "../../subzero_amd/csrc/offset.hpp"
+namespace {
+struct HostPaths {
+  const std::vector<szo::OPath> *p;
+  struct Ring { const szo::OPath *r; szv::Pt operator()(int i) const { szv::Pt q; q.x = (*r)[(size_t)i].X; q.y = (*r)[(size_t)i].Y; return q; } };
+  int count() const { return (int)p->size(); }
+  int len(int k) const { return (int)(*p)[(size_t)k].size(); }
+  Ring ring(int k) const { Ring g = {&(*p)[(size_t)k]}; return g; }
+};
+}
+extern "C" int host_offset(const int64_t *x, const int64_t *y, const int32_t *ring_off, int nrings, double delta, int join, double info,
+                           int64_t *outx, int64_t *outy, int64_t out_cap, int32_t *out_ring_off, int64_t ring_cap, int32_t *nrings_out) {
+  szo::Offsetter co;
+  if (info > 0 && join == 1) co.ArcTolerance = info;
+  if (info > 0 && join == 2) co.MiterLimit = info;
+  for (int r = 0; r < nrings; ++r) co.add_path(x + ring_off[r], y + ring_off[r], ring_off[r + 1] - ring_off[r]);
+  co.fix_orientations();
+  co.do_offset(delta, join);
+  HostPaths hp = {&co.dest};
+  int total = 4;
+  for (size_t i = 0; i < co.dest.size(); ++i) total += (int)co.dest[i].size();
+  int st = szv::ST_WORKSPACE;
+  std::vector<char> ws;
+  Sink s;
+  for (int cap = total, tier = 0; st == szv::ST_WORKSPACE && tier < 5; ++tier, cap *= 8) {
+    ws.resize(szv::workspace_bytes(cap) + 16);
+    void *w = (void *)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
+    s.ox = outx; s.oy = outy; s.cap_v = out_cap; s.ring_off = out_ring_off; s.cap_r = ring_cap; s.nv = 0; s.nr = 0;
+    out_ring_off[0] = 0;
+    st = szv::offset_cleanup(w, cap, hp, delta > 0, s);
+  }
+  *nrings_out = (int32_t)s.nr;
+  return st;
+}

@@ -83,3 +83,18 @@ def test_floe_struct_round_trip():
     assert hoststep.compare_states(S, T) == [] and np.array_equal(S.mcX, T.mcX) and np.array_equal(S.mcA, T.mcA)
     sh = mx.to_numpy(mx.get_field(F, 3, "StressH"))
     assert sh.shape == (2, 2, 5) and sh[1, 0, 2] == S.StressH[3, 2, 1] and sh[0, 1, 2] == S.StressH[3, 2, 2]
+
+
+@pytest.mark.parametrize("args,text", [
+    (lambda: [ring([0, 9, 9], [0, 0, 9]), mx.row([1, 2])], "Second input must be either a structure (a second polygon) or a scalar double (outset Delta)."),
+    (lambda: [ring([0, 9, 9], [0, 0, 9]), mx.scalar(2), mx.string("x")], "Invalid MiterType string."),
+    (lambda: [ring([0, 9, 9], [0, 0, 9]), mx.scalar(2), mx.string("round")], "The MITERINFO (fourth argument) must specify the arc tolerance for round joints."),
+    (lambda: [ring([0, 9, 9], [0, 0, 9]), mx.scalar(2), mx.string("m"), mx.scalar(-1)], "The MITERINFO must be a positive double."),
+    (lambda: [ring([0, 9, 9], [0, 0, 9]), mx.scalar(2), mx.string("m"), mx.row([2, 3])], "The MITERINFO (fourth argument) must be a scalar double."),
+    (lambda: [ring([0, 9, 9], [0, 0, 9]), mx.scalar(3), mx.scalar(1)], "second input must be a polygon structure."),
+])
+def test_clipper_offset_mode_argument_errors_have_the_reference_texts(clipper, args, text):
+    # (mexclipper.cpp:146-203, :304-309; every one is raised before the GPU is touched)
+    with pytest.raises(mx.MexError) as e:
+        clipper.call(1, *args())
+    assert str(e.value) == text
