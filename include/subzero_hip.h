@@ -298,8 +298,11 @@ int szStepShardEnd(szContext *ctx, const void *d_recv, szStepStats *stats);
  * the GPU (ring against rectangle).  out: 18 fields of Ny x Nx doubles each, MATLAB column-major (element (jj, ii) at
  * jj + Ny * ii, jj counted from the top row as calc_eulerian_data.m:75 flips y), in the order
  *   u v du dv stress stressxx stressyx stressxy stressyy strainux strainvx strainuy strainvy c Over Mtot area h
- * (the fields of the struct the reference returns).  Nb must be 0: cells with topography subtracted (:10-24,:139-141)
- * are not provided.  kernel_ms (may be NULL): HIP-event time of the cell kernel. */
+ * (the fields of the struct the reference returns).  Nb > 0: the first Nb live floes are the topography -- they are
+ * not averaged and their union is cut out of the cells (:10-24,:141-143); the cells whose rectangle meets the bounding
+ * box of such a floe are computed with the clip kernel (rectangle 'dif' topography, then 'int' each floe: the polyshape
+ * operations restated by the fixed-point clip, as polyclip.m uses it), every other cell by the plain rectangle clip.
+ * kernel_ms (may be NULL): HIP-event time of the cell kernel. */
 int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const double *c2_boundary, int periodic, double *out, double *kernel_ms);
 
 /* ---- corner grinding, the per-vertex decision: Physical_Processes/corners.m:13-92 ---------------

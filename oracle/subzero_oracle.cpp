@@ -175,6 +175,43 @@ double polyarea(const double *x, const double *y, int n) {
 
 double hyp(double a, double b) { return sqrt(a * a + b * b); }
 
+// clipper(Subj, Clip, method, subjFill, clipFill) with several contours per operand (mexclipper.cpp:13-62,204-305), rings
+// in metres converted as polyclip.m:63-67 does; needs the reference build (the host build's batch entry is single-ring)
+std::vector<Ring> polyclip_paths(const std::vector<Ring> &A, const std::vector<Ring> &B, int method, int fs, int fc, bool &ok) {
+  std::vector<Ring> out;
+  ok = true;
+  if (!g_ref_clip) { ok = false; return out; }
+  std::vector<int64_t> ax, ay, bx, by;
+  std::vector<int32_t> aoff(1, 0), boff(1, 0);
+  for (size_t r = 0; r < A.size(); ++r) { for (size_t k = 0; k < A[r].x.size(); ++k) { ax.push_back(to_fixed(A[r].x[k])); ay.push_back(to_fixed(A[r].y[k])); } aoff.push_back((int32_t)ax.size()); }
+  for (size_t r = 0; r < B.size(); ++r) { for (size_t k = 0; k < B[r].x.size(); ++k) { bx.push_back(to_fixed(B[r].x[k])); by.push_back(to_fixed(B[r].y[k])); } boff.push_back((int32_t)bx.size()); }
+  ax.push_back(0); ay.push_back(0); bx.push_back(0); by.push_back(0);
+  int cap = 4 * (int)(ax.size() + bx.size()) + 64;
+  for (int attempt = 0; attempt < 6; ++attempt, cap *= 8) {
+    std::vector<int64_t> ox(cap), oy(cap);
+    std::vector<int32_t> roff(cap + 1);
+    int32_t nr = 0;
+    int rc = g_ref_clip(ax.data(), ay.data(), aoff.data(), (int)A.size(), bx.data(), by.data(), boff.data(), (int)B.size(), method, fs, fc,
+                        ox.data(), oy.data(), cap, roff.data(), cap, &nr);
+    if (rc == 3) continue;
+    if (rc != 0) { ok = false; return out; }
+    out.resize(nr);
+    for (int r = 0; r < nr; ++r)
+      for (int v = roff[r]; v < roff[r + 1]; ++v) { out[r].x.push_back((double)ox[v] / 4294967296.0); out[r].y.push_back((double)oy[v] / 4294967296.0); }
+    return out;
+  }
+  ok = false;
+  return out;
+}
+// area(polyshape) of a region given by its rings (outer rings and holes come out of the clip in opposite senses): the
+// signed shoelace sums, each relative to its ring's first vertex, added up
+double rings_area(const std::vector<Ring> &R) {
+  double s = 0;
+  for (size_t r = 0; r < R.size(); ++r) s += ring_area_signed(R[r].x.data(), R[r].y.data(), (int)R[r].x.size());
+  return fabs(s);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // InterX.m:54-81 -- all crossings of two polylines (here: closed rings), sorted unique rows
 // ---------------------------------------------------------------------------------------------
@@ -1075,13 +1112,31 @@ extern "C" double or_ring_box_area(const double *x, const double *y, int n, doub
 // out: 18 fields of Ny x Nx (MATLAB column-major: element (jj, ii) at jj + Ny * ii), in the order
 // u v du dv stress stressxx stressyx stressxy stressyy strainux strainvx strainuy strainvy c Over Mtot area h
 extern "C" int or_eulerian(const OrFloes *F, int Nx, int Ny, int Nb, const double *c2b, int PERIODIC, double *out) {
-  if (Nb > 0) return -3;
+  if (Nb > 0 && !g_ref_clip) return -3;      // the topography path clips operands of several contours: reference build only
   const int N0 = F->n;
   double Lx = c2b[0], Ly = c2b[1], xmin = c2b[0], ymin = c2b[1];
   for (int k = 1; k < 5; ++k) { Lx = std::max(Lx, c2b[2 * k]); Ly = std::max(Ly, c2b[2 * k + 1]); xmin = std::min(xmin, c2b[2 * k]); ymin = std::min(ymin, c2b[2 * k + 1]); }
   struct Ent { int src; double x, y; };
   std::vector<Ent> E;
-  for (int i = 0; i < N0; ++i) if (F->alive[i]) { Ent e = {i, F->Xi[i], F->Yi[i]}; E.push_back(e); }   // :7-8
+  // :7-8 live floes; :10-24 the first Nb of them are the topography: their union is cut out of the cells, they do not
+  // count towards the averages
+  std::vector<Ring> topo;
+  {
+    int seen = 0;
+    for (int i = 0; i < N0; ++i) {
+      if (!F->alive[i]) continue;
+      if (seen < Nb) {
+        ++seen;
+        int v0 = F->vert_off[i], nv = F->vert_off[i + 1] - v0;
+        Ring r;
+        for (int k = 0; k < nv; ++k) { r.x.push_back(F->cax[v0 + k] + F->Xi[i]); r.y.push_back(F->cay[v0 + k] + F->Yi[i]); }
+        if (ring_area_signed(r.x.data(), r.y.data(), nv) < 0) { std::reverse(r.x.begin(), r.x.end()); std::reverse(r.y.begin(), r.y.end()); }
+        topo.push_back(r);
+        continue;
+      }
+      Ent e = {i, F->Xi[i], F->Yi[i]}; E.push_back(e);
+    }
+  }
   auto sgn = [](double v) { return (v > 0) ? 1.0 : (v < 0 ? -1.0 : 0.0); };
   auto extent = [&](const Ent &e, int dim) {
     int v0 = F->vert_off[e.src], nv = F->vert_off[e.src + 1] - v0;
@@ -1123,7 +1178,24 @@ extern "C" int or_eulerian(const OrFloes *F, int Nx, int Ny, int Nb, const doubl
       if (!(Mpre > 0)) continue;                                           // :136-137
       const double xl = xg[ii], xh = xg[ii + 1], yh = yg[jj], yl = yg[jj + 1];
       double bxs[4] = {xl, xl, xh, xh}, bys[4] = {yh, yl, yl, yh};         // :140 bound
-      const double abox = ring_area(bxs, bys, 4);
+      double abox = ring_area(bxs, bys, 4);
+      // :141-143 box = subtract(box, boundaries).  Only a cell whose rectangle meets the bounding box of a topography
+      // floe can lose anything; such a cell goes through the clipper (the polyshape operations restated by the
+      // reference's own fixed-point clip, as polyclip.m uses it), every other cell keeps the plain rectangle.
+      std::vector<Ring> near_topo;
+      for (size_t t = 0; t < topo.size(); ++t) {
+        double x0 = topo[t].x[0], x1 = x0, y0 = topo[t].y[0], y1 = y0;
+        for (size_t k = 1; k < topo[t].x.size(); ++k) { x0 = std::min(x0, topo[t].x[k]); x1 = std::max(x1, topo[t].x[k]); y0 = std::min(y0, topo[t].y[k]); y1 = std::max(y1, topo[t].y[k]); }
+        if (!(x1 < xl || x0 > xh || y1 < yl || y0 > yh)) near_topo.push_back(topo[t]);
+      }
+      std::vector<Ring> cut_box;
+      if (!near_topo.empty()) {
+        Ring b; b.x.assign(bxs, bxs + 4); b.y.assign(bys, bys + 4);
+        bool ok = true;
+        cut_box = polyclip_paths(std::vector<Ring>(1, b), near_topo, 0, 0, 1, ok);    // 'dif', clip fill non-zero = the union of :16-20
+        if (!ok) return -4;
+        abox = rings_area(cut_box);
+      }
       std::vector<int> fn; Vec Aover;
       for (size_t q = 0; q < live.size(); ++q) {
         const Ent &en = E[live[q]];
@@ -1131,7 +1203,15 @@ extern "C" int or_eulerian(const OrFloes *F, int Nx, int Ny, int Nb, const doubl
         if (nv > 1 && F->cax[v0] == F->cax[v0 + nv - 1] && F->cay[v0] == F->cay[v0 + nv - 1]) --nv;   // polyshape drops the closing copy
         Vec rx(nv), ry(nv);
         for (int k = 0; k < nv; ++k) { rx[k] = F->cax[v0 + k] + en.x; ry[k] = F->cay[v0 + k] + en.y; }
-        double a = ring_box_area(rx, ry, xl, xh, yl, yh);
+        double a;
+        if (near_topo.empty()) a = ring_box_area(rx, ry, xl, xh, yl, yh);
+        else if (cut_box.empty()) a = 0;
+        else {
+          Ring f; f.x = rx; f.y = ry;
+          bool ok = true;
+          a = rings_area(polyclip_paths(cut_box, std::vector<Ring>(1, f), 1, 0, 0, ok));   // :154 intersect(box, poly)
+          if (!ok) return -4;
+        }
         if (a != 0) { fn.push_back(live[q]); Aover.push_back(a); }          // :150-151
       }
       double Mtot = 0, Atot = 0;

@@ -5,6 +5,7 @@
 //                 cell's sums over the hits in ascending floe order, operation for operation as :152-178 read
 // The list of live floes and their periodic images (a few hundred ids and positions) is put together on the host from
 // the downloaded per-floe extents -- including the reference's own quirk in the Y images (:58-67).
+#include <algorithm>
 #include "step_state.hpp"
 #include "eulerian.hpp"
 
@@ -24,8 +25,12 @@ __global__ void k_eul_extent(Floes F, double *ext2) {
 
 __device__ inline double nz(double v) { return v != v ? 0.0 : v; }
 
+// cells whose rectangle loses a piece to the topography (Nb > 0) come with their potential floes and the overlaps
+// already clipped (ov_*: szEulerianData ran them through the clip kernel); every other cell is done here
+struct EulOverride { const int *cell, *off, *ent; const double *area, *abox; };
+
 __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int M, int Nx, int Ny, const double *xg, const double *yg,
-                                                  double r_max, double *out, int *overflow) {
+                                                  double r_max, double *out, int *overflow, EulOverride ov) {
   __shared__ int hit_e[EUL_CAP];
   __shared__ double hit_a[EUL_CAP];
   __shared__ int npot;
@@ -34,7 +39,14 @@ __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int
   __syncthreads();
   const double xl = xg[ii], xh = xg[ii + 1], yh = yg[jj], yl = yg[jj + 1];
   const double xc = 0.5 * (xg[ii] + xg[ii + 1]), yc = 0.5 * (yg[jj] + yg[jj + 1]);
-  for (int e = threadIdx.x; e < M; e += blockDim.x) {
+  const int ovc = ov.cell ? ov.cell[blockIdx.x] : -1;
+  if (ovc >= 0) {
+    const int o0 = ov.off[ovc], cnt = ov.off[ovc + 1] - o0;
+    if (cnt > EUL_CAP) { if (threadIdx.x == 0) atomicAdd(overflow, 1); return; }
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) { hit_e[q] = ov.ent[o0 + q]; hit_a[q] = ov.area[o0 + q]; }
+    if (threadIdx.x == 0) npot = cnt;
+  }
+  for (int e = threadIdx.x; e < M && ovc < 0; e += blockDim.x) {
     const EulEnt en = E[e];
     const double ddx = xc - en.x, ddy = yc - en.y;
     const double pint = ::sqrt(ddx * ddx + ddy * ddy) - (F.rmax[en.src] + r_max);   // :123
@@ -47,7 +59,7 @@ __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int
   if (npot > EUL_CAP) { if (threadIdx.x == 0) atomicAdd(overflow, 1); return; }
   const int np = npot;
   // Mtot of :136 (any positive mass among the potential floes lets the cell through); then the overlaps
-  for (int q = threadIdx.x; q < np; q += blockDim.x) {
+  for (int q = threadIdx.x; q < np && ovc < 0; q += blockDim.x) {
     const EulEnt en = E[hit_e[q]];
     const int v0 = F.vert_off[en.src];
     int nv = F.vert_off[en.src + 1] - v0;
@@ -69,6 +81,7 @@ __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int
   double bxs[4] = {xl, xl, xh, xh}, bys[4] = {yh, yl, yl, yh};
   double abox;
   { double s = 0; for (int i = 0; i < 4; ++i) { int k = (i + 1) & 3; double ax = bxs[i] - bxs[0], ay = bys[i] - bys[0], bx = bxs[k] - bxs[0], by = bys[k] - bys[0]; s += ax * by - bx * ay; } abox = szs::absd(0.5 * s); }
+  if (ovc >= 0) abox = ov.abox[ovc];
   // drop the floes without a piece in the cell (:150-151)
   int nf = 0;
   for (int q = 0; q < np; ++q) if (hit_a[q] != 0) { hit_e[nf] = hit_e[q]; hit_a[nf] = hit_a[q]; ++nf; }
@@ -105,7 +118,7 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   if (!ctx || !c2b || !out || Nx < 1 || Ny < 1) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szEulerianData: no floes uploaded");
-  if (Nb > 0) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szEulerianData: Nb > 0 (topography subtracted from the cells, calc_eulerian_data.m:10-24,139-141) is not provided");
+  if (Nb < 0) return SZ_ERR_BAD_ARG;
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int n = S->n;
@@ -127,7 +140,12 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   // the live floes and their periodic images (:7-8, :29-69), with their extents translated along
   std::vector<EulEnt> E;
   std::vector<double> ex, ey;     // max |x|, max |y| of each entry's ring at its own position
-  for (int i = 0; i < n; ++i) if (alive[i]) { EulEnt e = {x[i], y[i], i, 0}; E.push_back(e); ex.push_back(ext[2 * i]); ey.push_back(ext[2 * i + 1]); }
+  std::vector<int> topo;          // :10-24 the first Nb live floes: their union is cut out of the cells, they are not averaged
+  for (int i = 0; i < n; ++i) {
+    if (!alive[i]) continue;
+    if ((int)topo.size() < Nb) { topo.push_back(i); continue; }
+    EulEnt e = {x[i], y[i], i, 0}; E.push_back(e); ex.push_back(ext[2 * i]); ey.push_back(ext[2 * i + 1]);
+  }
   if (periodic && !E.empty()) {
     const size_t n1 = E.size();
     for (size_t i = 0; i < n1; ++i)
@@ -146,8 +164,143 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   const double dx = absd(xg[1] - xg[0]), dy = absd(yg[1] - yg[0]);
   const double r_max = ::sqrt((dx / 2) * (dx / 2) + (dy / 2) * (dy / 2));
   const size_t cells = (size_t)Nx * Ny;
+  // ---- cells that meet the topography (Nb > 0): box = subtract(box, boundaries), overlap = intersect(box, poly) (:141-154)
+  // through the clip kernel (szClipPathsBatch: the polyshape operations restated by the fixed-point clip, as polyclip.m
+  // uses it).  Only a cell whose rectangle meets the bounding box of a topography floe can lose anything.
+  DevBuf d_ovc, d_ovo, d_ove, d_ova, d_ovb;
+  auto cleanup2 = [&]() { sz_release(d_ovc); sz_release(d_ovo); sz_release(d_ove); sz_release(d_ova); sz_release(d_ovb); };
+  EulOverride ov = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!topo.empty() && M > 0) {
+    const size_t nvt = (size_t)S->nverts;
+    std::vector<double> cax(nvt + 1), cay(nvt + 1), rmax((size_t)n);
+    he = hipMemcpyAsync(cax.data(), S->F.cax, nvt * 8, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(cay.data(), S->F.cay, nvt * 8, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(rmax.data(), S->F.rmax, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szEulerianData: %s", hipGetErrorString(he)); }
+    const int *vo = S->h_vert_off.data();
+    auto signed_area = [](const double *px, const double *py, int m) {       // shoelace relative to the first vertex
+      if (m < 3) return 0.0;
+      double a = 0;
+      for (int i = 0; i < m; ++i) { const int k = (i + 1 == m) ? 0 : i + 1; const double ax = px[i] - px[0], ay = py[i] - py[0], bx = px[k] - px[0], by = py[k] - py[0]; a += ax * by - bx * ay; }
+      return 0.5 * a;
+    };
+    // topography rings in metres (positive sense), their boxes, and in fixed point
+    struct TRing { std::vector<double> x, y; double x0, x1, y0, y1; std::vector<int64_t> fx, fy; };
+    std::vector<TRing> T(topo.size());
+    for (size_t t = 0; t < topo.size(); ++t) {
+      const int i = topo[t], v0 = vo[i], nv = vo[i + 1] - v0;
+      TRing &r = T[t];
+      for (int k = 0; k < nv; ++k) { r.x.push_back(cax[v0 + k] + x[i]); r.y.push_back(cay[v0 + k] + y[i]); }
+      if (signed_area(r.x.data(), r.y.data(), nv) < 0) { std::reverse(r.x.begin(), r.x.end()); std::reverse(r.y.begin(), r.y.end()); }
+      r.x0 = r.x1 = r.x[0]; r.y0 = r.y1 = r.y[0];
+      for (int k = 1; k < nv; ++k) { r.x0 = szc::mind(r.x0, r.x[k]); r.x1 = szc::maxd(r.x1, r.x[k]); r.y0 = szc::mind(r.y0, r.y[k]); r.y1 = szc::maxd(r.y1, r.y[k]); }
+      for (int k = 0; k < nv; ++k) { r.fx.push_back(szc::to_fixed(r.x[k])); r.fy.push_back(szc::to_fixed(r.y[k])); }
+    }
+    std::vector<int> ovc(cells, -1), cut_cells;           // cell -> index among the cut cells
+    std::vector<int64_t> ax, ay, bx, by;
+    std::vector<int32_t> aro(1, 0), apo(1, 0), bro(1, 0), bpo(1, 0);
+    for (int ii = 0; ii < Nx; ++ii)
+      for (int jj = 0; jj < Ny; ++jj) {
+        const double xl = xg[ii], xh = xg[ii + 1], yh = yg[jj], yl = yg[jj + 1];
+        bool any = false;
+        for (size_t t = 0; t < T.size(); ++t) {
+          if (T[t].x1 < xl || T[t].x0 > xh || T[t].y1 < yl || T[t].y0 > yh) continue;
+          any = true;
+          bx.insert(bx.end(), T[t].fx.begin(), T[t].fx.end()); by.insert(by.end(), T[t].fy.begin(), T[t].fy.end());
+          bro.push_back((int32_t)bx.size());
+        }
+        if (!any) continue;
+        const double bxs[4] = {xl, xl, xh, xh}, bys[4] = {yh, yl, yl, yh};
+        for (int k = 0; k < 4; ++k) { ax.push_back(szc::to_fixed(bxs[k])); ay.push_back(szc::to_fixed(bys[k])); }
+        aro.push_back((int32_t)ax.size()); apo.push_back((int32_t)aro.size() - 1); bpo.push_back((int32_t)bro.size() - 1);
+        ovc[(size_t)ii * Ny + jj] = (int)cut_cells.size();
+        cut_cells.push_back(ii * Ny + jj);
+      }
+    const int nc = (int)cut_cells.size();
+    if (nc > 0) {
+      // batch 1: rectangle minus the union of the topography floes near it ('dif', clip fill non-zero)
+      auto run_batch = [&](int np, std::vector<int64_t> &sx, std::vector<int64_t> &sy, std::vector<int32_t> &sro, std::vector<int32_t> &spo,
+                           std::vector<int64_t> &cx, std::vector<int64_t> &cy, std::vector<int32_t> &cro, std::vector<int32_t> &cpo, int method, int fc,
+                           std::vector<int64_t> &ox, std::vector<int64_t> &oy, std::vector<int32_t> &oro, std::vector<int32_t> &opo) -> int {
+        sx.push_back(0); sy.push_back(0); cx.push_back(0); cy.push_back(0);
+        int64_t cap = 4 * (int64_t)(sx.size() + cx.size()) + 64 * (int64_t)np + 64;
+        std::vector<int32_t> stt((size_t)np + 1);
+        for (;;) {
+          ox.assign((size_t)cap, 0); oy.assign((size_t)cap, 0); oro.assign((size_t)cap + 1, 0); opo.assign((size_t)np + 1, 0);
+          const int r = szClipPathsBatch(ctx, np, sx.data(), sy.data(), sro.data(), spo.data(), cx.data(), cy.data(), cro.data(), cpo.data(), method, 0, fc,
+                                         ox.data(), oy.data(), cap, oro.data(), cap, opo.data(), stt.data());
+          if (r == SZ_ERR_CAPACITY) { cap *= 4; continue; }
+          if (r != SZ_OK) return r;
+          for (int p = 0; p < np; ++p) if (stt[p] != SZ_CLIP_OK) return sz_fail(ctx, SZ_ERR_HIP, "szEulerianData: a cell hit the reference's \"Clipper Error.\" condition");
+          return SZ_OK;
+        }
+      };
+      auto rings_area = [&](const std::vector<int64_t> &ox, const std::vector<int64_t> &oy, const std::vector<int32_t> &oro, int r0, int r1) {
+        double sum = 0;
+        std::vector<double> px, py;
+        for (int r = r0; r < r1; ++r) {
+          const int m = oro[r + 1] - oro[r];
+          px.resize((size_t)m); py.resize((size_t)m);
+          for (int k = 0; k < m; ++k) { px[k] = (double)ox[oro[r] + k] / 4294967296.0; py[k] = (double)oy[oro[r] + k] / 4294967296.0; }
+          sum += signed_area(px.data(), py.data(), m);
+        }
+        return absd(sum);
+      };
+      std::vector<int64_t> c1x, c1y; std::vector<int32_t> c1ro, c1po;
+      if ((rc = run_batch(nc, ax, ay, aro, apo, bx, by, bro, bpo, SZ_CLIP_DIFFERENCE, SZ_FILL_NONZERO, c1x, c1y, c1ro, c1po))) { cleanup(); return rc; }
+      std::vector<double> ovb((size_t)nc);
+      for (int c = 0; c < nc; ++c) ovb[c] = rings_area(c1x, c1y, c1ro, c1po[c], c1po[c + 1]);
+      // the potential floes of each cut cell (:122-128) and batch 2: what is left of the rectangle against each of them
+      std::vector<int32_t> ovo(1, 0), ove;
+      std::vector<int> pair_cell;
+      std::vector<int64_t> sx, sy, fx, fy;
+      std::vector<int32_t> sro(1, 0), spo(1, 0), fro(1, 0), fpo(1, 0);
+      for (int c = 0; c < nc; ++c) {
+        const int ii = cut_cells[c] / Ny, jj = cut_cells[c] % Ny;
+        const double xc = 0.5 * (xg[ii] + xg[ii + 1]), yc = 0.5 * (yg[jj] + yg[jj + 1]);
+        for (int e = 0; e < M; ++e) {
+          const double ddx = xc - E[e].x, ddy = yc - E[e].y;
+          const double pint = ::sqrt(ddx * ddx + ddy * ddy) - (rmax[E[e].src] + r_max);
+          if (!(pint < 0)) continue;
+          ove.push_back(e);
+          if (c1po[c + 1] == c1po[c]) continue;            // nothing of the rectangle is left: no overlap to compute
+          for (int r = c1po[c]; r < c1po[c + 1]; ++r) {
+            sx.insert(sx.end(), c1x.begin() + c1ro[r], c1x.begin() + c1ro[r + 1]); sy.insert(sy.end(), c1y.begin() + c1ro[r], c1y.begin() + c1ro[r + 1]);
+            sro.push_back((int32_t)sx.size());
+          }
+          spo.push_back((int32_t)sro.size() - 1);
+          const int src = E[e].src, v0 = vo[src];
+          int nv = vo[src + 1] - v0;
+          if (nv > 1 && cax[v0] == cax[v0 + nv - 1] && cay[v0] == cay[v0 + nv - 1]) --nv;
+          for (int k = 0; k < nv; ++k) { fx.push_back(szc::to_fixed(cax[v0 + k] + E[e].x)); fy.push_back(szc::to_fixed(cay[v0 + k] + E[e].y)); }
+          fro.push_back((int32_t)fx.size()); fpo.push_back((int32_t)fro.size() - 1);
+          pair_cell.push_back((int)ove.size() - 1);
+        }
+        ovo.push_back((int32_t)ove.size());
+      }
+      std::vector<double> ova(ove.size() + 1, 0.0);
+      const int np2 = (int)pair_cell.size();
+      if (np2 > 0) {
+        std::vector<int64_t> c2x, c2y; std::vector<int32_t> c2ro, c2po;
+        if ((rc = run_batch(np2, sx, sy, sro, spo, fx, fy, fro, fpo, SZ_CLIP_INTERSECTION, SZ_FILL_EVENODD, c2x, c2y, c2ro, c2po))) { cleanup(); return rc; }
+        for (int p = 0; p < np2; ++p) ova[(size_t)pair_cell[p]] = rings_area(c2x, c2y, c2ro, c2po[p], c2po[p + 1]);
+      }
+      ove.push_back(0);
+      if ((rc = sz_reserve(ctx, d_ovc, cells * 4)) || (rc = sz_reserve(ctx, d_ovo, ovo.size() * 4)) || (rc = sz_reserve(ctx, d_ove, ove.size() * 4)) ||
+          (rc = sz_reserve(ctx, d_ova, ova.size() * 8)) || (rc = sz_reserve(ctx, d_ovb, ovb.size() * 8))) { cleanup(); cleanup2(); return rc; }
+      he = hipMemcpyAsync(d_ovc.p, ovc.data(), cells * 4, hipMemcpyHostToDevice, st);
+      if (he == hipSuccess) he = hipMemcpyAsync(d_ovo.p, ovo.data(), ovo.size() * 4, hipMemcpyHostToDevice, st);
+      if (he == hipSuccess) he = hipMemcpyAsync(d_ove.p, ove.data(), ove.size() * 4, hipMemcpyHostToDevice, st);
+      if (he == hipSuccess) he = hipMemcpyAsync(d_ova.p, ova.data(), ova.size() * 8, hipMemcpyHostToDevice, st);
+      if (he == hipSuccess) he = hipMemcpyAsync(d_ovb.p, ovb.data(), ovb.size() * 8, hipMemcpyHostToDevice, st);
+      if (he == hipSuccess) he = hipStreamSynchronize(st);      // (the host vectors go out of scope below)
+      if (he != hipSuccess) { cleanup(); cleanup2(); return sz_fail(ctx, SZ_ERR_HIP, "szEulerianData: %s", hipGetErrorString(he)); }
+      ov.cell = (const int *)d_ovc.p; ov.off = (const int *)d_ovo.p; ov.ent = (const int *)d_ove.p; ov.area = (const double *)d_ova.p; ov.abox = (const double *)d_ovb.p;
+    }
+  }
   if ((rc = sz_reserve(ctx, d_ent, (size_t)(M + 1) * sizeof(EulEnt))) || (rc = sz_reserve(ctx, d_grid, grid.size() * 8)) ||
-      (rc = sz_reserve(ctx, d_out, EUL_FIELDS * cells * 8)) || (rc = sz_reserve(ctx, d_flag, 16))) { cleanup(); return rc; }
+      (rc = sz_reserve(ctx, d_out, EUL_FIELDS * cells * 8)) || (rc = sz_reserve(ctx, d_flag, 16))) { cleanup(); cleanup2(); return rc; }
   he = hipMemcpyAsync(d_ent.p, E.data(), (size_t)M * sizeof(EulEnt), hipMemcpyHostToDevice, st);
   if (he == hipSuccess) he = hipMemcpyAsync(d_grid.p, grid.data(), grid.size() * 8, hipMemcpyHostToDevice, st);
   if (he == hipSuccess) he = hipMemsetAsync(d_out.p, 0, EUL_FIELDS * cells * 8, st);
@@ -155,7 +308,7 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
   if (he == hipSuccess && M > 0)
     hipLaunchKernelGGL(k_eul_cells, dim3((unsigned)cells), dim3(256), 0, st, S->F, (const EulEnt *)d_ent.p, M, Nx, Ny,
-                       (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p);
+                       (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p, ov);
   if (he == hipSuccess) he = hipEventRecord(ctx->ev1, st);
   int over = 0;
   if (he == hipSuccess) he = hipMemcpyAsync(out, d_out.p, EUL_FIELDS * cells * 8, hipMemcpyDeviceToHost, st);
@@ -163,7 +316,7 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   if (he == hipSuccess) he = hipStreamSynchronize(st);
   float ms = 0;
   if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-  cleanup();
+  cleanup(); cleanup2();
   if (he != hipSuccess) return sz_fail(ctx, SZ_ERR_HIP, "szEulerianData: %s", hipGetErrorString(he));
   if (over) return sz_fail(ctx, SZ_ERR_WORKSPACE, "szEulerianData: a grid cell has more than %d potential floes (use a finer grid)", (int)EUL_CAP);
   if (kernel_ms) *kernel_ms = ms;

@@ -40,7 +40,7 @@
 //       for a floe the loop of :55-56 skips.  The caller draws `rand(n,1) > C(q).angles/Anorm` and calls frac_corner as
 //       before.
 //   eul = subzero_step('eulerian', Nx, Ny, Nb, c2_boundary, PERIODIC)
-//       calc_eulerian_data.m:1-192 on the resident floes: the struct of Ny x Nx fields the reference returns (Nb = 0).
+//       calc_eulerian_data.m:1-192 on the resident floes: the struct of Ny x Nx fields the reference returns.
 //   D = subzero_step('deform', ids)
 //       after a 'step': fracture_floe.m:14-52 for Floe(ids).  D(q).changed; when 1, D(q).Xi / Yi / area / c_alpha are
 //       the values :46-48 assign (c_alpha 2 x m, open).  The resident floes are not modified.

@@ -50,3 +50,37 @@ def test_cell_sums_conserve_area_and_mass():
     e = oracle.eulerian_data(A, 8, 8, 0, P.c2_boundary, False)
     assert np.allclose(e["c"], e["area"] / cell, rtol=1e-12) and abs(e["area"].sum() - A.area.sum()) < 1e-3 * A.area.sum()
     assert np.abs(e["u"]).max() > 0 and np.isfinite(e["stress"]).all() and np.abs(e["stress"]).max() > 0
+
+
+def test_topography_is_cut_out_of_the_cells():
+    """Nb > 0 (calc_eulerian_data.m:10-24,141-143) on a hand-computed case: one island, one floe beside it, one floe
+    leaning over it; then the tiling pack with its first floes declared topography."""
+    if g.ref_lib() is None:
+        pytest.skip("the topography path clips operands of several contours: reference build only")
+    from subzero_amd import synth
+
+    def box(cx, cy, h):
+        return np.array([[cx - h, cy - h], [cx - h, cy + h], [cx + h, cy + h], [cx + h, cy - h]], float)
+    L = 1e5
+    polys = [box(-5e4, 5e4, 1e4),            # the island: 4e8 m2, inside the upper-left cell of a 2 x 2 grid
+             box(5e4, 5e4, 2e4),             # a floe in the upper-right cell, clear of the island
+             box(-3.5e4, 5e4, 1e4)]          # a floe overlapping the island's right half by 5e3 x 2e4
+    S = synth.build_state(polys, height=1.0, seed=1, n_stress=2, n_mc=50)
+    P = synth.StepParams(dt=10, periodic=False)
+    e = oracle.eulerian_data(S, 2, 2, 1, P.c2_boundary, False)
+    cell = L * L
+    # (rows count from the top: element [0, 0] is the upper-left cell)
+    assert abs(e["c"][0, 1] - 16e8 / cell) < 1e-12                                # untouched cell: plain rectangle
+    left_free = cell - 4e8                                                         # the island is cut out of its cell
+    assert abs(e["c"][0, 0] - (4e8 - 1e8) / left_free) < 1e-9                      # and out of the floe leaning over it
+    assert abs(e["area"][0, 0] - 3e8) < 1e-3 and e["c"][1, 0] == 0 and e["c"][1, 1] == 0
+    assert abs(e["Mtot"][0, 0] - S.mass[2] * 3e8 / 4e8) < 1e-3 * S.mass[2]
+    # with Nb = 0 the island is one more floe
+    e0 = oracle.eulerian_data(S, 2, 2, 0, P.c2_boundary, False)
+    assert abs(e0["c"][0, 0] - 8e8 / cell) < 1e-12
+    # the tiling pack: whatever the topography covers is missing from ice area and from the cells' free area alike
+    S, P = scenes.pack(300, periodic=False)
+    nb = 5
+    e = oracle.eulerian_data(S, 6, 6, nb, P.c2_boundary, False)
+    assert abs(e["area"].sum() - S.area[nb:].sum()) <= 1e-7 * S.area.sum()
+    assert np.nanmax(np.abs(e["c"] - 1.0)) < 1e-6

@@ -37,3 +37,36 @@ def test_eulerian_fields_match_the_oracle(ctx, scene, periodic, grid):
         assert np.array_equal(want[k], got[k]), (k, float(np.abs(want[k] - got[k]).max()))
     assert want["c"].max() > 0.5 and np.abs(want["stress"]).max() > 0 and np.abs(want["u"]).max() > 0
     print("eulerian %s %dx%d: %.3f ms" % (scene, Nx, Ny, ms))
+
+
+@pytest.mark.parametrize("scene,grid", [("nares", (8, 20)), ("nares", (3, 4)), ("pack_nb", (12, 9))])
+def test_eulerian_fields_with_topography(ctx, scene, grid):
+    """Nb > 0 (calc_eulerian_data.m:10-24,141-143): the first Nb floes are cut out of the cells and do not count; the
+    cells that meet them go through the clip kernel, the others through the plain rectangle clip."""
+    if scene == "nares":
+        S, P = scenes.nares_standin()
+        periodic = False
+    else:
+        S, P = scenes.pack(500, periodic=True)
+        S.nb = 4
+        S.Xi += 300.0
+        periodic = True
+    P.set_reference_ocean()
+    A, G = S.copy(), S.copy()
+    sim = capi.FloeInteractions(ctx, G)
+    for it in range(6):
+        P.doInt = int(it % 5 == 0)
+        oracle.step(A, P, threads=8); sim.step(P)
+    sim.download(capi.SYNC_ALL)
+    import hoststep
+    hoststep.check_stress(A, G)
+    A.Stress[:] = G.Stress
+    Nx, Ny = grid
+    nb = int(S.nb)
+    want = oracle.eulerian_data(A, Nx, Ny, nb, P.c2_boundary, periodic)
+    got, ms = sim.eulerian_data(Nx, Ny, nb, P.c2_boundary, periodic)
+    plain = oracle.eulerian_data(A, Nx, Ny, 0, P.c2_boundary, periodic)
+    for k in oracle.EULERIAN_FIELDS:
+        assert np.array_equal(want[k], got[k], equal_nan=True), (k, float(np.nanmax(np.abs(want[k] - got[k]))))
+    assert (want["c"] != plain["c"]).any() and want["Mtot"].sum() < plain["Mtot"].sum()      # the topography was taken out
+    print("eulerian with topography %s %dx%d: %.3f ms in the cell kernel, %d cells changed" % (scene, Nx, Ny, ms, int((want["c"] != plain["c"]).sum())))
