@@ -299,6 +299,8 @@ class SpatialInteractions:
         self.exchanges = 0
         self.bytes_sent = 0
         self.regrown = 0
+        self.rounds = 0                      # grouped send / recv rounds so far (one per step in steady state)
+        self.last_out, self.last_in = {}, {}   # per edge: (records, doubles, migrants) of the last message sent / received
         self.last = None
 
     def _views(self, buf, caps, bulk_row):
@@ -313,12 +315,28 @@ class SpatialInteractions:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
 
+    @staticmethod
+    def _plan(c):
+        """Transfer size agreed for this step on an edge, from what travelled over it last step (records, doubles,
+        migrants): both ends evaluate this on the same numbers."""
+        # (no room is agreed for the 49 KB rows of floes that change strip: they are rare and travel in a second round)
+        return (c[0] + c[0] // 4 + 16, c[1] + c[1] // 4 + 1024, 0)
+
     def step(self, P):
+        """pack -> exchange -> unpack -> step.  In steady state the exchange is ONE grouped round of send / recv per step:
+        each message travels as header + the leading part of its three arrays, sized from what the same edge carried
+        last step plus a margin (both ends know that number); the header says how much of it is used.  Only the
+        first step, and a step whose message outgrew the agreed size, take a second round with the exact sizes."""
         be, dist = self.be, self.dist
         if self.world == 1:
             return be.step(P)
         left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
         with be.stream_scope():
+            bulk_row = be.bulk_row()
+            plan_out = {k: self._plan(c) for k, c in self.last_out.items()}
+            plan_in = {k: self._plan(c) for k, c in self.last_in.items()}
+            for pl in list(plan_out.values()) + list(plan_in.values()):      # my buffers hold what is agreed to travel
+                self.caps = tuple(max(a, b) for a, b in zip(self.caps, pl))
             # my messages: a message that does not fit (more floes changed strip than there is room for) is packed
             # again into larger buffers -- nothing has been sent yet, nothing is lost (include/subzero_hip.h)
             while True:
@@ -332,49 +350,79 @@ class SpatialInteractions:
                              max(2 * caps[2], int(sent.need_migrants)))
                 self.regrown += 1
             hl, hr = bool(sent.has_left), bool(sent.has_right)
-            bulk_row = be.bulk_row()
             v = {k: self._views(b, caps, bulk_row) for k, b in bufs.items()}
-            # round 1: headers (tags name the direction of travel: on a ring of two both neighbours are the same peer)
-            ops = []
-            if hl: ops.append(dist.P2POp(dist.isend, v["send_left"][0], left, self.group, tag=1))
-            if hr: ops.append(dist.P2POp(dist.isend, v["send_right"][0], right, self.group, tag=2))
-            if hr: ops.append(dist.P2POp(dist.irecv, v["from_right"][0], right, self.group, tag=1))
-            if hl: ops.append(dist.P2POp(dist.irecv, v["from_left"][0], left, self.group, tag=2))
-            self._round(ops)
-            hdr = {k: be.header(v[k][0]) for k in ("from_left", "from_right") if (hl if k == "from_left" else hr)}
-            # a neighbour whose message is larger than my buffers (it has grown its own): lay my receive buffers out
-            # for what the headers announce before anything else arrives
-            rcaps = tuple(max([caps[q]] + [h[q] for h in hdr.values()]) for q in range(3))
-            if rcaps != caps:
-                rbytes = be.message_bytes(rcaps)
-                for k in hdr:
-                    head = v[k][0].clone()
-                    bufs[k] = be.buffer(k, rbytes)
-                    v[k] = self._views(bufs[k], rcaps, bulk_row)
-                    v[k][0].copy_(head)
-                self.caps = rcaps
-                self.regrown += 1
-            # round 2: the used part of each array
-            ops = []
-            def parts(key, n_rec, n_dbl, n_migr):
+            out_cnt = {"left": (int(sent.left_records), int(sent.left_doubles), int(sent.left_migrants)),
+                       "right": (int(sent.right_records), int(sent.right_doubles), int(sent.right_migrants))}
+            # (edge, peer, key of my send buffer, tag of what I send, key of my receive buffer, tag of what I receive);
+            # tags name the direction of travel: on a ring of two both neighbours are the same peer, and the order of
+            # posting below -- sends leftward then rightward, receives from the right then from the left -- matches on
+            # both ends for backends that match by order
+            edges = [e for e in (("left", left, "send_left", 1, "from_left", 2), ("right", right, "send_right", 2, "from_right", 1))
+                     if (hl if e[0] == "left" else hr)]
+            recv_order = list(reversed(edges))
+
+            def parts(key, cnt):
                 _, rec, dbl, bulk = v[key]
                 out = []
-                if n_rec: out += [rec[:4 * n_rec], dbl[:8 * n_dbl]]
-                if n_migr: out.append(bulk[:n_migr * bulk_row])
+                if cnt[0]: out.append(rec[:4 * cnt[0]])
+                if cnt[1]: out.append(dbl[:8 * cnt[1]])
+                if cnt[2]: out.append(bulk[:cnt[2] * bulk_row])
                 return out
-            if hl:
-                for t in parts("send_left", sent.left_records, sent.left_doubles, sent.left_migrants):
-                    ops.append(dist.P2POp(dist.isend, t, left, self.group, tag=1)); self.bytes_sent += t.numel()
-            if hr:
-                for t in parts("send_right", sent.right_records, sent.right_doubles, sent.right_migrants):
-                    ops.append(dist.P2POp(dist.isend, t, right, self.group, tag=2)); self.bytes_sent += t.numel()
-            if hr:
-                for t in parts("from_right", *hdr["from_right"][:3]):
-                    ops.append(dist.P2POp(dist.irecv, t, right, self.group, tag=1))
-            if hl:
-                for t in parts("from_left", *hdr["from_left"][:3]):
-                    ops.append(dist.P2POp(dist.irecv, t, left, self.group, tag=2))
+
+            def relayout(rcaps):
+                """receive buffers laid out for larger capacities; what has arrived of each message moves along"""
+                rbytes = be.message_bytes(rcaps)
+                for e in edges:
+                    k = e[4]
+                    old = [t.clone() for t in v[k]]
+                    bufs[k] = be.buffer(k, rbytes)
+                    v[k] = self._views(bufs[k], rcaps, bulk_row)
+                    for a, b in zip(v[k], old):
+                        m = min(a.numel(), b.numel())
+                        a[:m].copy_(b[:m])
+                self.regrown += 1
+
+            steady = all(e[0] in plan_out and e[0] in plan_in for e in edges)
+            rcaps = caps
+            ops = []
+            for e in edges:                                   # headers always travel
+                ops.append(dist.P2POp(dist.isend, v[e[2]][0], e[1], self.group, tag=e[3])); self.bytes_sent += 64
+                if steady:
+                    for t in parts(e[2], plan_out[e[0]]):
+                        ops.append(dist.P2POp(dist.isend, t, e[1], self.group, tag=e[3])); self.bytes_sent += t.numel()
+            for e in recv_order:
+                ops.append(dist.P2POp(dist.irecv, v[e[4]][0], e[1], self.group, tag=e[5]))
+                if steady:
+                    for t in parts(e[4], plan_in[e[0]]):
+                        ops.append(dist.P2POp(dist.irecv, t, e[1], self.group, tag=e[5]))
             self._round(ops)
+            self.rounds += 1
+            hdr = {e[0]: be.header(v[e[4]][0])[:3] for e in edges}
+            # second round: everything on the first step; afterwards, per edge, the two arrays of records in full when
+            # they outgrew what was agreed, and the rows of the floes that changed strip when there are any
+            def rest(cnt, plan):
+                if not steady: return cnt
+                big = cnt[0] > plan[0] or cnt[1] > plan[1]
+                return (cnt[0] if big else 0, cnt[1] if big else 0, cnt[2] if cnt[2] > plan[2] else 0)
+            rest_out = {e[0]: rest(out_cnt[e[0]], plan_out.get(e[0])) for e in edges}
+            rest_in = {e[0]: rest(hdr[e[0]], plan_in.get(e[0])) for e in edges}
+            if any(any(c) for c in rest_out.values()) or any(any(c) for c in rest_in.values()):
+                need = tuple(max([rcaps[q]] + [hdr[e[0]][q] for e in edges]) for q in range(3))
+                if need != rcaps:                             # a neighbour's message is larger than my buffers: lay them out again
+                    rcaps = need
+                    relayout(rcaps)
+                    self.caps = tuple(max(a, b) for a, b in zip(self.caps, rcaps))
+                ops = []
+                for e in edges:
+                    for t in parts(e[2], rest_out[e[0]]):
+                        ops.append(dist.P2POp(dist.isend, t, e[1], self.group, tag=e[3])); self.bytes_sent += t.numel()
+                for e in recv_order:
+                    for t in parts(e[4], rest_in[e[0]]):
+                        ops.append(dist.P2POp(dist.irecv, t, e[1], self.group, tag=e[5]))
+                self._round(ops)
+                self.rounds += 1
+            for e in edges:
+                self.last_out[e[0]] = out_cnt[e[0]]; self.last_in[e[0]] = hdr[e[0]]
             self.exchanges += 1
             got = be.unpack(bufs["from_left"] if hl else None, bufs["from_right"] if hr else None, rcaps)
             self.last = (sent, got)

@@ -179,10 +179,10 @@ def _worker(rank, world, port, scene, steps, drift, q):
             most_present = max(most_present, int(sim.last[1].n_present))
         moved = int((own != owned0).sum())
         dist.destroy_process_group()
-        q.put((rank, "ok", moved, be.migrants_in, most_present, int(own.sum()), sim.bytes_sent // max(sim.exchanges, 1), len(r1.inter), sim.regrown))
+        q.put((rank, "ok", moved, be.migrants_in, most_present, int(own.sum()), sim.bytes_sent // max(sim.exchanges, 1), len(r1.inter), sim.regrown, sim.rounds, sim.exchanges))
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0, 0, 0, 0, 0, 0))
+        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0, 0, 0, 0, 0, 0, 0, 0))
 
 
 def run(world, scene, steps, drift):
@@ -211,6 +211,10 @@ def test_spatial_step_equals_single_process(world, periodic):
     assert res[0][7] > 100                              # contacts were exercised
     for r in res:
         assert r[4] < total, "a rank held current data for every floe: nothing was sharded"
+        # grouped rounds of send / recv: two on the first step, afterwards one per step plus one whenever floes change
+        # strip (their 5 KB rows of history and points here -- 49 KB in a model run -- travel separately) or a message
+        # outgrows the size agreed from the step before
+        assert r[10] == 8 and r[10] + 1 <= r[9] <= 2 * r[10], (r[9], r[10])
 
 
 def test_messages_grow_when_more_floes_change_strip_than_fit():
@@ -218,3 +222,11 @@ def test_messages_grow_when_more_floes_change_strip_than_fit():
     for what the header announces -- same results, nobody raises, nobody waits for a peer that has left."""
     res = run(2, ("pack", (1800,), {"periodic": True, "n_stress": 6, "n_mc": 80, "tiny_migrant_room": True}), 6, 90.0)
     assert sum(r[3] for r in res) > 4 and sum(r[8] for r in res) > 0
+
+
+def test_one_round_per_step_when_no_floe_changes_strip():
+    """A pack at rest but for its collisions: after the first step every exchange is a single grouped round."""
+    res = run(2, ("pack", (1800,), {"periodic": True, "n_stress": 6, "n_mc": 80}), 6, 0.0)
+    for r in res:
+        assert r[10] == 6 and r[9] == 7, (r[9], r[10])
+    assert sum(r[3] for r in res) == 0
