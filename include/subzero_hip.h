@@ -371,6 +371,12 @@ int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int
                   int64_t cap_migrants, szSpatialInfo *info);
 int szSpatialUnpack(szContext *ctx, const void *d_from_left, const void *d_from_right, int64_t cap_records,
                     int64_t cap_doubles, int64_t cap_migrants, szSpatialInfo *info);
+/* szSpatialUnpack for a caller that has read the message headers itself (it needs them to size the second exchange
+ * round): left_counts / right_counts = {records, doubles, migrants} of the received messages; nothing is read back
+ * from the device, and with info == NULL nothing is counted either: no host round trip at all. */
+int szSpatialUnpackKnown(szContext *ctx, const void *d_from_left, const void *d_from_right, int64_t cap_records,
+                         int64_t cap_doubles, int64_t cap_migrants, const int64_t *left_counts, const int64_t *right_counts,
+                         szSpatialInfo *info);
 int szSpatialOwned(szContext *ctx, uint8_t *owned);   /* owned[i] = 1: this rank integrates floe i (n bytes) */
 
 /* clipper(P, delta, type [, info]) offset mode (mexclipper.cpp:146-203): ClipperOffset with AddPaths(P, jt,

@@ -137,8 +137,8 @@ int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int
   return SZ_OK;
 }
 
-int szSpatialUnpack(szContext *ctx, const void *d_left, const void *d_right, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr,
-                    szSpatialInfo *info) {
+static int unpack_impl(szContext *ctx, const void *d_left, const void *d_right, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr,
+                       const int64_t *known_left, const int64_t *known_right, szSpatialInfo *info) {
   if (!ctx) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
   if (!S || !S->W.owned) return sz_fail(ctx, SZ_ERR_STATE, "szSpatialUnpack: szSpatialInit first");
@@ -151,8 +151,12 @@ int szSpatialUnpack(szContext *ctx, const void *d_left, const void *d_right, int
   for (int side = 0; side < 2; ++side) {
     if (!bufs[side]) continue;
     SpatialMsg m = sp_msg_view((char *)bufs[side], cap_rec, cap_dbl, cap_migr, row);
-    SZ_HIP(ctx, hipMemcpyAsync(seen[side], m.hdr, sizeof(seen[side]), hipMemcpyDeviceToHost, st));
-    SZ_HIP(ctx, hipStreamSynchronize(st));
+    const int64_t *known = side ? known_right : known_left;
+    if (known) { for (int k = 0; k < 3; ++k) seen[side][k] = known[k]; seen[side][3] = SP_OK; }   // (the caller has read the header already)
+    else {
+      SZ_HIP(ctx, hipMemcpyAsync(seen[side], m.hdr, sizeof(seen[side]), hipMemcpyDeviceToHost, st));
+      SZ_HIP(ctx, hipStreamSynchronize(st));
+    }
     if (seen[side][3] != SP_OK) continue;            // the sender could not fit its floes: the caller repeats this edge, larger
     const long long nrec = seen[side][0];
     if (nrec <= 0) continue;
@@ -178,6 +182,15 @@ int szSpatialUnpack(szContext *ctx, const void *d_left, const void *d_right, int
     info->n_owned = (int64_t)c[0]; info->n_present = (int64_t)c[1];
   }
   return SZ_OK;
+}
+
+int szSpatialUnpack(szContext *ctx, const void *d_left, const void *d_right, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr,
+                    szSpatialInfo *info) {
+  return unpack_impl(ctx, d_left, d_right, cap_rec, cap_dbl, cap_migr, nullptr, nullptr, info);
+}
+int szSpatialUnpackKnown(szContext *ctx, const void *d_left, const void *d_right, int64_t cap_rec, int64_t cap_dbl, int64_t cap_migr,
+                         const int64_t *left_counts, const int64_t *right_counts, szSpatialInfo *info) {
+  return unpack_impl(ctx, d_left, d_right, cap_rec, cap_dbl, cap_migr, left_counts, right_counts, info);
 }
 
 int szSpatialOwned(szContext *ctx, uint8_t *owned) {

@@ -256,11 +256,21 @@ class GpuSpatialBackend:
                        "szSpatialPack")
         return info
 
-    def unpack(self, from_left, from_right, caps):
-        info = SpatialInfo()
+    def unpack(self, from_left, from_right, caps, counts=None, want_info=True):
+        """counts: {"left": (records, doubles, migrants), "right": ...} when the caller has read the headers already;
+        want_info False: no count of owned / present floes either -- the unpack is then queued without a host round trip."""
+        info = SpatialInfo() if want_info else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        self.ctx.check(self.ctx.L.szSpatialUnpack(self.ctx.h, p(from_left), p(from_right), caps[0], caps[1], caps[2],
-                                                  ctypes.byref(info)), "szSpatialUnpack")
+        if counts is None:
+            self.ctx.check(self.ctx.L.szSpatialUnpack(self.ctx.h, p(from_left), p(from_right), caps[0], caps[1], caps[2],
+                                                      ctypes.byref(info)), "szSpatialUnpack")
+            return info
+        arr = lambda c: (ctypes.c_int64 * 3)(*c) if c is not None else None
+        self.ctx.L.szSpatialUnpackKnown.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(SpatialInfo)]
+        self.ctx.check(self.ctx.L.szSpatialUnpackKnown(self.ctx.h, p(from_left), p(from_right), caps[0], caps[1], caps[2],
+                                                       arr(counts.get("left")), arr(counts.get("right")),
+                                                       ctypes.byref(info) if want_info else None), "szSpatialUnpackKnown")
         return info
 
     def step(self, P):
@@ -291,9 +301,10 @@ class SpatialInteractions:
     the used part of the three arrays of each message (record offsets, record doubles, bulk rows of floes that
     changed strip) -- nothing is sized by guesswork, nothing is padded on the wire."""
 
-    def __init__(self, backend, rank, world, n_floes, n_vertices, group=None):
+    def __init__(self, backend, rank, world, n_floes, n_vertices, group=None, count_present=True):
         import torch.distributed as dist
         self.dist, self.be, self.rank, self.world, self.group = dist, backend, rank, world, group
+        self.count_present = count_present   # False: no owned / present counts per step (they cost a host round trip)
         # local capacities of the message buffers: every floe could be in a message; a few dozen change strip at most
         self.caps = (int(n_floes), int(47 * n_floes + 2 * n_vertices), int(max(64, n_floes // 16)))
         self.exchanges = 0
@@ -424,7 +435,7 @@ class SpatialInteractions:
             for e in edges:
                 self.last_out[e[0]] = out_cnt[e[0]]; self.last_in[e[0]] = hdr[e[0]]
             self.exchanges += 1
-            got = be.unpack(bufs["from_left"] if hl else None, bufs["from_right"] if hr else None, rcaps)
+            got = be.unpack(bufs["from_left"] if hl else None, bufs["from_right"] if hr else None, rcaps, counts=hdr, want_info=self.count_present)
             self.last = (sent, got)
             return be.step(P)
 
@@ -443,8 +454,11 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
     be = GpuSpatialBackend(S, local_rank, rank, world, edges, halo)
     sim = SpatialInteractions(be, rank, world, S.n, int(S.vert_off[-1]))
     it = 0
+    present = S.n if world == 1 else 0
     for _ in range(warmup):
         P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+        if sim.last: present = max(present, int(sim.last[1].n_present))
+    sim.count_present = False        # (the counts of owned / present floes cost a host round trip per step: warm-up only)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     narrow_ms = 0.0; pairs = 0; pair_bytes = 0.0
@@ -460,7 +474,7 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
     off, rows = be.sim.interactions()
     mine = be.owned()
     keep = np.repeat(mine, np.diff(off))
-    cnt = torch.tensor([capi.collision_count(rows[keep]), float(pairs), float(mine.sum()), float(sim.last[1].n_present if sim.last else S.n),
+    cnt = torch.tensor([capi.collision_count(rows[keep]), float(pairs), float(mine.sum()), float(present),
                         float(sim.bytes_sent / max(sim.exchanges, 1))], dtype=torch.float64, device=be.device)
     tot = cnt.clone(); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -80,7 +80,7 @@ class HostSpatialBackend:
                                         ctypes.c_void_p(right.data_ptr()), caps[0], caps[1], caps[2], raw) == 0
         return self._info(raw)
 
-    def unpack(self, from_left, from_right, caps):
+    def unpack(self, from_left, from_right, caps, counts=None, want_info=True):
         raw = (ctypes.c_int64 * 14)()
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         assert self.L.host_spatial_unpack(ctypes.byref(self.cf), p(from_left), p(from_right), caps[0], caps[1], caps[2], raw) == 0

@@ -70,8 +70,14 @@ def test_emulated_ranks_match_the_oracle(world, periodic):
         own = np.zeros(S.n, int)
         for R, sent in zip(ranks, infos):
             with R.be.stream_scope():
-                got = R.be.unpack(R.buf["from_left"] if sent.has_left else None, R.buf["from_right"] if sent.has_right else None, R.caps)
-                present_max = max(present_max, int(got.n_present))
+                fl = R.buf["from_left"] if sent.has_left else None; fr = R.buf["from_right"] if sent.has_right else None
+                if it % 2:      # the caller has read the headers (as SpatialInteractions does): nothing is read back by the unpack
+                    counts = {k: R.be.header(R.views(key)[0])[:3] for k, key, has in (("left", "from_left", sent.has_left), ("right", "from_right", sent.has_right)) if has}
+                    got = R.be.unpack(fl, fr, R.caps, counts=counts, want_info=(it % 4 == 1))
+                else:
+                    got = R.be.unpack(fl, fr, R.caps)
+                if got is not None:
+                    present_max = max(present_max, int(got.n_present))
                 R.be.step(P)
             G = R.be.sim.download(capi.SYNC_ALL)
             off, rows = R.be.sim.interactions()
