@@ -225,11 +225,101 @@ __global__ void k_cell_fill(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < dev_next(W)) cell_fill(e, F, W);
 }
-__global__ void k_broad_scan(Floes F, Params P, Work W) { // thread (i, c9): 9 consecutive threads share floe i
+__global__ void k_broad_scan(int skip, Floes F, Params P, Work W) { // thread (i, c9): 9 consecutive threads share floe i; starts `skip` floes after the first
   int N = dev_next(W);
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int i = (int)(t / 9) + F.nb, c9 = (int)(t % 9);
+  int i = (int)(t / 9) + F.nb + skip, c9 = (int)(t % 9);
   if (i < N) broad_scan(i, c9, N, F, P, W);
+}
+// The candidate list of a REAL floe in one go -- k_broad_scan + k_broad_filter + pair_count with a wave per floe instead
+// of a thread (one-level grids and lists of up to 64 entries; the thread-per-floe kernels stay for everything else and
+// for the ghosts, whose lists start from their root's finished list).  Lanes test the items of the 3 x 3 cells side by
+// side, the hits are ranked by index with shuffles (ascending j), the `mems` rule of :93-113 is a duplicate test --
+// the first floe with a given FloeNum is always kept, so a later one is "already listed" exactly when an earlier
+// entry carries the same number -- and the pairs and their vertex total are a ballot and a wave sum.  Same lists, same
+// counts as the thread-per-floe kernels (every parity test runs through this one).
+__global__ void __launch_bounds__(64) k_broad_wave(Floes F, Params P, Work W) {
+  __shared__ int hit[64], sorted[64], s_end[9], s_c0[9], s_cn[9];
+  const int i = F.nb + blockIdx.x, lane = threadIdx.x;
+  if (i >= F.n) return;
+  const int N = dev_next(W);
+  const int si = W.ext_src[i];
+  const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
+  int H = 0;
+  if (F.alive[si] && !(xi != xi) && P.COLLISION && is_present(si, W)) {
+    const int gx0 = cell_coord(xi, W.lvl_x0[0], W.lvl_cs[0], W.lvl_cx[0]), gy0 = cell_coord(yi, W.lvl_y0[0], W.lvl_cs[0], W.lvl_cy[0]);
+    // lanes 0..8: extent of one neighbour cell; exclusive prefix over the nine
+    int c0 = 0, cn = 0;
+    if (lane < 9) {
+      const int gx = gx0 + (lane % 3) - 1, gy = gy0 + (lane / 3) - 1;
+      if (gx >= 0 && gx < W.lvl_cx[0] && gy >= 0 && gy < W.lvl_cy[0]) {
+        const int c = W.lvl_base[0] + gy * W.lvl_cx[0] + gx;
+        c0 = W.cell_off[c]; cn = W.cell_off[c + 1] - c0;
+      }
+    }
+    int pre = cn;                                     // inclusive scan over lanes 0..8 (zeros elsewhere)
+    for (int d = 1; d < 16; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+    if (lane < 9) { s_end[lane] = pre; s_c0[lane] = c0; s_cn[lane] = cn; }
+    __syncthreads();
+    const int T = s_end[8];
+    for (int base = 0; base < T; base += 64) {
+      const int t = base + lane;
+      bool ok = false;
+      int j = 0;
+      if (t < T) {
+        int cell = 0;                                 // the cell whose range holds item t
+        for (int c = 0; c < 8; ++c) if (t >= s_end[c]) cell = c + 1;
+        const int q = s_c0[cell] + (t - (s_end[cell] - s_cn[cell]));
+        const CellItem it = W.cell_item[q];
+        j = it.e;
+        if (j > i) {
+          const double dx = xi - it.x, dy = yi - it.y, R = ri + it.r, d2 = dx * dx + dy * dy;
+          ok = !(d2 > R * R * 1.000001) && (::sqrt(d2) < R);       // :103
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) { const int r = H + __popcll(m & ((1ULL << lane) - 1ULL)); if (r < 64) hit[r] = j; }
+      H += __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (H > W.pot_cap || H > 64) {                      // the list does not fit: the host grows the lists and runs the front again
+    if (lane == 0) { atomicAdd(&W.counters[C_ERR_POT], 1ULL); atomicMax(&W.counters[C_NEED_POT], (unsigned long long)H); }
+    H = 0;                                            // (nothing of this step's lists is used after such a report)
+  }
+  // ascending j: rank = how many hits are smaller
+  const int mine = lane < H ? hit[lane] : 0x7fffffff;
+  int rank = 0;
+  for (int k = 0; k < H; ++k) rank += (hit[k] < mine) ? 1 : 0;
+  if (lane < H) sorted[rank] = mine;
+  __syncthreads();
+  // `mems` (:93-99,113): an entry whose FloeNum an earlier entry carries stays only if the pair spans the domain
+  const int j = lane < H ? sorted[lane] : 0;
+  const int num = lane < H ? W.ext_num[j] : 0;       // FloeNum of the entry: negative for a ghost (FloeNums are >= 1)
+  const int key = iabs(num);
+  bool keep = lane < H;
+  if (P.PERIODIC) {
+    bool dup = false;                                // an earlier entry IS the floe this one is an image of
+    for (int k = 0; k < H; ++k) { const int nk = __shfl(num, k); if (k < lane && lane < H && nk == key) dup = true; }
+    if (keep && dup) {
+      const double lim = szc::mind(2 * P.Lx, 2 * P.Ly), R = ri + F.rmax[W.ext_src[j]];
+      keep = 2 * R > lim;
+    }
+  }
+  const unsigned long long km = __ballot(keep);
+  const int K = __popcll(km);
+  if (keep) W.pot_list[(size_t)i * W.pot_cap + __popcll(km & ((1ULL << lane) - 1ULL))] = j + 1;
+  // pairs of this floe and their vertex total (pair_count)
+  const bool rel = keep && pair_relevant(i, j, W);
+  const int ni = W.ext_nv[i];
+  long long nv = rel ? (long long)(ni + W.ext_nv[j]) : 0;
+  if (rel) (void)__hip_atomic_fetch_add(&W.inc_pre[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int d = 32; d > 0; d >>= 1) nv += __shfl_xor(nv, d);
+  int cnt = __popcll(__ballot(rel));
+  if (lane == 0) {
+    if (has_wall_pair(i, N, F, P, W)) { ++cnt; nv += ni + 4; }
+    W.pot_cnt[i] = K; W.pair_cnt[i] = cnt; W.pair_nv[i] = nv;
+  }
 }
 // 64 floes per workgroup; each thread sorts and filters its candidate list in its own slice of LDS
 // (2 * pot_cap + 1 ints: the odd stride spreads the threads over the banks), or of `spill` when that does not fit
@@ -526,6 +616,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   if (const char *v = getenv("SUBZERO_SPECULATE")) S->no_speculation = atoi(v) == 0;
+  if (const char *v = getenv("SUBZERO_BROAD_WAVE")) S->broad_wave = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -615,11 +706,20 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
       launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
       hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
     }
-    hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, F, P, W);
+    // real floes: a wave per floe does scan, sort, filter and pair count in one launch when the grid has one level and
+    // the lists are short (the common case); ghosts -- whose lists start from their root's -- and everything else go
+    // through the thread-per-floe kernels
+    const bool wave = S->broad_wave && W.n_levels == 1 && W.pot_cap <= 64 && n > F.nb;
+    if (wave) {
+      hipLaunchKernelGGL(k_broad_wave, dim3((unsigned)(n - F.nb)), dim3(64), 0, st, F, P, W);
+      if (P.PERIODIC) hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(cap - n), 256), dim3(256), 0, st, n - F.nb, F, P, W);
+    } else {
+      hipLaunchKernelGGL(k_broad_scan, grid_for(9 * (i64)(P.PERIODIC ? cap : n), 256), dim3(256), 0, st, 0, F, P, W);
+    }
     {
       int lanes; size_t lds; int *spill = nullptr;
       if ((rc = filter_launch_shape(ctx, S, 3 * (i64)n + 64, lanes, lds, spill))) return rc;
-      hipLaunchKernelGGL(k_broad_filter, grid_for(n, lanes), dim3(64), lds, st, 1, lanes, F, P, W, spill);
+      if (!wave) hipLaunchKernelGGL(k_broad_filter, grid_for(n, lanes), dim3(64), lds, st, 1, lanes, F, P, W, spill);
       if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, lanes), dim3(64), lds, st, 0, lanes, F, P, W, spill);
     }
     launch_scan(st, S->scan_agg, cap, ScanPairs{W});

@@ -269,11 +269,11 @@ SZ_HD int cell_at(int level, double x, double y, const Work &W) {
          cell_coord(x, W.lvl_x0[level], W.lvl_cs[level], W.lvl_cx[level]);
 }
 // Levels for a field whose candidate floes have radii up to r_max, 90 % of them up to r_p90: the base level takes
-// everything up to min(r_max, 1.5 r_p90) (one level when the sizes are alike), every further level doubles the radius,
+// everything up to min(r_max, 2 r_p90) (one level when the sizes are alike: a Voronoi pack has r_max = 1.6 r_p90), every further level doubles the radius,
 // the top level is open-ended.  Grids span [-L - cs, L + cs] (ghosts lie up to one radius outside the box).
 SZ_HD void grid_levels(double r_max, double r_p90, double Lx, double Ly, Work &W) {
   if (!(r_max > 0)) r_max = 0.5;
-  double r0 = 1.5 * r_p90;
+  double r0 = 2.0 * r_p90;
   if (!(r0 > 0) || r0 > r_max) r0 = r_max;
   const int top = (int)Work::MAX_LEVELS - 1;
   double rt = r0;

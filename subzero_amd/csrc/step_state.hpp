@@ -52,6 +52,7 @@ struct StepState {
   int force_exchange = 0;
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
+  int broad_wave = 1;   // the wave-per-floe broad phase for real floes (SUBZERO_BROAD_WAVE=0: thread-per-floe kernels only)
   int big_lanes = 16;             // pairs per wave of the second fast pass (32-vertex blocks, SUBZERO_BIG_LANES; 0: no such pass)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
                                   // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
