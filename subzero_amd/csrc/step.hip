@@ -346,11 +346,25 @@ __global__ void k_pair_expand(Floes F, Params P, Work W, unsigned long long scra
 // before it; a hipMemcpyAsync of 150 bytes costs a copy-engine start of ~6 us in the middle of the step)
 // (reset_next >= 0: the counters are then set up for the next step, with C_NEXT = reset_next, so that it need not
 // start with a launch that clears them)
-__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next) {
+// (go: what the back half of the step -- contact rows, calc_trajectory -- is to do, see GoRule.  A back half queued
+// behind the narrow phase without a host round trip runs only if the narrow phase left nothing for the host to do;
+// its kernels return at once otherwise, and so does the reset of the counters.)
+struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; };   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
+enum { GO_LEAVE = 0, GO_SET = 1, GO_IF_CLEAN = 2 };
+__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go) {
   const unsigned e = threadIdx.x;
   if (e >= (unsigned)C_COUNT) return;
-  host_copy[e] = counters[e];
-  if (reset_next >= 0 && e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL;
+  unsigned long long go = counters[C_GO];
+  if (rule.mode == GO_SET) go = 1;
+  else if (rule.mode == GO_IF_CLEAN)
+    go = !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
+           counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] ||
+           2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap) ? 1ULL : 0ULL;
+  const unsigned long long v = (e == C_GO) ? go : counters[e];
+  host_copy[e] = v;
+  const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
+  if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
+  else if (e == C_GO) counters[e] = go;
 }
 static_assert(C_COUNT <= 64, "k_publish is launched with one wave");
 // `lanes` of the 64 lanes of each wave carry a pair (the rest stay idle): with only ~4e4 pairs per step the
@@ -436,12 +450,14 @@ __global__ void k_import(i64 np, int world, i64 seg_max, i64 rows_max, char *rec
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np) import_pair(p, np, world, seg_max, rows_max, recv, W);
 }
-__global__ void k_incoming(i64 np, Work W) {
+__global__ void k_incoming(i64 np, Work W) {   // (np may be a capacity: the pairs are those of C_NPAIRS)
+  if (!W.counters[C_GO]) return;
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < np) incoming(p, W);
+  if (p < np && p < (i64)W.counters[C_NPAIRS]) incoming(p, W);
 }
 __global__ void __launch_bounds__(64) k_row_count(int lanes, Work W, int *spill) { // slices of LDS (or of `spill`) as in k_broad_filter
   extern __shared__ int filter_lds[];
+  if (!W.counters[C_GO]) return;
   int N = dev_next(W);
   if ((int)threadIdx.x >= lanes) return;
   int i = blockIdx.x * lanes + threadIdx.x;
@@ -450,26 +466,31 @@ __global__ void __launch_bounds__(64) k_row_count(int lanes, Work W, int *spill)
   if (i < N) row_count(i, W, tmp);
 }
 __global__ void k_row_fill(Floes F, Params P, Work W) {
+  if (!W.counters[C_GO]) return;
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) row_fill(i, N, F, P, W);
 }
 __global__ void k_transfer_collect(Floes F, Work W) {
+  if (!W.counters[C_GO]) return;
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) transfer_collect(i, F, W);
 }
 __global__ void k_transfer_apply(Floes F, Work W) {
+  if (!W.counters[C_GO]) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < W.cap_ext) transfer_apply(i, F, W);
 }
 __global__ void k_integrate_pre(Floes F, Params P, Work W) {
+  if (!W.counters[C_GO]) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
   if (i < F.n) integrate_pre(i, F, P, W);
   int z = blockIdx.x * blockDim.x + threadIdx.x;
   if (z < F.nb) { F.collision_force[2 * z] = 0; F.collision_force[2 * z + 1] = 0; F.collision_torque[z] = 0; F.OverlapArea[z] = 0; }
 }
 __global__ void k_integrate_post(Floes F, Params P, Work W) {
+  if (!W.counters[C_GO]) return;
   int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
   if (i < F.n) integrate_post(i, F, P, W);
 }
@@ -497,7 +518,7 @@ __global__ void __launch_bounds__(256) k_forcing(int first, int last, Floes F, P
   __shared__ double red[3];
   __shared__ int scnt;
   const int i = blockIdx.x + first;
-  if (i >= last) return;
+  if (i >= last || !W.counters[C_GO]) return;
   if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
   const int t = threadIdx.x;
   const int nmc = F.n_mc;
@@ -616,6 +637,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_FAST_PATH")) S->fast_path = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FAST_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->fast_lanes = l; }
   if (const char *v = getenv("SUBZERO_SPECULATE")) S->no_speculation = atoi(v) == 0;
+  if (const char *v = getenv("SUBZERO_SPECULATE_BACK")) S->no_back_speculation = atoi(v) == 0;
   if (const char *v = getenv("SUBZERO_BROAD_WAVE")) S->broad_wave = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -635,7 +657,7 @@ extern "C" {
 // front : ghosts, grid, broad-phase, flat pair list, per-pair buffers      (every rank, identical results)
 // narrow: pair_contact on the pairs [lo, hi) + capacity-tier retries       (one segment per rank)
 // back  : mirror lists, contact rows, sums, calc_trajectory                (every rank, identical results)
-enum { STEP_RETRY_EXACT = 1000 };   // internal: the speculative step did not fit its capacities; run it again the exact way
+enum { STEP_RETRY_EXACT = 1000, STEP_BACK_NOGO = 1001 };   // internal: the speculative step did not fit its capacities; run it again the exact way
 static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool speculative = false) {
   hipStream_t st = ctx->stream;
   int rc;
@@ -726,7 +748,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
     if (speculative) break;   // no read-back here: the counts are checked with those of the narrow phase (step_narrow)
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
     if (c[C_NEED_MC]) {   // nothing of the floe array has been touched yet: the caller regenerates the points and steps again
@@ -777,10 +799,10 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
   return SZ_OK;
 }
 
-static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
+// first pass of the narrow phase over the pairs [lo, hi) and the counters after it; no read-back
+static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool queue_back) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
-  unsigned long long *c = S->c;
   SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
   const bool convex = S->convex_fast != 0 && S->fast_path == 0;
   const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
@@ -804,9 +826,21 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
+  // the counters for the host -- and for the back half of the step, which runs only once the narrow phase is complete:
+  // queued right behind this launch (queue_back) it goes ahead if nothing was deferred and everything fitted
+  const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows} : GoRule{GO_SET, 0, 0, 0};
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0);
   SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipStreamSynchronize(st));
+  return SZ_OK;
+}
+
+// after the read-back of the first pass: capacities of a speculative step, then the pairs the first pass deferred
+static int step_narrow_rest(szContext *ctx, StepState *S) {
+  hipStream_t st = ctx->stream;
+  Floes &F = S->F; Work &W = S->W; Params &P = S->P;
+  unsigned long long *c = S->c;
+  const bool convex = S->convex_fast != 0 && S->fast_path == 0;
+  const bool fast = S->fast_path != 0 || convex;
   if (S->speculating) {
     // The front stages ran without a read-back, for capacities taken from the last step.  Nothing of the floe array
     // has been changed so far (the narrow phase writes its own buffers only), so whatever does not fit is simply done
@@ -828,7 +862,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
       SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->bump, 8, hipMemcpyHostToDevice, st));
     }
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -864,7 +898,7 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
     else
       hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -873,6 +907,13 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
   S->pair_rows_local = (i64)c[C_PAIRROWS];
   S->pair_rows_total = S->pair_rows_local;   // (the sharded step replaces this by the sum over the ranks)
   return SZ_OK;
+}
+
+static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
+  int rc;
+  if ((rc = step_narrow_first(ctx, S, lo, hi, false))) return rc;
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return step_narrow_rest(ctx, S);
 }
 
 static int step_forcing(szContext *ctx, StepState *S, int first, int last) {
@@ -891,7 +932,7 @@ static int force_cnt_max(const StepState *S, int w) { return (S->n - S->nb + w -
 static int step_back_a(szContext *ctx, StepState *S) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
-  const i64 np = S->np;
+  const i64 np = S->back_queued ? S->spec_np : S->np;     // (queued behind the narrow phase: a capacity, the device knows the count)
   const int n = S->n, cap = W.cap_ext;
   int rc;
   if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
@@ -904,7 +945,7 @@ static int step_back_a(szContext *ctx, StepState *S) {
   // No host round trip here: every contact row of a pair appears at most twice in the CSR (once for each floe
   // of the pair), so the pair rows counted by the narrow phase bound it; the exact count and the overflow flag
   // of the mirror lists are read with the counters at the end of the step.
-  const i64 nr_cap = 2 * S->pair_rows_total + 1;
+  const i64 nr_cap = S->back_queued ? S->spec_rows : 2 * S->pair_rows_total + 1;
   if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)nr_cap))) return rc;
   W.rows = (double *)S->rows.p; W.cap_rows = nr_cap;
   hipLaunchKernelGGL(k_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
@@ -920,19 +961,27 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   unsigned long long *c = S->c;
-  const i64 np = S->np;
   const int n = S->n;
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0}, S->back_queued ? 1 : 0);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (S->back_queued) {
+    S->back_queued = false;
+    if (!c[C_GO]) return STEP_BACK_NOGO;     // the narrow phase left work for the host: nothing after it has run, the counters are as it left them
+    S->speculating = false;
+    S->np = (i64)c[C_NPAIRS]; S->nvt = (i64)c[C_NVTOT]; S->N = (int)c[C_NEXT];
+    S->pair_rows_local = S->pair_rows_total = (i64)c[C_PAIRROWS];
+    S->retried = 0;
+  }
   S->counters_clean = true;
   S->nr = (i64)c[C_NROWS];
   if (c[C_ERR_INC]) return sz_fail(ctx, SZ_ERR_WORKSPACE, "contact mirror: a floe has more than %d incoming pairs", W.pot_cap);
   if (c[C_ERR_MC])
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
+  const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
   if (stats) {
     float ms;
@@ -951,6 +1000,11 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
 static void spec_caps(StepState *S) {
   S->spec_np = S->np + S->np / 4 + 1024;
   S->spec_nvt = S->nvt + S->nvt / 4 + 16384;
+  const i64 rows = 2 * S->pair_rows_total + 1;
+  S->spec_rows = rows + rows / 4 + 4096;
+  // the back half is queued behind the narrow phase of the next step when this one deferred nothing (a field whose
+  // floes lean on the walls defers pairs every step: its steps keep the read-back in the middle)
+  S->back_spec_ok = !S->no_back_speculation && S->retried == 0 && S->c[C_BIG] == 0 && S->world <= 1;
 }
 static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
   int rc;
@@ -969,7 +1023,24 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   // a margin, and validated at the one read-back after the narrow phase (one host round trip fewer per step).
   if (S->spec_np > 0 && !S->no_speculation && S->convex_fast && !S->fast_path) {
     if ((rc = step_front(ctx, S, hp, true))) return rc;
-    rc = step_narrow(ctx, S, 0, S->spec_np);
+    const bool queue_back = S->back_spec_ok;
+    if ((rc = step_narrow_first(ctx, S, 0, S->spec_np, queue_back))) return rc;
+    if (queue_back) {
+      // the whole step in one go: the back half runs if the narrow phase completed every pair within the capacities,
+      // and does nothing at all otherwise (the floe array is untouched until then)
+      S->back_queued = true;
+      rc = step_back(ctx, S, stats);
+      if (rc != STEP_BACK_NOGO) {
+        S->back_queued = false;
+        if (!rc) spec_caps(S);
+        return rc;
+      }
+      ++S->back_misses;
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0}, 0);   // from here on the host decides
+      SZ_HIP(ctx, hipGetLastError());
+    }
+    SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = step_narrow_rest(ctx, S);
     if (rc != STEP_RETRY_EXACT) {
       if (rc) return rc;
       rc = step_back(ctx, S, stats);

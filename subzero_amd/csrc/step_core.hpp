@@ -60,7 +60,7 @@ struct Params {
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test

@@ -65,6 +65,9 @@ struct StepState {
   bool stepped = false;
   bool speculating = false, no_speculation = false;   // szStep queues front + narrow phase without the read-back in between
   i64 spec_np = 0, spec_nvt = 0, spec_misses = 0;     // ... sized by these capacities (0: no previous step to size from)
+  i64 spec_rows = 0, back_misses = 0;                 // the back half of the step queued behind the narrow phase as well: contact-row room it is sized for
+  bool back_queued = false;                           // this step's back half was queued behind the narrow phase (set while it is in flight)
+  bool back_spec_ok = false, no_back_speculation = false;   // ... when the previous step deferred no pair (SUBZERO_SPECULATE_BACK=0: never)
   bool counters_clean = false;    // the last step ended by resetting the device counters (k_publish with reset)
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

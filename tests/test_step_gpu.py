@@ -200,3 +200,37 @@ def test_edge_cases(ctx, periodic, nb, collision):
     assert np.array_equal(A.kill, G.kill) and np.array_equal(A.transfer, G.transfer)
     if nb == 0 and collision:
         assert G.kill[0] == 2 and G.transfer[1] == 1
+
+
+def test_back_half_queued_behind_the_narrow_phase_falls_back_when_pairs_are_deferred(ctx):
+    """Steady steps queue the whole step without a host round trip; a step whose narrow phase defers pairs (here: two
+    floes made to coincide exactly, every vertex a tie) must notice on the device, do nothing after the narrow phase,
+    and be finished the ordinary way -- same results either way, and the same again with the queueing switched off."""
+    for env in (None, "0"):
+        if env is not None:
+            import os
+            os.environ["SUBZERO_SPECULATE_BACK"] = env
+        try:
+            S, P = scenes.pack(400, periodic=True)
+            P.set_reference_ocean()
+            A, G = S.copy(), S.copy()
+            sim = capi.FloeInteractions(ctx, G)
+            retried = []
+            for it in range(12):
+                P.doInt = int(it % 5 == 0)
+                if it in (6, 9):            # floe 12 is put down with its first vertex exactly on floe 11's: a tie the fast pass hands on
+                    for T in (A, G):
+                        a, b = T.vert_off[11], T.vert_off[12]
+                        T.Xi[12] = (T.cax[a] + T.Xi[11]) - T.cax[b]; T.Yi[12] = (T.cay[a] + T.Yi[11]) - T.cay[b]
+                    sim.update(np.array([13], np.int32), capi.F_STATE)
+                ra = oracle.step(A, P, threads=8)
+                st = sim.step(P)
+                retried.append(int(st.retried))
+                off, rows = sim.interactions()
+                sim.download(capi.SYNC_ALL)
+                assert np.array_equal(off, ra.inter_off) and np.array_equal(rows, ra.inter), it
+                assert [b for b in hoststep.compare_states(A, G) if b[0] != "StressH"] == [], it
+            assert sum(1 for r in retried if r == 0) >= 6 and max(retried) > 0, retried       # steady steps, and steps that deferred pairs
+        finally:
+            if env is not None:
+                os.environ.pop("SUBZERO_SPECULATE_BACK", None)
