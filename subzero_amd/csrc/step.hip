@@ -87,8 +87,9 @@ __global__ void k_counters_clear(Floes F, Work W) {
   int e = threadIdx.x;
   if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
 }
-__global__ void k_ext_clear(Floes F, Params P, Work W) {
+__global__ void k_ext_clear(Floes F, Params P, Work W) {   // (and the cells of the broad-phase grid: one launch fewer)
   int e = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int c = e; c <= W.lvl_base[W.n_levels]; c += gridDim.x * blockDim.x) { W.cell_cnt[c] = 0; W.cell_fill[c] = 0; }
   if (e < W.cap_ext) { ext_clear(e, W); marks_clear(e, F); }
   if (e < F.n) ext_init(e, F, W);
   if (e >= F.nb && e < F.n) mc_precheck(e, F, P, W);
@@ -212,10 +213,6 @@ __global__ void k_broad(int lo_is_real, Floes F, Params P, Work W) {
   if (lo_is_real) { i += F.nb; if (i >= F.n) return; }
   else { i += F.n; if (i >= N) return; }
   broad(i, N, F, P, W);
-}
-__global__ void k_cell_clear(Work W) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c <= W.lvl_base[W.n_levels]) { W.cell_cnt[c] = 0; W.cell_fill[c] = 0; }
 }
 __global__ void k_cell_count(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -705,25 +702,50 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
   SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
   unsigned long long *c = S->c;
   S->mc_empty.clear();
+  // per-pair buffers and scratch for np pairs with nvt ring vertices in all (grow-only); -> bytes of the closed-form
+  // part of the scratch arena (the retry tiers allocate behind it)
+  i64 main_bytes = 0;
+  auto bind_pairs = [&](i64 np, i64 nvt) -> int {
+    const size_t npa = (size_t)np + 1;
+    if ((rc = sz_reserve(ctx, S->pair_i, npa * 4)) || (rc = sz_reserve(ctx, S->pair_j, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->pair_nvoff, npa * 8)) || (rc = sz_reserve(ctx, S->pair_scr, npa * 8)) ||
+        (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->big_list, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
+    main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
+    const i64 reserve = main_bytes / 2 + (8 << 20);
+    if ((rc = sz_reserve(ctx, S->scratch, (size_t)(main_bytes + reserve)))) return rc;
+    W.cap_pairs = (i64)npa;
+    W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
+    W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
+    W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
+    W.big_list = (int *)S->big_list.p;
+    W.pair_rowoff = (i64 *)S->pair_rowoff.p;
+    W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
+    W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
+    return SZ_OK;
+  };
   for (int attempt = 0;; ++attempt) {
     if (attempt > 0 || !S->counters_clean) hipLaunchKernelGGL(k_counters_clear, dim3(1), dim3(64), 0, st, F, W);
     S->counters_clean = false;
-    hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, P, W);
+    // hierarchy of uniform grids (step_core.hpp grid_levels); positions outside clamp to the border cells
+    grid_levels(S->rmax_max, S->rmax_p90, P.Lx, P.Ly, W);
+    const size_t nc = (size_t)W.lvl_base[W.n_levels] + 1;
+    if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
+        (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, (size_t)cap * sizeof(CellItem)))) return rc;
+    W.cell_item = (CellItem *)S->cell_item.p;
+    W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
+    hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, P, W);   // (clears the cells as well)
     if (P.PERIODIC) {
       for (int dim = 0; dim < 2; ++dim) {
         int bound = (dim == 0) ? n : 2 * n;
         launch_scan(st, S->scan_agg, bound, ScanGhost{dim, F, P, W});   // flags, slots and the ghosts themselves
       }
     }
-    // hierarchy of uniform grids (step_core.hpp grid_levels); positions outside clamp to the border cells
     {
-      grid_levels(S->rmax_max, S->rmax_p90, P.Lx, P.Ly, W);
-      const size_t nc = (size_t)W.lvl_base[W.n_levels] + 1;
-      if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_off, nc * 4)) ||
-          (rc = sz_reserve(ctx, S->cell_fill, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, (size_t)cap * sizeof(CellItem)))) return rc;
-      W.cell_item = (CellItem *)S->cell_item.p;
-      W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
-      hipLaunchKernelGGL(k_cell_clear, grid_for((i64)nc, 256), dim3(256), 0, st, W);
       hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
       launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
       hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
@@ -744,7 +766,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
       if (!wave) hipLaunchKernelGGL(k_broad_filter, grid_for(n, lanes), dim3(64), lds, st, 1, lanes, F, P, W, spill);
       if (P.PERIODIC) hipLaunchKernelGGL(k_broad_filter, grid_for(3 * (i64)n, lanes), dim3(64), lds, st, 0, lanes, F, P, W, spill);
     }
-    launch_scan(st, S->scan_agg, cap, ScanPairs{W});
+    launch_scan(st, S->scan_agg, cap, ScanPairs{W});   // (writing the pair records from inside this scan was measured: +19 us, the per-floe loops serialise in its 1024-thread workgroups)
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
     if (speculative) break;   // no read-back here: the counts are checked with those of the narrow phase (step_narrow)
@@ -773,27 +795,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
   const i64 np = speculative ? S->spec_np : (i64)c[C_NPAIRS], nvt = speculative ? S->spec_nvt : (i64)c[C_NVTOT];
   S->np = np; S->nvt = nvt; S->N = (int)c[C_NEXT]; S->retried = 0;
 
-  // per-pair buffers and scratch, sized for this step (grow-only)
-  const size_t npa = (size_t)np + 1;
-  if ((rc = sz_reserve(ctx, S->pair_i, npa * 4)) || (rc = sz_reserve(ctx, S->pair_j, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->pair_nvoff, npa * 8)) || (rc = sz_reserve(ctx, S->pair_scr, npa * 8)) ||
-      (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->big_list, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
-      (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
-  const i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
-  const i64 reserve = main_bytes / 2 + (8 << 20);
-  if ((rc = sz_reserve(ctx, S->scratch, (size_t)(main_bytes + reserve)))) return rc;
-  W.cap_pairs = (i64)npa;
-  W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
-  W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
-  W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
-  W.big_list = (int *)S->big_list.p;
-  W.pair_rowoff = (i64 *)S->pair_rowoff.p;
-  W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
-  W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
+  if ((rc = bind_pairs(np, nvt))) return rc;
   hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W, (unsigned long long)main_bytes);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
