@@ -391,7 +391,7 @@ static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock)
 #ifndef SZ_CONVEX_WAVES_ATTR
 #define SZ_CONVEX_WAVES_ATTR
 #endif
-__global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 first, i64 count, const unsigned long long *dev_count, int lanes, Floes F, Params P, Work W) {
+__global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 first, i64 count, const unsigned long long *dev_count, int lanes, Floes F, Params P, Work W, const int *order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)threadIdx.x >= lanes) return;
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 f
 #if defined(SZ_WAVE_CYCLES)
   const unsigned long long t0 = wall_clock64();
 #endif
-  if (t < count) narrow_convex(first + t, (const int *)nullptr, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
+  if (t < count) narrow_convex(order ? t : first + t, order, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
 #if defined(SZ_WAVE_CYCLES)
   if (threadIdx.x == 0 && blockIdx.x < (1u << 17)) sz_wave_cycles[blockIdx.x] = wall_clock64() - t0;
 #endif
@@ -815,8 +815,38 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
       int L = S->convex_lanes;
       const i64 expect = S->speculating ? S->last_npairs : hi - lo;   // (speculative step: the launch covers a capacity, the pairs are about last step's)
       if (L == 0) { const i64 want = (expect + 1023) / 1024; L = (int)(want < 16 ? 16 : want > 64 ? 64 : want); }
+      const int *order = nullptr;
+#if defined(SZ_SORT_EXPERIMENT)
+      // EXPERIMENT (diagnostic build): the pairs handed to the waves in descending order of their vertex total, sorted
+      // on the host -- does a wave of like pairs finish sooner?
+      static DevBuf d_order;
+      if (!S->speculating && lo == 0 && getenv("SUBZERO_SORT_PAIRS")) {
+        const i64 np = hi;
+        std::vector<int> pi((size_t)np), pj((size_t)np), nvx((size_t)W.cap_ext), ord((size_t)np);
+        SZ_HIP(ctx, hipStreamSynchronize(st));
+        SZ_HIP(ctx, hipMemcpy(pi.data(), W.pair_i, (size_t)np * 4, hipMemcpyDeviceToHost));
+        SZ_HIP(ctx, hipMemcpy(pj.data(), W.pair_j, (size_t)np * 4, hipMemcpyDeviceToHost));
+        SZ_HIP(ctx, hipMemcpy(nvx.data(), W.ext_nv, (size_t)W.cap_ext * 4, hipMemcpyDeviceToHost));
+        for (i64 p = 0; p < np; ++p) ord[(size_t)p] = (int)p;
+        const int mode = atoi(getenv("SUBZERO_SORT_PAIRS"));
+        auto key = [&](int p) { const int a = nvx[(size_t)pi[(size_t)p]], b = pj[(size_t)p] >= 0 ? nvx[(size_t)pj[(size_t)p]] : 4; return (mode == 2 || mode == 4) ? (a > b ? a : b) : a + b; };
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key(a) > key(b); });
+        if (mode >= 3) {   // dealt out: wave w gets the pairs w, w + nw, w + 2 nw ... of the sorted order (a like mix in every wave)
+          const i64 nw = (np + L - 1) / L;
+          std::vector<int> dealt((size_t)np);
+          i64 at = 0;
+          for (i64 w = 0; w < nw; ++w) for (i64 k = w; k < np; k += nw) dealt[(size_t)at++] = ord[(size_t)k];
+          ord.swap(dealt);
+        }
+        int rc2 = sz_reserve(ctx, d_order, (size_t)np * 4 + 16);
+        if (rc2) return rc2;
+        SZ_HIP(ctx, hipMemcpy(d_order.p, ord.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+        order = (const int *)d_order.p;
+        SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
+      }
+#endif
       hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo,
-                         S->speculating ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr, L, F, P, W);
+                         S->speculating ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr, L, F, P, W, order);
     } else if (fast) {
       const int L = S->fast_lanes;
       const size_t lds = (size_t)L * FAST_WS_STRIDE;
