@@ -7,6 +7,7 @@ clip libraries used as checkers (TEST INFRASTRUCTURE):
 import ctypes
 import os
 import subprocess
+import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -304,7 +305,7 @@ def rect_pairs(n, seed=0, grid=8):
 
 def _build_if_needed(path, cmd):
     if not os.path.exists(path):
-        subprocess.check_call(cmd, cwd=ROOT)
+        subprocess.check_call(cmd, cwd=ROOT, stdout=sys.stderr)
 
 
 def ref_lib():
@@ -312,7 +313,7 @@ def ref_lib():
     if not os.path.exists(path):
         if not os.path.isdir("/root/reference"):
             return None
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=sys.stderr)
     L = ctypes.CDLL(path)
     L.ref_clip_batch.argtypes = [ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p, ctypes.c_int,
                                  _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import subprocess
+import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -77,7 +78,7 @@ def lib():
     path = os.path.join(ROOT, "oracle", "_build", "libsubzero_oracle.so")
     srcs = [os.path.join(ROOT, "oracle", f) for f in ("subzero_oracle.cpp", "subzero_oracle.h", "or_math.h")]
     if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=sys.stderr)   # (bench.py prints ONE line on stdout)
     L = ctypes.CDLL(path)
     L.or_set_clipper.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.or_set_mode.argtypes = [ctypes.c_int]
@@ -101,7 +102,7 @@ def lib():
     # device engine (which the CPU suite pins bit-exactly to the reference through the golden vectors)
     ref = os.path.join(ROOT, "oracle", "_ref", "libclipper_ref.so")
     if not os.path.exists(ref) and os.path.isdir("/root/reference/private"):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=sys.stderr)
     if os.path.exists(ref):
         rc = L.or_set_clipper(ref.encode(), 0); L.clip_kind = "reference"
     else:
