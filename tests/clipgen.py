@@ -500,3 +500,17 @@ def run_host_offset(rings, delta, join, info=0.0):
             continue
         assert rc == 0, rc
         return [np.stack([ox[roff[r]:roff[r + 1]], oy[roff[r]:roff[r + 1]]], 1) for r in range(nr.value)]
+
+
+def offset_golden():
+    """[(rings, delta, join, info, expected rings)] of tests/golden/offset_golden.npz (outputs of the reference build)."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "offset_golden.npz"))
+    cases = []
+    for c in range(len(d["params"])):
+        rings = [np.stack([d["x"][d["ring_off"][r]:d["ring_off"][r + 1]], d["y"][d["ring_off"][r]:d["ring_off"][r + 1]]], 1)
+                 for r in range(d["case_ring0"][c], d["case_ring0"][c + 1])]
+        want = [np.stack([d["out_x"][d["out_ring_off"][r]:d["out_ring_off"][r + 1]], d["out_y"][d["out_ring_off"][r]:d["out_ring_off"][r + 1]]], 1)
+                for r in range(d["case_out0"][c], d["case_out0"][c + 1])]
+        delta, join, info = d["params"][c]
+        cases.append((rings, float(delta), int(join), float(info), want))
+    return cases

@@ -7,7 +7,7 @@ import pytest
 
 import clipgen as g
 
-pytestmark = pytest.mark.skipif(g.ref_lib() is None, reason="reference Clipper build not present")
+needs_ref = pytest.mark.skipif(g.ref_lib() is None, reason="reference Clipper build not present")
 
 
 def fx(a):
@@ -18,6 +18,7 @@ def same(a, b):
     return len(a) == len(b) and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
 
 
+@needs_ref
 def test_square_known_answers():
     sq = np.array([[0, 0], [100, 0], [100, 100], [0, 100]], np.int64)
     out = g.run_host_offset([sq], 10.0, 2)                     # miter, default limit 2: plain corners
@@ -31,6 +32,7 @@ def test_square_known_answers():
     assert same(out, g.run_ref_offset([sq[::-1]], 10.0, 0)) and len(out[0]) == 8
 
 
+@needs_ref
 @pytest.mark.parametrize("seed", range(6))
 def test_floe_outlines_against_the_reference(seed):
     shapes, _ = g.load_shapes()
@@ -51,6 +53,7 @@ def test_floe_outlines_against_the_reference(seed):
     assert n == 160
 
 
+@needs_ref
 def test_degenerate_inputs():
     tri = np.array([[0, 0], [50, 0], [0, 50]], np.int64)
     for rings in ([np.array([[0, 0], [10, 0]], np.int64)],              # fewer than three distinct points: ignored (AddPath)
@@ -61,3 +64,12 @@ def test_degenerate_inputs():
     dup = np.array([[0, 0], [0, 0], [40, 0], [40, 40], [40, 40], [0, 40], [0, 0]], np.int64)   # repeated and closing points
     for join in (0, 2):
         assert same(g.run_ref_offset([dup], 4.0, join), g.run_host_offset([dup], 4.0, join))
+
+
+def test_golden_vectors_of_the_reference_build():
+    """tests/golden/offset_golden.npz (made by tests/golden/make_offset_golden.py from the reference's ClipperOffset): the
+    fixture needs no reference build to check against."""
+    cases = g.offset_golden()
+    assert len(cases) == 48
+    for rings, delta, join, info, want in cases:
+        assert same(want, g.run_host_offset(rings, delta, join, info)), (delta, join, info)

@@ -61,3 +61,8 @@ def test_clipper_gateway_offset_mode():
         for r, w in enumerate(want):
             x = mx.to_numpy(mx.get_field(out, r, "x")).ravel(); y = mx.to_numpy(mx.get_field(out, r, "y")).ravel()
             assert x.dtype == np.float64 and np.array_equal(x, w[:, 0].astype(float)) and np.array_equal(y, w[:, 1].astype(float))
+
+
+def test_offset_golden_vectors(ctx):
+    for rings, delta, join, info, want in g.offset_golden():
+        assert same(want, ctx.offset_paths(rings, delta, join, info)), (delta, join, info)
