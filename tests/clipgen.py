@@ -336,6 +336,20 @@ def host_lib():
     return L
 
 
+def team_lib():
+    """tests/hostsim/libteam_clip_host.so: the team form of the fast intersection (teamclip.hpp), lanes as fibers."""
+    path = os.path.join(ROOT, "tests", "hostsim", "libteam_clip_host.so")
+    srcs = [os.path.join(ROOT, "tests", "hostsim", f) for f in ("team_clip_host.cpp", "team_host.hpp")]
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("vatti.hpp", "convex.hpp", "team.hpp", "teamclip.hpp")]
+    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               srcs[0], "-o", path])
+    L = ctypes.CDLL(path)
+    L.host_team_clip_batch.argtypes = [ctypes.c_int, ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p,
+                                       _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
+    return L
+
+
 class ClipResult:
     def __init__(self, x, y, ring_off, pair_ring_off, status):
         self.x, self.y, self.ring_off, self.pair_ring_off, self.status = x, y, ring_off, pair_ring_off, status
@@ -385,6 +399,37 @@ def run_host(ps, method, fill_s=0, fill_c=0, fast=0, trim=0):
     L.host_clip_set_fast(0)
     L.host_clip_set_trim(0)
     return r
+
+
+def run_team(ps, G=16):
+    """The intersection by a team of G lanes (teamclip.hpp on the host, lanes as fibers): status 100 = bailed out."""
+    L = team_lib()
+    ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st = _alloc(ps)
+    rc = L.host_team_clip_batch(G, len(ps), ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st)
+    assert rc == 0, rc
+    r = ClipResult(ox, oy, roff, proff, st)
+    sites = (ctypes.c_longlong * 128)()
+    L.host_team_bail_sites(sites)
+    r.bail_sites = {i: int(sites[i]) for i in range(128) if sites[i]}
+    return r
+
+
+def compare_where_done(ref, team, n):
+    """compare() on the pairs the team form completed (status != 100); -> (bad, completed)."""
+    bad, done = [], 0
+    for p in range(n):
+        if team.status[p] == 100:
+            continue
+        done += 1
+        if ref.status[p] != team.status[p]:
+            bad.append((p, "status", int(ref.status[p]), int(team.status[p]))); continue
+        a, b = ref.rings(p), team.rings(p)
+        if len(a) != len(b):
+            bad.append((p, "nrings", len(a), len(b))); continue
+        for k in range(len(a)):
+            if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
+                bad.append((p, "ring%d" % k, a[k].shape, b[k].shape)); break
+    return bad, done
 
 
 def compare(r1, r2, n):
