@@ -405,6 +405,18 @@ __global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 f
 #endif
 }
 
+// The team pass (teamcontact.hpp): G lanes per candidate pair, 64 / G pairs per wave, one wave per workgroup; each
+// team's whole working set is its TeamBlock of LDS, only the contact rows and the per-pair words go to HBM.
+template <int G>
+__global__ void __launch_bounds__(64) k_narrow_team(i64 first, i64 count, const unsigned long long *dev_count, Floes F, Params P, Work W) {
+  __shared__ sztm::TeamBlock blocks[64 / G];
+  const sztm::Team<G> T = sztm::Team<G>::here();
+  const int tw = sztm::Team<G>::index_in_wave();
+  const i64 t = (i64)blockIdx.x * (64 / G) + tw;
+  if (dev_count && t >= (i64)*dev_count) return;
+  if (t < count) narrow_team(first + t, T, &blocks[tw], F, P, W);
+}
+
 // Second fast pass: the pairs the first one found too long for its 16-vertex blocks but not for 32-vertex ones (many-
 // sided and mildly evolved floes), a few lanes per wave (1128 B of LDS each).  What it does not cover joins the list of
 // the general kernel.
@@ -627,6 +639,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_TEAM")) { int g = atoi(v); if (g == 0 || g == 16 || g == 32) S->team = g; }
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LDS")) { int b = atoi(v); if (b >= 0 && b <= 40 * 1024) S->retry_lds = b; }
@@ -712,7 +725,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
         (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
         (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
-        (rc = sz_reserve(ctx, S->big_list, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
     main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -722,7 +735,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
     W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
     W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
-    W.big_list = (int *)S->big_list.p;
+    W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p;
     W.pair_rowoff = (i64 *)S->pair_rowoff.p;
     W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
     W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
@@ -809,7 +822,16 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   const bool convex = S->convex_fast != 0 && S->fast_path == 0;
   const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
   if (hi > lo) {
-    if (convex) {
+    const unsigned long long *dev_np = S->speculating ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr;
+    if (convex && S->team) {
+      // the team pass over every pair, then the lane-per-pair fast path over what it handed on (a device-side list: the
+      // launch covers the pair count and its workgroups beyond the list return at once)
+      if (S->team == 32) hipLaunchKernelGGL(k_narrow_team<32>, grid_for(hi - lo, 2), dim3(64), 0, st, lo, hi - lo, dev_np, F, P, W);
+      else hipLaunchKernelGGL(k_narrow_team<16>, grid_for(hi - lo, 4), dim3(64), 0, st, lo, hi - lo, dev_np, F, P, W);
+      const int L = 16;
+      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, (i64)0, hi - lo,
+                         (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
+    } else if (convex) {
       // one wave per SIMD is all this kernel can use (it is bound by the path of its longest lane): as few pairs
       // per wave as still give every one of the 1024 SIMDs at most one wave -- fewer lanes, less divergence
       int L = S->convex_lanes;

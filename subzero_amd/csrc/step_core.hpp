@@ -16,6 +16,7 @@
 // ascending partner), so forces do not depend on scheduling.
 #pragma once
 #include "contact.hpp"
+#include "teamcontact.hpp"
 #include "detmath.hpp"
 
 namespace szs {
@@ -60,7 +61,7 @@ struct Params {
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -92,6 +93,7 @@ struct Work {
   int *pair_nrows, *pair_status, *pair_flag; // flag: 1 sentinel +Inf, 2 sentinel -Inf, 4 contributes rows
   int *retry_list;
   int *big_list;                // pairs the first pass hands to the fast path on the 32-vertex block (C_BIG of them)
+  int *team_list;               // pairs the team pass hands to the lane-per-pair fast path (C_TEAM of them)
   int *touch_list;              // pairs whose first clip found overlap regions (two-stage fast path)
   int *pair_nreg;               // regions of the first clip
   // mirrored rows
@@ -142,11 +144,12 @@ __device__ inline int atomic_max(int *p, int v) { return atomicMax(p, v); }
 __device__ inline unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { return atomicMax(p, v); }
 __device__ inline void atomic_inc_noret(int *p) { (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
-inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
-inline int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
-inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
-inline unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
-inline void atomic_inc_noret(int *p) { ++*p; }
+// (host build, and the host pass of hipcc, where __device__ functions that name these are parsed but never run)
+SZ_HD unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+SZ_HD int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
+SZ_HD int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+SZ_HD unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
+SZ_HD void atomic_inc_noret(int *p) { ++*p; }
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -626,6 +629,70 @@ SZ_HD void narrow_lds(i64 t, const int *list, int mult, const Floes &F, const Pa
 template <class Blk>
 SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P, Work &W, Blk *blk) {
   narrow_t<true, Blk>(p, list, 1, F, P, W, nullptr, 0, blk);
+}
+// The pair by a TEAM of lanes (teamcontact.hpp): the first pass of the default path.  Same bookkeeping as narrow_t --
+// the pair's slice of the scratch arena only holds its contact rows here, everything else of the model lives in the
+// team's block of LDS -- written by one lane.  What the team form does not cover goes to `team_list` and is redone by
+// the lane-per-pair fast path (narrow_convex), whose own leftovers take the general sweep as before.
+template <int G>
+SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, const Floes &F, const Params &P, Work &W) {
+  const int i = W.pair_i[p], j = W.pair_j[p];
+  const int si = W.ext_src[i];
+  const int v1 = F.vert_off[si], n1 = F.vert_off[si + 1] - v1;
+  const szc::RingD ring1 = {F.cax + v1, F.cay + v1, W.ext_x[i], W.ext_y[i], n1, 0};
+  const szc::Body b1 = {W.ext_x[i], W.ext_y[i], F.Ui[si], F.Vi[si], F.ksi_ice[si], F.h[si], F.area[si]};
+  szc::RingD ring2;
+  szc::Body b2;
+  const bool boundary = (j == WALL);
+  int n2;
+  if (boundary) {
+    n2 = 4;
+    const szc::RingD r = {nullptr, nullptr, 0.0, 0.0, 4, 0};   // (the team form never reads the box as a ring: walls are deferred)
+    ring2 = r;
+    const szc::Body b = {P.fb_Xi, P.fb_Yi, P.fb_Ui, P.fb_Vi, P.fb_ksi_ice, P.fb_h, P.fb_area};
+    b2 = b;
+  } else {
+    const int sj = W.ext_src[j];
+    const int v2 = F.vert_off[sj];
+    n2 = F.vert_off[sj + 1] - v2;
+    const szc::RingD r = {F.cax + v2, F.cay + v2, W.ext_x[j], W.ext_y[j], n2, 0};
+    ring2 = r;
+    const szc::Body b = {W.ext_x[j], W.ext_y[j], F.Ui[sj], F.Vi[sj], F.ksi_ice[sj], F.h[sj], F.area[sj]};
+    b2 = b;
+  }
+  const i64 bytes = scratch_bytes_for((i64)n1 + n2, 1);
+  const i64 off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
+  szc::PairScratch S;
+  const bool fits = off + bytes <= W.scratch_bytes && carve(W.scratch + off, bytes, n1, n2, 1, S);
+  if (T.lane == 0) {
+    W.pair_scr[p] = off; W.pair_mult[p] = 1;
+    W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
+  }
+  if (!fits) {
+    if (T.lane == 0) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); }
+    return;
+  }
+  szc::PairOut out;
+  const int st = sztm::pair_contact_team(T, B, ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
+                                         P.mu, P.nu, S.rows, S.cap_rows, out);
+  if (T.lane != 0) return;
+  W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);
+  W.pair_status[p] = st;
+  if (st == szc::ST_DEFER_BIG) { const unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL); W.big_list[k] = (int)p; return; }
+  if (st == szc::ST_DEFER || st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
+    const unsigned long long k = atomic_add(&W.counters[C_TEAM], 1ULL);
+    W.team_list[k] = (int)p;
+    return;
+  }
+  if (st != szv::ST_OK) { atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
+  int flag = 0;
+  double sabs = 0;
+  for (int r = 0; r < out.nrows; ++r) sabs += absd(S.rows[5 * r]) + absd(S.rows[5 * r + 1]);
+  if (sabs != 0) flag |= 4;                                       // :135 / :157
+  else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
+  W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
+  W.pair_flag[p] = flag;
+  if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
 }
 // ---- two-stage fast path: compact sweep records in a block of LDS (`fast_ws`), first clip for every pair
 // (narrow_a), the rest only for the pairs that overlap (narrow_b).  Pairs that do not fit the compact tier,

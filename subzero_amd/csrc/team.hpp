@@ -57,7 +57,14 @@ struct Team {
     const int sh = (int)((threadIdx.x & 63) & ~(G - 1));
     return (unsigned)(m >> sh) & (G == 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u));
   }
-  __device__ void sync(int) const { __syncthreads(); }   // one wave per workgroup: orders the LDS traffic of the wave
+  // the lanes of a team are lanes of one wave and the LDS serves a wave's accesses in order: all that is needed is
+  // that the compiler keeps this lane's LDS writes before, and its reads after, this point (no s_barrier: teams of one
+  // wave may stand at different syncs)
+  __device__ void sync(int) const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
 #else
   // ---- host: fibers --------------------------------------------------------------------------------------------
   HostTeamRt *rt;

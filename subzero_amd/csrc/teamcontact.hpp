@@ -1,0 +1,497 @@
+// teamcontact.hpp -- one candidate pair of the narrow phase by a TEAM of lanes (team.hpp): the contact model of the
+// reference's collisions/floe_interactions.m:1-199 with the work of every loop over vertices, edges and edge pairs
+// spread over the lanes, on top of the team form of the single-minimum intersection (teamclip.hpp).
+//
+// It is contact.hpp's pair_contact_fast / pair_finish (one lane per pair) restated, expression for expression:
+//   * both rings sit in the team's block of LDS in metres for the whole model; the two overlap regions too, converted
+//     to metres once (every use of a region coordinate in the model is from_fixed of it);
+//   * InterX (InterX.m:54-81): lane j tests segment j of ring 2 against every segment of ring 1, the few segment pairs
+//     that pass the first sign test are finished one per lane and made a sorted set by ranking;
+//   * sums whose order the result depends on (region area, centroid, polyarea, the sums of :117-137) are formed in the
+//     reference's order from terms the lanes computed side by side; sums of small integers and minima are order-free;
+//   * inpolygon and the 1e-6 m clearance certificates run an edge per lane.
+// What the fast path does not cover comes back as ST_DEFER (ST_DEFER_BIG) exactly as from pair_contact_fast: the pair
+// is redone by the lane-per-pair kernels, so every pair still goes through arithmetic that is checked against the oracle.
+#pragma once
+#include "contact.hpp"
+#include "teamclip.hpp"
+
+namespace sztm {
+
+using szc::absd;
+using szc::maxd;
+using szc::mind;
+using szc::hyp;
+
+enum { T_CAPP = 16, T_CAPR = 32 };   // crossings kept (sorted set) / segment pairs that reach the second test
+
+struct TeamBlock {
+  double mx[2][T_NV], my[2][T_NV];           // both rings in metres (c_alpha + position)
+  union Coord { i64 f; double m; };
+  Coord qx[2][T_CAPV], qy[2][T_CAPV];        // the overlap regions of clip 1 / clip 2: fixed point out of the clip, metres afterwards
+  double px[T_CAPP], py[T_CAPP];             // InterX crossings: sorted, unique
+  union {
+    ClipScratch clip;
+    double terms[4][T_CAPV];
+    struct { double x[T_CAPR], y[T_CAPR]; int key[T_CAPR]; unsigned char dup[T_CAPR]; } raw;
+  } u;
+};
+
+template <int G>
+SZ_TEAM int min_all_int(const Team<G> &T, int v, int site) {
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) { const int u = T.shfl(v, T.lane ^ d, site + d); v = (u < v) ? u : v; }
+  return v;
+}
+
+// one overlap region in metres, as the model reads it
+struct RegionM {
+  const TeamBlock::Coord *x, *y;
+  int n;
+  SZ_HD double X(int k) const { return x[k].m; }
+  SZ_HD double Y(int k) const { return y[k].m; }
+};
+
+// the clip of the two staged rings (ring 0 moved by (sx, sy) when `shifted`) into region slot `slot`, converted to
+// metres; *nr = its vertex count (0: no overlap)
+template <int G>
+SZ_TEAM int clip_staged(const Team<G> &T, TeamBlock *B, int n1, int n2, bool shifted, double sx, double sy, int slot, int *nr) {
+  ClipScratch *S = &B->u.clip;
+  for (int k = T.lane; k < n1; k += G) {
+    double X = B->mx[0][k], Y = B->my[0][k];
+    if (shifted) { X = X + sx; Y = Y + sy; }
+    S->fx[0][k] = szx::to_fixed_in_range(X); S->fy[0][k] = szx::to_fixed_in_range(Y);
+  }
+  for (int k = T.lane; k < n2; k += G) { S->fx[1][k] = szx::to_fixed_in_range(B->mx[1][k]); S->fy[1][k] = szx::to_fixed_in_range(B->my[1][k]); }
+  T.sync(TEAM_SITE);
+  const int st = team_clip(T, S, n1, n2, &B->qx[slot][0].f, &B->qy[slot][0].f, nr);
+  if (st != szv::ST_OK) return st;
+  // (team_clip ends with a sync: the ring is visible)  polyclip.m:67 once per vertex
+  i64 vx[(T_CAPV + G - 1) / G], vy[(T_CAPV + G - 1) / G];
+#pragma unroll
+  for (int q = 0; q < (T_CAPV + G - 1) / G; ++q) { const int k = T.lane + q * G; vx[q] = vy[q] = 0; if (k < *nr) { vx[q] = B->qx[slot][k].f; vy[q] = B->qy[slot][k].f; } }
+#pragma unroll
+  for (int q = 0; q < (T_CAPV + G - 1) / G; ++q) { const int k = T.lane + q * G; if (k < *nr) { B->qx[slot][k].m = szc::from_fixed(vx[q]); B->qy[slot][k].m = szc::from_fixed(vy[q]); } }
+  T.sync(TEAM_SITE);
+  return szv::ST_OK;
+}
+
+// sum of terms[0 .. n) in index order
+SZ_HD double sum_in_order(const double *t, int n) { double s = 0; for (int i = 0; i < n; ++i) s += t[i]; return s; }
+
+// area(polyshape) of a region: |shoelace| relative to the first vertex (contact.hpp region_area)
+template <int G>
+SZ_TEAM double region_area_team(const Team<G> &T, TeamBlock *B, const RegionM &R) {
+  if (R.n < 3) return 0;
+  const double x0 = R.X(0), y0 = R.Y(0);
+  for (int i = T.lane; i < R.n; i += G) {
+    const int k = (i + 1 == R.n) ? 0 : i + 1;
+    const double ax = R.X(i) - x0, ay = R.Y(i) - y0, bx = R.X(k) - x0, by = R.Y(k) - y0;
+    B->u.terms[0][i] = ax * by - bx * ay;
+  }
+  T.sync(TEAM_SITE);
+  const double s = sum_in_order(B->u.terms[0], R.n);
+  T.sync(TEAM_SITE);
+  return absd(0.5 * s);
+}
+template <int G>
+SZ_TEAM void region_centroid_team(const Team<G> &T, TeamBlock *B, const RegionM &R, double &cx, double &cy) {
+  const double x0 = R.X(0), y0 = R.Y(0);
+  for (int i = T.lane; i < R.n; i += G) {
+    const int k = (i + 1 == R.n) ? 0 : i + 1;
+    const double ax = R.X(i) - x0, ay = R.Y(i) - y0, bx = R.X(k) - x0, by = R.Y(k) - y0;
+    const double w = ax * by - bx * ay;
+    B->u.terms[0][i] = w; B->u.terms[1][i] = (ax + bx) * w; B->u.terms[2][i] = (ay + by) * w;
+  }
+  T.sync(TEAM_SITE);
+  const double s = sum_in_order(B->u.terms[0], R.n), sx = sum_in_order(B->u.terms[1], R.n), sy = sum_in_order(B->u.terms[2], R.n);
+  T.sync(TEAM_SITE);
+  cx = x0 + sx / (3.0 * s);
+  cy = y0 + sy / (3.0 * s);
+}
+// polyarea.m (contact.hpp region_polyarea)
+template <int G>
+SZ_TEAM double region_polyarea_team(const Team<G> &T, TeamBlock *B, const RegionM &R) {
+  for (int i = T.lane; i < R.n; i += G) {
+    const int k = (i + 1 == R.n) ? 0 : i + 1;
+    B->u.terms[0][i] = (R.X(k) - R.X(i)) * (R.Y(k) + R.Y(i));
+  }
+  T.sync(TEAM_SITE);
+  const double s = sum_in_order(B->u.terms[0], R.n);
+  T.sync(TEAM_SITE);
+  return absd(s / 2);
+}
+
+// what edge m of the region contributes to inpolygon.m:150-224 for the point (x, y): the quadrant step (a small
+// integer) and the on-the-edge flag
+SZ_HD void inpoly_edge(double x, double y, double xa, double ya, double xb, double yb, int &dq_out, bool &on) {
+  const double avx = absd(0.5 * (xa + xb)), avy = absd(0.5 * (ya + yb));
+  double sf = maxd(avx, avy);
+  sf = maxd(sf, avx * avy);
+  const double ax = xa - x, ay = ya - y, bx = xb - x, by = yb - y;
+  int qa, qb;
+  { const bool px = ax > 0, py = ay > 0; qa = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+  { const bool px = bx > 0, py = by > 0; qb = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+  const double cp = ax * by - bx * ay;
+  int scp = (cp > 0) ? 1 : (cp < 0 ? -1 : 0);
+  if (absd(cp) < sf * SZC_EPS * 3) scp = 0;
+  const double dp = ax * bx + ay * by;
+  int dq = qb - qa;
+  if (dq == 3 || dq == -3) dq = -dq / 3;
+  if (dq == 2 || dq == -2) dq = 2 * scp;
+  dq_out = dq;
+  on = (scp == 0 && dp <= 0);
+}
+// inpolygon of one point against a region, every lane for itself (contact.hpp in_region on metres)
+SZ_HD bool in_region_m(double x, double y, const RegionM &R) {
+  double mnx = R.X(0), mxx = mnx, mny = R.Y(0), mxy = mny;
+  for (int k = 1; k < R.n; ++k) { const double vx = R.X(k), vy = R.Y(k); mnx = mind(mnx, vx); mxx = maxd(mxx, vx); mny = mind(mny, vy); mxy = maxd(mxy, vy); }
+  if (!(x >= mnx && x <= mxx && y >= mny && y <= mxy)) return false;
+  int sumdq = 0; bool on = false;
+  for (int m = 0; m < R.n; ++m) {
+    const int m1 = (m + 1 == R.n) ? 0 : m + 1;
+    int dq; bool o;
+    inpoly_edge(x, y, R.X(m), R.Y(m), R.X(m1), R.Y(m1), dq, o);
+    sumdq += dq; on = on || o;
+  }
+  return (sumdq != 0) || on;
+}
+// contact.hpp clearly_inside for one point known to the whole team: an edge per lane
+template <int G>
+SZ_TEAM bool clearly_inside_team(const Team<G> &T, double x, double y, const RegionM &R, double margin) {
+  if (R.n < 3) return false;
+  double mnx = SZC_INF, mxx = -SZC_INF, mny = SZC_INF, mxy = -SZC_INF;
+  int sumdq = 0; bool on = false, clear = true;
+  for (int m = T.lane; m < R.n; m += G) {
+    const int m1 = (m + 1 == R.n) ? 0 : m + 1;
+    const double xa = R.X(m), ya = R.Y(m), xb = R.X(m1), yb = R.Y(m1);
+    mnx = mind(mnx, xa); mxx = maxd(mxx, xa); mny = mind(mny, ya); mxy = maxd(mxy, ya);
+    int dq; bool o;
+    inpoly_edge(x, y, xa, ya, xb, yb, dq, o);
+    sumdq += dq; on = on || o;
+    const double ex = xb - xa, ey = yb - ya, px = x - xa, py = y - ya;
+    const double ee = ex * ex + ey * ey;
+    double t = (ee > 0) ? (px * ex + py * ey) / ee : 0;
+    if (t < 0) t = 0;
+    if (t > 1) t = 1;
+    const double dx = px - t * ex, dy = py - t * ey;
+    if (!(dx * dx + dy * dy > margin * margin)) clear = false;
+  }
+  mnx = T.min_all(mnx, TEAM_SITE); mxx = T.max_all(mxx, TEAM_SITE); mny = T.min_all(mny, TEAM_SITE); mxy = T.max_all(mxy, TEAM_SITE);
+  sumdq = T.sum_all(sumdq, TEAM_SITE);
+  const unsigned onm = T.ballot(on, TEAM_SITE), notclear = T.ballot(!clear, TEAM_SITE);
+  if (!(x >= mnx && x <= mxx && y >= mny && y <= mxy)) return false;
+  if (!((sumdq != 0) || onm != 0)) return false;
+  return notclear == 0;
+}
+
+// InterX.m:54-81 on the two staged rings (closed by one more vertex when extra is set): the sorted set of crossings in
+// B->px / py.  -> their number, or -1 when the lists do not hold them / a coordinate is not finite (the caller defers)
+template <int G>
+SZ_TEAM int crossings_team(const Team<G> &T, TeamBlock *B, int n1, int extra1, int n2, int extra2) {
+  enum { JT = (T_NV + 1 + G - 1) / G };
+  const int m1 = n1 + extra1 - 1, m2 = n2 + extra2 - 1;
+  if (m1 <= 0 || m2 <= 0) return 0;
+  // lane j: segment j of ring 2 (and j + G ...)
+  double x2a[JT], y2a[JT], x2b[JT], y2b[JT];
+  unsigned hit[JT];
+#pragma unroll
+  for (int q = 0; q < JT; ++q) {
+    const int j = T.lane + q * G;
+    hit[q] = 0; x2a[q] = y2a[q] = x2b[q] = y2b[q] = 0;
+    if (j < m2) {
+      const int ja = (j >= n2) ? 0 : j, jb = (j + 1 >= n2) ? 0 : j + 1;
+      x2a[q] = B->mx[1][ja]; y2a[q] = B->my[1][ja]; x2b[q] = B->mx[1][jb]; y2b[q] = B->my[1][jb];
+    }
+  }
+  for (int i = 0; i < m1; ++i) {
+    const int ia = (i >= n1) ? 0 : i, ib = (i + 1 >= n1) ? 0 : i + 1;
+    const double x1a = B->mx[0][ia], y1a = B->my[0][ia], x1b = B->mx[0][ib], y1b = B->my[0][ib];
+    const double dx1 = x1b - x1a, dy1 = y1b - y1a;
+    const double S1 = dx1 * y1a - dy1 * x1a;
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+      const double a = dx1 * y2a[q] - dy1 * x2a[q], b = dx1 * y2b[q] - dy1 * x2b[q];
+      if (T.lane + q * G < m2 && ((a - S1) * (b - S1)) <= 0) hit[q] |= 1u << i;
+    }
+  }
+  // the segment pairs that passed: second sign test, the point; appended in rounds of one per lane
+  int nraw = 0;
+  bool overflow = false, notfinite = false;
+  for (;;) {
+    bool have = false;
+#pragma unroll
+    for (int q = 0; q < JT; ++q) have = have || hit[q] != 0;
+    if (!T.any(have, TEAM_SITE)) break;
+    bool valid = false;
+    double X = 0, Y = 0;
+    int key = 0;
+    if (have) {
+      int q = 0;
+#pragma unroll
+      for (int qq = JT - 1; qq >= 0; --qq) if (hit[qq] != 0) q = qq;
+      unsigned hq = 0; double ax2 = 0, ay2 = 0, bx2 = 0, by2 = 0;
+#pragma unroll
+      for (int qq = 0; qq < JT; ++qq) if (qq == q) { hq = hit[qq]; ax2 = x2a[qq]; ay2 = y2a[qq]; bx2 = x2b[qq]; by2 = y2b[qq]; }
+      const int i = __builtin_ctz(hq);
+#pragma unroll
+      for (int qq = 0; qq < JT; ++qq) if (qq == q) hit[qq] &= hit[qq] - 1;
+      const int ia = (i >= n1) ? 0 : i, ib = (i + 1 >= n1) ? 0 : i + 1;
+      const double x1a = B->mx[0][ia], y1a = B->my[0][ia], x1b = B->mx[0][ib], y1b = B->my[0][ib];
+      const double dx1 = x1b - x1a, dy1 = y1b - y1a;
+      const double S1 = dx1 * y1a - dy1 * x1a;
+      const double dx2 = bx2 - ax2, dy2 = by2 - ay2;
+      const double S2 = dx2 * ay2 - dy2 * ax2;
+      const double c = y1a * dx2 - x1a * dy2, d = y1b * dx2 - x1b * dy2;
+      if (((c - S2) * (d - S2)) <= 0) {
+        const double L = dy2 * dx1 - dy1 * dx2;
+        if (L != 0) {
+          X = (dx2 * S1 - dx1 * S2) / L;
+          Y = (dy2 * S1 - dy1 * S2) / L;
+          valid = true;
+          key = i * 64 + (T.lane + q * G);
+          if (!(absd(X) < 1.7976931348623157e308) || !(absd(Y) < 1.7976931348623157e308)) notfinite = true;
+        }
+      }
+    }
+    const unsigned vm = T.ballot(valid, TEAM_SITE);
+    if (valid) {
+      const int at = nraw + __builtin_popcount(vm & ((1u << T.lane) - 1u));
+      if (at < (int)T_CAPR) { B->u.raw.x[at] = X; B->u.raw.y[at] = Y; B->u.raw.key[at] = key; } else overflow = true;
+    }
+    nraw += __builtin_popcount(vm);
+  }
+  if (T.any(overflow || notfinite, TEAM_SITE)) return -1;
+  if (nraw == 0) return 0;
+  T.sync(TEAM_SITE);
+  // unique(...,'rows'): of equal points the one found first (segment-of-ring-1 major) stays; ascending x, then y
+  for (int q = T.lane; q < nraw; q += G) {
+    const double X = B->u.raw.x[q], Y = B->u.raw.y[q];
+    const int key = B->u.raw.key[q];
+    bool dup = false;
+    for (int m = 0; m < nraw; ++m) if (B->u.raw.key[m] < key && B->u.raw.x[m] == X && B->u.raw.y[m] == Y) dup = true;
+    B->u.raw.dup[q] = dup ? 1 : 0;
+  }
+  T.sync(TEAM_SITE);
+  int np = 0;
+  for (int m = 0; m < nraw; ++m) np += B->u.raw.dup[m] ? 0 : 1;
+  if (np > (int)T_CAPP) return -1;
+  for (int q = T.lane; q < nraw; q += G) {
+    if (B->u.raw.dup[q]) continue;
+    const double X = B->u.raw.x[q], Y = B->u.raw.y[q];
+    int rank = 0;
+    for (int m = 0; m < nraw; ++m)
+      if (!B->u.raw.dup[m] && (B->u.raw.x[m] < X || (B->u.raw.x[m] == X && B->u.raw.y[m] < Y))) ++rank;
+    B->px[rank] = X; B->py[rank] = Y;
+  }
+  T.sync(TEAM_SITE);
+  return np;
+}
+
+// |p_poly_dist| < 1e-8 of one point against staged ring 0 closed as the model closes it (contact.hpp dist_to_ring on RingL)
+SZ_HD bool closer_than_1e8_staged(double xp, double yp, const TeamBlock *B, int n1, int extra1) {
+  szc::RingL c = {B->mx[0], B->my[0], n1, extra1};
+  return szc::dist_to_ring(xp, yp, c) < 1e-8;
+}
+
+// The pair.  Same contract as contact.hpp pair_contact_fast; `rows` (5 doubles per contact row) is written by one lane.
+// Every lane returns the same status and fills `out` the same.
+template <int G>
+SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const szc::RingD &ring1, const szc::Body &f1, const szc::RingD &ring2,
+                              const szc::Body &f2, bool boundary, const double *c2b, bool periodic, double Modulus, double dt,
+                              double mu, double nu, double *rows, int cap_rows, szc::PairOut &out) {
+  out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
+  // ---- bounding boxes: of everything the rings hold, whatever their length ----
+  szc::Box b1, b2;
+  {
+    double x0 = SZC_INF, x1 = -SZC_INF, y0 = SZC_INF, y1 = -SZC_INF;
+    for (int k = T.lane; k < ring1.n; k += G) { const double X = ring1.X(k), Y = ring1.Y(k); x0 = mind(x0, X); x1 = maxd(x1, X); y0 = mind(y0, Y); y1 = maxd(y1, Y); }
+    b1.x0 = T.min_all(x0, TEAM_SITE); b1.x1 = T.max_all(x1, TEAM_SITE); b1.y0 = T.min_all(y0, TEAM_SITE); b1.y1 = T.max_all(y1, TEAM_SITE);
+  }
+  if (boundary) {   // only floes at the walls need the clip against the box (general sweep: the box has horizontal edges)
+    if (ring1.n > 0 && szc::well_inside_box(b1, c2b)) { szc::no_contact(out); return szv::ST_OK; }
+    return szc::ST_DEFER;
+  }
+  {
+    double x0 = SZC_INF, x1 = -SZC_INF, y0 = SZC_INF, y1 = -SZC_INF;
+    for (int k = T.lane; k < ring2.n; k += G) { const double X = ring2.X(k), Y = ring2.Y(k); x0 = mind(x0, X); x1 = maxd(x1, X); y0 = mind(y0, Y); y1 = maxd(y1, Y); }
+    b2.x0 = T.min_all(x0, TEAM_SITE); b2.x1 = T.max_all(x1, TEAM_SITE); b2.y0 = T.min_all(y0, TEAM_SITE); b2.y1 = T.max_all(y1, TEAM_SITE);
+  }
+  // a ring stored closed that is one vertex too long for the block is staged without the copy when the closure rule
+  // of the model (:62-67) puts it back (contact.hpp pair_contact_fast)
+  int n1 = ring1.n, n2 = ring2.n;
+  if (n1 == (int)T_NV + 1 && ring1.X(n1 - 1) == ring1.X(0) && ring1.Y(n1 - 1) == ring1.Y(0) &&
+      hyp(ring1.X(0) - ring1.X(n1 - 2), ring1.Y(0) - ring1.Y(n1 - 2)) > 1) --n1;
+  if (n2 == (int)T_NV + 1 && ring2.X(n2 - 1) == ring2.X(0) && ring2.Y(n2 - 1) == ring2.Y(0) &&
+      hyp(ring2.X(0) - ring2.X(n2 - 2), ring2.Y(0) - ring2.Y(n2 - 2)) > 1) --n2;
+  if (n1 > (int)T_NV || n2 > (int)T_NV || n1 < 1 || n2 < 1) {
+    if (ring1.n > 0 && ring2.n > 0 && szc::boxes_apart(b1, b2)) { szc::no_contact(out); return szv::ST_OK; }
+    return (n1 <= (int)szx::FastBlockBig::NV && n2 <= (int)szx::FastBlockBig::NV && n1 >= 1 && n2 >= 1) ? (int)szc::ST_DEFER_BIG : (int)szc::ST_DEFER;
+  }
+  // (the staged rings leave the closing copy out: the boxes above include it, it is a copy of vertex 0)
+  const double safe = SZX_FIXED_SAFE_METRES - 2;
+  bool in_range = true;
+  for (int k = T.lane; k < n1; k += G) { const double X = ring1.X(k), Y = ring1.Y(k); in_range = in_range && absd(X) < safe && absd(Y) < safe; B->mx[0][k] = X; B->my[0][k] = Y; }
+  for (int k = T.lane; k < n2; k += G) { const double X = ring2.X(k), Y = ring2.Y(k); in_range = in_range && absd(X) < safe && absd(Y) < safe; B->mx[1][k] = X; B->my[1][k] = Y; }
+  if (T.any(!in_range, TEAM_SITE)) return szc::ST_DEFER;
+  if (szc::boxes_apart(b1, b2)) { szc::no_contact(out); return szv::ST_OK; }
+  T.sync(TEAM_SITE);
+  // ---- first clip (:29) ----
+  int nr = 0;
+  int st = clip_staged(T, B, n1, n2, false, 0.0, 0.0, 0, &nr);
+  if (st == szx::ST_BAIL) return szc::ST_DEFER;
+  if (st != szv::ST_OK) return st;
+  const int nreg = nr > 0 ? 1 : 0;
+  const RegionM R = {B->qx[0], B->qy[0], nr};
+  // ---- pair_finish ----
+  double h1 = f1.h, h2 = f2.h;                                                            // :10-21
+  double r1 = ::sqrt(f1.area), r2 = ::sqrt(f2.area);
+  double Force_factor = Modulus * (h1 * h2) / (h1 * r2 + h2 * r1);
+  double overlap0 = 0;
+  if (r1 > 1e5 || r2 > 1e5) {
+    r1 = mind(r1, r2);
+    h1 = mind(h1, h2);
+    Force_factor = Modulus * h1 / r1;
+  }
+  const double Gm = Modulus / (2 * (1 + nu));
+  const double Ar = nreg ? region_area_team(T, B, R) : 0.0;
+  {                                                                                       // :54-60
+    double bxmax = c2b[0], bxmin = c2b[0], bymax = c2b[1], bymin = c2b[1];
+    for (int k = 1; k < 5; ++k) {
+      bxmax = maxd(bxmax, c2b[2 * k]); bxmin = mind(bxmin, c2b[2 * k]);
+      bymax = maxd(bymax, c2b[2 * k + 1]); bymin = mind(bymin, c2b[2 * k + 1]);
+    }
+    double barea;
+    {
+      double s = 0;
+      for (int i = 0; i < 4; ++i) {
+        const int k = (i + 1 == 4) ? 0 : i + 1;
+        const double ax = c2b[2 * i] - c2b[0], ay = c2b[2 * i + 1] - c2b[1];
+        const double bx = c2b[2 * k] - c2b[0], by = c2b[2 * k + 1] - c2b[1];
+        s += ax * by - bx * ay;
+      }
+      barea = absd(0.5 * s);
+    }
+    // (the box of the staged ring: the closing copy left out is a copy of vertex 0)
+    const bool inside = (b1.x1 < bxmax && b1.x0 > bxmin && b1.y1 < bymax && b1.y0 > bymin);
+    if (inside || f2.area < 0.95 * barea || periodic) {
+      double sumAr = 0;
+      if (nreg) sumAr += Ar;
+      if (sumAr / f1.area > 0.55) overlap0 = SZC_INF;
+      else if (sumAr / f2.area > 0.55) overlap0 = -SZC_INF;
+    }
+  }
+  // :62-67 close the rings
+  const int extra1 = (hyp(B->mx[0][0] - B->mx[0][n1 - 1], B->my[0][0] - B->my[0][n1 - 1]) > 1) ? 1 : 0;
+  const int extra2 = (hyp(B->mx[1][0] - B->mx[1][n2 - 1], B->my[1][0] - B->my[1][n2 - 1]) > 1) ? 1 : 0;
+  const int np = crossings_team(T, B, n1, extra1, n2, extra2);                             // :70
+  if (np < 0) return szc::ST_DEFER;
+  if (np < 2 || szc::is_inf(overlap0) || nreg == 0) {                                      // :71-74
+    out.has_sentinel = 1;
+    out.sentinel = overlap0;
+    return szv::ST_OK;
+  }
+  const int N1 = n1 + extra1 - 1, N2 = n2 + extra2 - 1;                                    // :78-79
+  const double Amin = (double)(N1 < N2 ? N1 : N2) * 100 / 1.75;
+  if (Ar < Amin) return szv::ST_OK;                                                        // :83
+  double cx, cy;
+  region_centroid_team(T, B, R, cx, cy);                                                   // :96-97
+  // :98-100 nearest region vertex of each crossing; keep those closer than 1 m (every lane the same loop: the
+  // region and the crossings are a handful of values in LDS)
+  int m = 0;
+  double p0x = 0, p0y = 0, p1x = 0, p1y = 0;
+  for (int q = 0; q < np; ++q) {
+    double best = SZC_INF; int bi = 0;
+    const double qx = B->px[q], qy = B->py[q];
+    for (int v = 0; v < nr; ++v) {
+      const double ddx = R.X(v) - qx, ddy = R.Y(v) - qy;
+      const double d2 = ddx * ddx + ddy * ddy;
+      if (d2 < best) { best = d2; bi = v; }
+    }
+    if (::sqrt(best) < 1) {
+      if (m == 0) { p0x = R.X(bi); p0y = R.Y(bi); }
+      else if (m == 1) { p1x = R.X(bi); p1y = R.Y(bi); }
+      ++m;
+    }
+  }
+  double fdx = 0, fdy = 0, dl = 0, pcx = cx, pcy = cy;
+  if (Ar == 0) { fdx = fdy = 0; pcx = pcy = 0; dl = 0; }                                   // :103-106
+  else if (m == 2) {                                                                       // :107-112
+    const double xgh = p1x - p0x, ygh = p1y - p0y;
+    const double b = ::sqrt(xgh * xgh + ygh * ygh);
+    fdx = -ygh / b; fdy = xgh / b;
+    dl = b;
+  } else if (m == 0) { fdx = fdy = 0; dl = 0; }                                            // :113-116
+  else {                                                                                   // :117-137, an edge of the region per lane
+    for (int e = T.lane; e < nr; e += G) {
+      const int e1 = (e + 1 == nr) ? 0 : e + 1;
+      const double xa = R.X(e), ya = R.Y(e), xb = R.X(e1), yb = R.Y(e1);
+      const double xgh = xb - xa, ygh = yb - ya;
+      const double xm = (xb + xa) / 2, ym = (yb + ya) / 2;
+      const double b = ::sqrt(xgh * xgh + ygh * ygh);
+      double nx = -ygh / b, ny = xgh / b;
+      const double xt = xm + nx / 100, yt = ym + ny / 100;
+      if (!in_region_m(xt, yt, R)) { nx = -nx; ny = -ny; }
+      const bool near = closer_than_1e8_staged(xm, ym, B, n1, extra1);                     // p_poly_dist(...) < 1e-8, :127
+      B->u.terms[0][e] = near ? 1.0 : 0.0;
+      B->u.terms[1][e] = (-Force_factor * b) * nx;
+      B->u.terms[2][e] = (-Force_factor * b) * ny;
+      B->u.terms[3][e] = b;
+    }
+    T.sync(TEAM_SITE);
+    int non = 0;
+    double sfx = 0, sfy = 0, sb = 0;
+    for (int e = 0; e < nr; ++e)
+      if (B->u.terms[0][e] != 0) { ++non; sfx += B->u.terms[1][e]; sfy += B->u.terms[2][e]; sb += B->u.terms[3][e]; }
+    T.sync(TEAM_SITE);
+    if (non < nr && non > 0) {
+      const double nrm = ::sqrt(sfx * sfx + sfy * sfy);
+      fdx = sfx / nrm; fdy = sfy / nrm;
+      dl = sb / non;
+    } else { fdx = fdy = 0; dl = 0; }
+  }
+  // :140-155 shift ring 1 by the unit direction and clip again (not shifted: the first clip again, same rings, same result)
+  const bool shifted = !(dl < 0.1);
+  if (!shifted) { fdx = 0; fdy = 0; }
+  int nt = nr, tslot = 0;
+  if (shifted) {
+    st = clip_staged(T, B, n1, n2, true, fdx, fdy, 1, &nt);
+    if (st == szx::ST_BAIL) return szc::ST_DEFER;
+    if (st != szv::ST_OK) return st;
+    tslot = 1;
+  }
+  if (nt > 0) {                                                                            // :156-165 (one region at most)
+    const RegionM Tn = {B->qx[tslot], B->qy[tslot], nt};
+    const double Anew = region_polyarea_team(T, B, Tn);
+    if (Anew / Ar - 1 > 0) {
+      // a point with a 1e-6 m disc inside both regions certifies that the third clip (:158-159) is not empty
+      bool overlaps = clearly_inside_team(T, cx, cy, R, 1e-6) && clearly_inside_team(T, cx, cy, Tn, 1e-6);
+      if (!overlaps && nt >= 3) {
+        double tx, ty;
+        region_centroid_team(T, B, Tn, tx, ty);
+        overlaps = clearly_inside_team(T, tx, ty, R, 1e-6) && clearly_inside_team(T, tx, ty, Tn, 1e-6);
+      }
+      if (!overlaps) return szc::ST_DEFER;                                                 // the third clip decides: general sweep
+      fdx = -fdx; fdy = -fdy;
+    }
+  }
+  const double Fx = fdx * Ar * Force_factor, Fy = fdy * Ar * Force_factor;                 // :167
+  // :170-183
+  const double v1x = f1.Ui + f1.ksi_ice * (pcx - f1.Xi), v1y = f1.Vi + f1.ksi_ice * (pcy - f1.Yi);
+  const double v2x = f2.Ui + f2.ksi_ice * (pcx - f2.Xi), v2y = f2.Vi + f2.ksi_ice * (pcy - f2.Yi);
+  const double vtx = v1x - v2x, vty = v1y - v2y;
+  double dtx, dty;
+  if (maxd(absd(vtx), absd(vty)) == 0) { dtx = 0; dty = 0; }
+  else { const double nv = ::sqrt(vtx * vtx + vty * vty); dtx = vtx / nv; dty = vty / nv; }
+  const double vn = ::sqrt(vtx * vtx + vty * vty);
+  const double coef = -(dtx * vtx + dty * vty) * dl * Gm * vn;
+  double ftx = coef * dtx * dt, fty = coef * dty * dt;
+  const double nF = ::sqrt(Fx * Fx + Fy * Fy);
+  if (::sqrt(ftx * ftx + fty * fty) > mu * nF) { ftx = -mu * nF * dtx; fty = -mu * nF * dty; }
+  if (out.nrows >= cap_rows) return szv::ST_OUT_CAPACITY;
+  if (T.lane == 0) { rows[0] = Fx + ftx; rows[1] = Fy + fty; rows[2] = pcx; rows[3] = pcy; rows[4] = Ar; }
+  out.nrows = 1;
+  return szv::ST_OK;
+}
+
+} // namespace sztm

@@ -39,6 +39,9 @@ static bool g_trim_off = false, g_prune_off = false;
 static long long g_prune_runs[2];
 #define SZC_PRUNE_PROBE(skipped) (++g_prune_runs[(skipped)])
 #define SZC_TRIM_OFF g_trim_off
+static long long g_team_bails[128];
+#define SZTM_BAIL_PROBE(site) (++g_team_bails[(site) & 127])
+#include "team_host.hpp"
 #include "../../subzero_amd/csrc/step_core.hpp"
 #include "../../subzero_amd/csrc/spatial_core.hpp"
 #include <stdint.h>
@@ -63,6 +66,8 @@ static std::vector<double> g_sums;
 static const void *g_sums_for = nullptr;
 extern "C" void host_keep_stress_sums(int on) { g_keep_sums = on; if (!on) g_sums_for = nullptr; }
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
+static long long g_team_pairs = 0, g_team_deferred = 0;
+extern "C" void host_team_counts(long long *pairs, long long *deferred, long long *sites) { *pairs = g_team_pairs; *deferred = g_team_deferred; for (int i = 0; i < 128; ++i) sites[i] = g_team_bails[i]; }
 extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
 extern "C" void host_set_trim(int on) { g_trim_off = !on; }
 extern "C" void host_set_prune(int on) { g_prune_off = !on; }
@@ -281,7 +286,7 @@ struct Sim {
     W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
     W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
     W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
-    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1);
+    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1); W.team_list = alloc<int>(pool, np + 1);
     W.touch_list = alloc<int>(pool, np + 1); W.pair_nreg = alloc<int>(pool, np + 1);
     for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
     i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -293,7 +298,29 @@ struct Sim {
   }
 
   // 0: general sweep only; 1: two-stage compact-record path first (the GPU's SUBZERO_FAST_PATH=1);
-  // 2: single-minimum fast path inside the general kernel (the GPU default)
+  // 2: single-minimum fast path, a lane per pair; 3 / 4: the team form first (16 / 32 lanes per pair, lanes as fibers:
+  // the GPU default), its leftovers through the lane-per-pair fast path
+  template <int G>
+  struct TeamJob {
+    Sim *self; i64 p; sztm::TeamBlock B; teamhost::Runtime *rt;
+    static void lane(void *a, int l) {
+      TeamJob *J = (TeamJob *)a;
+      sztm::Team<G> T; T.lane = l; T.rt = J->rt;
+      narrow_team(J->p, T, &J->B, J->self->F, J->self->P, J->self->W);
+    }
+  };
+  template <int G>
+  void team_pass(i64 lo, i64 hi) {
+    static thread_local teamhost::Runtime rt;
+    static thread_local TeamJob<G> J;
+    J.self = this; J.rt = &rt;
+    for (i64 p = lo; p < hi; ++p) {
+      J.p = p;
+      rt.run(G, &TeamJob<G>::lane, &J);
+      if (!teamhost::exited_together(rt)) { fprintf(stderr, "narrow_team: the lanes of a team did not return together (pair %lld)\n", (long long)p); abort(); }
+    }
+    g_team_pairs += hi - lo; g_team_deferred += (long long)W.counters[C_TEAM];
+  }
   int narrow_range(i64 lo, i64 hi) {
     const bool two_stage = (g_narrow_mode == 1);
     std::vector<char> fast(szv::workspace_bytes_compact() + 64);
@@ -305,6 +332,12 @@ struct Sim {
       for (i64 t = 0; t < nt; ++t) narrow_b(t, F, P, W, fw);
     } else {
       szx::FastBlock blk;
+      if (g_narrow_mode == 3 || g_narrow_mode == 4) {
+        W.counters[C_TEAM] = 0;
+        if (g_narrow_mode == 3) team_pass<16>(lo, hi); else team_pass<32>(lo, hi);
+        std::vector<int> tl(W.team_list, W.team_list + W.counters[C_TEAM]);
+        for (size_t t = 0; t < tl.size(); ++t) narrow_convex((i64)t, tl.data(), F, P, W, &blk);
+      } else
       for (i64 p = lo; p < hi; ++p) {
         if (g_narrow_mode == 2) narrow_convex(p, nullptr, F, P, W, &blk);
         else narrow(p, nullptr, 1, F, P, W);
@@ -324,7 +357,7 @@ struct Sim {
       list.assign(W.retry_list, W.retry_list + W.counters[C_RETRY]);
       W.counters[C_RETRY] = 0;
       // as step_narrow does: the fast path's leftovers at 1x go through k_narrow_lds (16 KB of LDS per lane)
-      const bool lds = g_narrow_mode == 2 && mult == 1;
+      const bool lds = g_narrow_mode >= 2 && mult == 1;
       std::vector<char> slice(16384 + 64);              // stands in for the lane's slice of LDS
       void *sl = (void *)(((uintptr_t)slice.data() + 15) & ~(uintptr_t)15);
       for (size_t t = 0; t < list.size(); ++t) {

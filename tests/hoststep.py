@@ -17,10 +17,12 @@ def lib():
         return _lib
     path = os.path.join(ROOT, "tests", "hostsim", "libstep_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "step_host.cpp")
-    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "convex.hpp", "trim.hpp", "detmath.hpp")]
+    hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "convex.hpp", "trim.hpp", "detmath.hpp",
+                                                                 "team.hpp", "teamclip.hpp", "teamcontact.hpp")]
+    hdrs.append(os.path.join(ROOT, "tests", "hostsim", "team_host.hpp"))
     if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-Wno-unused-function", src, "-o", path])
+                               "-Wno-unused-function", "-Wno-unknown-pragmas", src, "-o", path])
     L = ctypes.CDLL(path)
     L.host_step.argtypes = [ctypes.POINTER(orc.CFloes), ctypes.POINTER(orc.CParams), orc._ip, orc._dp,
                             ctypes.c_int64, orc._ip, orc._ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
@@ -101,8 +103,17 @@ def compare_states(A, B, exact=True, rtol=1e-10):
 
 
 def set_narrow_mode(mode):
-    """0: general sweep only; 1: two-stage compact-record path; 2: single-minimum fast path (GPU default)."""
+    """0: general sweep only; 1: two-stage compact-record path; 2: single-minimum fast path, a lane per pair;
+    3 / 4: the team form first (16 / 32 lanes per pair, the GPU default), its leftovers through mode 2's path."""
     lib().host_set_narrow_mode(int(mode))
+
+
+def team_counts():
+    """(pairs the team pass saw, pairs it handed on, {bail-out site: count}) so far."""
+    a, b = ctypes.c_longlong(), ctypes.c_longlong()
+    sites = (ctypes.c_longlong * 128)()
+    lib().host_team_counts(ctypes.byref(a), ctypes.byref(b), sites)
+    return a.value, b.value, {i: int(sites[i]) for i in range(128) if sites[i]}
 
 
 def fast_counts():
