@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsubzero_hip.so")
+LIB_PATH = os.environ.get("SUBZERO_HIP_LIB") or os.path.join(_HERE, "csrc", "libsubzero_hip.so")   # (the variable: diagnostic builds of the same library)
 
 SZ_OK = 0
 SZ_ERR_NO_DEVICE = -1

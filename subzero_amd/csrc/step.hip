@@ -405,18 +405,6 @@ __global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 f
 #endif
 }
 
-// The team pass (teamcontact.hpp): G lanes per candidate pair, 64 / G pairs per wave, one wave per workgroup; each
-// team's whole working set is its TeamBlock of LDS, only the contact rows and the per-pair words go to HBM.
-template <int G>
-__global__ void __launch_bounds__(64) k_narrow_team(i64 first, i64 count, const unsigned long long *dev_count, Floes F, Params P, Work W) {
-  __shared__ sztm::TeamBlock blocks[64 / G];
-  const sztm::Team<G> T = sztm::Team<G>::here();
-  const int tw = sztm::Team<G>::index_in_wave();
-  const i64 t = (i64)blockIdx.x * (64 / G) + tw;
-  if (dev_count && t >= (i64)*dev_count) return;
-  if (t < count) narrow_team(first + t, T, &blocks[tw], F, P, W);
-}
-
 // Second fast pass: the pairs the first one found too long for its 16-vertex blocks but not for 32-vertex ones (many-
 // sided and mildly evolved floes), a few lanes per wave (1128 B of LDS each).  What it does not cover joins the list of
 // the general kernel.
@@ -639,7 +627,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_NARROW_LANES")) { int l = atoi(v); if (l >= 1 && l <= 64) S->narrow_lanes = l; }
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
-  if (const char *v = getenv("SUBZERO_TEAM")) { int g = atoi(v); if (g == 0 || g == 16 || g == 32) S->team = g; }
+  if (const char *v = getenv("SUBZERO_TEAM")) S->team = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LDS")) { int b = atoi(v); if (b >= 0 && b <= 40 * 1024) S->retry_lds = b; }
@@ -668,7 +656,7 @@ extern "C" {
 // narrow: pair_contact on the pairs [lo, hi) + capacity-tier retries       (one segment per rank)
 // back  : mirror lists, contact rows, sums, calc_trajectory                (every rank, identical results)
 enum { STEP_RETRY_EXACT = 1000, STEP_BACK_NOGO = 1001 };   // internal: the speculative step did not fit its capacities; run it again the exact way
-static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool speculative = false) {
+static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool speculative = false, bool classify = true) {
   hipStream_t st = ctx->stream;
   int rc;
   // ocean / wind grids: uploaded on the first step and whenever the forcing is refreshed
@@ -706,6 +694,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     if (P.c2_boundary[2 * k] > P.Lx) P.Lx = P.c2_boundary[2 * k];
     if (P.c2_boundary[2 * k + 1] > P.Ly) P.Ly = P.c2_boundary[2 * k + 1];
   }
+  boundary_summary(P);
   Floes &F = S->F;
   Work &W = S->W;
   const int n = S->n;
@@ -725,7 +714,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
         (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
         (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
-        (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) || (rc = sz_reserve(ctx, S->wide_list, npa * 4)) || (rc = sz_reserve(ctx, S->live_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
     main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -735,7 +724,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
     W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
     W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
-    W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p;
+    W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p; W.wide_list = (int *)S->wide_list.p; W.live_list = (int *)S->live_list.p;
     W.pair_rowoff = (i64 *)S->pair_rowoff.p;
     W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
     W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
@@ -810,6 +799,10 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
 
   if ((rc = bind_pairs(np, nvt))) return rc;
   hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W, (unsigned long long)main_bytes);
+  // the pairs sorted for the team pass (narrow_team.hip): boxes apart -> answered, the others onto their kernel's list
+  S->classified = classify && S->team != 0 && S->convex_fast != 0 && S->fast_path == 0;
+  if (S->classified)
+    sz_launch_pair_classify(st, np, speculative ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr, P, W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -826,8 +819,8 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
     if (convex && S->team) {
       // the team pass over every pair, then the lane-per-pair fast path over what it handed on (a device-side list: the
       // launch covers the pair count and its workgroups beyond the list return at once)
-      if (S->team == 32) hipLaunchKernelGGL(k_narrow_team<32>, grid_for(hi - lo, 2), dim3(64), 0, st, lo, hi - lo, dev_np, F, P, W);
-      else hipLaunchKernelGGL(k_narrow_team<16>, grid_for(hi - lo, 4), dim3(64), 0, st, lo, hi - lo, dev_np, F, P, W);
+      if (S->classified) sz_launch_narrow_team(st, hi - lo, F, P, W);
+      else sz_launch_narrow_team_range(st, lo, hi - lo, F, P, W);
       const int L = 16;
       hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, (i64)0, hi - lo,
                          (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
@@ -1122,7 +1115,7 @@ int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world
   memset(info, 0, sizeof(*info));
   info->seg_rows = -1;
   int rc;
-  if ((rc = step_front(ctx, S, hp))) { info->status = rc; info->replicated_failure = 1; return rc; }
+  if ((rc = step_front(ctx, S, hp, false, false))) { info->status = rc; info->replicated_failure = 1; return rc; }
   S->rank = rank; S->world = world;
   shard_range(S->np, rank, world, S->seg_lo, S->seg_hi);
   rc = step_narrow(ctx, S, S->seg_lo, S->seg_hi);

@@ -56,12 +56,53 @@ struct Params {
   double fCoriolis, turn_angle;
   double Lx, Ly; // max of c2_boundary rows (:9-10), filled by the host wrapper
   double Xo_max, Xo_min, Yo_max, Yo_min; // extent of the ocean grid axes (calc_trajectory.m:116), filled by the host wrapper (axis_extent)
+  // what the contact model derives from c2_boundary alone, once per step on the host (boundary_summary) -- a kernel that
+  // walks the array itself reads it through a pointer, which puts the by-value Params into scratch memory:
+  double bnd_xmax, bnd_xmin, bnd_ymax, bnd_ymin, bnd_area;   // floe_interactions.m:54-60: extent of the 5 closed corners, area of the box
+  int bnd_rect, bnd_pad;                                     // 1: the 4 corners form an axis-aligned rectangle (contact.hpp well_inside_box)
 };
+// (the expressions of contact.hpp pair_finish / well_inside_box on c2_boundary, evaluated once)
+SZ_HD void boundary_summary(Params &P) {
+  const double *c = P.c2_boundary;
+  double bxmax = c[0], bxmin = c[0], bymax = c[1], bymin = c[1];
+  for (int k = 1; k < 5; ++k) {
+    bxmax = szc::maxd(bxmax, c[2 * k]); bxmin = szc::mind(bxmin, c[2 * k]);
+    bymax = szc::maxd(bymax, c[2 * k + 1]); bymin = szc::mind(bymin, c[2 * k + 1]);
+  }
+  double sum = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int k = (i + 1 == 4) ? 0 : i + 1;
+    const double ax = c[2 * i] - c[0], ay = c[2 * i + 1] - c[1];
+    const double bx = c[2 * k] - c[0], by = c[2 * k + 1] - c[1];
+    sum += ax * by - bx * ay;
+  }
+  P.bnd_xmax = bxmax; P.bnd_xmin = bxmin; P.bnd_ymax = bymax; P.bnd_ymin = bymin; P.bnd_area = szc::absd(0.5 * sum);
+  // well_inside_box: extent of the first 4 corners (the 5th closes the ring: a copy of the first whenever the box is a
+  // rectangle the test accepts -- else the flag is off and the pair is left to the lane-per-pair path)
+  double x0 = c[0], x1 = c[0], y0 = c[1], y1 = c[1];
+  for (int k = 1; k < 4; ++k) { x0 = szc::mind(x0, c[2 * k]); x1 = szc::maxd(x1, c[2 * k]); y0 = szc::mind(y0, c[2 * k + 1]); y1 = szc::maxd(y1, c[2 * k + 1]); }
+  bool rect = (c[8] == c[0] && c[9] == c[1]);
+  for (int k = 0; k < 4; ++k) {
+    const double x = c[2 * k], y = c[2 * k + 1];
+    if (!((x == x0 || x == x1) && (y == y0 || y == y1))) rect = false;
+    const int k1 = (k + 1) & 3;
+    if (!((x == c[2 * k1]) != (y == c[2 * k1 + 1]))) rect = false;
+  }
+  P.bnd_rect = rect ? 1 : 0; P.bnd_pad = 0;
+}
+
+// one entry of ext_rec
+enum { REC_X = 0, REC_Y, REC_UI, REC_VI, REC_KSI, REC_H, REC_AREA, REC_BX0, REC_BX1, REC_BY0, REC_BY1,
+       REC_NSTAGE,     // vertices to stage: the stored length, one less when the ring is stored closed and one too long for the block (contact.hpp pair_contact_fast); -1: too long
+       REC_NSTORED,    // the stored length
+       REC_INRANGE,    // 1: every staged coordinate is within the fast path's fixed-point range
+       REC_WORDS = 16, RING_SLOTS = 16 };
+static_assert((int)RING_SLOTS == (int)sztm::T_NV, "the staged rings are what the team's block holds");
 
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -76,6 +117,9 @@ struct Work {
   int *ext_src, *ext_num, *ext_parent, *xg_of, *yg_of;
   int *ext_nv;                  // stored ring length of the entry's floe (vert_off difference), so that pair sizing needs one lookup
   double *ext_x, *ext_y;
+  // what the team pass of the narrow phase reads of an entry, laid out for one coalesced load each (cell_count):
+  double *ext_rec;              // [REC_WORDS * cap_ext] position, velocities, thickness, area, bounding box, ring length
+  double *ext_ring;             // [2 * RING_SLOTS * cap_ext] the first RING_SLOTS vertices of the ring at the entry's position: x then y
   int *flag, *scan;             // cap_ext
   unsigned long long *counters; // C_COUNT
   // broad-phase
@@ -94,6 +138,8 @@ struct Work {
   int *retry_list;
   int *big_list;                // pairs the first pass hands to the fast path on the 32-vertex block (C_BIG of them)
   int *team_list;               // pairs the team pass hands to the lane-per-pair fast path (C_TEAM of them)
+  int *wide_list;               // pairs with more vertices than a 16-lane team has lanes: 32 lanes each (C_WIDE of them)
+  int *live_list;               // pairs whose bounding boxes meet and that fit a 16-lane team (C_LIVE of them; pair_classify)
   int *touch_list;              // pairs whose first clip found overlap regions (two-stage fast path)
   int *pair_nreg;               // regions of the first clip
   // mirrored rows
@@ -143,6 +189,7 @@ __device__ inline int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 __device__ inline int atomic_max(int *p, int v) { return atomicMax(p, v); }
 __device__ inline unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { return atomicMax(p, v); }
 __device__ inline void atomic_inc_noret(int *p) { (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void atomic_add_noret(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 // (host build, and the host pass of hipcc, where __device__ functions that name these are parsed but never run)
 SZ_HD unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
@@ -150,6 +197,7 @@ SZ_HD int atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
 SZ_HD int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 SZ_HD unsigned long long atomic_max(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 SZ_HD void atomic_inc_noret(int *p) { ++*p; }
+SZ_HD void atomic_add_noret(unsigned long long *p, unsigned long long v) { *p += v; }
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -310,6 +358,31 @@ SZ_HD int cell_of(int e, const Floes &F, const Work &W) {
 SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && e >= F.nb && is_present(s, W); }
 SZ_HD void cell_count(int e, const Floes &F, Work &W) {
   if (in_grid(e, F, W)) atomic_add(&W.cell_cnt[cell_of(e, F, W)], 1);
+  // what the narrow phase's team pass needs of the entry, once per step instead of once per pair: the ring where the
+  // entry lies (ghosts: their own position) -- c_alpha + position, the sums every pair would otherwise form again --
+  // its bounding box (contact.hpp ring_box), the scalars of floe_interactions.m:10-21,170-183
+  const int s = W.ext_src[e];
+  const int v0 = F.vert_off[s], n = F.vert_off[s + 1] - v0;
+  const szc::RingD ring = {F.cax + v0, F.cay + v0, W.ext_x[e], W.ext_y[e], n, 0};
+  szc::Box b;
+  szc::ring_box(ring, b);
+  int nstage = n;
+  if (n == (int)RING_SLOTS + 1 && ring.X(n - 1) == ring.X(0) && ring.Y(n - 1) == ring.Y(0) &&
+      szc::hyp(ring.X(0) - ring.X(n - 2), ring.Y(0) - ring.Y(n - 2)) > 1) --nstage;
+  if (nstage > (int)RING_SLOTS || nstage < 1) nstage = -1;
+  const double safe = SZX_FIXED_SAFE_METRES - 2;
+  bool in_range = true;
+  double *rx = W.ext_ring + 2 * (size_t)RING_SLOTS * e, *ry = rx + RING_SLOTS;
+  for (int k = 0; k < nstage; ++k) {
+    const double X = ring.X(k), Y = ring.Y(k);
+    in_range = in_range && szc::absd(X) < safe && szc::absd(Y) < safe;
+    rx[k] = X; ry[k] = Y;
+  }
+  double *o = W.ext_rec + (size_t)REC_WORDS * e;
+  o[REC_X] = W.ext_x[e]; o[REC_Y] = W.ext_y[e]; o[REC_UI] = F.Ui[s]; o[REC_VI] = F.Vi[s]; o[REC_KSI] = F.ksi_ice[s];
+  o[REC_H] = F.h[s]; o[REC_AREA] = F.area[s];
+  o[REC_BX0] = b.x0; o[REC_BX1] = b.x1; o[REC_BY0] = b.y0; o[REC_BY1] = b.y1;
+  o[REC_NSTAGE] = (double)nstage; o[REC_NSTORED] = (double)n; o[REC_INRANGE] = in_range ? 1.0 : 0.0;
 }
 SZ_HD void cell_fill(int e, const Floes &F, Work &W) {
   const int s = W.ext_src[e];
@@ -630,56 +703,104 @@ template <class Blk>
 SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P, Work &W, Blk *blk) {
   narrow_t<true, Blk>(p, list, 1, F, P, W, nullptr, 0, blk);
 }
-// The pair by a TEAM of lanes (teamcontact.hpp): the first pass of the default path.  Same bookkeeping as narrow_t --
-// the pair's slice of the scratch arena only holds its contact rows here, everything else of the model lives in the
-// team's block of LDS -- written by one lane.  What the team form does not cover goes to `team_list` and is redone by
-// the lane-per-pair fast path (narrow_convex), whose own leftovers take the general sweep as before.
+// Sorting the candidate pairs before the narrow phase, a thread per pair (the first questions of contact.hpp
+// pair_contact_fast, answered from the entries' records): a pair whose bounding boxes are apart -- a quarter of the
+// candidates of a packed field -- or whose floe lies well inside the domain box is DONE here with the no-contact
+// result; the others are appended to the list of the kernel that takes them, so that the team pass runs on dense teams:
+//   live_list  16 lanes per pair          wide_list  32 lanes per pair (more than 16 scanlines)
+//   team_list  the lane-per-pair kernels (walls, rings too long for the block, coordinates out of the fast range)
+// The order inside a list is arbitrary (every pair writes its own words).  Returns the class; the caller appends.
+enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3 };
+SZ_HD int pair_classify(i64 p, const Params &P, Work &W) {
+  const int i = W.pair_i[p], j = W.pair_j[p];
+  const bool boundary = (j == WALL);
+  const double *ri = W.ext_rec + (size_t)REC_WORDS * i, *rj = boundary ? ri : W.ext_rec + (size_t)REC_WORDS * j;
+  const int n1 = (int)ri[REC_NSTORED], n2 = boundary ? 4 : (int)rj[REC_NSTORED];
+  const i64 off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
+  W.pair_scr[p] = off; W.pair_mult[p] = 1; W.pair_nrows[p] = 0; W.pair_flag[p] = 0; W.pair_rowoff[p] = off / 8;
+  if (off + scratch_bytes_for((i64)n1 + n2, 1) > W.scratch_bytes) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); return PC_DONE; }
+  W.pair_status[p] = szv::ST_OK;
+  const szc::Box b1 = {ri[REC_BX0], ri[REC_BX1], ri[REC_BY0], ri[REC_BY1]};
+  if (boundary) {
+    const double gap = 1e-6;
+    if (n1 > 0 && P.bnd_rect && b1.x0 > P.bnd_xmin + gap && b1.x1 < P.bnd_xmax - gap && b1.y0 > P.bnd_ymin + gap && b1.y1 < P.bnd_ymax - gap) return PC_DONE;
+    return PC_OTHER;
+  }
+  const szc::Box b2 = {rj[REC_BX0], rj[REC_BX1], rj[REC_BY0], rj[REC_BY1]};
+  const bool apart = szc::boxes_apart(b1, b2);
+  if (ri[REC_NSTAGE] < 1 || rj[REC_NSTAGE] < 1) return (n1 > 0 && n2 > 0 && apart) ? PC_DONE : PC_OTHER;
+  if (ri[REC_INRANGE] == 0 || rj[REC_INRANGE] == 0) return PC_OTHER;
+  if (apart) return PC_DONE;
+  return (n1 + n2 - 2 > 16) ? PC_WIDE : PC_LIVE;
+}
+SZ_HD void pair_classified(i64 p, int cls, Work &W) {   // (the kernel appends a wave at a time instead)
+  if (cls == PC_LIVE) W.live_list[atomic_add(&W.counters[C_LIVE], 1ULL)] = (int)p;
+  else if (cls == PC_WIDE) W.wide_list[atomic_add(&W.counters[C_WIDE], 1ULL)] = (int)p;
+  else if (cls == PC_OTHER) W.team_list[atomic_add(&W.counters[C_TEAM], 1ULL)] = (int)p;
+}
+
+// The pair by a TEAM of lanes (teamcontact.hpp): the first pass of the default path.  Two dependent rounds of loads:
+// the pair (i, j), then -- one coalesced load each -- the two entries' records and staged rings (cell_count).  Only the
+// contact row and the per-pair result words go to HBM, written by one lane; the row sits at the start of the pair's
+// slice of the scratch arena (closed form, as in narrow_t; a pair handed on is laid out afresh by the kernel that redoes
+// it).  What the team form does not cover goes to `team_list` and is redone by the lane-per-pair fast path
+// (narrow_convex), whose own leftovers take the general sweep as before; a pair with more vertices than the team has
+// lanes goes to `wide_list` (the same pass with 32 lanes per pair).
 template <int G>
 SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, const Floes &F, const Params &P, Work &W) {
+  SZTM_PHASE(0);
   const int i = W.pair_i[p], j = W.pair_j[p];
-  const int si = W.ext_src[i];
-  const int v1 = F.vert_off[si], n1 = F.vert_off[si + 1] - v1;
-  const szc::RingD ring1 = {F.cax + v1, F.cay + v1, W.ext_x[i], W.ext_y[i], n1, 0};
-  const szc::Body b1 = {W.ext_x[i], W.ext_y[i], F.Ui[si], F.Vi[si], F.ksi_ice[si], F.h[si], F.area[si]};
-  szc::RingD ring2;
-  szc::Body b2;
   const bool boundary = (j == WALL);
-  int n2;
-  if (boundary) {
-    n2 = 4;
-    const szc::RingD r = {nullptr, nullptr, 0.0, 0.0, 4, 0};   // (the team form never reads the box as a ring: walls are deferred)
-    ring2 = r;
-    const szc::Body b = {P.fb_Xi, P.fb_Yi, P.fb_Ui, P.fb_Vi, P.fb_ksi_ice, P.fb_h, P.fb_area};
-    b2 = b;
-  } else {
-    const int sj = W.ext_src[j];
-    const int v2 = F.vert_off[sj];
-    n2 = F.vert_off[sj + 1] - v2;
-    const szc::RingD r = {F.cax + v2, F.cay + v2, W.ext_x[j], W.ext_y[j], n2, 0};
-    ring2 = r;
-    const szc::Body b = {W.ext_x[j], W.ext_y[j], F.Ui[sj], F.Vi[sj], F.ksi_ice[sj], F.h[sj], F.area[sj]};
-    b2 = b;
+  const i64 nvoff = W.pair_nvoff[p];
+  // lane l: word l of the records, vertex l of the rings
+  {
+    const int l = T.lane & 15, half = T.lane >> 4;               // (32-lane teams: the upper half loads the partner's)
+    const double *ri = W.ext_rec + (size_t)REC_WORDS * i, *rj = boundary ? ri : W.ext_rec + (size_t)REC_WORDS * j;
+    const double *gi = W.ext_ring + 2 * (size_t)RING_SLOTS * i, *gj = boundary ? gi : W.ext_ring + 2 * (size_t)RING_SLOTS * j;
+    if (G == 16) {
+      const double a = ri[l], b = rj[l], xi = gi[l], yi = gi[RING_SLOTS + l], xj = gj[l], yj = gj[RING_SLOTS + l];
+      B->u.rec[0][l] = a; B->u.rec[1][l] = b; B->mx[0][l] = xi; B->my[0][l] = yi; B->mx[1][l] = xj; B->my[1][l] = yj;
+    } else {
+      const double a = (half ? rj : ri)[l], x = (half ? gj : gi)[l], y = (half ? gj : gi)[RING_SLOTS + l];
+      B->u.rec[half][l] = a; B->mx[half][l] = x; B->my[half][l] = y;
+    }
   }
+  T.sync(TEAM_SITE);
+  const int n1 = (int)B->u.rec[0][REC_NSTORED], n2 = boundary ? 4 : (int)B->u.rec[1][REC_NSTORED];
   const i64 bytes = scratch_bytes_for((i64)n1 + n2, 1);
-  const i64 off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
-  szc::PairScratch S;
-  const bool fits = off + bytes <= W.scratch_bytes && carve(W.scratch + off, bytes, n1, n2, 1, S);
+  const i64 off = (i64)SCR_PER_V * (nvoff + 2 * p) + (i64)SCR_PER_PAIR * p;
   if (T.lane == 0) {
     W.pair_scr[p] = off; W.pair_mult[p] = 1;
     W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
+    W.pair_rowoff[p] = off / 8;
   }
-  if (!fits) {
+  if (!(off + bytes <= W.scratch_bytes)) {
     if (T.lane == 0) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); }
     return;
   }
+  const szc::Box bx1 = {B->u.rec[0][REC_BX0], B->u.rec[0][REC_BX1], B->u.rec[0][REC_BY0], B->u.rec[0][REC_BY1]};
+  const szc::Box bx2 = {B->u.rec[1][REC_BX0], B->u.rec[1][REC_BX1], B->u.rec[1][REC_BY0], B->u.rec[1][REC_BY1]};
+  sztm::Staged sg;
+  sg.n1 = (int)B->u.rec[0][REC_NSTAGE]; sg.n2 = (int)B->u.rec[1][REC_NSTAGE];
+  sg.stored1 = n1; sg.stored2 = n2;
+  sg.in_range = B->u.rec[0][REC_INRANGE] != 0 && B->u.rec[1][REC_INRANGE] != 0;
+  // the bodies (contact.hpp Body) stay in the block: words REC_X .. REC_AREA of the records, in that order
+  static_assert((int)REC_X == (int)sztm::BODY_X && (int)REC_AREA == (int)sztm::BODY_AREA && (int)REC_KSI == (int)sztm::BODY_KSI, "record and body word order");
+  if (T.lane < (int)sztm::BODY_WORDS) {
+    const int w = T.lane;
+    // (a pair with the domain box never gets as far as its second body here: it is answered from the floe's bounding
+    // box or handed to the general sweep)
+    B->body[0][w] = B->u.rec[0][w]; B->body[1][w] = B->u.rec[1][w];
+  }
+  T.sync(TEAM_SITE);
   szc::PairOut out;
-  const int st = sztm::pair_contact_team(T, B, ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
-                                         P.mu, P.nu, S.rows, S.cap_rows, out);
+  double row[5] = {0, 0, 0, 0, 0};
+  sztm::BoundaryBox bb = {P.bnd_xmax, P.bnd_xmin, P.bnd_ymax, P.bnd_ymin, P.bnd_area, P.bnd_rect != 0};
+  const int st = sztm::pair_contact_team(T, B, sg, bx1, bx2, boundary, bb, P.PERIODIC != 0, P.Modulus, P.dt, P.mu, P.nu, row, out);
   if (T.lane != 0) return;
-  W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);
   W.pair_status[p] = st;
   if (st == szc::ST_DEFER_BIG) { const unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL); W.big_list[k] = (int)p; return; }
-  if (st == szc::ST_DEFER || st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
+  if (st == szc::ST_DEFER || st == sztm::ST_DEFER_WIDE || st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
     const unsigned long long k = atomic_add(&W.counters[C_TEAM], 1ULL);
     W.team_list[k] = (int)p;
     return;
@@ -687,12 +808,16 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   if (st != szv::ST_OK) { atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
   int flag = 0;
   double sabs = 0;
-  for (int r = 0; r < out.nrows; ++r) sabs += absd(S.rows[5 * r]) + absd(S.rows[5 * r + 1]);
+  if (out.nrows > 0) sabs += absd(row[0]) + absd(row[1]);
   if (sabs != 0) flag |= 4;                                       // :135 / :157
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
-  W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
-  W.pair_flag[p] = flag;
-  if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+  if (flag & 4) {
+    double *rows = (double *)(W.scratch + off);
+    rows[0] = row[0]; rows[1] = row[1]; rows[2] = row[2]; rows[3] = row[3]; rows[4] = row[4];
+    W.pair_nrows[p] = out.nrows;
+    atomic_add_noret(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+  }
+  if (flag) W.pair_flag[p] = flag;
 }
 // ---- two-stage fast path: compact sweep records in a block of LDS (`fast_ws`), first clip for every pair
 // (narrow_a), the rest only for the pairs that overlap (narrow_b).  Pairs that do not fit the compact tier,

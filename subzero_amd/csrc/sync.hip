@@ -92,7 +92,7 @@ void destroy_state(StepState *S) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->big_list, &S->team_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
+                    &S->retry_copy, &S->big_list, &S->team_list, &S->wide_list, &S->live_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
                     &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->pot_list, &S->inc_list,
                     &S->stage_d, &S->stage_i, &S->stage_ids, &S->sp_masks, &S->sp_edges_dev, &S->sp_counts};
   for (DevBuf *b : more) sz_release(*b);
@@ -173,7 +173,7 @@ int build_state(szContext *ctx, const szFloeState *h, StepState *old, const int3
   W.cap_ext = (int)cap; W.pot_cap = S->pot_cap;
 #define NEW(field, count) if ((rc = dev_alloc(ctx, S, W.field, (size_t)(count)))) return rc;
   NEW(ext_src, cap) NEW(ext_num, cap) NEW(ext_parent, cap) NEW(xg_of, cap) NEW(yg_of, cap) NEW(ext_nv, cap)
-  NEW(ext_x, cap) NEW(ext_y, cap) NEW(flag, cap) NEW(scan, cap) NEW(counters, C_COUNT)
+  NEW(ext_x, cap) NEW(ext_y, cap) NEW(ext_rec, (size_t)REC_WORDS * cap) NEW(ext_ring, 2 * (size_t)RING_SLOTS * cap) NEW(flag, cap) NEW(scan, cap) NEW(counters, C_COUNT)
   NEW(pot_cnt, cap)
   NEW(pair_cnt, cap) NEW(pair_nv, cap) NEW(pair_base, cap + 1) NEW(nv_base, cap + 1)
   NEW(inc_cnt, cap) NEW(inc_pre, cap) NEW(mc_cnt, n) NEW(mc_list, n)

@@ -23,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define SZ_TEAM __device__ inline
+#define SZ_TEAM_NOINLINE __device__ __attribute__((noinline))
 #else
 #define SZ_TEAM inline
+#define SZ_TEAM_NOINLINE inline __attribute__((noinline))
 #endif
 
 namespace sztm {

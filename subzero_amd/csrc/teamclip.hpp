@@ -33,11 +33,15 @@ namespace sztm {
 using szv::Pt;
 using szv::same;
 
-enum { T_NV = 16, T_EV = 2 * T_NV, T_CAPX = 16, T_CAPV = 32 };
+enum { T_NV = 16, T_EV = 2 * T_NV, T_CAPX = 8, T_CAPV = 16 };   // vertices per ring, scanlines, crossings of all beams, vertices of the output ring
 
 #ifndef SZTM_BAIL_PROBE
 #define SZTM_BAIL_PROBE(site) ((void)(site))   // the host test build histograms the bail-out sites here
 #endif
+#ifndef SZTM_PHASE
+#define SZTM_PHASE(k) ((void)0)   // a diagnostic build attributes the kernel's time to its parts here (narrow_team.hip)
+#endif
+enum { ST_WIDE = 104 };   // more vertices in the two rings than the team has lanes
 #define SZTM_BAIL(site) do { if (T.lane == 0) { SZTM_BAIL_PROBE(site); } return (int)szx::ST_BAIL; } while (0)
 
 // the team's scratch for one clip (LDS): both rings in fixed point, the slope of every ring edge, the vertices of
@@ -50,7 +54,6 @@ struct ClipScratch {
   int pc[T_EV];                   // event s: four 8-bit counts (slot = ring * 2 + bound) of bound vertices above it
   unsigned char ev[T_EV];         // event s: ring << 4 | vertex
   int rank_bot[2], rank_top[2];
-  int key_start, key_close;
 };
 
 struct Bounds { int n, bot, top, dirl, ptop; };   // cleaned ring: vertex count, bottom / top vertex, direction of the left bound, position of the top along it
@@ -78,15 +81,24 @@ SZ_HD bool active_edge(const ClipScratch *S, const Bounds &g, int r, int b, int 
   return true;
 }
 SZ_HD int pc_field(int pc, int slot) { return (pc >> (8 * slot)) & 0xff; }
+// the record of ring r by value (a run-time index into the pair of records would put them into scratch memory)
+SZ_HD Bounds ring_of(const Bounds *g, int r) {
+  Bounds b;
+  b.n = r ? g[1].n : g[0].n; b.bot = r ? g[1].bot : g[0].bot; b.top = r ? g[1].top : g[0].top;
+  b.dirl = r ? g[1].dirl : g[0].dirl; b.ptop = r ? g[1].ptop : g[0].ptop;
+  return b;
+}
 
 // S->fx / fy [r][0 .. n_r) hold the rings (a closing duplicate may follow the stored vertices), visible to the team.
-// ST_OK: *out_n vertices in ox / oy (0 = no overlap); ST_BAIL: not the plain case.  Every lane returns the same.
+// ST_OK: *out_n vertices in ox / oy (0 = no overlap); ST_BAIL: not the plain case -- or more vertices in the two rings
+// together than the team has lanes (one scanline per lane).  Every lane returns the same.
 template <int G>
 SZ_TEAM int team_clip(const Team<G> &T, ClipScratch *S, int na, int nb, i64 *ox, i64 *oy, int *out_n) {
-  enum { IT = T_EV / G };
+  SZTM_PHASE(10);
   *out_n = 0;
   Bounds g[2];
   // ---- closing duplicates (clipper.cpp:1055-1058), uniform over the team ----
+#pragma unroll
   for (int r = 0; r < 2; ++r) {
     int hi = (r ? nb : na) - 1;
     if (hi + 1 > (int)T_NV) SZTM_BAIL(2);
@@ -97,48 +109,45 @@ SZ_TEAM int team_clip(const Team<G> &T, ClipScratch *S, int na, int nb, i64 *ox,
     if (hi < 2) SZTM_BAIL(1);
     g[r].n = hi + 1;
   }
-  // ---- every vertex: kept by the general code? local minimum / maximum? slope of its edge ----
-  bool v_valid[IT];
-  int v_r[IT], v_l[IT];
-  i64 v_y[IT];
+  const int n0 = g[0].n, M = g[0].n + g[1].n;
+  if (M > G) { if (T.lane == 0) { SZTM_BAIL_PROBE(43); } return (int)ST_WIDE; }   // (the caller sends such a pair to a wider team)
+  SZTM_PHASE(11);
+  // ---- every vertex (lanes 0 .. n0-1: ring 0, the next n1: ring 1): kept by the general code? local minimum /
+  // maximum? slope of its edge ----
+  const int v_r = (T.lane >= n0) ? 1 : 0, v_l = T.lane - (v_r ? n0 : 0);
+  const bool v_valid = T.lane < M;
+  i64 v_y = 0;
   {
-    unsigned bad = 0, mins[2] = {0, 0}, maxs[2] = {0, 0};
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      const int v = T.lane + j * G, r = v >> 4, l = v & 15;
-      const int n = g[r].n;
-      const bool valid = l < n;
-      v_valid[j] = valid; v_r[j] = r; v_l[j] = l; v_y[j] = 0;
-      int why = 0;
-      bool is_min = false, is_max = false;
-      if (valid) {
-        const int lp = (l == 0) ? n - 1 : l - 1, ln = (l + 1 == n) ? 0 : l + 1;
-        Pt c, p, q;
-        c.x = S->fx[r][l]; c.y = S->fy[r][l]; p.x = S->fx[r][lp]; p.y = S->fy[r][lp]; q.x = S->fx[r][ln]; q.y = S->fy[r][ln];
-        v_y[j] = c.y;
-        const i64 lim = 0x3FFFFFFFFFFFFFFFLL;
-        if (c.x > lim || c.y > lim || -c.x > lim || -c.y > lim) why = 3;
-        else if (same(c, q) || collinear3_filtered(p, c, q)) why = 4;
-        else if (c.y == q.y) why = 5;
-        else {
-          S->slope[r][l] = (double)(q.x - c.x) / (double)(q.y - c.y);
-          is_min = c.y > p.y && c.y > q.y;
-          is_max = c.y < p.y && c.y < q.y;
-        }
+    int why = 0;
+    bool is_min = false, is_max = false;
+    if (v_valid) {
+      const int n = v_r ? g[1].n : g[0].n, l = v_l;
+      const int lp = (l == 0) ? n - 1 : l - 1, ln = (l + 1 == n) ? 0 : l + 1;
+      Pt c, p, q;
+      c.x = S->fx[v_r][l]; c.y = S->fy[v_r][l]; p.x = S->fx[v_r][lp]; p.y = S->fy[v_r][lp]; q.x = S->fx[v_r][ln]; q.y = S->fy[v_r][ln];
+      v_y = c.y;
+      const i64 lim = 0x3FFFFFFFFFFFFFFFLL;
+      if (c.x > lim || c.y > lim || -c.x > lim || -c.y > lim) why = 3;
+      else if (same(c, q) || collinear3_filtered(p, c, q)) why = 4;
+      else if (c.y == q.y) why = 5;
+      else {
+        S->slope[v_r][l] = (double)(q.x - c.x) / (double)(q.y - c.y);
+        is_min = c.y > p.y && c.y > q.y;
+        is_max = c.y < p.y && c.y < q.y;
       }
-      // (IT == 1: ring = lane >> 4, the ballots hold both rings side by side; IT == 2: iteration j is ring j)
-      const unsigned bm = T.ballot(why != 0, TEAM_SITE + j), mn = T.ballot(is_min, TEAM_SITE + j), mx = T.ballot(is_max, TEAM_SITE + j);
-      bad |= bm;
-      if (IT == 1) { mins[0] = mn & 0xffffu; mins[1] = mn >> 16; maxs[0] = mx & 0xffffu; maxs[1] = mx >> 16; }
-      else { mins[j & 1] = mn; maxs[j & 1] = mx; }
     }
+    const unsigned bad = T.ballot(why != 0, TEAM_SITE), mn = T.ballot(is_min, TEAM_SITE), mx = T.ballot(is_max, TEAM_SITE);
     if (bad) SZTM_BAIL(34);
+    const unsigned lo = (1u << n0) - 1u;
+    const unsigned mins[2] = {mn & lo, mn >> n0}, maxs[2] = {mx & lo, mx >> n0};
+#pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (__builtin_popcount(mins[r]) != 1 || __builtin_popcount(maxs[r]) != 1) SZTM_BAIL(36);
       g[r].bot = __builtin_ctz(mins[r]); g[r].top = __builtin_ctz(maxs[r]);
     }
   }
   T.sync(TEAM_SITE);
+#pragma unroll
   for (int r = 0; r < 2; ++r) {
     // the left bound starts with the edge of larger slope (clipper.cpp:1194-1204)
     const int n = g[r].n, bot = g[r].bot;
@@ -149,152 +158,133 @@ SZ_TEAM int team_clip(const Team<G> &T, ClipScratch *S, int na, int nb, i64 *ox,
     if (pt < 0) pt += n;
     g[r].ptop = pt;
   }
-  const int M = g[0].n + g[1].n;
+  SZTM_PHASE(12);
   // ---- sweep order: rank of every vertex by descending y; which bounds it lies on ----
   {
-    int rank[IT], ties[IT];
+    int rank = 0, ties = 0;
 #pragma unroll
-    for (int j = 0; j < IT; ++j) { rank[j] = 0; ties[j] = 0; }
     for (int r = 0; r < 2; ++r)
       for (int k = 0; k < g[r].n; ++k) {
         const i64 y = S->fy[r][k];
-#pragma unroll
-        for (int j = 0; j < IT; ++j) { rank[j] += (y > v_y[j]) ? 1 : 0; ties[j] += (y == v_y[j]) ? 1 : 0; }
+        rank += (y > v_y) ? 1 : 0; ties += (y == v_y) ? 1 : 0;
       }
-    bool tie = false;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) tie = tie || (v_valid[j] && ties[j] != 1);
-    if (T.any(tie, TEAM_SITE)) SZTM_BAIL(40);                 // two vertices on one scanline
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      if (!v_valid[j]) continue;
-      const int r = v_r[j], l = v_l[j], n = g[r].n;
-      int pl = (g[r].dirl > 0) ? l - g[r].bot : g[r].bot - l;   // position along the left bound
-      if (pl < 0) pl += n;
-      const bool onL = pl <= g[r].ptop, onR = pl >= g[r].ptop || pl == 0;
-      S->ev[rank[j]] = (unsigned char)(r << 4 | l);
-      S->pc[rank[j]] = (onL ? 1 << (8 * (r * 2)) : 0) | (onR ? 1 << (8 * (r * 2 + 1)) : 0);
-      if (l == g[r].bot) S->rank_bot[r] = rank[j];
-      if (l == g[r].top) S->rank_top[r] = rank[j];
+    if (T.any(v_valid && ties != 1, TEAM_SITE)) SZTM_BAIL(40);   // two vertices on one scanline
+    if (v_valid) {
+      const Bounds gr = ring_of(g, v_r);
+      int pl = (gr.dirl > 0) ? v_l - gr.bot : gr.bot - v_l;      // position along the left bound
+      if (pl < 0) pl += gr.n;
+      const bool onL = pl <= gr.ptop, onR = pl >= gr.ptop || pl == 0;
+      S->ev[rank] = (unsigned char)(v_r << 4 | v_l);
+      S->pc[rank] = (onL ? 1 << (8 * (v_r * 2)) : 0) | (onR ? 1 << (8 * (v_r * 2 + 1)) : 0);
+      if (v_l == gr.bot) S->rank_bot[v_r] = rank;
+      if (v_l == gr.top) S->rank_top[v_r] = rank;
     }
   }
   T.sync(TEAM_SITE);
-  // ---- bound vertices above every scanline: exclusive prefix sum of the packed flags in sweep order ----
+  SZTM_PHASE(13);
+  // ---- lane s takes scanline s.  Bound vertices above it: exclusive prefix sum of the packed flags in sweep order ----
+  const int s = T.lane;
+  int pcs;
   {
-    int mine[IT], carry = 0;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      const int s = j * G + T.lane;
-      mine[j] = (s < M) ? S->pc[s] : 0;
-      int tot;
-      const int ex = T.scan_excl(mine[j], &tot, TEAM_SITE + 1000 * j);
-      if (s < M) S->pc[s] = ex + carry;
-      carry += tot;
-    }
+    int tot;
+    pcs = T.scan_excl((s < M) ? S->pc[s] : 0, &tot, TEAM_SITE);
+    if (s < M) S->pc[s] = pcs;                                // (the lanes that compute the crossing points read it)
   }
   T.sync(TEAM_SITE);
   const int s_ins = S->rank_bot[0] > S->rank_bot[1] ? S->rank_bot[0] : S->rank_bot[1];   // the upper ring's local minimum
   const int s_end = S->rank_top[0] < S->rank_top[1] ? S->rank_top[0] : S->rank_top[1];   // the first local maximum
   if (s_end < s_ins) return szv::ST_OK;                       // the y-ranges are disjoint: no overlap
+  SZTM_PHASE(14);
   // ---- every scanline in the common range: active edges below it, their order below and at it, the crossings ----
   // st: bits 0-7 order below (slot at position p in bits 2p, 2p+1), 8-11 crossed (combo = a * 2 + b), 12-15 ring 0's
   // edge is the left one below, 16 the ring inserted here starts the output ring, 17 the scanline is in range
-  int st[IT], xbase[IT];
+  int st = 0;
+  const bool in_range = s < M && s >= s_ins && s <= s_end;
+  const int evs = S->ev[s & (T_EV - 1)], e_r = evs >> 4, e_l = evs & 15;
   {
     int why = 0;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      const int s = j * G + T.lane;
-      st[j] = 0;
-      if (!(s < M && s >= s_ins && s <= s_end)) continue;
-      st[j] = 1 << 17;
-      const int evs = S->ev[s], r = evs >> 4, l = evs & 15, pcs = S->pc[s];
-      const i64 ys = S->fy[r][l];
+    if (in_range) {
+      st = 1 << 17;
+      const i64 ys = S->fy[e_r][e_l];
       if (s == s_ins) {
         // insertion of ring r's local minimum between the two edges of the other ring (clipper.cpp:1978-2077)
-        const int ro = 1 - r;
+        const int ro = 1 - e_r;
+        const Bounds go = ring_of(g, ro);
         szx::CEdge e0, e1;
-        if (!active_edge(S, g[ro], ro, 0, pc_field(pcs, ro * 2), e0) || !active_edge(S, g[ro], ro, 1, pc_field(pcs, ro * 2 + 1), e1)) { why = 50; continue; }
-        const i64 x0 = szx::cx_at(e0, ys), x1 = szx::cx_at(e1, ys), bx = S->fx[r][l];
-        if (x0 > x1) { why = 51; continue; }
-        if (bx == x0 || bx == x1) { why = 19; continue; }      // a tie: vertex on an edge or coincident vertices
-        if (x0 < bx && bx < x1) st[j] |= 1 << 16;              // inside the other ring -> contributing -> AddLocalMinPoly
-        continue;
-      }
-      const int evp = S->ev[s - 1];
-      const i64 yp = S->fy[evp >> 4][evp & 15];
-      i64 xb[4], xt[4];
-      bool startsb[4], endst[4];
-      bool ok = true;
+        if (!active_edge(S, go, ro, 0, pc_field(pcs, ro * 2), e0) || !active_edge(S, go, ro, 1, pc_field(pcs, ro * 2 + 1), e1)) why = 50;
+        else {
+          const i64 x0 = szx::cx_at(e0, ys), x1 = szx::cx_at(e1, ys), bx = S->fx[e_r][e_l];
+          if (x0 > x1) why = 51;
+          else if (bx == x0 || bx == x1) why = 19;            // a tie: vertex on an edge or coincident vertices
+          else if (x0 < bx && bx < x1) st |= 1 << 16;         // inside the other ring -> contributing -> AddLocalMinPoly
+        }
+      } else {
+        const int evp = S->ev[(s - 1) & (T_EV - 1)];
+        const i64 yp = S->fy[evp >> 4][evp & 15];
+        i64 xb[4], xt[4];
+        bool startsb[4], endst[4];
+        bool ok = true;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        szx::CEdge e;
-        if (!active_edge(S, g[k >> 1], k >> 1, k & 1, pc_field(pcs, k), e)) { ok = false; xb[k] = xt[k] = 0; startsb[k] = endst[k] = false; continue; }
-        xb[k] = e.bot.x + szv::rnd(e.slope * (double)(yp - e.bot.y));
-        xt[k] = szx::cx_at(e, ys);
-        startsb[k] = (e.bot.y == yp); endst[k] = (e.top.y == ys);
-      }
-      if (!ok) { why = 52; continue; }
-      // the two bounds of one ring do not cross; they meet only at the ring's own bottom / top vertex
-      for (int q = 0; q < 2; ++q) {
-        const int L = 2 * q, R = 2 * q + 1;
-        if (xb[L] > xb[R] || xt[L] > xt[R]) why = 7;
-        if (xb[L] == xb[R] && !(startsb[L] && startsb[R])) why = 53;
-        if (xt[L] == xt[R] && !(endst[L] && endst[R])) why = 53;
-      }
-      int crossed = 0, left0 = 0;
+        for (int k = 0; k < 4; ++k) {
+          szx::CEdge e;
+          if (!active_edge(S, g[k >> 1], k >> 1, k & 1, pc_field(pcs, k), e)) { ok = false; xb[k] = xt[k] = 0; startsb[k] = endst[k] = false; continue; }
+          xb[k] = e.bot.x + szv::rnd(e.slope * (double)(yp - e.bot.y));
+          xt[k] = szx::cx_at(e, ys);
+          startsb[k] = (e.bot.y == yp); endst[k] = (e.top.y == ys);
+        }
+        if (!ok) why = 52;
+        // the two bounds of one ring do not cross; they meet only at the ring's own bottom / top vertex
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int a = c >> 1, b = 2 + (c & 1);
-        if (xb[a] == xb[b] || xt[a] == xt[b]) why = 10;        // a tie between the two rings
-        const bool lb = xb[a] < xb[b], lt = xt[a] < xt[b];
-        if (lb != lt) crossed |= 1 << c;
-        if (lb) left0 |= 1 << c;
-      }
-      if (why) continue;
-      int order = 0;
+        for (int q = 0; q < 2; ++q) {
+          const int L = 2 * q, R = 2 * q + 1;
+          if (xb[L] > xb[R] || xt[L] > xt[R]) why = 7;
+          if (xb[L] == xb[R] && !(startsb[L] && startsb[R])) why = 53;
+          if (xt[L] == xt[R] && !(endst[L] && endst[R])) why = 53;
+        }
+        int crossed = 0, left0 = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        int pos = 0;
+        for (int c = 0; c < 4; ++c) {
+          const int a = c >> 1, b = 2 + (c & 1);
+          if (xb[a] == xb[b] || xt[a] == xt[b]) why = 10;      // a tie between the two rings
+          const bool lb = xb[a] < xb[b], lt = xt[a] < xt[b];
+          if (lb != lt) crossed |= 1 << c;
+          if (lb) left0 |= 1 << c;
+        }
+        int order = 0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) pos += (xb[m] < xb[k] || (xb[m] == xb[k] && m < k)) ? 1 : 0;
-        order |= k << (2 * pos);
+        for (int k = 0; k < 4; ++k) {
+          int pos = 0;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) pos += (xb[m] < xb[k] || (xb[m] == xb[k] && m < k)) ? 1 : 0;
+          order |= k << (2 * pos);
+        }
+        st |= order | crossed << 8 | left0 << 12;
       }
-      st[j] |= order | crossed << 8 | left0 << 12;
     }
     const unsigned bad = T.ballot(why != 0, TEAM_SITE);
     if (bad) { const int w = T.shfl(why, __builtin_ctz(bad), TEAM_SITE); SZTM_BAIL(w); }
   }
+  SZTM_PHASE(15);
   // ---- the crossings of all beams, one lane each (clipper.cpp:622-689, :2868-2876) ----
-  int nX;
+  int nX, xbase;
   {
-    int cnts = 0;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) cnts |= __builtin_popcount((st[j] >> 8) & 15) << (8 * j);
-    int tot;
-    int ex = T.scan_excl(cnts, &tot, TEAM_SITE);
-    nX = 0;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) { xbase[j] = nX + ((ex >> (8 * j)) & 0xff); nX += (tot >> (8 * j)) & 0xff; }
+    const int crossed = (st >> 8) & 15;
+    xbase = T.scan_excl(__builtin_popcount(crossed), &nX, TEAM_SITE);
     if (nX > (int)T_CAPX) SZTM_BAIL(9);
+    int k = xbase;
 #pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      const int crossed = (st[j] >> 8) & 15;
-      int k = xbase[j];
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (crossed >> c & 1) { S->xinfo[k] = (j * G + T.lane) | c << 8 | ((st[j] >> (12 + c)) & 1) << 10; ++k; }
-    }
+    for (int c = 0; c < 4; ++c)
+      if (crossed >> c & 1) { S->xinfo[k & (T_CAPX - 1)] = s | c << 8 | ((st >> (12 + c)) & 1) << 10; ++k; }
   }
   if (nX > 0) {
     T.sync(TEAM_SITE);
-    for (int k = T.lane; k < nX; k += G) {
-      const int info = S->xinfo[k], s = info & 0xff, c = (info >> 8) & 3;
-      const int evs = S->ev[s], evp = S->ev[s - 1], pcs = S->pc[s];
-      const i64 ys = S->fy[evs >> 4][evs & 15], yp = S->fy[evp >> 4][evp & 15];
+    if (T.lane < nX) {
+      const int k = T.lane, info = S->xinfo[k], xs = info & 0xff, c = (info >> 8) & 3;
+      const int ev1 = S->ev[xs], ev0 = S->ev[xs - 1], pcx = S->pc[xs];
+      const i64 ys = S->fy[ev1 >> 4][ev1 & 15], yp = S->fy[ev0 >> 4][ev0 & 15];
       szx::CEdge ea, eb;
-      (void)active_edge(S, g[0], 0, c >> 1, pc_field(pcs, c >> 1), ea);
-      (void)active_edge(S, g[1], 1, c & 1, pc_field(pcs, 2 + (c & 1)), eb);
+      (void)active_edge(S, g[0], 0, c >> 1, pc_field(pcx, c >> 1), ea);
+      (void)active_edge(S, g[1], 1, c & 1, pc_field(pcx, 2 + (c & 1)), eb);
       const bool a_left = (info >> 10) & 1;
       const szx::CEdge e1 = a_left ? ea : eb, e2 = a_left ? eb : ea;
       int extra = 0;
@@ -310,25 +300,19 @@ SZ_TEAM int team_clip(const Team<G> &T, ClipScratch *S, int na, int nb, i64 *ox,
     }
     T.sync(TEAM_SITE);
   }
+  SZTM_PHASE(16);
   // ---- what every scanline emits: the crossings of its beam in the order of their y, then its vertex ----
   // One byte per emission, in order: bits 0-3 the crossing (index into xpt), 4-5 the side (0: front of the output ring =
   // its left side, 1: back, 2: the point the ring starts with), 6 it closes the ring, 7 it is the scanline's vertex.
-  unsigned long long em[IT];
-  int em_n[IT];
+  unsigned long long em = 0;
+  int em_n = 0;
   {
     int why = 0;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      em[j] = 0; em_n[j] = 0;
-      if (!(st[j] >> 17 & 1)) continue;
-      const int s = j * G + T.lane;
-      const int evs = S->ev[s], r = evs >> 4, l = evs & 15;
-      if (s == s_ins) {
-        if (st[j] >> 16 & 1) { em[j] = 0x80 | 2 << 4; em_n[j] = 1; }
-        continue;
-      }
-      int order = st[j] & 0xff;
-      const int crossed = (st[j] >> 8) & 15, nc = __builtin_popcount(crossed);
+    if (in_range && s == s_ins) {
+      if (st >> 16 & 1) { em = 0x80 | 2 << 4; em_n = 1; }
+    } else if (in_range) {
+      int order = st & 0xff;
+      const int crossed = (st >> 8) & 15, nc = __builtin_popcount(crossed);
       // contributing: an odd number of the other ring's edges to the left (position p in `order`)
       auto contributes = [&](int p) SZX_INLINE {
         const int me = (order >> (2 * p)) & 3;
@@ -349,133 +333,115 @@ SZ_TEAM int team_clip(const Team<G> &T, ClipScratch *S, int na, int nb, i64 *ox,
         int ks[4]; i64 ky[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          ks[i] = (i < nc) ? xbase[j] + i : -1;
-          ky[i] = (i < nc) ? S->xpt[(xbase[j] + i) & (T_CAPX - 1)].y : (i64)0x8000000000000000ULL;
+          ks[i] = (i < nc) ? xbase + i : -1;
+          ky[i] = (i < nc) ? S->xpt[(xbase + i) & (T_CAPX - 1)].y : (i64)0x8000000000000000ULL;
         }
 #define SZTM_CSWAP(a, b) { if (ky[b] > ky[a]) { const i64 ty = ky[a]; ky[a] = ky[b]; ky[b] = ty; const int tk = ks[a]; ks[a] = ks[b]; ks[b] = tk; } }
         if (nc > 1) { SZTM_CSWAP(0, 1) SZTM_CSWAP(2, 3) SZTM_CSWAP(0, 2) SZTM_CSWAP(1, 3) SZTM_CSWAP(1, 2) }
 #undef SZTM_CSWAP
 #pragma unroll
         for (int i = 0; i < 3; ++i) if (i + 1 < nc && ky[i] == ky[i + 1]) why = 41;
+        for (int i = 0; i < nc && !why; ++i) {
+          int k = ks[0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i >= nc || why) continue;
-          const int k = ks[i], info = S->xinfo[k & (T_CAPX - 1)], c = (info >> 8) & 3;
-          if (info >> 12 & 1) { why = 8; continue; }
+          for (int q = 1; q < 4; ++q) if (q == i) k = ks[q];
+          const int info = S->xinfo[k & (T_CAPX - 1)], c = (info >> 8) & 3;
+          if (info >> 12 & 1) { why = 8; break; }
           const int sa = c >> 1, sb = 2 + (c & 1);
           const bool a_left = (info >> 10) & 1;
           const int e1 = a_left ? sa : sb, e2 = a_left ? sb : sa;
           const int p1 = pos_of(e1), p2 = pos_of(e2);
-          if (p2 != p1 + 1) { why = 11; continue; }            // the general code would reorder: leave it to it
+          if (p2 != p1 + 1) { why = 11; break; }               // the general code would reorder: leave it to it
           const bool c1 = contributes(p1), c2 = contributes(p2);
           int rec = k;
           if (c1 && c2) {                                      // AddLocalMaxPoly: the ring closes here
-            if ((e1 & 1) != 0 || (e2 & 1) != 1) { why = 54; continue; }
+            if ((e1 & 1) != 0 || (e2 & 1) != 1) { why = 54; break; }
             rec |= (e1 & 1) << 4 | 1 << 6;
           } else if (c1 || c2) {                               // the contributing edge emits and hands its side over
-            if ((e1 & 1) != (e2 & 1)) { why = 55; continue; }
+            if ((e1 & 1) != (e2 & 1)) { why = 55; break; }
             rec |= (e1 & 1) << 4;
           } else {                                             // AddLocalMinPoly: the ring starts at a crossing
-            if (!(info >> 11 & 1)) { why = 13; continue; }     // e1 crosses from left to right: its slope is the smaller
-            if ((e1 & 1) != 1 || (e2 & 1) != 0) { why = 56; continue; }
+            if (!(info >> 11 & 1)) { why = 13; break; }        // e1 crosses from left to right: its slope is the smaller
+            if ((e1 & 1) != 1 || (e2 & 1) != 0) { why = 56; break; }
             rec |= 2 << 4;
           }
-          em[j] |= (unsigned long long)rec << (8 * em_n[j]);
-          ++em_n[j];
+          em |= (unsigned long long)rec << (8 * em_n);
+          ++em_n;
           order = (order & ~(15 << (2 * p1))) | e2 << (2 * p1) | e1 << (2 * p2);
         }
-        if (why) continue;
       }
-      // the vertex on this scanline (clipper.cpp:3009-3113): the top of its ring, or an intermediate vertex of a bound
-      if (l == g[r].top) {
-        const int pa = pos_of(r * 2), pb = pos_of(r * 2 + 1);
-        if (pb != pa + 1) { why = 14; continue; }
-        if (contributes(pa)) { em[j] |= (unsigned long long)(0x80 | 1 << 6) << (8 * em_n[j]); ++em_n[j]; }
-      } else {
-        int pl = (g[r].dirl > 0) ? l - g[r].bot : g[r].bot - l;
-        if (pl < 0) pl += g[r].n;
-        const int bnd = (pl < g[r].ptop) ? 0 : 1;
-        if (contributes(pos_of(r * 2 + bnd))) { em[j] |= (unsigned long long)(0x80 | bnd << 4) << (8 * em_n[j]); ++em_n[j]; }
+      if (!why) {
+        // the vertex on this scanline (clipper.cpp:3009-3113): the top of its ring, or an intermediate vertex of a bound
+        const Bounds gr = ring_of(g, e_r);
+        if (e_l == gr.top) {
+          const int pa = pos_of(e_r * 2), pb = pos_of(e_r * 2 + 1);
+          if (pb != pa + 1) why = 14;
+          else if (contributes(pa)) { em |= (unsigned long long)(0x80 | 1 << 6) << (8 * em_n); ++em_n; }
+        } else {
+          int pl = (gr.dirl > 0) ? e_l - gr.bot : gr.bot - e_l;
+          if (pl < 0) pl += gr.n;
+          const int bnd = (pl < gr.ptop) ? 0 : 1;
+          if (contributes(pos_of(e_r * 2 + bnd))) { em |= (unsigned long long)(0x80 | bnd << 4) << (8 * em_n); ++em_n; }
+        }
       }
     }
     const unsigned bad = T.ballot(why != 0, TEAM_SITE);
     if (bad) { const int w = T.shfl(why, __builtin_ctz(bad), TEAM_SITE); SZTM_BAIL(w); }
   }
+  SZTM_PHASE(17);
   // ---- where the points go: front insertions before the start point in reverse order, back insertions after it ----
   int NF, NB;
   {
-    // packed per lane: front / back emissions of iteration j in bytes 2j / 2j + 1 (j < 2); starts, closes, all in a second word
-    int cnts = 0, flags = 0;
+    // packed per lane: front emissions, back emissions, starts, closes in a byte each
+    int cnts = 0;
 #pragma unroll
-    for (int j = 0; j < IT; ++j)
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        if (i >= em_n[j]) continue;
-        const int rec = (int)(em[j] >> (8 * i)) & 0xff, sd = (rec >> 4) & 3;
-        if (sd == 0) cnts += 1 << (16 * j); else if (sd == 1) cnts += 1 << (16 * j + 8); else flags += 1;
-        if (rec >> 6 & 1) flags += 1 << 8;
-        flags += 1 << 16;
-      }
+    for (int i = 0; i < 5; ++i) {
+      if (i >= em_n) continue;
+      const int rec = (int)(em >> (8 * i)) & 0xff, sd = (rec >> 4) & 3;
+      cnts += (sd == 0) ? 1 : (sd == 1) ? 1 << 8 : 1 << 16;
+      if (rec >> 6 & 1) cnts += 1 << 24;
+    }
     int tot;
     const int ex = T.scan_excl(cnts, &tot, TEAM_SITE);
-    const int ftot = T.sum_all(flags, TEAM_SITE);
-    const int nstart = ftot & 0xff, nclose = (ftot >> 8) & 0xff, nall = ftot >> 16;
-    if (nall == 0) return szv::ST_OK;                          // nothing contributes: no overlap
+    NF = tot & 0xff; NB = (tot >> 8) & 0xff;
+    const int nstart = (tot >> 16) & 0xff, nclose = (tot >> 24) & 0xff;
+    if (NF + NB + nstart == 0) return szv::ST_OK;              // nothing contributes: no overlap
     if (nstart != 1) SZTM_BAIL(12);                            // no start point, or a second output ring
     if (nclose != 1) SZTM_BAIL(21);
-    int f0[IT], b0[IT];
-    NF = 0; NB = 0;
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      f0[j] = NF + ((ex >> (16 * j)) & 0xff); b0[j] = NB + ((ex >> (16 * j + 8)) & 0xff);
-      NF += (tot >> (16 * j)) & 0xff; NB += (tot >> (16 * j + 8)) & 0xff;
-    }
     const int cnt = NF + 1 + NB;
     if (cnt > (int)T_CAPV) SZTM_BAIL(20);
     // the ring is open from its start point to the point that closes it: nothing is emitted outside (AddOutPt on a
-    // closed ring would be an error of the general code, clipper.cpp:1890)
-#pragma unroll
-    for (int j = 0; j < IT; ++j)
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        if (i >= em_n[j]) continue;
-        const int rec = (int)(em[j] >> (8 * i)) & 0xff, key = (j * G + T.lane) * 8 + i;
-        if (((rec >> 4) & 3) == 2) S->key_start = key;
-        if (rec >> 6 & 1) S->key_close = key;
-      }
-    T.sync(TEAM_SITE);
-    const int ks = S->key_start, kc = S->key_close;
+    // closed ring would be an error of the general code, clipper.cpp:1890).  In sweep order: the start point comes
+    // before every emission (none before it in the prefix), the closing point after every other one.
+    const int f0 = ex & 0xff, b0 = (ex >> 8) & 0xff, starts_before = (ex >> 16) & 0xff, closes_before = (ex >> 24) & 0xff;
     bool outside = false;
+    int nf = 0, nb2 = 0, seen_start = starts_before, seen_close = closes_before;
 #pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      int nf = 0, nb2 = 0;
-      const int s = j * G + T.lane;
-      const int evs = S->ev[s & (T_EV - 1)];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        if (i >= em_n[j]) continue;
-        const int rec = (int)(em[j] >> (8 * i)) & 0xff, key = s * 8 + i, sd = (rec >> 4) & 3;
-        int at;
-        if (sd == 2) at = NF;
-        else {
-          if (key < ks || key > kc) outside = true;
-          if (sd == 0) { at = NF - 1 - (f0[j] + nf); ++nf; } else { at = NF + 1 + b0[j] + nb2; ++nb2; }
-        }
-        Pt pt;
-        if (rec & 0x80) { pt.x = S->fx[evs >> 4][evs & 15]; pt.y = S->fy[evs >> 4][evs & 15]; }
-        else pt = S->xpt[rec & 15];
-        if (at >= 0 && at < (int)T_CAPV) { ox[at] = pt.x; oy[at] = pt.y; }
+    for (int i = 0; i < 5; ++i) {
+      if (i >= em_n) continue;
+      const int rec = (int)(em >> (8 * i)) & 0xff, sd = (rec >> 4) & 3;
+      int at;
+      if (sd == 2) { at = NF; if (f0 + nf + b0 + nb2 != 0 || seen_close) outside = true; seen_start = 1; }
+      else {
+        if (!seen_start || seen_close) outside = true;
+        if (sd == 0) { at = NF - 1 - (f0 + nf); ++nf; } else { at = NF + 1 + b0 + nb2; ++nb2; }
       }
+      if (rec >> 6 & 1) seen_close = 1;
+      Pt pt;
+      if (rec & 0x80) { pt.x = S->fx[e_r][e_l]; pt.y = S->fy[e_r][e_l]; }
+      else pt = S->xpt[rec & (T_CAPX - 1)];
+      if (at >= 0 && at < (int)T_CAPV) { ox[at] = pt.x; oy[at] = pt.y; }
     }
     if (T.any(outside, TEAM_SITE)) SZTM_BAIL(57);
   }
   T.sync(TEAM_SITE);
+  SZTM_PHASE(18);
   // ---- the finished ring: FixupOutPolygon would drop duplicate / collinear points (left to the general code), the
   // orientation from Area(outRec) in the order of the list (clipper.cpp:405-416), BuildResult from pts.prev backwards ----
   const int cnt = NF + 1 + NB;
   if (cnt < 3) SZTM_BAIL(22);
-  double *terms = (double *)&S->xpt[0];      // (the crossing points are in the ring by now)
-  static_assert(sizeof(((ClipScratch *)0)->xpt) >= 8 * T_CAPV, "the area terms borrow the crossing points' room");
+  double *terms = (double *)&S->fx[0][0];    // (the rings' vertices are in the output ring by now)
+  static_assert(sizeof(((ClipScratch *)0)->fx) >= 8 * T_CAPV, "the area terms borrow the rings' room");
   {
     bool bad = false;
     for (int i = T.lane; i < cnt; i += G) {
@@ -505,6 +471,7 @@ SZ_TEAM int team_clip(const Team<G> &T, ClipScratch *S, int na, int nb, i64 *ox,
     for (int q = 0; q < Q; ++q) { const int i = T.lane + q * G; if (i < cnt) { ox[i] = mv[q].x; oy[i] = mv[q].y; } }
   }
   T.sync(TEAM_SITE);
+  SZTM_PHASE(19);
   *out_n = cnt;
   return szv::ST_OK;
 }

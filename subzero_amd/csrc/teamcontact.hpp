@@ -23,14 +23,18 @@ using szc::maxd;
 using szc::mind;
 using szc::hyp;
 
-enum { T_CAPP = 16, T_CAPR = 32 };   // crossings kept (sorted set) / segment pairs that reach the second test
+enum { T_CAPP = 8, T_CAPR = 16 };   // crossings kept (sorted set) / segment pairs that reach the second test
+enum { ST_DEFER_WIDE = 103 };        // "redo this pair with a wider team": the two rings have more vertices than the team has lanes
+enum { BODY_X = 0, BODY_Y, BODY_UI, BODY_VI, BODY_KSI, BODY_H, BODY_AREA, BODY_WORDS = 8 };   // (the order of step_core.hpp's records)
 
 struct TeamBlock {
   double mx[2][T_NV], my[2][T_NV];           // both rings in metres (c_alpha + position)
   union Coord { i64 f; double m; };
   Coord qx[2][T_CAPV], qy[2][T_CAPV];        // the overlap regions of clip 1 / clip 2: fixed point out of the clip, metres afterwards
   double px[T_CAPP], py[T_CAPP];             // InterX crossings: sorted, unique
+  double body[2][BODY_WORDS];                // what floe_interactions.m reads of floe1 / floe2 (contact.hpp Body)
   union {
+    double rec[2][16];                       // the two entries' records as loaded (step_core.hpp narrow_team), until the first clip
     ClipScratch clip;
     double terms[4][T_CAPV];
     struct { double x[T_CAPR], y[T_CAPR]; int key[T_CAPR]; unsigned char dup[T_CAPR]; } raw;
@@ -294,97 +298,84 @@ SZ_HD bool closer_than_1e8_staged(double xp, double yp, const TeamBlock *B, int 
   return szc::dist_to_ring(xp, yp, c) < 1e-8;
 }
 
-// The pair.  Same contract as contact.hpp pair_contact_fast; `rows` (5 doubles per contact row) is written by one lane.
-// Every lane returns the same status and fills `out` the same.
+// what narrow_team has put into the block: both rings in mx / my (sg.n1, sg.n2 vertices: the stored length, one less
+// for a ring stored closed that is one vertex too long for the block -- the closure rule of the model, :62-67, puts the
+// copy back; -1: too long), the bodies in `body`
+struct Staged { int n1, n2, stored1, stored2; bool in_range; };
+// the domain box as the model uses it (step_core.hpp boundary_summary)
+struct BoundaryBox { double xmax, xmin, ymax, ymin, area; bool rect; };
+
+// The pair.  Same contract as contact.hpp pair_contact_fast, on rings already staged (b1, b2: the bounding boxes of
+// everything the rings hold, formed once per floe and step -- step_core.hpp cell_count); row: the contact row
+// [Fx, Fy, Px, Py, overlap] when out.nrows == 1.  Every lane returns the same status, `out` and row.
 template <int G>
-SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const szc::RingD &ring1, const szc::Body &f1, const szc::RingD &ring2,
-                              const szc::Body &f2, bool boundary, const double *c2b, bool periodic, double Modulus, double dt,
-                              double mu, double nu, double *rows, int cap_rows, szc::PairOut &out) {
+SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, const szc::Box &b1, const szc::Box &b2, bool boundary,
+                              const BoundaryBox &bb, bool periodic, double Modulus, double dt, double mu, double nu, double *row, szc::PairOut &out) {
+  SZTM_PHASE(1);
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
-  // ---- bounding boxes: of everything the rings hold, whatever their length ----
-  szc::Box b1, b2;
-  {
-    double x0 = SZC_INF, x1 = -SZC_INF, y0 = SZC_INF, y1 = -SZC_INF;
-    for (int k = T.lane; k < ring1.n; k += G) { const double X = ring1.X(k), Y = ring1.Y(k); x0 = mind(x0, X); x1 = maxd(x1, X); y0 = mind(y0, Y); y1 = maxd(y1, Y); }
-    b1.x0 = T.min_all(x0, TEAM_SITE); b1.x1 = T.max_all(x1, TEAM_SITE); b1.y0 = T.min_all(y0, TEAM_SITE); b1.y1 = T.max_all(y1, TEAM_SITE);
-  }
   if (boundary) {   // only floes at the walls need the clip against the box (general sweep: the box has horizontal edges)
-    if (ring1.n > 0 && szc::well_inside_box(b1, c2b)) { szc::no_contact(out); return szv::ST_OK; }
+    // (contact.hpp well_inside_box: the floe's box more than 1e-6 m inside an axis-aligned rectangular domain box;
+    // bb.rect also asks the ring to be closed by a copy of its first corner, so that the 4- and 5-corner extents agree)
+    const double gap = 1e-6;
+    if (sg.stored1 > 0 && bb.rect && b1.x0 > bb.xmin + gap && b1.x1 < bb.xmax - gap && b1.y0 > bb.ymin + gap && b1.y1 < bb.ymax - gap) { szc::no_contact(out); return szv::ST_OK; }
     return szc::ST_DEFER;
   }
-  {
-    double x0 = SZC_INF, x1 = -SZC_INF, y0 = SZC_INF, y1 = -SZC_INF;
-    for (int k = T.lane; k < ring2.n; k += G) { const double X = ring2.X(k), Y = ring2.Y(k); x0 = mind(x0, X); x1 = maxd(x1, X); y0 = mind(y0, Y); y1 = maxd(y1, Y); }
-    b2.x0 = T.min_all(x0, TEAM_SITE); b2.x1 = T.max_all(x1, TEAM_SITE); b2.y0 = T.min_all(y0, TEAM_SITE); b2.y1 = T.max_all(y1, TEAM_SITE);
+  const int n1 = sg.n1, n2 = sg.n2;
+  if (n1 < 1 || n2 < 1) {   // too long for the block: the lane-per-pair kernels' business -- unless the boxes are apart
+    if (sg.stored1 > 0 && sg.stored2 > 0 && szc::boxes_apart(b1, b2)) { szc::no_contact(out); return szv::ST_OK; }
+    return (sg.stored1 <= (int)szx::FastBlockBig::NV && sg.stored2 <= (int)szx::FastBlockBig::NV && sg.stored1 >= 1 && sg.stored2 >= 1) ? (int)szc::ST_DEFER_BIG : (int)szc::ST_DEFER;
   }
-  // a ring stored closed that is one vertex too long for the block is staged without the copy when the closure rule
-  // of the model (:62-67) puts it back (contact.hpp pair_contact_fast)
-  int n1 = ring1.n, n2 = ring2.n;
-  if (n1 == (int)T_NV + 1 && ring1.X(n1 - 1) == ring1.X(0) && ring1.Y(n1 - 1) == ring1.Y(0) &&
-      hyp(ring1.X(0) - ring1.X(n1 - 2), ring1.Y(0) - ring1.Y(n1 - 2)) > 1) --n1;
-  if (n2 == (int)T_NV + 1 && ring2.X(n2 - 1) == ring2.X(0) && ring2.Y(n2 - 1) == ring2.Y(0) &&
-      hyp(ring2.X(0) - ring2.X(n2 - 2), ring2.Y(0) - ring2.Y(n2 - 2)) > 1) --n2;
-  if (n1 > (int)T_NV || n2 > (int)T_NV || n1 < 1 || n2 < 1) {
-    if (ring1.n > 0 && ring2.n > 0 && szc::boxes_apart(b1, b2)) { szc::no_contact(out); return szv::ST_OK; }
-    return (n1 <= (int)szx::FastBlockBig::NV && n2 <= (int)szx::FastBlockBig::NV && n1 >= 1 && n2 >= 1) ? (int)szc::ST_DEFER_BIG : (int)szc::ST_DEFER;
-  }
-  // (the staged rings leave the closing copy out: the boxes above include it, it is a copy of vertex 0)
-  const double safe = SZX_FIXED_SAFE_METRES - 2;
-  bool in_range = true;
-  for (int k = T.lane; k < n1; k += G) { const double X = ring1.X(k), Y = ring1.Y(k); in_range = in_range && absd(X) < safe && absd(Y) < safe; B->mx[0][k] = X; B->my[0][k] = Y; }
-  for (int k = T.lane; k < n2; k += G) { const double X = ring2.X(k), Y = ring2.Y(k); in_range = in_range && absd(X) < safe && absd(Y) < safe; B->mx[1][k] = X; B->my[1][k] = Y; }
-  if (T.any(!in_range, TEAM_SITE)) return szc::ST_DEFER;
+  if (!sg.in_range) return szc::ST_DEFER;
   if (szc::boxes_apart(b1, b2)) { szc::no_contact(out); return szv::ST_OK; }
+  if (n1 + n2 - 2 > G) return ST_DEFER_WIDE;   // (even with a closing copy in each ring: more scanlines than lanes)
   T.sync(TEAM_SITE);
-  // ---- first clip (:29) ----
-  int nr = 0;
-  int st = clip_staged(T, B, n1, n2, false, 0.0, 0.0, 0, &nr);
+  SZTM_PHASE(2);
+  // ---- the first clip (:29), the model up to the force direction, the second clip (:140-155): one instance of the
+  // clip in the code, passed through twice (the kernel must stay within the instruction cache) ----
+  int nr = 0, nt = 0, tslot = 0;
+  double Ar = 0, cx = 0, cy = 0, fdx = 0, fdy = 0, dl = 0, pcx = 0, pcy = 0, Force_factor = 0;
+  const double Gm = Modulus / (2 * (1 + nu));
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+  int nout = 0;
+  const int st = clip_staged(T, B, n1, n2, pass == 1, fdx, fdy, pass, &nout);
+  if (st == ST_WIDE) return ST_DEFER_WIDE;
   if (st == szx::ST_BAIL) return szc::ST_DEFER;
   if (st != szv::ST_OK) return st;
+  if (pass == 1) { nt = nout; tslot = 1; break; }
+  nr = nout;
   const int nreg = nr > 0 ? 1 : 0;
   const RegionM R = {B->qx[0], B->qy[0], nr};
+  SZTM_PHASE(3);
   // ---- pair_finish ----
-  double h1 = f1.h, h2 = f2.h;                                                            // :10-21
-  double r1 = ::sqrt(f1.area), r2 = ::sqrt(f2.area);
-  double Force_factor = Modulus * (h1 * h2) / (h1 * r2 + h2 * r1);
+  const double area1 = B->body[0][BODY_AREA], area2 = B->body[1][BODY_AREA];
+  double h1 = B->body[0][BODY_H], h2 = B->body[1][BODY_H];                                // :10-21
+  double r1 = ::sqrt(area1), r2 = ::sqrt(area2);
+  Force_factor = Modulus * (h1 * h2) / (h1 * r2 + h2 * r1);
   double overlap0 = 0;
   if (r1 > 1e5 || r2 > 1e5) {
     r1 = mind(r1, r2);
     h1 = mind(h1, h2);
     Force_factor = Modulus * h1 / r1;
   }
-  const double Gm = Modulus / (2 * (1 + nu));
-  const double Ar = nreg ? region_area_team(T, B, R) : 0.0;
+  Ar = nreg ? region_area_team(T, B, R) : 0.0;
+  SZTM_PHASE(4);
   {                                                                                       // :54-60
-    double bxmax = c2b[0], bxmin = c2b[0], bymax = c2b[1], bymin = c2b[1];
-    for (int k = 1; k < 5; ++k) {
-      bxmax = maxd(bxmax, c2b[2 * k]); bxmin = mind(bxmin, c2b[2 * k]);
-      bymax = maxd(bymax, c2b[2 * k + 1]); bymin = mind(bymin, c2b[2 * k + 1]);
-    }
-    double barea;
-    {
-      double s = 0;
-      for (int i = 0; i < 4; ++i) {
-        const int k = (i + 1 == 4) ? 0 : i + 1;
-        const double ax = c2b[2 * i] - c2b[0], ay = c2b[2 * i + 1] - c2b[1];
-        const double bx = c2b[2 * k] - c2b[0], by = c2b[2 * k + 1] - c2b[1];
-        s += ax * by - bx * ay;
-      }
-      barea = absd(0.5 * s);
-    }
+    const double bxmax = bb.xmax, bxmin = bb.xmin, bymax = bb.ymax, bymin = bb.ymin, barea = bb.area;
     // (the box of the staged ring: the closing copy left out is a copy of vertex 0)
     const bool inside = (b1.x1 < bxmax && b1.x0 > bxmin && b1.y1 < bymax && b1.y0 > bymin);
-    if (inside || f2.area < 0.95 * barea || periodic) {
+    if (inside || area2 < 0.95 * barea || periodic) {
       double sumAr = 0;
       if (nreg) sumAr += Ar;
-      if (sumAr / f1.area > 0.55) overlap0 = SZC_INF;
-      else if (sumAr / f2.area > 0.55) overlap0 = -SZC_INF;
+      if (sumAr / area1 > 0.55) overlap0 = SZC_INF;
+      else if (sumAr / area2 > 0.55) overlap0 = -SZC_INF;
     }
   }
   // :62-67 close the rings
   const int extra1 = (hyp(B->mx[0][0] - B->mx[0][n1 - 1], B->my[0][0] - B->my[0][n1 - 1]) > 1) ? 1 : 0;
   const int extra2 = (hyp(B->mx[1][0] - B->mx[1][n2 - 1], B->my[1][0] - B->my[1][n2 - 1]) > 1) ? 1 : 0;
   const int np = crossings_team(T, B, n1, extra1, n2, extra2);                             // :70
+  SZTM_PHASE(5);
   if (np < 0) return szc::ST_DEFER;
   if (np < 2 || szc::is_inf(overlap0) || nreg == 0) {                                      // :71-74
     out.has_sentinel = 1;
@@ -394,7 +385,6 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const szc::RingD &
   const int N1 = n1 + extra1 - 1, N2 = n2 + extra2 - 1;                                    // :78-79
   const double Amin = (double)(N1 < N2 ? N1 : N2) * 100 / 1.75;
   if (Ar < Amin) return szv::ST_OK;                                                        // :83
-  double cx, cy;
   region_centroid_team(T, B, R, cx, cy);                                                   // :96-97
   // :98-100 nearest region vertex of each crossing; keep those closer than 1 m (every lane the same loop: the
   // region and the crossings are a handful of values in LDS)
@@ -414,7 +404,7 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const szc::RingD &
       ++m;
     }
   }
-  double fdx = 0, fdy = 0, dl = 0, pcx = cx, pcy = cy;
+  fdx = 0; fdy = 0; dl = 0; pcx = cx; pcy = cy;
   if (Ar == 0) { fdx = fdy = 0; pcx = pcy = 0; dl = 0; }                                   // :103-106
   else if (m == 2) {                                                                       // :107-112
     const double xgh = p1x - p0x, ygh = p1y - p0y;
@@ -450,35 +440,39 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const szc::RingD &
       dl = sb / non;
     } else { fdx = fdy = 0; dl = 0; }
   }
+  SZTM_PHASE(6);
   // :140-155 shift ring 1 by the unit direction and clip again (not shifted: the first clip again, same rings, same result)
-  const bool shifted = !(dl < 0.1);
-  if (!shifted) { fdx = 0; fdy = 0; }
-  int nt = nr, tslot = 0;
-  if (shifted) {
-    st = clip_staged(T, B, n1, n2, true, fdx, fdy, 1, &nt);
-    if (st == szx::ST_BAIL) return szc::ST_DEFER;
-    if (st != szv::ST_OK) return st;
-    tslot = 1;
+  if (dl < 0.1) { fdx = 0; fdy = 0; nt = nr; tslot = 0; break; }
   }
+  const RegionM R = {B->qx[0], B->qy[0], nr};
+  SZTM_PHASE(7);
   if (nt > 0) {                                                                            // :156-165 (one region at most)
     const RegionM Tn = {B->qx[tslot], B->qy[tslot], nt};
     const double Anew = region_polyarea_team(T, B, Tn);
     if (Anew / Ar - 1 > 0) {
       // a point with a 1e-6 m disc inside both regions certifies that the third clip (:158-159) is not empty
-      bool overlaps = clearly_inside_team(T, cx, cy, R, 1e-6) && clearly_inside_team(T, cx, cy, Tn, 1e-6);
-      if (!overlaps && nt >= 3) {
-        double tx, ty;
-        region_centroid_team(T, B, Tn, tx, ty);
-        overlaps = clearly_inside_team(T, tx, ty, R, 1e-6) && clearly_inside_team(T, tx, ty, Tn, 1e-6);
+      // (the centroid of the original overlap first -- the larger, shifted one normally contains it -- then the
+      // centroid of the shifted overlap; one instance of the test in the code)
+      bool overlaps = false;
+#pragma nounroll
+      for (int attempt = 0; attempt < 2 && !overlaps; ++attempt) {
+        double x = cx, y = cy;
+        if (attempt == 1) { if (nt < 3) break; region_centroid_team(T, B, Tn, x, y); }
+        bool ok = true;
+#pragma nounroll
+        for (int w = 0; w < 2 && ok; ++w) ok = clearly_inside_team(T, x, y, w ? Tn : R, 1e-6);
+        overlaps = ok;
       }
       if (!overlaps) return szc::ST_DEFER;                                                 // the third clip decides: general sweep
       fdx = -fdx; fdy = -fdy;
     }
   }
+  SZTM_PHASE(8);
   const double Fx = fdx * Ar * Force_factor, Fy = fdy * Ar * Force_factor;                 // :167
   // :170-183
-  const double v1x = f1.Ui + f1.ksi_ice * (pcx - f1.Xi), v1y = f1.Vi + f1.ksi_ice * (pcy - f1.Yi);
-  const double v2x = f2.Ui + f2.ksi_ice * (pcx - f2.Xi), v2y = f2.Vi + f2.ksi_ice * (pcy - f2.Yi);
+  const double *f1 = B->body[0], *f2 = B->body[1];
+  const double v1x = f1[BODY_UI] + f1[BODY_KSI] * (pcx - f1[BODY_X]), v1y = f1[BODY_VI] + f1[BODY_KSI] * (pcy - f1[BODY_Y]);
+  const double v2x = f2[BODY_UI] + f2[BODY_KSI] * (pcx - f2[BODY_X]), v2y = f2[BODY_VI] + f2[BODY_KSI] * (pcy - f2[BODY_Y]);
   const double vtx = v1x - v2x, vty = v1y - v2y;
   double dtx, dty;
   if (maxd(absd(vtx), absd(vty)) == 0) { dtx = 0; dty = 0; }
@@ -488,8 +482,8 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const szc::RingD &
   double ftx = coef * dtx * dt, fty = coef * dty * dt;
   const double nF = ::sqrt(Fx * Fx + Fy * Fy);
   if (::sqrt(ftx * ftx + fty * fty) > mu * nF) { ftx = -mu * nF * dtx; fty = -mu * nF * dty; }
-  if (out.nrows >= cap_rows) return szv::ST_OUT_CAPACITY;
-  if (T.lane == 0) { rows[0] = Fx + ftx; rows[1] = Fy + fty; rows[2] = pcx; rows[3] = pcy; rows[4] = Ar; }
+  row[0] = Fx + ftx; row[1] = Fy + fty; row[2] = pcx; row[3] = pcy; row[4] = Ar;
+  SZTM_PHASE(9);
   out.nrows = 1;
   return szv::ST_OK;
 }

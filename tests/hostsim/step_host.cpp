@@ -58,7 +58,7 @@ static std::vector<unsigned char> g_sp_masks;     // present[n] then owned[n]
 static std::vector<double> g_sp_edges;
 static int g_sp_rank = 0, g_sp_world = 1;
 static double g_sp_halo = 0;
-static int g_narrow_mode = 2;
+static int g_narrow_mode = 3;   // (the GPU default: team pass first)
 static long long g_big_pairs = 0;
 extern "C" long long host_big_pairs(void) { return g_big_pairs; }
 static int g_keep_sums = 0;
@@ -66,7 +66,7 @@ static std::vector<double> g_sums;
 static const void *g_sums_for = nullptr;
 extern "C" void host_keep_stress_sums(int on) { g_keep_sums = on; if (!on) g_sums_for = nullptr; }
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
-static long long g_team_pairs = 0, g_team_deferred = 0;
+static long long g_team_pairs = 0, g_team_deferred = 0, g_team_wide = 0;
 extern "C" void host_team_counts(long long *pairs, long long *deferred, long long *sites) { *pairs = g_team_pairs; *deferred = g_team_deferred; for (int i = 0; i < 128; ++i) sites[i] = g_team_bails[i]; }
 extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
 extern "C" void host_set_trim(int on) { g_trim_off = !on; }
@@ -194,12 +194,13 @@ struct Sim {
     axis_extent(P.Xo, P.nxo, P.Xo_max, P.Xo_min); axis_extent(P.Yo, P.nyo, P.Yo_max, P.Yo_min);
     P.Lx = P.c2_boundary[0]; P.Ly = P.c2_boundary[1];
     for (int k = 1; k < 5; ++k) { P.Lx = szc::maxd(P.Lx, P.c2_boundary[2 * k]); P.Ly = szc::maxd(P.Ly, P.c2_boundary[2 * k + 1]); }
+    boundary_summary(P);
     memset(&W, 0, sizeof(W));
     cap = 4 * n;
     W.cap_ext = cap; W.pot_cap = pot_cap < 0 ? -pot_cap : pot_cap;
     W.ext_src = alloc<int>(pool, cap); W.ext_num = alloc<int>(pool, cap); W.ext_parent = alloc<int>(pool, cap); W.ext_nv = alloc<int>(pool, cap);
     W.xg_of = alloc<int>(pool, cap); W.yg_of = alloc<int>(pool, cap);
-    W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap);
+    W.ext_x = alloc<double>(pool, cap); W.ext_y = alloc<double>(pool, cap); W.ext_rec = alloc<double>(pool, (size_t)REC_WORDS * cap); W.ext_ring = alloc<double>(pool, 2 * (size_t)RING_SLOTS * cap);
     W.flag = alloc<int>(pool, cap); W.scan = alloc<int>(pool, cap);
     W.counters = alloc<unsigned long long>(pool, C_COUNT);
     W.pot_cnt = alloc<int>(pool, cap); W.pot_list = alloc<int>(pool, (size_t)cap * W.pot_cap);
@@ -286,7 +287,7 @@ struct Sim {
     W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
     W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
     W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
-    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1); W.team_list = alloc<int>(pool, np + 1);
+    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1); W.team_list = alloc<int>(pool, np + 1); W.wide_list = alloc<int>(pool, np + 1); W.live_list = alloc<int>(pool, np + 1);
     W.touch_list = alloc<int>(pool, np + 1); W.pair_nreg = alloc<int>(pool, np + 1);
     for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
     i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -310,16 +311,16 @@ struct Sim {
     }
   };
   template <int G>
-  void team_pass(i64 lo, i64 hi) {
+  void team_pass(i64 lo, i64 hi, const int *list) {
     static thread_local teamhost::Runtime rt;
     static thread_local TeamJob<G> J;
     J.self = this; J.rt = &rt;
     for (i64 p = lo; p < hi; ++p) {
-      J.p = p;
+      J.p = list ? (i64)list[p] : p;
       rt.run(G, &TeamJob<G>::lane, &J);
       if (!teamhost::exited_together(rt)) { fprintf(stderr, "narrow_team: the lanes of a team did not return together (pair %lld)\n", (long long)p); abort(); }
     }
-    g_team_pairs += hi - lo; g_team_deferred += (long long)W.counters[C_TEAM];
+    if (!list) g_team_pairs += hi - lo;
   }
   int narrow_range(i64 lo, i64 hi) {
     const bool two_stage = (g_narrow_mode == 1);
@@ -333,8 +334,18 @@ struct Sim {
     } else {
       szx::FastBlock blk;
       if (g_narrow_mode == 3 || g_narrow_mode == 4) {
-        W.counters[C_TEAM] = 0;
-        if (g_narrow_mode == 3) team_pass<16>(lo, hi); else team_pass<32>(lo, hi);
+        // mode 3: as the GPU's default path -- the pairs sorted by pair_classify, 16 lanes for the live list, 32 for the
+        // wide one; mode 4: 32 lanes for every pair of the range, unsorted (the sharded step)
+        W.counters[C_TEAM] = 0; W.counters[C_WIDE] = 0; W.counters[C_LIVE] = 0;
+        if (g_narrow_mode == 3 && lo == 0 && hi == np) {
+          for (i64 p = hi - 1; p >= lo; --p) pair_classified(p, pair_classify(p, P, W), W);   // any order
+          std::vector<int> ll(W.live_list, W.live_list + W.counters[C_LIVE]), wl(W.wide_list, W.wide_list + W.counters[C_WIDE]);
+          g_team_wide += (long long)wl.size();
+          team_pass<32>(0, (i64)wl.size(), wl.data());
+          team_pass<16>(0, (i64)ll.size(), ll.data());
+          g_team_pairs += hi - lo;
+        } else team_pass<32>(lo, hi, nullptr);
+        g_team_deferred += (long long)W.counters[C_TEAM];
         std::vector<int> tl(W.team_list, W.team_list + W.counters[C_TEAM]);
         for (size_t t = 0; t < tl.size(); ++t) narrow_convex((i64)t, tl.data(), F, P, W, &blk);
       } else

@@ -86,9 +86,10 @@ def test_device_pipeline_matches_oracle_periodic(binned):
     assert r.n_ext > S.n and len(r.inter) > 0          # ghosts and contacts were actually exercised
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_every_narrow_phase_variant_matches_oracle(mode):
-    """General sweep only / two-stage compact path / single-minimum fast path (convex.hpp, the GPU default)."""
+    """General sweep only / two-stage compact path / single-minimum fast path, a lane per pair (convex.hpp) / the team
+    form first: pairs sorted, 16 or 32 lanes per pair (teamcontact.hpp, the GPU default) / 32 lanes for all, unsorted."""
     hoststep.set_narrow_mode(mode)
     try:
         h0, b0 = hoststep.fast_counts()
@@ -97,10 +98,10 @@ def test_every_narrow_phase_variant_matches_oracle(mode):
         h1, b1 = hoststep.fast_counts()
         if mode == 2:   # step 0 has every neighbour pair sharing an edge exactly (all bail); later steps do not
             assert h1 - h0 > 1000 and b1 - b0 > 0, (h1 - h0, b1 - b0)
-        else:
+        elif mode < 2:
             assert h1 == h0 and b1 == b0
     finally:
-        hoststep.set_narrow_mode(2)
+        hoststep.set_narrow_mode(3)
 
 
 def test_long_convex_rings_are_handed_to_the_general_sweep():
