@@ -7,14 +7,14 @@ floe field; every 10th step refreshes the ocean/wind forcing, as the reference d
 concentration 1.0, periodic box, dt = 10 s (the configuration the metric's target is quoted on).
 
 One JSON line on stdout (rank 0).  `value` is floe-timesteps/s with all inputs resident in HBM.
-  roofline     : the pair-interaction kernel (k_narrow_convex: first pass of the narrow phase over every candidate
-                 pair) priced by the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per ring vertex of both rings +
-                 2 x 56 B of body scalars + 56 B per contact row) over its HIP-event duration, against the
-                 8 TB/s HBM3E peak.  The kernel is bound by the issue rate and latency of divergent int64/FP64
-                 code (one pair per lane), not by HBM: the fraction is reported as computed ("limiter" says so).
-                 `traffic` is the PMC figure of THIS round's profile of the same command
-                 (profiles/r02_pmc_narrow.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes); null
-                 when that file is absent -- a bench run cannot collect PMC counters by itself.
+  roofline     : the pair-interaction kernel (k_narrow_team: a team of 16 or 32 lanes per candidate pair, all pairs
+                 whose bounding boxes meet) priced by the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per ring vertex of
+                 both rings + 2 x 56 B of body scalars + 56 B per contact row, summed over ALL candidate pairs of the
+                 step) over the HIP-event duration of the narrow phase, against the 8 TB/s HBM3E peak.  The kernel is
+                 bound by the vector issue rate of irregular int64/FP64 geometry, not by HBM: the fraction is reported
+                 as computed ("limiter" says so).  `traffic` is the PMC figure of THIS round's profile of the same
+                 command (profiles/r03_pmc_narrow.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes);
+                 null when that file is absent -- a bench run cannot collect PMC counters by itself.
   cpu_baseline : the CPU oracle (C++ restatement of the MATLAB path around the reference's own Clipper)
                  on the host cores, a bounded sample of the same workload.  TEST INFRASTRUCTURE timed as a
                  baseline only; the product path never calls it.
@@ -131,6 +131,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Called without a launcher: start the N ranks ourselves -- fresh child processes (one per GPU, RCCL between
+        # them), before this process has touched the GPU -- and pass their one JSON line through.  Never an n_gpus = 1
+        # line for --gpus N.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     from subzero_amd import capi
     if world > 1 or os.environ.get("SUBZERO_FORCE_SHARDED") == "1":   # the env hook rehearses the N>1 code on one GPU
@@ -171,11 +183,11 @@ def main():
     k = args.steps
     achieved = (pair_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
     traffic = traffic_src = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_narrow.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_narrow.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            traffic_src = "profiles/r02_pmc_narrow.json"
+            traffic_src = "profiles/r03_pmc_narrow.json"
         except Exception:
             traffic = None
     out = {
@@ -191,10 +203,11 @@ def main():
         "candidate_pairs_per_s": pairs / el,
         "contact_rows_last_step": int(len(inter)), "collisions_last_step": collisions,
         "device_ms_per_step": dev_ms / k,
-        "roofline": {"bound": "hbm", "kernel": "k_narrow_convex (pair interaction: clip + contact force, first pass over all pairs)",
+        "roofline": {"bound": "hbm", "kernel": "k_narrow_team (pair interaction: clip + contact force of every candidate pair whose boxes meet; "
+                                               "the boxes-apart pairs are answered by k_pair_classify in front of it)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "limiter": "issue rate and latency of divergent int64/FP64 code (one pair per lane), not HBM",
+                     "limiter": "FP64 / int64 vector issue of irregular geometry (16 lanes per pair, ~5.4e3 vector instructions per wave of four pairs), not HBM",
                      "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
     }
     if not args.no_cpu_baseline:

@@ -181,8 +181,8 @@ extern "C" int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, in
   cleanup();
   int64_t at = 0;
   for (int s = 0; s < nsel; ++s) {
-    if (chg[s] < 0) return sz_fail(ctx, SZ_ERR_WORKSPACE, "szFractureDeform: the piece of floe %d outgrew its slot", (int)ids[s]);
     if (chg[s] == -2) return sz_fail(ctx, SZ_ERR_HIP, "szFractureDeform: floe %d: the reference's \"Clipper Error.\" condition", (int)ids[s]);
+    if (chg[s] < 0) return sz_fail(ctx, SZ_ERR_WORKSPACE, "szFractureDeform: the piece of floe %d outgrew its slot", (int)ids[s]);
     changed[s] = chg[s];
     Xi[s] = chg[s] ? scal[s] : 0; Yi[s] = chg[s] ? scal[(size_t)nsel + s] : 0; area[s] = chg[s] ? scal[2 * (size_t)nsel + s] : 0;
     if (chg[s]) {

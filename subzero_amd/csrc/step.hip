@@ -812,6 +812,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
+  bool team_timed = false;
   const bool convex = S->convex_fast != 0 && S->fast_path == 0;
   const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
   if (hi > lo) {
@@ -821,6 +822,8 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
       // launch covers the pair count and its workgroups beyond the list return at once)
       if (S->classified) sz_launch_narrow_team(st, hi - lo, F, P, W);
       else sz_launch_narrow_team_range(st, lo, hi - lo, F, P, W);
+      SZ_HIP(ctx, hipEventRecord(S->ev[3], st));   // narrow_ms = the team pass alone (the kernel bench.py prices)
+      team_timed = true;
       const int L = 16;
       hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, (i64)0, hi - lo,
                          (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
@@ -872,7 +875,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
     }
     SZ_HIP(ctx, hipGetLastError());
   }
-  SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
+  if (!team_timed) SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
   // the counters for the host -- and for the back half of the step, which runs only once the narrow phase is complete:
   // queued right behind this launch (queue_back) it goes ahead if nothing was deferred and everything fitted
   const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows} : GoRule{GO_SET, 0, 0, 0};

@@ -55,7 +55,8 @@ struct StepState {
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
   int broad_wave = 1;   // the wave-per-floe broad phase for real floes (SUBZERO_BROAD_WAVE=0: thread-per-floe kernels only)
-  int big_lanes = 16;             // pairs per wave of the second fast pass (32-vertex blocks, SUBZERO_BIG_LANES; 0: no such pass)
+  int big_lanes = 0;              // pairs per wave of the second fast pass (32-vertex blocks, SUBZERO_BIG_LANES; 0: no such pass: its pairs take
+                                  // the general kernel -- the default until the round-1 fault of that kernel is settled)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep
                                   // the chip at about two waves per SIMD (SUBZERO_RETRY_LANES)
   int retry_lds_max = 65536;      // ... and what it may grow to while the launch still fits the chip at once (SUBZERO_RETRY_LDS_MAX)

@@ -58,33 +58,34 @@ __global__ void k_state_move(Floes F, const int *ids, int cnt, double *pd, int *
 // rows of a [floe][row_len] array <-> packed rows, one workgroup-stride loop per listed floe
 template <class T>
 __global__ void k_rows_move(T *arr, size_t row_len, const int *ids, int cnt, T *packed, int to_device) {
-  const int k = blockIdx.y;
-  if (k >= cnt) return;
-  T *row = arr + (size_t)(ids[k] - 1) * row_len, *pk = packed + (size_t)k * row_len;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < row_len; q += (size_t)gridDim.x * blockDim.x) {
-    if (to_device) row[q] = pk[q]; else pk[q] = row[q];
+  for (int k = blockIdx.y; k < cnt; k += gridDim.y) {     // (gridDim.y stops at 65535: the rows are strided over)
+    T *row = arr + (size_t)(ids[k] - 1) * row_len, *pk = packed + (size_t)k * row_len;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < row_len; q += (size_t)gridDim.x * blockDim.x) {
+      if (to_device) row[q] = pk[q]; else pk[q] = row[q];
+    }
   }
 }
 // ring vertices of the listed floes: packed back to back in list order, off[k] = vertices before floe k of the list
 __global__ void k_ring_move(Floes F, const int *ids, const int *off, int cnt, double *packed, int total, int to_device) {
-  const int k = blockIdx.y;
-  if (k >= cnt) return;
-  const int i = ids[k] - 1, v0 = F.vert_off[i], nv = F.vert_off[i + 1] - v0;
   double *arrs[4] = {F.c0x, F.c0y, F.cax, F.cay};
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += gridDim.x * blockDim.x)
-    for (int a = 0; a < 4; ++a) {
-      double *pk = packed + (size_t)a * total + off[k] + q;
-      if (to_device) arrs[a][v0 + q] = *pk; else *pk = arrs[a][v0 + q];
-    }
+  for (int k = blockIdx.y; k < cnt; k += gridDim.y) {
+    const int i = ids[k] - 1, v0 = F.vert_off[i], nv = F.vert_off[i + 1] - v0;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += gridDim.x * blockDim.x)
+      for (int a = 0; a < 4; ++a) {
+        double *pk = packed + (size_t)a * total + off[k] + q;
+        if (to_device) arrs[a][v0 + q] = *pk; else *pk = arrs[a][v0 + q];
+      }
+  }
 }
 // bulk histories of the new array taken from the previous one on the device (szFloesResync): new floe k <- old floe src[k]
 template <class T>
 __global__ void k_rows_inherit(T *dst, const T *old, size_t row_len, const int *src, int n_new) {
-  const int k = blockIdx.y;
-  if (k >= n_new || src[k] <= 0) return;
-  const T *from = old + (size_t)(src[k] - 1) * row_len;
-  T *to = dst + (size_t)k * row_len;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < row_len; q += (size_t)gridDim.x * blockDim.x) to[q] = from[q];
+  for (int k = blockIdx.y; k < n_new; k += gridDim.y) {
+    if (src[k] <= 0) continue;
+    const T *from = old + (size_t)(src[k] - 1) * row_len;
+    T *to = dst + (size_t)k * row_len;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < row_len; q += (size_t)gridDim.x * blockDim.x) to[q] = from[q];
+  }
 }
 
 void destroy_state(StepState *S) {
@@ -144,7 +145,7 @@ int build_state(szContext *ctx, const szFloeState *h, StepState *old, const int3
         (rc = dev_alloc(ctx, S, F.mcY, (size_t)n * mc_row)) || (rc = dev_alloc(ctx, S, F.mcA, (size_t)n * mc_row))) return rc;
     int *d_src = nullptr;
     if ((rc = dev_put(ctx, S, d_src, src, (size_t)n))) return rc;
-    const dim3 g(8, (unsigned)n);
+    const dim3 g(8, (unsigned)(n < 65535 ? n : 65535));
     hipLaunchKernelGGL(k_rows_inherit<double>, g, dim3(256), 0, ctx->stream, F.StressH, (const double *)old->F.StressH, sh_row, (const int *)d_src, n);
     hipLaunchKernelGGL(k_rows_inherit<double>, g, dim3(256), 0, ctx->stream, F.mcX, (const double *)old->F.mcX, mc_row, (const int *)d_src, n);
     hipLaunchKernelGGL(k_rows_inherit<double>, g, dim3(256), 0, ctx->stream, F.mcY, (const double *)old->F.mcY, mc_row, (const int *)d_src, n);
@@ -274,7 +275,7 @@ int move_fields(szContext *ctx, StepState *S, szFloeState *h, const int32_t *ids
           memcpy(&pk[(size_t)a * total + off[k]], arrs[a] + S->h_vert_off[ids[k] - 1], (size_t)(off[k + 1] - off[k]) * 8);
       SZ_HIP(ctx, hipMemcpyAsync(S->stage_d.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_ring_move, dim3(2, (unsigned)nids), dim3(64), 0, st, F, (const int *)d_ids, (const int *)d_off, nids, (double *)S->stage_d.p, total, to_device ? 1 : 0);
+    hipLaunchKernelGGL(k_ring_move, dim3(2, (unsigned)(nids < 65535 ? nids : 65535)), dim3(64), 0, st, F, (const int *)d_ids, (const int *)d_off, nids, (double *)S->stage_d.p, total, to_device ? 1 : 0);
     if (!to_device) {
       SZ_HIP(ctx, hipMemcpyAsync(pk.data(), S->stage_d.p, pk.size() * 8, hipMemcpyDeviceToHost, st));
       SZ_HIP(ctx, hipStreamSynchronize(st));
@@ -298,7 +299,7 @@ int move_fields(szContext *ctx, StepState *S, szFloeState *h, const int32_t *ids
       for (int k = 0; k < nids; ++k) memcpy(&pk[(size_t)k * row_bytes], (const char *)b.host + (size_t)(ids[k] - 1) * row_bytes, row_bytes);
       SZ_HIP(ctx, hipMemcpyAsync(S->stage_d.p, pk.data(), pk.size(), dir, st));
     }
-    const dim3 g(8, (unsigned)nids);
+    const dim3 g(8, (unsigned)(nids < 65535 ? nids : 65535));
     if (b.elem == 8) hipLaunchKernelGGL(k_rows_move<double>, g, dim3(256), 0, st, (double *)b.dev, b.row_len, (const int *)d_ids, nids, (double *)S->stage_d.p, to_device ? 1 : 0);
     else hipLaunchKernelGGL(k_rows_move<unsigned char>, g, dim3(256), 0, st, (unsigned char *)b.dev, b.row_len, (const int *)d_ids, nids, (unsigned char *)S->stage_d.p, to_device ? 1 : 0);
     if (!to_device) {

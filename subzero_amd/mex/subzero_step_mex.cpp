@@ -82,6 +82,29 @@ struct Soa {
 #undef P
     return s;
   }
+  // rows `ids` (1-based) of the field groups in `what` taken over from `from` (same n, same ring layout): what an
+  // 'update' has sent to the device -- and nothing else, so that a floe changed in MATLAB but not listed is still seen
+  // as changed by the next 'resync'
+  void take_rows(const Soa &from, const int32_t *ids, int nids, int what) {
+    for (int k = 0; k < nids; ++k) {
+      const size_t i = (size_t)ids[k] - 1;
+      if (what & SZ_F_STATE) {
+#define R1(f) f[i] = from.f[i];
+        R1(Xi) R1(Yi) R1(alpha_i) R1(Ui) R1(Vi) R1(ksi_ice) R1(h) R1(area) R1(mass) R1(inertia_moment) R1(rmax) R1(dXi_p) R1(dYi_p)
+        R1(dUi_p) R1(dVi_p) R1(dalpha_i_p) R1(dksi_ice_p) R1(FxOA) R1(FyOA) R1(torqueOA) R1(alive) R1(StressCount) R1(collision_torque) R1(OverlapArea)
+#undef R1
+        for (int q = 0; q < 4; ++q) Stress[4 * i + q] = from.Stress[4 * i + q];
+        for (int q = 0; q < 4; ++q) strain[4 * i + q] = from.strain[4 * i + q];
+        for (int q = 0; q < 2; ++q) collision_force[2 * i + q] = from.collision_force[2 * i + q];
+      }
+      if (what & SZ_F_RING)
+        for (int v = vert_off[i]; v < vert_off[i + 1]; ++v) { c0x[v] = from.c0x[v]; c0y[v] = from.c0y[v]; cax[v] = from.cax[v]; cay[v] = from.cay[v]; }
+      if (what & SZ_F_STRESSH)
+        for (size_t q = 0; q < 4 * (size_t)n_stress; ++q) StressH[4 * (size_t)n_stress * i + q] = from.StressH[4 * (size_t)n_stress * i + q];
+      if (what & SZ_F_MC)
+        for (size_t q = 0; q < (size_t)n_mc; ++q) { mcX[(size_t)n_mc * i + q] = from.mcX[(size_t)n_mc * i + q]; mcY[(size_t)n_mc * i + q] = from.mcY[(size_t)n_mc * i + q]; mcA[(size_t)n_mc * i + q] = from.mcA[(size_t)n_mc * i + q]; }
+    }
+  }
 };
 Soa g_soa;              // the resident array as the gateway knows it
 bool g_resident = false;
@@ -383,7 +406,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       if (g_state_ahead && (what & (SZ_F_STATE | SZ_F_RING)))
         mexErrMsgTxt("subzero_step('update'): the device has stepped ('advance') since this Floe array was current; 'fetch' the floes ('sr') before changing and updating them");
       check(szFloesUpdate(g_ctx, &s, ids.data(), (int32_t)ids.size(), what));
-      g_soa = S;
+      g_soa.take_rows(S, ids.data(), (int)ids.size(), what);   // (szFloesUpdate has checked that the ring layout is the resident one)
       return;
     }
     szFloeState s = g_soa.view();

@@ -278,3 +278,29 @@ def test_advance_leaves_the_state_on_the_device_until_it_is_fetched(stepgw):
     mx.read_floes(F, G)
     bad = [b for b in hoststep.compare_states(A, G) if b[0] not in ("StressH", "kill", "transfer", "Stress")]
     assert bad == [], bad
+
+
+def test_update_of_some_floes_does_not_hide_a_change_of_another_from_resync(stepgw):
+    """'update' takes over only the rows it sent.  A floe reshaped in MATLAB but not listed in the update is
+    still a changed floe for the next 'resync' (its device-resident history is replaced by what the array carries),
+    while the floes that stayed keep the history the device has accumulated."""
+    S, P = scenes.pack(60, periodic=True, n_stress=4, n_mc=60)
+    G = S.copy()
+    stepgw.call(0, mx.string("close"))
+    F, = stepgw.call(1, mx.string("upload"), mx.floe_struct(G), mx.scalar(0))
+    for it in range(3):                                   # the device's history moves on; StressH is not written back
+        P.doInt = int(it == 0)
+        F = gw_step(stepgw, F, P)[0]
+    stale = mx.to_numpy(mx.get_field(F, 8, "StressH")).copy()
+    # MATLAB edits floe 5 (a velocity) and reshapes floe 9 (smaller outline), but lists only floe 5 in the update
+    mx.set_field(F, 4, "Ui", mx.scalar(0.125))
+    for name in ("c0", "c_alpha"):
+        mx.set_field(F, 8, name, mx.numeric(0.5 * mx.to_numpy(mx.get_field(F, 8, name))))
+    mx.set_field(F, 8, "area", mx.scalar(0.25 * float(mx.to_numpy(mx.get_field(F, 8, "area")).ravel()[0])))
+    mx.set_field(F, 8, "rmax", mx.scalar(0.5 * float(mx.to_numpy(mx.get_field(F, 8, "rmax")).ravel()[0])))
+    stepgw.call(0, mx.string("update"), F, mx.row([5]), mx.string("s"))
+    F, = stepgw.call(1, mx.string("resync"), F, mx.scalar(0))
+    H, = stepgw.call(1, mx.string("fetch"), F, mx.row([5, 9, 10]), mx.string("h"))
+    assert np.array_equal(mx.to_numpy(mx.get_field(H, 8, "StressH")), stale)          # reshaped: the array's history
+    for i in (4, 9):                                                                      # stayed: the device's history
+        assert not np.array_equal(mx.to_numpy(mx.get_field(H, i, "StressH")), mx.to_numpy(mx.get_field(F, i, "StressH")))
