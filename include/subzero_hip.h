@@ -366,6 +366,10 @@ typedef struct szSpatialInfo {
   int32_t overflow, has_left, has_right, reserved;
 } szSpatialInfo;
 int szSpatialInit(szContext *ctx, int rank, int world, const double *edges, double halo);
+/* The axis the strips are cut along: 0 = x (the default), 1 = y -- for a box that is longer in y, e.g. the 2e5 x 1e6 m
+ * channel of /root/reference/Initialize_Model/initialize_boundaries.m:14-16.  Call before szSpatialInit; `edges` are then
+ * values of that coordinate. */
+int szSpatialSetAxis(szContext *ctx, int axis);
 int64_t szSpatialMessageBytes(szContext *ctx, int64_t cap_records, int64_t cap_doubles, int64_t cap_migrants);
 int szSpatialPack(szContext *ctx, int periodic, void *d_left, void *d_right, int64_t cap_records, int64_t cap_doubles,
                   int64_t cap_migrants, szSpatialInfo *info);

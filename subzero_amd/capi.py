@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
+    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",

@@ -49,6 +49,13 @@ __global__ void k_sp_count(Floes F, const unsigned char *present, const unsigned
 
 extern "C" {
 
+int szSpatialSetAxis(szContext *ctx, int axis) {
+  if (!ctx || (axis != 0 && axis != 1)) return SZ_ERR_BAD_ARG;
+  if (!ctx->step) return sz_fail(ctx, SZ_ERR_STATE, "szSpatialSetAxis: no floes uploaded");
+  ctx->step->sp_axis = axis;
+  return SZ_OK;
+}
+
 int szSpatialInit(szContext *ctx, int rank, int world, const double *edges, double halo) {
   if (!ctx || !edges || world < 1 || rank < 0 || rank >= world) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
@@ -71,10 +78,12 @@ int szSpatialInit(szContext *ctx, int rank, int world, const double *edges, doub
       (rc = sz_reserve(ctx, S->sp_counts, 64))) return rc;
   // ownership of the uploaded array: the strip of each centroid (every rank was handed the same array)
   std::vector<unsigned char> m(2 * (size_t)n, 0);
-  std::vector<double> x((size_t)n);
-  SZ_HIP(ctx, hipMemcpy(x.data(), S->F.Xi, (size_t)n * 8, hipMemcpyDeviceToHost));
+  std::vector<double> x((size_t)n), xs((size_t)n);
+  SZ_HIP(ctx, hipMemcpy(x.data(), S->sp_axis ? S->F.Yi : S->F.Xi, (size_t)n * 8, hipMemcpyDeviceToHost));
+  SZ_HIP(ctx, hipMemcpy(xs.data(), S->F.Xi, (size_t)n * 8, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; ++i) {
-    const bool mine = sp_strip_of(x[i], edges, world) == rank || (x[i] != x[i] && rank == 0);   // (a sacked floe, NaN, stays with rank 0)
+    const bool nan = x[i] != x[i] || xs[i] != xs[i];
+    const bool mine = nan ? rank == 0 : sp_strip_of(x[i], edges, world) == rank;   // (a sacked floe, NaN, stays with rank 0)
     m[i] = mine; m[(size_t)n + i] = mine;
   }
   SZ_HIP(ctx, hipMemcpy(S->sp_masks.p, m.data(), m.size(), hipMemcpyHostToDevice));
@@ -96,6 +105,7 @@ static SpatialGeom geom_of(const StepState *S, int periodic) {
   g.lo = S->sp_edges[S->sp_rank]; g.hi = S->sp_edges[S->sp_rank + 1]; g.halo = S->sp_halo;
   g.has_left = S->sp_world > 1 && (periodic || S->sp_rank > 0);
   g.has_right = S->sp_world > 1 && (periodic || S->sp_rank < S->sp_world - 1);
+  g.axis = S->sp_axis;
   return g;
 }
 

@@ -1,7 +1,8 @@
 // spatial_core.hpp -- the spatially sharded step (BASELINE north_star: "floes are spatially binned and
 // sharded across the GPUs of one node with RCCL halo exchange of ghost-floe state over xGMI") as kernel bodies.
 //
-// Partition.  The domain is cut along x into `world` strips whose edges lie on multiples of the broad-phase bin
+// Partition.  The domain is cut along one axis -- x, or y when the box is longer that way (SpatialGeom::axis: the Nares
+// channel of BASELINE configs[4] is 2e5 x 1e6 m) -- into `world` strips whose edges lie on multiples of the broad-phase bin
 // (>= 2 max rmax) and balance the floe count; a floe belongs to the rank whose strip holds its centroid.  Every rank
 // keeps the floe arrays at their GLOBAL size and index -- a floe's index, and with it every index comparison of
 // floe_interactions_all.m (j > i, ascending partner order, the mems filter), means the same on every rank -- but only
@@ -30,6 +31,7 @@ struct SpatialGeom {
   double lo, hi;        // my strip [lo, hi)
   double halo;          // width of the halo region along x
   int has_left, has_right;
+  int axis;             // 0: strips along x (edges are x values), 1: along y
 };
 
 // one message (to one neighbour) as the device sees it
@@ -104,8 +106,8 @@ SZ_HD void sp_classify(int i, const Floes &F, const Work &W, const SpatialGeom &
                        unsigned char *owned, SpatialMsg &left, SpatialMsg &right) {
   if (!owned[i]) { present[i] = 0; return; }
   present[i] = 1;
-  const double x = F.Xi[i];
-  if (!F.alive[i] || x != x) return;                 // dead or sacked floes stay where they are, nobody needs them
+  const double x = g.axis ? F.Yi[i] : F.Xi[i];       // (the coordinate the strips are cut along)
+  if (!F.alive[i] || x != x || F.Xi[i] != F.Xi[i]) return;   // dead or sacked floes stay where they are, nobody needs them
   const int s = sp_strip_of(x, edges, g.world);
   const int lrank = (g.rank + g.world - 1) % g.world, rrank = (g.rank + 1) % g.world;
   if (s != g.rank && g.world > 1) {

@@ -36,7 +36,7 @@ struct StepState {
   double rmax_max = 0, rmax_p90 = 0; // over the floes that can be candidates (i >= Nb)
   double rmax_max_all = 0;           // over all floes (the reach of the spatially sharded step)
   // spatially sharded step (spatial.hip)
-  int sp_rank = 0, sp_world = 1;
+  int sp_rank = 0, sp_world = 1, sp_axis = 0;   // (axis the strips are cut along: 0 x, 1 y; szSpatialSetAxis)
   double sp_halo = 0;
   std::vector<double> sp_edges;
   DevBuf sp_masks, sp_edges_dev, sp_counts;   // present[n] then owned[n]; strip edges; two counters

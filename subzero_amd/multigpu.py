@@ -191,14 +191,21 @@ class SpatialInfo(ctypes.Structure):
                [(k, ctypes.c_int32) for k in ("overflow", "has_left", "has_right", "reserved")]
 
 
-def strip_edges(floes, world, Lx, halo=None):
-    """Edges of `world` x-strips over [-Lx, Lx]: floe-count quantiles of the centroids, moved onto multiples of the
-    broad-phase bin (2 max rmax) and kept at least `halo` (default 2 x reach = 4 max rmax) wide.  Every rank computes
-    the same edges from the same uploaded array."""
+def strip_axis(Lx, Ly):
+    """The axis the domain is cut along: its longer one (0 = x, 1 = y), so that the strips are as wide against the
+    halo as the box allows (the 2e5 x 1e6 m channel of initialize_boundaries.m:14-16 is cut along y)."""
+    return 1 if Ly > Lx else 0
+
+
+def strip_edges(floes, world, Lx, halo=None, axis=0):
+    """Edges of `world` strips over [-Lx, Lx] along `axis` (Lx = the half-extent of the box along it): floe-count
+    quantiles of the centroids, moved onto multiples of the broad-phase bin (2 max rmax) and kept at least `halo`
+    (default 2 x reach = 4 max rmax) wide.  Every rank computes the same edges from the same uploaded array."""
     rmax = float(np.max(floes.rmax))
     bin_ = 2 * rmax
     halo = 4 * rmax if halo is None else halo
-    x = np.sort(floes.Xi[np.isfinite(floes.Xi) & (floes.alive > 0)])
+    c = floes.Yi if axis else floes.Xi
+    x = np.sort(c[np.isfinite(floes.Xi) & np.isfinite(floes.Yi) & (floes.alive > 0)])
     edges = [-float(Lx)]
     for k in range(1, world):
         q = x[min(len(x) - 1, (len(x) * k) // world)] if len(x) else -Lx + 2 * Lx * k / world
@@ -213,7 +220,7 @@ def strip_edges(floes, world, Lx, halo=None):
 class GpuSpatialBackend:
     """One GPU of the spatially sharded job: szContext, device-resident array, torch CUDA tensors as messages."""
 
-    def __init__(self, floes, local_rank, rank, world, edges, halo):
+    def __init__(self, floes, local_rank, rank, world, edges, halo, axis=0):
         import torch
         from . import capi
         self.torch, self.capi = torch, capi
@@ -233,6 +240,7 @@ class GpuSpatialBackend:
         self.stream = torch.cuda.Stream(self.device)
         self.ctx.check(L.szSetStream(self.ctx.h, ctypes.c_void_p(self.stream.cuda_stream)), "szSetStream")
         e = np.ascontiguousarray(edges, np.float64)
+        self.ctx.check(L.szSpatialSetAxis(self.ctx.h, int(axis)), "szSpatialSetAxis")
         self.ctx.check(L.szSpatialInit(self.ctx.h, rank, world, e.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), halo), "szSpatialInit")
         self._bufs = {}
 
@@ -449,9 +457,10 @@ class SpatialInteractions:
 def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
     """`steps` timed steps of the spatially sharded job on the field S; -> (seconds: max over ranks, stats)."""
     from . import capi
-    Lx = float(P.c2_boundary[0].max())
-    edges, halo = strip_edges(S, world, Lx)
-    be = GpuSpatialBackend(S, local_rank, rank, world, edges, halo)
+    Lx, Ly = float(P.c2_boundary[0].max()), float(P.c2_boundary[1].max())
+    axis = strip_axis(Lx, Ly)
+    edges, halo = strip_edges(S, world, Ly if axis else Lx, axis=axis)
+    be = GpuSpatialBackend(S, local_rank, rank, world, edges, halo, axis=axis)
     sim = SpatialInteractions(be, rank, world, S.n, int(S.vert_off[-1]))
     it = 0
     present = S.n if world == 1 else 0
@@ -481,7 +490,7 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
     stats = {"collisions_last_step": float(tot[0]), "pairs_evaluated": float(tot[1]), "owned_floes_rank0": int(cnt[2]),
              "present_floes_max": int(mx[3]), "bytes_sent_per_rank_step_max": float(mx[4]),
              "narrow_ms": narrow_ms / max(steps, 1), "pair_bytes": pair_bytes / max(steps, 1), "halo_m": halo,
-             "strip_edges_m": [float(e) for e in edges]}
+             "strip_axis": "y" if axis else "x", "strip_edges_m": [float(e) for e in edges]}
     be.close()
     return float(el.item()), stats
 

@@ -56,7 +56,7 @@ using namespace szs;
 static bool g_sp_active = false;
 static std::vector<unsigned char> g_sp_masks;     // present[n] then owned[n]
 static std::vector<double> g_sp_edges;
-static int g_sp_rank = 0, g_sp_world = 1;
+static int g_sp_rank = 0, g_sp_world = 1, g_sp_axis = 0;
 static double g_sp_halo = 0;
 static int g_narrow_mode = 3;   // (the GPU default: team pass first)
 static long long g_big_pairs = 0;
@@ -481,6 +481,7 @@ int host_last_ghosts(int *src, int *parent, double *x, double *y, int cap) {
 }
 
 // ---- spatially sharded form, mirroring szSpatialInit / Pack / Unpack (then host_step as usual) ----
+void host_spatial_axis(int axis) { g_sp_axis = axis ? 1 : 0; }
 int host_spatial_init(HFloes *hf, int rank, int world, const double *edges, double halo) {
   const int n = hf->n;
   double rm = 0;
@@ -492,8 +493,9 @@ int host_spatial_init(HFloes *hf, int rank, int world, const double *edges, doub
   g_sp_edges.assign(edges, edges + world + 1);
   g_sp_masks.assign(2 * (size_t)n, 0);
   for (int i = 0; i < n; ++i) {
-    const double x = hf->Xi[i];
-    const bool mine = sp_strip_of(x, edges, world) == rank || (x != x && rank == 0);
+    const double x = g_sp_axis ? hf->Yi[i] : hf->Xi[i];
+    const bool nan = x != x || hf->Xi[i] != hf->Xi[i];
+    const bool mine = nan ? rank == 0 : sp_strip_of(x, edges, world) == rank;
     g_sp_masks[i] = mine; g_sp_masks[(size_t)n + i] = mine;
   }
   g_sp_active = true;
@@ -510,6 +512,7 @@ static SpatialGeom host_geom(int periodic) {
   g.lo = g_sp_edges[g_sp_rank]; g.hi = g_sp_edges[g_sp_rank + 1]; g.halo = g_sp_halo;
   g.has_left = g_sp_world > 1 && (periodic || g_sp_rank > 0);
   g.has_right = g_sp_world > 1 && (periodic || g_sp_rank < g_sp_world - 1);
+  g.axis = g_sp_axis;
   return g;
 }
 // info: [left rec, dbl, migr, right rec, dbl, migr, need rec, dbl, migr, overflow, has_left, has_right, n_owned, n_present]

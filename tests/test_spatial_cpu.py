@@ -30,7 +30,7 @@ def _free_port():
 class HostSpatialBackend:
     """multigpu.SpatialInteractions backend on tests/hostsim (CPU tensors as messages)."""
 
-    def __init__(self, floes, rank, world, edges, halo):
+    def __init__(self, floes, rank, world, edges, halo, axis=0):
         import torch
         import hoststep
         import oracle
@@ -49,6 +49,7 @@ class HostSpatialBackend:
         L.host_spatial_owned.argtypes = [ctypes.POINTER(ctypes.c_uint8), ctypes.c_int]
         e = np.ascontiguousarray(edges, np.float64)
         hoststep.keep_stress_sums(True)       # the sums of the stress history are device state that lives across steps
+        L.host_spatial_axis(int(axis))
         assert L.host_spatial_init(ctypes.byref(self.cf), rank, world, oracle._p(e), halo) == 0
         self._bufs = {}
         self.migrants_in = 0
@@ -135,14 +136,14 @@ def _worker(rank, world, port, scene, steps, drift, q):
         import scenes
         from subzero_amd import multigpu
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        kw = dict(scene[2]); tiny = kw.pop("tiny_migrant_room", False)
+        kw = dict(scene[2]); tiny = kw.pop("tiny_migrant_room", False); axis = kw.pop("strip_axis", 0)
         S, P = getattr(scenes, scene[0])(*scene[1], **kw)
         P.set_reference_ocean()
-        S.Ui += drift                                  # a common drift: floes cross strip edges (and the periodic edge)
+        (S.Vi if axis else S.Ui)[:] += drift           # a common drift: floes cross strip edges (and the periodic edge)
         ref = S.copy()
-        Lx = float(P.c2_boundary[0].max())
-        edges, halo = multigpu.strip_edges(S, world, Lx)
-        be = HostSpatialBackend(S, rank, world, edges, halo)
+        Lx = float(P.c2_boundary[axis].max())
+        edges, halo = multigpu.strip_edges(S, world, Lx, axis=axis)
+        be = HostSpatialBackend(S, rank, world, edges, halo, axis=axis)
         sim = multigpu.SpatialInteractions(be, rank, world, S.n, int(S.vert_off[-1]))
         if tiny:                                       # room for ONE floe changing strip: messages must grow, on both ends
             sim.caps = (sim.caps[0], sim.caps[1], 1)
@@ -215,6 +216,15 @@ def test_spatial_step_equals_single_process(world, periodic):
         # strip (their 5 KB rows of history and points here -- 49 KB in a model run -- travel separately) or a message
         # outgrows the size agreed from the step before
         assert r[10] == 8 and r[10] + 1 <= r[9] <= 2 * r[10], (r[9], r[10])
+
+
+def test_strips_along_y_equal_single_process():
+    """The same partition cut along y (multigpu.strip_axis picks the longer side of the box: the 2e5 x 1e6 m channel of
+    BASELINE configs[4]): floes drift in y across the strip edges and the periodic edge."""
+    res = run(2, ("pack", (1800,), {"periodic": True, "n_stress": 6, "n_mc": 80, "strip_axis": 1}), 6, 45.0)
+    assert sum(r[3] for r in res) > 0 and res[0][7] > 100
+    from subzero_amd import multigpu
+    assert multigpu.strip_axis(2e5, 1e6) == 1 and multigpu.strip_axis(1e5, 1e5) == 0
 
 
 def test_messages_grow_when_more_floes_change_strip_than_fit():
