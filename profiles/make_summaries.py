@@ -18,7 +18,7 @@ import os
 import shutil
 import sys
 
-HOT = "k_narrow_convex"   # the kernel bench.py's roofline object prices
+HOT = "k_narrow_team"   # the kernel bench.py's roofline object prices (rounds 1-2: k_narrow_convex)
 
 
 def short(name):

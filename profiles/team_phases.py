@@ -19,10 +19,16 @@ nm = []
 for it in range(steps):
     P.doInt = int(it % 10 == 0); st = sim.step(P)
     nm.append(st.narrow_ms)
-nw = min((st.n_pairs + 64 // G - 1) // (64 // G), 1 << 15)
-out = (ctypes.c_ulonglong * (nw * 48))()
+nw = 16384  # (records of workgroups that did not run stay zero and are dropped below)
+SL = 50
+out = (ctypes.c_ulonglong * (nw * SL))()
 ctx.L.szDebugTeamPhases(out, nw)
-v = np.array(list(out), float).reshape(nw, 48) / 100.0     # microseconds
+raw = np.array(list(out), float).reshape(nw, SL)
+alive = (raw[:, 49] > 0) & (raw[:, 48] > raw[:, 48].max() - 1e5)    # this launch's workgroups (earlier, larger launches leave records behind)
+raw = raw[alive]; nw = int(alive.sum())
+t0 = raw[:, 48].min()
+start = (raw[:, 48] - t0) / 100.0; end = (raw[:, 49] - t0) / 100.0
+v = raw[:, :48] / 100.0     # microseconds
 names = {0: "pair setup (loads, slice)", 1: "staging", 2: "clip 1: to fixed point", 3: "region to metres, area", 4: "merge flags, closing, InterX",
          5: "centroid, nearest vertices, direction", 6: "clip 2: to fixed point", 7: "polyarea, certificates", 8: "force, row", 9: "bookkeeping",
          10: "clip: closing duplicates", 11: "clip: vertex scan", 12: "clip: ranks, events", 13: "clip: prefix counts",
@@ -31,6 +37,16 @@ names = {0: "pair setup (loads, slice)", 1: "staging", 2: "clip 1: to fixed poin
 for k in range(30, 40):
     names[k] = "2nd " + names[k - 20]
 tot = v.sum(1)
+print('kernel span %.1f us; waves alive over time:' % end.max())
+for t in np.arange(0, end.max(), end.max() / 16):
+    print('   t=%6.1f us  running %5d  started %5d' % (t, int(((start <= t) & (end > t)).sum()), int((start <= t).sum())))
+dur = end - start
+print('wave duration: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f' % (dur.mean(), *np.percentile(dur, [10, 50, 90]), dur.max()))
+idx = np.nonzero(alive)[0]
+order = np.argsort(-dur)[:12]
+print('slowest workgroups (block index, us, time in part 1 staging / waiting):', [(int(idx[o]), round(float(dur[o]), 1), round(float(v[o, 1]), 1)) for o in order])
+half = nw // 2
+print('first half of the blocks (hot list first): mean duration %.1f; second half: %.1f' % (dur[:half].mean(), dur[half:].mean()))
 print("G %d pairs %d waves %d  narrow_ms of the last steps %s; lane 0 of each wave, microseconds" % (G, st.n_pairs, nw, np.round(nm[-5:], 3)))
 print("wave total: mean %.2f p50 %.2f p90 %.2f max %.2f" % (tot.mean(), *np.percentile(tot, [50, 90]), tot.max()))
 full = v[:, 8] > 0        # waves whose first team went all the way to a contact row

@@ -9,7 +9,7 @@
 // teamcontact.hpp / teamclip.hpp (SZTM_PHASE(k) = "entering part k"; 100 MHz wall clock), kept per wave in LDS and
 // written out when the wave's first team is done; the last launch's records are read with szDebugTeamPhases.
 #include <hip/hip_runtime.h>
-#define SZ_TP_SLOTS 48
+#define SZ_TP_SLOTS 50    // 0-47: time per part, 48: start of the wave, 49: its end (100 MHz wall clock)
 #define SZ_TP_WAVES (1 << 15)
 __device__ unsigned long long sz_team_phase[(size_t)SZ_TP_WAVES * SZ_TP_SLOTS];
 __shared__ unsigned long long sz_tp_acc[SZ_TP_SLOTS];
@@ -21,36 +21,51 @@ extern "C" int szDebugTeamPhases(unsigned long long *out, int nwaves) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_team_phase), sizeof(unsigned long long) * (size_t)nwaves * SZ_TP_SLOTS) == hipSuccess ? 0 : -1;
 }
 #endif
+#include <stdlib.h>
 #include "step_state.hpp"
 
 namespace {
 #ifndef SZ_TEAM_WAVES
 #define SZ_TEAM_WAVES 3   // waves per SIMD the kernel is built for: 168 registers (at 128, for 4 waves, it spills 76 of them and is 8 % slower)
 #endif
-// One launch for both team widths: the first WIDE_BLOCKS workgroups take the pairs of W.wide_list with 32 lanes each
-// (striding over the list: few pairs, and they start first), the others the pairs of W.live_list with 16 lanes each,
-// four per wave (lists by pair_classify; counts on the device).  `count` bounds the live pairs the grid was sized for.
-enum { WIDE_BLOCKS = 128 };
-__global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team(i64 count, Floes F, Params P, Work W) {
+// One launch for the three lists of pair_classify (counts on the device); a wave takes four pairs of 16 lanes (or two
+// of 32) at a time.  The grid is laid out from what the lists held in the step before -- any size is correct, the
+// waves stride over their list:
+//   blocks [0, wide_blocks)            wide_list, 32 lanes per pair         (few, and the longest: first)
+//   the next hot_blocks                live_list (in contact last step: the whole model, ~45 us a wave) -- a wave each
+//   the next cold_blocks               cold_list (most stop at the no-row certificate, ~9 us a wave) -- several waves'
+//                                      worth per workgroup: the dispatcher starts ~110 workgroups per microsecond
+//                                      (measured), short-lived ones one by one leave the chip a third empty
+__global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team(int wide_blocks, int hot_blocks, int cold_blocks, int ratio, Floes F, Params P, Work W) {
   __shared__ sztm::TeamBlock blocks[4];
 #if defined(SZ_TEAM_PHASES)
-  if (threadIdx.x == 0) { for (int k = 0; k < SZ_TP_SLOTS; ++k) sz_tp_acc[k] = 0; sz_tp_cur = 0; sz_tp_base = 0; sz_tp_last = wall_clock64(); }
+  if (threadIdx.x == 0) { for (int k = 0; k < SZ_TP_SLOTS; ++k) sz_tp_acc[k] = 0; sz_tp_cur = 0; sz_tp_base = 0; sz_tp_last = wall_clock64(); sz_tp_acc[48] = sz_tp_last; }
 #endif
-  if (blockIdx.x < WIDE_BLOCKS) {
+  const int b = (int)blockIdx.x;
+  if (b < wide_blocks) {
     const sztm::Team<32> T = sztm::Team<32>::here();
     const int tw = sztm::Team<32>::index_in_wave();
     const i64 n = (i64)W.counters[C_WIDE];
-    for (i64 t = (i64)blockIdx.x * 2 + tw; t < n; t += (i64)WIDE_BLOCKS * 2) narrow_team((i64)W.wide_list[t], T, &blocks[tw], F, P, W);
+    for (i64 t = (i64)b * 2 + tw; t < n; t += (i64)wide_blocks * 2) narrow_team((i64)W.wide_list[t], T, &blocks[tw], F, P, W, false, true);
   } else {
     const sztm::Team<16> T = sztm::Team<16>::here();
     const int tw = sztm::Team<16>::index_in_wave();
-    const i64 n = (i64)W.counters[C_LIVE];
-    const i64 t = (i64)(blockIdx.x - WIDE_BLOCKS) * 4 + tw;
-    if (t < n && t < count) narrow_team((i64)W.live_list[t], T, &blocks[tw], F, P, W);
+    // hot and cold workgroups take turns in the order of dispatch (`ratio` hot ones, then a cold one): both kinds run
+    // for tens of microseconds, and a kind left for the end would leave the chip part empty for its whole duration
+    const int k = b - wide_blocks, g = k / (ratio + 1), r = k % (ratio + 1);
+    if (r < ratio) {
+      const int h = g * ratio + r;
+      const i64 n = (i64)W.counters[C_LIVE];
+      if (h < hot_blocks) for (i64 t = (i64)h * 4 + tw; t < n; t += (i64)hot_blocks * 4) narrow_team((i64)W.live_list[t], T, &blocks[tw], F, P, W, false, true);
+    } else if (g < cold_blocks) {
+      const i64 n = (i64)W.counters[C_COLD];
+      for (i64 t = (i64)g * 4 + tw; t < n; t += (i64)cold_blocks * 4) narrow_team((i64)W.cold_list[t], T, &blocks[tw], F, P, W, true, true);
+    }
   }
 #if defined(SZ_TEAM_PHASES)
   SZTM_PHASE(47);
-  if (threadIdx.x == 0 && blockIdx.x >= WIDE_BLOCKS && blockIdx.x - WIDE_BLOCKS < SZ_TP_WAVES) for (int k = 0; k < SZ_TP_SLOTS; ++k) sz_team_phase[(size_t)(blockIdx.x - WIDE_BLOCKS) * SZ_TP_SLOTS + k] = sz_tp_acc[k];
+  if (threadIdx.x == 0) { sz_tp_acc[49] = wall_clock64(); }
+  if (threadIdx.x == 0 && blockIdx.x < SZ_TP_WAVES) for (int k = 0; k < SZ_TP_SLOTS; ++k) sz_team_phase[(size_t)blockIdx.x * SZ_TP_SLOTS + k] = sz_tp_acc[k];
 #endif
 }
 // the pairs [first, first + count) with G lanes each (the sharded step: a segment of the pair list; no classification)
@@ -69,30 +84,41 @@ __global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team_range(i64 fir
 }
 // pair_classify for the pairs [0, count) (*dev_count of them when the host does not know the count yet): the lists are
 // appended to a wave at a time (one atomic per wave and list)
-__global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned long long *dev_count, Params P, Work W) {
+__global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned long long *dev_count, int prev_n, Params P, Work W) {
   const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   const i64 n = dev_count ? (i64)*dev_count : count;
-  const int cls = (p < n && p < count) ? pair_classify(p, P, W) : (int)PC_DONE;
+  const int cls = (p < n && p < count) ? pair_classify(p, prev_n, P, W) : (int)PC_DONE;
   const int lane = threadIdx.x & 63;
-  for (int c = PC_LIVE; c <= PC_OTHER; ++c) {
+  for (int c = PC_LIVE; c <= PC_COLD; ++c) {
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
     unsigned long long base = 0;
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : C_TEAM], (unsigned long long)__popcll(m));
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : c == PC_COLD ? C_COLD : C_TEAM], (unsigned long long)__popcll(m));
     base = __shfl(base, __builtin_ctzll(m));
-    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
+    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : c == PC_COLD ? W.cold_list : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
   }
 }
 }
 
-void sz_launch_pair_classify(hipStream_t st, i64 count, const unsigned long long *dev_count, const Params &P, const Work &W) {
+void sz_launch_pair_classify(hipStream_t st, i64 count, const unsigned long long *dev_count, int prev_n, const Params &P, const Work &W) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_pair_classify, grid_for(count, 256), dim3(256), 0, st, count, dev_count, P, W);
+  hipLaunchKernelGGL(k_pair_classify, grid_for(count, 256), dim3(256), 0, st, count, dev_count, prev_n, P, W);
 }
-// the team pass over the classified pairs (count: the live pairs the launch is sized for, at most all candidates)
-void sz_launch_narrow_team(hipStream_t st, i64 count, const Floes &F, const Params &P, const Work &W) {
+// the team pass over the classified pairs: `count` candidates; hot / cold / wide: what the three lists held in the step
+// before (negative: unknown -- every pair may be on any list)
+void sz_launch_narrow_team(hipStream_t st, i64 count, i64 hot, i64 cold, i64 wide, const Floes &F, const Params &P, const Work &W) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_narrow_team, dim3((unsigned)(WIDE_BLOCKS + (count + 3) / 4)), dim3(64), 0, st, count, F, P, W);
+  if (hot < 0) { hot = count; cold = count; wide = count / 16; }
+  const i64 hb = (hot + hot / 8) / 4 + 8;              // a wave of four per workgroup, with room for the list to grow
+  static int chunk = 0;                                // waves' worth of cold pairs per workgroup (SUBZERO_COLD_CHUNK)
+  if (!chunk) { const char *v = getenv("SUBZERO_COLD_CHUNK"); chunk = v ? atoi(v) : 1; if (chunk < 1 || chunk > 16) chunk = 1; }   // (measured at 1e4 floes: 1 -> 0.133 ms, 2 -> 0.139, 4 -> 0.172)
+  const i64 cb = (cold + cold / 8) / (4 * chunk) + 8;
+  i64 wb = (wide + 1) / 2 + 4;
+  if (wb > 512) wb = 512;
+  i64 ratio = (hb + cb / 2) / cb;                       // hot workgroups per cold one in the order of dispatch
+  if (ratio < 1) ratio = 1;
+  const i64 groups = std::max((hb + ratio - 1) / ratio, cb);
+  hipLaunchKernelGGL(k_narrow_team, dim3((unsigned)(wb + groups * (ratio + 1))), dim3(64), 0, st, (int)wb, (int)hb, (int)cb, (int)ratio, F, P, W);
 }
 // ... over a range of the pair list, unclassified, 32 lanes per pair (the sharded step: a segment of the pair list)
 void sz_launch_narrow_team_range(hipStream_t st, i64 first, i64 count, const Floes &F, const Params &P, const Work &W) {

@@ -714,7 +714,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
         (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
         (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
-        (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) || (rc = sz_reserve(ctx, S->wide_list, npa * 4)) || (rc = sz_reserve(ctx, S->live_list, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) || (rc = sz_reserve(ctx, S->wide_list, npa * 4)) || (rc = sz_reserve(ctx, S->live_list, npa * 4)) || (rc = sz_reserve(ctx, S->cold_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
     main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -724,7 +724,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
     W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
     W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
-    W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p; W.wide_list = (int *)S->wide_list.p; W.live_list = (int *)S->live_list.p;
+    W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p; W.wide_list = (int *)S->wide_list.p; W.live_list = (int *)S->live_list.p; W.cold_list = (int *)S->cold_list.p;
     W.pair_rowoff = (i64 *)S->pair_rowoff.p;
     W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
     W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
@@ -802,7 +802,8 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
   // the pairs sorted for the team pass (narrow_team.hip): boxes apart -> answered, the others onto their kernel's list
   S->classified = classify && S->team != 0 && S->convex_fast != 0 && S->fast_path == 0;
   if (S->classified)
-    sz_launch_pair_classify(st, np, speculative ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr, P, W);
+    sz_launch_pair_classify(st, np, speculative ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr,
+                            (S->stepped && getenv("SUBZERO_NO_HINT") == nullptr) ? S->last_next : 0, P, W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -820,7 +821,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
     if (convex && S->team) {
       // the team pass over every pair, then the lane-per-pair fast path over what it handed on (a device-side list: the
       // launch covers the pair count and its workgroups beyond the list return at once)
-      if (S->classified) sz_launch_narrow_team(st, hi - lo, F, P, W);
+      if (S->classified) sz_launch_narrow_team(st, hi - lo, S->stepped ? S->last_hot : -1, S->last_cold, S->last_wide, F, P, W);
       else sz_launch_narrow_team_range(st, lo, hi - lo, F, P, W);
       SZ_HIP(ctx, hipEventRecord(S->ev[3], st));   // narrow_ms = the team pass alone (the kernel bench.py prices)
       team_timed = true;
@@ -1033,6 +1034,8 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
   const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
+  S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE];
+  if (getenv("SUBZERO_DEBUG_LISTS")) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS]);
   if (stats) {
     float ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;

@@ -102,7 +102,7 @@ static_assert((int)RING_SLOTS == (int)sztm::T_NV, "the staged rings are what the
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COLD, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -139,7 +139,8 @@ struct Work {
   int *big_list;                // pairs the first pass hands to the fast path on the 32-vertex block (C_BIG of them)
   int *team_list;               // pairs the team pass hands to the lane-per-pair fast path (C_TEAM of them)
   int *wide_list;               // pairs with more vertices than a 16-lane team has lanes: 32 lanes each (C_WIDE of them)
-  int *live_list;               // pairs whose bounding boxes meet and that fit a 16-lane team (C_LIVE of them; pair_classify)
+  int *live_list;               // pairs whose bounding boxes meet and that fit a 16-lane team, in contact in the step before (C_LIVE of them; pair_classify)
+  int *cold_list;               // ... not in contact in the step before (C_COLD of them)
   int *touch_list;              // pairs whose first clip found overlap regions (two-stage fast path)
   int *pair_nreg;               // regions of the first clip
   // mirrored rows
@@ -708,10 +709,15 @@ SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P
 // candidates of a packed field -- or whose floe lies well inside the domain box is DONE here with the no-contact
 // result; the others are appended to the list of the kernel that takes them, so that the team pass runs on dense teams:
 //   live_list  16 lanes per pair          wide_list  32 lanes per pair (more than 16 scanlines)
+//   cold_list  16 lanes per pair, the pairs that were NOT in contact in the step before: a wave of four pairs takes as
+//              long as its longest, and a pair in contact runs the whole model while one that is not stops after the
+//              first clip -- floes move metres per step, so last step's contact rows (still in W.rows / W.row_off when
+//              this runs; prev_n = entries of last step's extended list, 0: none) say which is which nearly always,
+//              and waves of like pairs waste no lanes.  A hint only: a wrong guess costs time, never a result.
 //   team_list  the lane-per-pair kernels (walls, rings too long for the block, coordinates out of the fast range)
 // The order inside a list is arbitrary (every pair writes its own words).  Returns the class; the caller appends.
-enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3 };
-SZ_HD int pair_classify(i64 p, const Params &P, Work &W) {
+enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3, PC_COLD = 4 };
+SZ_HD int pair_classify(i64 p, int prev_n, const Params &P, Work &W) {
   const int i = W.pair_i[p], j = W.pair_j[p];
   const bool boundary = (j == WALL);
   const double *ri = W.ext_rec + (size_t)REC_WORDS * i, *rj = boundary ? ri : W.ext_rec + (size_t)REC_WORDS * j;
@@ -731,10 +737,20 @@ SZ_HD int pair_classify(i64 p, const Params &P, Work &W) {
   if (ri[REC_NSTAGE] < 1 || rj[REC_NSTAGE] < 1) return (n1 > 0 && n2 > 0 && apart) ? PC_DONE : PC_OTHER;
   if (ri[REC_INRANGE] == 0 || rj[REC_INRANGE] == 0) return PC_OTHER;
   if (apart) return PC_DONE;
-  return (n1 + n2 - 2 > 16) ? PC_WIDE : PC_LIVE;
+  if (n1 + n2 - 2 > 16) return PC_WIDE;
+  if (i < prev_n && W.rows != nullptr) {
+    const i64 r0 = W.row_off[i];
+    i64 r1 = W.row_off[i + 1];
+    if (r1 > r0 + 64) r1 = r0 + 64;
+    if (r1 > W.cap_rows) r1 = W.cap_rows;
+    const double want = (double)(j + 1);
+    for (i64 r = r0; r < r1; ++r) if (W.rows[7 * r] == want) return PC_LIVE;
+  }
+  return PC_COLD;
 }
 SZ_HD void pair_classified(i64 p, int cls, Work &W) {   // (the kernel appends a wave at a time instead)
   if (cls == PC_LIVE) W.live_list[atomic_add(&W.counters[C_LIVE], 1ULL)] = (int)p;
+  else if (cls == PC_COLD) W.cold_list[atomic_add(&W.counters[C_COLD], 1ULL)] = (int)p;
   else if (cls == PC_WIDE) W.wide_list[atomic_add(&W.counters[C_WIDE], 1ULL)] = (int)p;
   else if (cls == PC_OTHER) W.team_list[atomic_add(&W.counters[C_TEAM], 1ULL)] = (int)p;
 }
@@ -747,7 +763,7 @@ SZ_HD void pair_classified(i64 p, int cls, Work &W) {   // (the kernel appends a
 // (narrow_convex), whose own leftovers take the general sweep as before; a pair with more vertices than the team has
 // lanes goes to `wide_list` (the same pass with 32 lanes per pair).
 template <int G>
-SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, const Floes &F, const Params &P, Work &W) {
+SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, const Floes &F, const Params &P, Work &W, bool cold = false, bool prepared = false) {
   SZTM_PHASE(0);
   const int i = W.pair_i[p], j = W.pair_j[p];
   const bool boundary = (j == WALL);
@@ -769,12 +785,13 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   const int n1 = (int)B->u.rec[0][REC_NSTORED], n2 = boundary ? 4 : (int)B->u.rec[1][REC_NSTORED];
   const i64 bytes = scratch_bytes_for((i64)n1 + n2, 1);
   const i64 off = (i64)SCR_PER_V * (nvoff + 2 * p) + (i64)SCR_PER_PAIR * p;
-  if (T.lane == 0) {
+  // (prepared: pair_classify has written the pair's words -- slice, no rows, status OK -- and checked the arena)
+  if (T.lane == 0 && !prepared) {
     W.pair_scr[p] = off; W.pair_mult[p] = 1;
     W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
     W.pair_rowoff[p] = off / 8;
   }
-  if (!(off + bytes <= W.scratch_bytes)) {
+  if (!prepared && !(off + bytes <= W.scratch_bytes)) {
     if (T.lane == 0) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); }
     return;
   }
@@ -784,6 +801,7 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   sg.n1 = (int)B->u.rec[0][REC_NSTAGE]; sg.n2 = (int)B->u.rec[1][REC_NSTAGE];
   sg.stored1 = n1; sg.stored2 = n2;
   sg.in_range = B->u.rec[0][REC_INRANGE] != 0 && B->u.rec[1][REC_INRANGE] != 0;
+  sg.cold = cold;
   // the bodies (contact.hpp Body) stay in the block: words REC_X .. REC_AREA of the records, in that order
   static_assert((int)REC_X == (int)sztm::BODY_X && (int)REC_AREA == (int)sztm::BODY_AREA && (int)REC_KSI == (int)sztm::BODY_KSI, "record and body word order");
   if (T.lane < (int)sztm::BODY_WORDS) {
@@ -798,7 +816,7 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   sztm::BoundaryBox bb = {P.bnd_xmax, P.bnd_xmin, P.bnd_ymax, P.bnd_ymin, P.bnd_area, P.bnd_rect != 0};
   const int st = sztm::pair_contact_team(T, B, sg, bx1, bx2, boundary, bb, P.PERIODIC != 0, P.Modulus, P.dt, P.mu, P.nu, row, out);
   if (T.lane != 0) return;
-  W.pair_status[p] = st;
+  if (!prepared || st != szv::ST_OK) W.pair_status[p] = st;
   if (st == szc::ST_DEFER_BIG) { const unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL); W.big_list[k] = (int)p; return; }
   if (st == szc::ST_DEFER || st == sztm::ST_DEFER_WIDE || st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
     const unsigned long long k = atomic_add(&W.counters[C_TEAM], 1ULL);

@@ -25,7 +25,7 @@ struct StepState {
   double xo_max = 0, xo_min = 0, yo_max = 0, yo_min = 0; // extent of the uploaded grid axes
   bool have_ocean = false;
   // grow-only per-step buffers
-  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy, big_list, team_list, wide_list, live_list;
+  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy, big_list, team_list, wide_list, live_list, cold_list;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_item;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
@@ -51,6 +51,7 @@ struct StepState {
   i64 nr = 0;
   int force_exchange = 0;
   int team = 1;                   // the team pass runs first (teamcontact.hpp; SUBZERO_TEAM=0: lane-per-pair fast path for all)
+  i64 last_hot = -1, last_cold = -1, last_wide = -1;   // what the team pass's lists held in the last step (sizes its grid)
   bool classified = false;        // this step's pairs went through pair_classify (live / wide / team lists are filled)
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
@@ -77,8 +78,8 @@ struct StepState {
 
 
 // narrow_team.hip: the team pass of the narrow phase
-void sz_launch_pair_classify(hipStream_t st, i64 count, const unsigned long long *dev_count, const Params &P, const Work &W);
-void sz_launch_narrow_team(hipStream_t st, i64 count, const Floes &F, const Params &P, const Work &W);
+void sz_launch_pair_classify(hipStream_t st, i64 count, const unsigned long long *dev_count, int prev_n, const Params &P, const Work &W);
+void sz_launch_narrow_team(hipStream_t st, i64 count, i64 hot, i64 cold, i64 wide, const Floes &F, const Params &P, const Work &W);
 void sz_launch_narrow_team_range(hipStream_t st, i64 first, i64 count, const Floes &F, const Params &P, const Work &W);
 
 inline dim3 grid_for(i64 n, int block) { return dim3((unsigned)((n + block - 1) / block > 0 ? (n + block - 1) / block : 1)); }

@@ -298,10 +298,50 @@ SZ_HD bool closer_than_1e8_staged(double xp, double yp, const TeamBlock *B, int 
   return szc::dist_to_ring(xp, yp, c) < 1e-8;
 }
 
+// A certificate that the model returns no contact row, from the projections of the two staged rings onto the normal n
+// and the direction t of an edge of either ring (an edge per lane, every lane over all vertices):
+//   * the projections onto n lie more than 1e-6 m apart: the convex hulls -- and the rings -- are more than 1e-6 m (4295
+//     units of the fixed-point grid) apart, the clip of the rounded rings is empty and InterX finds no crossing (its
+//     sign tests differ from exact arithmetic by ~1e-10 m at these coordinates): floe_interactions.m returns its
+//     no-contact form ([0 0], [0 0], 0; :43-74) -- the argument of contact.hpp boxes_apart with an edge normal in place
+//     of a coordinate axis;
+//   * or the overlap of the two hulls fits a rectangle d x w (d: overlap of the projections onto n, w: onto t; both
+//     grown by the rounding of the projections and of the clip) of less area than `amin`, a lower bound of the model's
+//     threshold (:78-83: regions below min(N1, N2) * 100 / 1.75 m^2 are skipped): whatever regions the clip returns
+//     lie inside both rings, hence inside that rectangle -- each is skipped, there are no rows; and with `amin` below
+//     0.55 of either floe's area (the caller checks) the merge flags of :54-60 stay 0 as well.
+// Either way every output of the pair is the no-contact result, without running the clip.  A `false` only means
+// "not certified": the caller runs the model.  Rounding: a projection is two products and a sum of coordinates below
+// `cmax`, off by less than 4e-16 (|nx| + |ny|) cmax; |nx| + |ny| bounds the length of n from above.  NaN compares false.
+template <int G>
+SZ_TEAM bool certainly_no_rows(const Team<G> &T, const TeamBlock *B, int n1, int n2, double cmax, double amin) {
+  bool found = false;
+  for (int k = T.lane; k < n1 + n2; k += G) {
+    const int r = (k >= n1) ? 1 : 0, l = k - (r ? n1 : 0), n = r ? n2 : n1, l1 = (l + 1 == n) ? 0 : l + 1;
+    const double nx = B->my[r][l1] - B->my[r][l], ny = B->mx[r][l] - B->mx[r][l1];
+    const double len = absd(nx) + absd(ny), len2 = nx * nx + ny * ny;
+    if (!(len2 > 0)) continue;                                 // (a repeated vertex is no axis)
+    double nlo0 = SZC_INF, nhi0 = -SZC_INF, nlo1 = SZC_INF, nhi1 = -SZC_INF, tlo0 = SZC_INF, thi0 = -SZC_INF, tlo1 = SZC_INF, thi1 = -SZC_INF;
+    for (int v = 0; v < n1; ++v) {
+      const double x = B->mx[0][v], y = B->my[0][v], pn = nx * x + ny * y, pt = nx * y - ny * x;
+      nlo0 = mind(nlo0, pn); nhi0 = maxd(nhi0, pn); tlo0 = mind(tlo0, pt); thi0 = maxd(thi0, pt);
+    }
+    for (int v = 0; v < n2; ++v) {
+      const double x = B->mx[1][v], y = B->my[1][v], pn = nx * x + ny * y, pt = nx * y - ny * x;
+      nlo1 = mind(nlo1, pn); nhi1 = maxd(nhi1, pn); tlo1 = mind(tlo1, pt); thi1 = maxd(thi1, pt);
+    }
+    const double slack = len * (1e-6 + 1e-15 * cmax);          // 1e-6 m and the rounding, in units of the projections
+    if (nlo1 - nhi0 > slack || nlo0 - nhi1 > slack) { found = true; continue; }
+    const double d = mind(nhi0, nhi1) - maxd(nlo0, nlo1) + 2 * slack, w = mind(thi0, thi1) - maxd(tlo0, tlo1) + 2 * slack;
+    if (d > 0 && w > 0 && (d * w) / len2 * (1 + 1e-9) < amin) found = true;   // (projections are lengths times |n|: the area is d w / |n|^2)
+  }
+  return T.any(found, TEAM_SITE);
+}
+
 // what narrow_team has put into the block: both rings in mx / my (sg.n1, sg.n2 vertices: the stored length, one less
 // for a ring stored closed that is one vertex too long for the block -- the closure rule of the model, :62-67, puts the
 // copy back; -1: too long), the bodies in `body`
-struct Staged { int n1, n2, stored1, stored2; bool in_range; };
+struct Staged { int n1, n2, stored1, stored2; bool in_range; bool cold; };   // cold: not in contact last step (a hint: try the cheap no-contact certificate first)
 // the domain box as the model uses it (step_core.hpp boundary_summary)
 struct BoundaryBox { double xmax, xmin, ymax, ymin, area; bool rect; };
 
@@ -328,6 +368,13 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, 
   if (!sg.in_range) return szc::ST_DEFER;
   if (szc::boxes_apart(b1, b2)) { szc::no_contact(out); return szv::ST_OK; }
   if (n1 + n2 - 2 > G) return ST_DEFER_WIDE;   // (even with a closing copy in each ring: more scanlines than lanes)
+  if (sg.cold) {
+    const double cmax = maxd(maxd(maxd(absd(b1.x0), absd(b1.x1)), maxd(absd(b1.y0), absd(b1.y1))), maxd(maxd(absd(b2.x0), absd(b2.x1)), maxd(absd(b2.y0), absd(b2.y1))));
+    // (N1, N2 of :78-79 are at least the staged lengths less one: the rings may be closed by one more vertex, :62-67)
+    double amin = (double)((n1 < n2 ? n1 : n2) - 1) * 100 / 1.75 * (1 - 1e-9);
+    if (!(amin < 0.55 * mind(B->body[0][BODY_AREA], B->body[1][BODY_AREA]))) amin = 0;
+    if (certainly_no_rows(T, B, n1, n2, cmax, amin)) { szc::no_contact(out); return szv::ST_OK; }
+  }
   T.sync(TEAM_SITE);
   SZTM_PHASE(2);
   // ---- the first clip (:29), the model up to the force direction, the second clip (:140-155): one instance of the

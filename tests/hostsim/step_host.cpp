@@ -66,7 +66,7 @@ static std::vector<double> g_sums;
 static const void *g_sums_for = nullptr;
 extern "C" void host_keep_stress_sums(int on) { g_keep_sums = on; if (!on) g_sums_for = nullptr; }
 extern "C" void host_set_narrow_mode(int m) { g_narrow_mode = m; }
-static long long g_team_pairs = 0, g_team_deferred = 0, g_team_wide = 0;
+static long long g_team_pairs = 0, g_team_deferred = 0, g_team_wide = 0, g_cold_toggle = 0;
 extern "C" void host_team_counts(long long *pairs, long long *deferred, long long *sites) { *pairs = g_team_pairs; *deferred = g_team_deferred; for (int i = 0; i < 128; ++i) sites[i] = g_team_bails[i]; }
 extern "C" void host_set_dump_third(int on) { g_dump_third = on; }
 extern "C" void host_set_trim(int on) { g_trim_off = !on; }
@@ -287,7 +287,7 @@ struct Sim {
     W.pair_i = alloc<int>(pool, np + 1); W.pair_j = alloc<int>(pool, np + 1); W.pair_nvoff = alloc<i64>(pool, np + 1);
     W.pair_scr = alloc<i64>(pool, np + 1); W.pair_mult = alloc<int>(pool, np + 1);
     W.pair_nrows = alloc<int>(pool, np + 1); W.pair_status = alloc<int>(pool, np + 1); W.pair_flag = alloc<int>(pool, np + 1);
-    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1); W.team_list = alloc<int>(pool, np + 1); W.wide_list = alloc<int>(pool, np + 1); W.live_list = alloc<int>(pool, np + 1);
+    W.retry_list = alloc<int>(pool, np + 1); W.pair_rowoff = alloc<i64>(pool, np + 1); W.big_list = alloc<int>(pool, np + 1); W.team_list = alloc<int>(pool, np + 1); W.wide_list = alloc<int>(pool, np + 1); W.live_list = alloc<int>(pool, np + 1); W.cold_list = alloc<int>(pool, np + 1);
     W.touch_list = alloc<int>(pool, np + 1); W.pair_nreg = alloc<int>(pool, np + 1);
     for (int i = 0; i < N; ++i) pair_expand(i, N, F, P, W);
     i64 main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
@@ -303,18 +303,18 @@ struct Sim {
   // the GPU default), its leftovers through the lane-per-pair fast path
   template <int G>
   struct TeamJob {
-    Sim *self; i64 p; sztm::TeamBlock B; teamhost::Runtime *rt;
+    Sim *self; i64 p; sztm::TeamBlock B; teamhost::Runtime *rt; bool cold, prepared;
     static void lane(void *a, int l) {
       TeamJob *J = (TeamJob *)a;
       sztm::Team<G> T; T.lane = l; T.rt = J->rt;
-      narrow_team(J->p, T, &J->B, J->self->F, J->self->P, J->self->W);
+      narrow_team(J->p, T, &J->B, J->self->F, J->self->P, J->self->W, J->cold, J->prepared);
     }
   };
   template <int G>
-  void team_pass(i64 lo, i64 hi, const int *list) {
+  void team_pass(i64 lo, i64 hi, const int *list, bool cold = false) {
     static thread_local teamhost::Runtime rt;
     static thread_local TeamJob<G> J;
-    J.self = this; J.rt = &rt;
+    J.self = this; J.rt = &rt; J.cold = cold; J.prepared = list != nullptr;   // (a list: the pairs pair_classify has prepared)
     for (i64 p = lo; p < hi; ++p) {
       J.p = list ? (i64)list[p] : p;
       rt.run(G, &TeamJob<G>::lane, &J);
@@ -338,11 +338,12 @@ struct Sim {
         // wide one; mode 4: 32 lanes for every pair of the range, unsorted (the sharded step)
         W.counters[C_TEAM] = 0; W.counters[C_WIDE] = 0; W.counters[C_LIVE] = 0;
         if (g_narrow_mode == 3 && lo == 0 && hi == np) {
-          for (i64 p = hi - 1; p >= lo; --p) pair_classified(p, pair_classify(p, P, W), W);   // any order
-          std::vector<int> ll(W.live_list, W.live_list + W.counters[C_LIVE]), wl(W.wide_list, W.wide_list + W.counters[C_WIDE]);
+          W.counters[C_COLD] = 0;
+          for (i64 p = hi - 1; p >= lo; --p) pair_classified(p, pair_classify(p, 0, P, W), W);   // any order (no contact rows of a step before here: all cold)
+          std::vector<int> ll(W.cold_list, W.cold_list + W.counters[C_COLD]), wl(W.wide_list, W.wide_list + W.counters[C_WIDE]);
           g_team_wide += (long long)wl.size();
           team_pass<32>(0, (i64)wl.size(), wl.data());
-          team_pass<16>(0, (i64)ll.size(), ll.data());
+          team_pass<16>(0, (i64)ll.size(), ll.data(), (g_cold_toggle++ & 1) != 0);   // (the certificate of the cold list on every other step: with and without it, same results)
           g_team_pairs += hi - lo;
         } else team_pass<32>(lo, hi, nullptr);
         g_team_deferred += (long long)W.counters[C_TEAM];
