@@ -7,14 +7,18 @@
 //   k_scan_reduce / k_scan_write                              exclusive scans, two launches of <= 256 workgroups
 //   k_cell_* / k_broad_scan / k_broad_filter                  uniform grid; thread per (floe, neighbour cell); thread per floe
 //   k_pair_expand                                             one thread per extended floe (the counts come from k_broad_filter)
-//   k_narrow_convex / k_narrow                                one lane per candidate pair, 64-lane workgroups: fast pass over all
-//                                                             pairs, general sweep for what it defers
+//   k_pair_classify / k_narrow_team (narrow_team.hip)         thread per pair: boxes apart -> answered, else onto its kernel's list;
+//                                                             a team of 16 (32) lanes per pair, four (two) pairs per wave
+//   k_narrow_convex / k_narrow / k_narrow_lds                 one lane per pair: the single-minimum fast path for what the team pass
+//                                                             hands on, the general sweep for what that defers
 //   k_incoming / k_row_count / k_row_fill / k_transfer_*      per pair / per extended floe
 //   k_integrate_pre / k_integrate_post                        one thread per real floe
 //   k_forcing                                                 one 256-thread workgroup per real floe (Monte-Carlo forcing)
-// Host read-backs per step: the pair count (sizes the pair scratch), the deferred / retried pairs of the narrow
-// phase, and the counters at the end, each published by k_publish into a pinned host buffer (buffers are grow-only,
-// owned by the context).  No CPU fallback exists: every failure is an error code.
+// Host read-backs per step: one, of the counters at its end (k_publish into a pinned host buffer), in a steady step --
+// the front stages and the narrow phase are sized from the step before, the back half runs behind a device-side flag
+// (C_GO); a step whose capacities do not fit, or whose narrow phase defers pairs to the general sweep, falls back to
+// the read-backs in the middle (pair count, deferred pairs).  Buffers are grow-only, owned by the context.  No CPU
+// fallback exists: every failure is an error code.
 #include <stdlib.h>
 #include <algorithm>
 #include "context.hpp"
