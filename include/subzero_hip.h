@@ -321,6 +321,22 @@ int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const double *c2_boun
 int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, int Nb, const double *c2_boundary, int32_t *offsets, int32_t *count,
                        double *angles, uint8_t *da, int64_t cap, int32_t *n_ext, double *kernel_ms);
 
+/* ---- corner grinding, the cut itself for the plain case: Physical_Processes/frac_corner.m:1-189 ------------------------
+ * For the floes ids[s] (1-based) and the `grind` flags the caller formed from szCornerCandidates' angles / da and its own
+ * draws (corners.m:91; at offsets[s] .. offsets[s + 1], the layout szCornerCandidates returned): the pieces frac_corner.m
+ * returns -- the floe with every broken corner replaced by its two cut points (:20-52, :159-185), then one triangle per
+ * corner (:54-136) -- when every such corner is convex, its cut stays inside the two adjacent edges, clear of the
+ * neighbouring cuts and of every other edge: then the polyshape operations of the reference have closed forms and no
+ * boolean operation is needed.  npieces[s] = 0: not that case, nothing returned for the floe -- leave it to frac_corner.m.
+ * Pieces of floe s: piece_off[s] .. piece_off[s + 1]; each 12 doubles
+ *   kind (0 floe, 1 triangle), Xi, Yi, area, mass, h, inertia_moment, rmax, alive, ksi_ice, factor, vertices
+ * (factor: what frac_corner.m multiplies Stress and StressH by, :121-122 / :171-172; dXi_p .. dksi_ice_p, Ui, Vi, strain,
+ * StressCount carry over from the floe, :128-137; alpha_i, FxOA, FyOA, torqueOA, the collision fields = 0) and its closed
+ * c_alpha = c0 ring at ring_off[piece] .. ring_off[piece + 1] of rx / ry.  The Monte-Carlo points of the new floes
+ * (:124-126) are rand: the caller draws them.  Conventions assumed of polyshape: DESIGN.md section 2. */
+int szCornerCuts(szContext *ctx, const int32_t *ids, int nsel, const int32_t *offsets, const uint8_t *grind, int32_t *npieces, int32_t *piece_off,
+                 double *pieces, int64_t cap_pieces, int32_t *ring_off, double *rx, double *ry, int64_t cap_ring, double *kernel_ms);
+
 /* ---- fracture, the deformation step: Physical_Processes/fracture_floe.m:14-52 ------------------
  * Call after a step, for the floes about to be fractured (fracture.m:51-55; ids 1-based).  Each is pushed by the
  * partner of its largest contact overlap: polyclip 'int' -> centroid and p_poly_dist of the overlap region -> partner

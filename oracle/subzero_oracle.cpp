@@ -1327,6 +1327,168 @@ extern "C" void or_polyangles(const double *x, const double *y, int n, double *o
   for (int k = 0; k < n; ++k) out[k] = a[k];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Physical_Processes/frac_corner.m:1-189 for ONE floe, restated for the case in which the reference's polyshape
+// operations have closed forms: every corner to break is convex and its cut (:20-52) stays inside the two adjacent
+// edges, clear of the neighbouring cuts and of every other edge of the outline.  poly1 (:66-93) is then the outline
+// with that corner replaced by the two cut points, poly2 the triangle, subtract(poly, union(...)) (:160-161) the
+// outline with every such corner replaced.  Returns the pieces in the order Floes = [FloeNEW fracturedFloes] (:188),
+// or nothing when the floe is not that case (the product then leaves it to frac_corner.m as well).
+// polyshape conventions assumed, unpinned by anything the reference holds: area / centroid = ring_area / ring_centroid
+// above; outlines clockwise from the first surviving vertex, a triangle from its first cut point.
+// x, y: poly.Vertices (the stored c_alpha without its closing copy, corners.m:63-68); out: 12 doubles per piece
+// [kind, Xi, Yi, area, mass, h, inertia_moment, rmax, alive, ksi_ice, factor of Stress / StressH, ring length], rings
+// closed (c_alpha = c0, :108-109).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct CornerPiece { double rec[12]; Vec cx, cy; };
+
+double polygon_moments(const Vec &cx, const Vec &cy, double h) {       // PolygonMoments.m:14-32, xy = c0' (closed ring)
+  const int N = (int)cx.size();
+  Vec x = cx, y = cy;
+  x.push_back(cx[0]); y.push_back(cy[0]);                             // :19-20
+  double Ixx = 0, Iyy = 0;
+  for (int i = 0; i < N; ++i) {
+    const double wi = x[i] * y[i + 1] - x[i + 1] * y[i];              // :22
+    Ixx += wi * ((y[i] + y[i + 1]) * (y[i] + y[i + 1]) - y[i] * y[i + 1]);   // :29
+    Iyy += wi * ((x[i] + x[i + 1]) * (x[i] + x[i + 1]) - x[i] * x[i + 1]);   // :30
+  }
+  return fabs(1.0 / 12 * Ixx + 1.0 / 12 * Iyy) * h * 920.0;          // :32
+}
+bool seg_touch(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
+  auto orient = [](double px, double py, double qx, double qy, double rx, double ry) { return (qx - px) * (ry - py) - (qy - py) * (rx - px); };
+  auto within = [](double px, double py, double qx, double qy, double rx, double ry) {
+    return std::min(px, qx) <= rx && rx <= std::max(px, qx) && std::min(py, qy) <= ry && ry <= std::max(py, qy);
+  };
+  const double o1 = orient(ax, ay, bx, by, cx, cy), o2 = orient(ax, ay, bx, by, dx, dy), o3 = orient(cx, cy, dx, dy, ax, ay), o4 = orient(cx, cy, dx, dy, bx, by);
+  if (o1 * o2 < 0 && o3 * o4 < 0) return true;
+  return (o1 == 0 && within(ax, ay, bx, by, cx, cy)) || (o2 == 0 && within(ax, ay, bx, by, dx, dy)) ||
+         (o3 == 0 && within(cx, cy, dx, dy, ax, ay)) || (o4 == 0 && within(cx, cy, dx, dy, bx, by));
+}
+CornerPiece make_piece(double kind, const Vec &vx, const Vec &vy, double mass, const OrFloes *F, int i, double factor) {
+  CornerPiece P;
+  double Xi, Yi;
+  ring_centroid(vx.data(), vy.data(), (int)vx.size(), Xi, Yi);        // :106 / :164
+  const double A = ring_area(vx.data(), vy.data(), (int)vx.size());   // :107 / :165
+  double r2 = 0;
+  for (size_t k = 0; k < vx.size(); ++k) { P.cx.push_back(vx[k] - Xi); P.cy.push_back(vy[k] - Yi); r2 = std::max(r2, (vx[k] - Xi) * (vx[k] - Xi) + (vy[k] - Yi) * (vy[k] - Yi)); }
+  P.cx.push_back(vx[0] - Xi); P.cy.push_back(vy[0] - Yi);             // :110 / :168
+  const double h = mass / (920.0 * A);                                // :109 / :167
+  P.rec[0] = kind; P.rec[1] = F->Xi[i] + Xi; P.rec[2] = F->Yi[i] + Yi; P.rec[3] = A; P.rec[4] = mass; P.rec[5] = h;
+  P.rec[6] = polygon_moments(P.cx, P.cy, h); P.rec[7] = sqrt(r2); P.rec[8] = (A < 1e4) ? 0.0 : 1.0;   // :112,:114,:129-131
+  P.rec[9] = A / F->area[i] * F->ksi_ice[i]; P.rec[10] = factor; P.rec[11] = (double)P.cx.size();   // :135, :121-122
+  return P;
+}
+std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_t *grind_in) {
+  std::vector<CornerPiece> none, out;
+  const int v0 = F->vert_off[i];
+  int n = F->vert_off[i + 1] - v0;
+  if (n > 1 && F->cax[v0] == F->cax[v0 + n - 1] && F->cay[v0] == F->cay[v0 + n - 1]) --n;
+  if (n < 3) return none;
+  Vec x(F->cax + v0, F->cax + v0 + n), y(F->cay + v0, F->cay + v0 + n);
+  std::vector<uint8_t> grind(grind_in, grind_in + n);
+  const Vec angles = polyangles(x, y);                                // :9
+  const double Anorm = 180.0 - 360.0 / n;                             // :10
+  {                                                                   // :11-14 unique(angles(grind))
+    Vec ga;
+    for (int k = 0; k < n; ++k) if (grind[k]) ga.push_back(angles[k]);
+    Vec u = ga;
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    if (u.size() < ga.size() && grind[0] && grind[n - 1]) grind[n - 1] = 0;
+  }
+  double alph = angles[0];
+  for (int k = 1; k < n; ++k) alph = std::min(alph, angles[k]);       // :15
+  const double Apoly = ring_area(x.data(), y.data(), n);
+  if (!(Apoly > 0)) return none;
+  struct Cut { double x1, y1, x2, y2; };
+  std::vector<Cut> cut(n);
+  int ng = 0;
+  for (int jj = 0; jj < n; ++jj) {
+    if (!grind[jj]) continue;
+    ++ng;
+    const int p = (jj + n - 1) % n, q = (jj + 1) % n;                 // :23-33
+    const double X1 = x[p], Y1 = y[p], X2 = x[jj], Y2 = y[jj], X3 = x[q], Y3 = y[q];
+    const double d1 = sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2)), d2 = sqrt((X3 - X2) * (X3 - X2) + (Y3 - Y2) * (Y3 - Y2));
+    const double d = std::min(d1, d2);                                // :34-35
+    Cut c;
+    if (fabs(X1 - X2) < 120 && fabs(Y1 - Y2) < 120) return none;      // :36 the whole edge goes: not the plain case
+    else if (fabs(d * alph / Anorm / 5) < 120) { c.x1 = X2 + 120 / d1 * (X1 - X2); c.y1 = Y2 + 120 / d1 * (Y1 - Y2); }   // :38-39
+    else { c.x1 = X2 + d / d1 * alph / Anorm * (X1 - X2) / 5; c.y1 = Y2 + d / d1 * alph / Anorm * (Y1 - Y2) / 5; }     // :41
+    if (fabs(X3 - X2) < 120 && fabs(Y3 - Y2) < 120) return none;      // :43
+    else if (fabs(d * alph / Anorm / 5) < 120) { c.x2 = X2 + 120 / d2 * (X3 - X2); c.y2 = Y2 + 120 / d2 * (Y3 - Y2); }   // :45-46
+    else { c.x2 = X2 + d / d2 * alph / Anorm * (X3 - X2) / 5; c.y2 = Y2 + d / d2 * alph / Anorm * (Y3 - Y2) / 5; }     // :48
+    if (fabs(c.x1 - c.x2) < 0.1) c.x1 = c.x1 + 1;                     // :50-52
+    cut[jj] = c;
+    // the plain case: a convex corner, cut points strictly inside the two edges, the cut clear of every other edge
+    if (angles[jj] >= 180) return none;
+    const double t1 = sqrt((c.x1 - X2) * (c.x1 - X2) + (c.y1 - Y2) * (c.y1 - Y2)), t2 = sqrt((c.x2 - X2) * (c.x2 - X2) + (c.y2 - Y2) * (c.y2 - Y2));
+    if (!(t1 > 0 && t1 < d1 && t2 > 0 && t2 < d2)) return none;
+    for (int e = 0; e < n; ++e) {
+      if (e == p || e == jj) continue;
+      if (seg_touch(c.x1, c.y1, c.x2, c.y2, x[e], y[e], x[(e + 1) % n], y[(e + 1) % n])) return none;
+    }
+  }
+  if (ng == 0) return none;
+  for (int k = 0; k < n; ++k) {                                       // neighbouring cuts on one edge must not meet
+    const int q = (k + 1) % n;
+    if (!(grind[k] && grind[q])) continue;
+    const double L = sqrt((x[q] - x[k]) * (x[q] - x[k]) + (y[q] - y[k]) * (y[q] - y[k]));
+    const double ta = sqrt((cut[k].x2 - x[k]) * (cut[k].x2 - x[k]) + (cut[k].y2 - y[k]) * (cut[k].y2 - y[k]));
+    const double tb = sqrt((cut[q].x1 - x[q]) * (cut[q].x1 - x[q]) + (cut[q].y1 - y[q]) * (cut[q].y1 - y[q]));
+    if (!(ta + tb < L)) return none;
+  }
+  // :159-185 the floe less its corners
+  Vec nx, ny;
+  for (int k = 0; k < n; ++k) {
+    if (grind[k]) { nx.push_back(cut[k].x1); ny.push_back(cut[k].y1); nx.push_back(cut[k].x2); ny.push_back(cut[k].y2); }
+    else { nx.push_back(x[k]); ny.push_back(y[k]); }
+  }
+  const double Anew = ring_area(nx.data(), ny.data(), (int)nx.size());
+  if (!(Anew > 0)) return none;
+  out.push_back(make_piece(0.0, nx, ny, F->mass[i] * Anew / Apoly, F, i, Anew / Apoly));   // :166, :171-172
+  // :54-136 one triangle per corner, with the Atot of poly1 and poly2 of ITS cut
+  for (int jj = 0; jj < n; ++jj) {
+    if (!grind[jj]) continue;
+    Vec tx = {cut[jj].x1, cut[jj].x2, x[jj]}, ty = {cut[jj].y1, cut[jj].y2, y[jj]};   // Pc2, :55 / :64 / :74
+    const double At = ring_area(tx.data(), ty.data(), 3);
+    if (!(At > 0)) return none;
+    Vec px, py;                                                       // Pc1
+    for (int k = 0; k < n; ++k) {
+      if (k == jj) { px.push_back(cut[jj].x1); py.push_back(cut[jj].y1); px.push_back(cut[jj].x2); py.push_back(cut[jj].y2); }
+      else { px.push_back(x[k]); py.push_back(y[k]); }
+    }
+    const double A1 = ring_area(px.data(), py.data(), (int)px.size());
+    double Atot = 0;                                                  // :95-97 a = R1(area(R1) > 10)
+    if (A1 > 10) Atot += A1;
+    if (At > 10) Atot += At;
+    if (!(Atot > 0)) return none;
+    const double Mtot = F->mass[i] * Atot / Apoly;                    // :98
+    if ((tx[1] - tx[0]) * (ty[2] - ty[0]) - (tx[2] - tx[0]) * (ty[1] - ty[0]) > 0) { std::swap(tx[1], tx[2]); std::swap(ty[1], ty[2]); }   // clockwise
+    out.push_back(make_piece(1.0, tx, ty, Mtot * At / Atot, F, i, At / Atot));   // :108, :121-122
+  }
+  return out;
+}
+} // namespace
+
+extern "C" int or_frac_corner(const OrFloes *F, const int *ids, int nsel, const int *offsets, const uint8_t *grind, int *npieces, int *piece_off,
+                              double *pieces, long long cap_pieces, int *ring_off, double *rx, double *ry, long long cap_ring) {
+  long long np = 0, nr = 0;
+  piece_off[0] = 0; ring_off[0] = 0;
+  for (int s = 0; s < nsel; ++s) {
+    const std::vector<CornerPiece> P = frac_corner_plain(F, ids[s] - 1, grind + offsets[s]);
+    npieces[s] = (int)P.size();
+    for (const CornerPiece &q : P) {
+      if (np + 1 > cap_pieces || nr + (long long)q.cx.size() > cap_ring) return -3;
+      for (int k = 0; k < 12; ++k) pieces[np * 12 + k] = q.rec[k];
+      for (size_t k = 0; k < q.cx.size(); ++k) { rx[nr + (long long)k] = q.cx[k]; ry[nr + (long long)k] = q.cy[k]; }
+      ++np; nr += (long long)q.cx.size(); ring_off[np] = (int)nr;
+    }
+    piece_off[s + 1] = (int)np;
+  }
+  return 0;
+}
+
 // ids[q]: 1-based floe numbers of Floe(~keep); inter_off / inter: the floes' contact rows (7 columns, CSR), as the step
 // left them.  offsets[nsub + 1], count[nsub], angles / da at the offsets (stored outline lengths back to back).
 extern "C" int or_corner_candidates(const OrFloes *F, const int *inter_off, const double *inter, const int *ids, int nsub, int Nb,

@@ -146,7 +146,7 @@ EXPORTS = [
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
-    "szEulerianData", "szCornerCandidates", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
+    "szEulerianData", "szCornerCandidates", "szCornerCuts", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
@@ -405,6 +405,27 @@ class FloeInteractions:
                                                      da.ctypes.data_as(u8), total, ctypes.byref(n_ext), ctypes.byref(ms)),
                        "szCornerCandidates")
         return offsets, count[:nsub], ang[:total], da[:total], n_ext.value, ms.value
+
+    def corner_cuts(self, ids, offsets, grind):
+        """frac_corner.m for the plain case (include/subzero_hip.h szCornerCuts): ids (1-based), offsets / grind as
+        corner_candidates laid them out -> (npieces per floe, piece_off, pieces [P x 12], rings: list of 2 x m closed c_alpha,
+        kernel ms).  npieces[s] = 0: leave floe s to frac_corner.m."""
+        ids = np.ascontiguousarray(ids, np.int32); offsets = np.ascontiguousarray(offsets, np.int32)
+        grind = np.ascontiguousarray(grind, np.uint8)
+        nsel = len(ids)
+        cap_p = int(nsel + grind.sum() + 1); cap_r = int(offsets[-1] + nsel + 5 * grind.sum() + 8)
+        npieces = np.zeros(max(nsel, 1), np.int32); poff = np.zeros(nsel + 1, np.int32)
+        pieces = np.zeros((cap_p, 12)); roff = np.zeros(cap_p + 1, np.int32); rx = np.zeros(cap_r); ry = np.zeros(cap_r)
+        ms = ctypes.c_double()
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        L = self.ctx.L
+        L.szCornerCuts.argtypes = [_vp, _ip, ctypes.c_int, _ip, u8, _ip, _ip, _dp, ctypes.c_int64, _ip, _dp, _dp, ctypes.c_int64, _dp]
+        self.ctx.check(L.szCornerCuts(self.ctx.h, ids.ctypes.data_as(_ip), nsel, offsets.ctypes.data_as(_ip), grind.ctypes.data_as(u8),
+                                      npieces.ctypes.data_as(_ip), poff.ctypes.data_as(_ip), pieces.ctypes.data_as(_dp), cap_p,
+                                      roff.ctypes.data_as(_ip), rx.ctypes.data_as(_dp), ry.ctypes.data_as(_dp), cap_r, ctypes.byref(ms)), "szCornerCuts")
+        P = int(poff[nsel])
+        rings = [np.stack([rx[roff[q]:roff[q + 1]], ry[roff[q]:roff[q + 1]]]) for q in range(P)]
+        return npieces[:nsel], poff, pieces[:P], rings, ms.value
 
     def fracture_deform(self, ids):
         """fracture_floe.m:14-52 for the floes ids (1-based) on the contact rows of the last step ->

@@ -64,7 +64,98 @@ __global__ void __launch_bounds__(64) k_corner_flags(Floes F, Work W, const int 
   }
 }
 
+// frac_corner.m for the plain case (corners.hpp frac_corner_plain): a thread per selected floe; every floe writes into the
+// slots the host laid out from its vertex and corner counts
+__global__ void k_corner_cuts(Floes F, const int *ids, int nsel, const int *voff, const unsigned char *grind_in, const int *slot_piece, const int *slot_ring,
+                              const int *slot_tmp, unsigned char *grind_tmp, double *tmpx, double *tmpy, int *npieces, double *rec, int *ring_off, double *rx, double *ry) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsel) return;
+  const int i = ids[s] - 1;
+  const int v0 = F.vert_off[i];
+  int n = F.vert_off[i + 1] - v0;
+  const double *x = F.cax + v0, *y = F.cay + v0;
+  if (n > 1 && x[0] == x[n - 1] && y[0] == y[n - 1]) --n;                      // corners.m:66-68
+  unsigned char *g = grind_tmp + voff[s];
+  for (int k = 0; k < n; ++k) g[k] = grind_in[voff[s] + k];
+  npieces[s] = szk::frac_corner_plain(x, y, n, g, F.mass[i], F.area[i], F.ksi_ice[i], F.Xi[i], F.Yi[i], tmpx + slot_tmp[s], tmpy + slot_tmp[s],
+                                      rec + (size_t)slot_piece[s] * szk::PIECE_WORDS, rx + slot_ring[s], ry + slot_ring[s], ring_off + slot_piece[s] + s, DetAcos());
+}
+
 } // namespace
+
+extern "C" int szCornerCuts(szContext *ctx, const int32_t *ids, int nsel, const int32_t *offsets, const uint8_t *grind, int32_t *npieces, int32_t *piece_off,
+                            double *pieces, int64_t cap_pieces, int32_t *ring_off, double *rx, double *ry, int64_t cap_ring, double *kernel_ms) {
+  if (!ctx || nsel < 0 || (nsel > 0 && (!ids || !offsets || !grind || !npieces)) || !piece_off || !ring_off) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szCornerCuts: no floes uploaded");
+  const int n = S->n;
+  piece_off[0] = 0; ring_off[0] = 0;
+  if (kernel_ms) *kernel_ms = 0;
+  if (nsel == 0) return SZ_OK;
+  // slots: 1 + ng pieces, n + 1 + 5 ng ring vertices, 5 n + 4 scratch values per floe
+  std::vector<int> sp((size_t)nsel + 1), sr((size_t)nsel + 1), stmp((size_t)nsel + 1);
+  sp[0] = sr[0] = stmp[0] = 0;
+  for (int s = 0; s < nsel; ++s) {
+    if (ids[s] < 1 || ids[s] > n) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szCornerCuts: ids[%d] = %d outside 1..%d", s, (int)ids[s], n);
+    const int nv = S->h_vert_off[ids[s]] - S->h_vert_off[ids[s] - 1];
+    if (offsets[s + 1] - offsets[s] < nv - 1) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szCornerCuts: offsets[%d]: room for %d vertices, the outline has %d", s, (int)(offsets[s + 1] - offsets[s]), nv);
+    int ng = 0;
+    for (int k = offsets[s]; k < offsets[s + 1]; ++k) ng += grind[k] ? 1 : 0;
+    sp[s + 1] = sp[s] + 1 + ng; sr[s + 1] = sr[s] + nv + 1 + 5 * ng; stmp[s + 1] = stmp[s] + 5 * nv + 4;
+  }
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t nvt = (size_t)offsets[nsel];
+  DevBuf d_ids, d_voff, d_g, d_gt, d_sp, d_sr, d_st, d_tx, d_ty, d_np, d_rec, d_ro, d_rx, d_ry;
+  DevBuf *all[] = {&d_ids, &d_voff, &d_g, &d_gt, &d_sp, &d_sr, &d_st, &d_tx, &d_ty, &d_np, &d_rec, &d_ro, &d_rx, &d_ry};
+  auto cleanup = [&]() { for (DevBuf *b : all) sz_release(*b); };
+  int rc;
+  if ((rc = sz_reserve(ctx, d_ids, (size_t)nsel * 4)) || (rc = sz_reserve(ctx, d_voff, ((size_t)nsel + 1) * 4)) || (rc = sz_reserve(ctx, d_g, nvt + 8)) ||
+      (rc = sz_reserve(ctx, d_gt, nvt + 8)) || (rc = sz_reserve(ctx, d_sp, ((size_t)nsel + 1) * 4)) || (rc = sz_reserve(ctx, d_sr, ((size_t)nsel + 1) * 4)) ||
+      (rc = sz_reserve(ctx, d_st, ((size_t)nsel + 1) * 4)) || (rc = sz_reserve(ctx, d_tx, (size_t)stmp[nsel] * 8 + 8)) || (rc = sz_reserve(ctx, d_ty, (size_t)stmp[nsel] * 8 + 8)) ||
+      (rc = sz_reserve(ctx, d_np, (size_t)nsel * 4)) || (rc = sz_reserve(ctx, d_rec, (size_t)sp[nsel] * szk::PIECE_WORDS * 8 + 8)) ||
+      (rc = sz_reserve(ctx, d_ro, ((size_t)sp[nsel] + nsel + 1) * 4)) || (rc = sz_reserve(ctx, d_rx, (size_t)sr[nsel] * 8 + 8)) || (rc = sz_reserve(ctx, d_ry, (size_t)sr[nsel] * 8 + 8))) { cleanup(); return rc; }
+  hipError_t he = hipMemcpyAsync(d_ids.p, ids, (size_t)nsel * 4, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_voff.p, offsets, ((size_t)nsel + 1) * 4, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_g.p, grind, nvt, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_sp.p, sp.data(), ((size_t)nsel + 1) * 4, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_sr.p, sr.data(), ((size_t)nsel + 1) * 4, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_st.p, stmp.data(), ((size_t)nsel + 1) * 4, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
+  if (he == hipSuccess)
+    hipLaunchKernelGGL(k_corner_cuts, grid_for(nsel, 64), dim3(64), 0, st, S->F, (const int *)d_ids.p, nsel, (const int *)d_voff.p, (const unsigned char *)d_g.p,
+                       (const int *)d_sp.p, (const int *)d_sr.p, (const int *)d_st.p, (unsigned char *)d_gt.p, (double *)d_tx.p, (double *)d_ty.p, (int *)d_np.p,
+                       (double *)d_rec.p, (int *)d_ro.p, (double *)d_rx.p, (double *)d_ry.p);
+  if (he == hipSuccess) he = hipEventRecord(ctx->ev1, st);
+  std::vector<int> h_np((size_t)nsel), h_ro((size_t)sp[nsel] + nsel + 1);
+  std::vector<double> h_rec((size_t)sp[nsel] * szk::PIECE_WORDS + 1), h_rx((size_t)sr[nsel] + 1), h_ry((size_t)sr[nsel] + 1);
+  if (he == hipSuccess) he = hipMemcpyAsync(h_np.data(), d_np.p, (size_t)nsel * 4, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(h_ro.data(), d_ro.p, h_ro.size() * 4, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(h_rec.data(), d_rec.p, (size_t)sp[nsel] * szk::PIECE_WORDS * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(h_rx.data(), d_rx.p, (size_t)sr[nsel] * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(h_ry.data(), d_ry.p, (size_t)sr[nsel] * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  float ms = 0;
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  cleanup();
+  if (he != hipSuccess) return sz_fail(ctx, SZ_ERR_HIP, "szCornerCuts: %s", hipGetErrorString(he));
+  if (kernel_ms) *kernel_ms = ms;
+  // pieces of the floes that were cut, back to back
+  int64_t np = 0, nr = 0;
+  for (int s = 0; s < nsel; ++s) {
+    npieces[s] = h_np[s];
+    const int *ro = h_ro.data() + sp[s] + s;
+    for (int q = 0; q < h_np[s]; ++q) {
+      const int m = ro[q + 1] - ro[q];
+      if (np + 1 > cap_pieces || nr + m > cap_ring) return sz_fail(ctx, SZ_ERR_CAPACITY, "szCornerCuts: output capacity (%lld pieces, %lld vertices) is too small", (long long)cap_pieces, (long long)cap_ring);
+      memcpy(pieces + np * szk::PIECE_WORDS, h_rec.data() + ((size_t)sp[s] + q) * szk::PIECE_WORDS, szk::PIECE_WORDS * 8);
+      memcpy(rx + nr, h_rx.data() + sr[s] + ro[q], (size_t)m * 8); memcpy(ry + nr, h_ry.data() + sr[s] + ro[q], (size_t)m * 8);
+      ++np; nr += m; ring_off[np] = (int32_t)nr;
+    }
+    piece_off[s + 1] = (int32_t)np;
+  }
+  return SZ_OK;
+}
 
 extern "C" int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, int Nb, const double *c2b, int32_t *offsets, int32_t *count,
                                   double *angles, uint8_t *da, int64_t cap, int32_t *n_ext, double *kernel_ms) {

@@ -118,4 +118,181 @@ SZ_HD int nearest_vertex(double px, double py, const double *x, const double *y,
   return best;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// frac_corner.m:1-189 for the PLAIN case: every corner to break off is convex, its two cut points lie
+// inside the two adjacent edges without meeting the cut of a neighbouring corner, and the cut neither crosses another
+// edge nor leaves an empty piece.  Then the reference's polyshape operations have closed forms: poly1 of :66-93 is the
+// outline with the one corner replaced by its two cut points, poly2 the triangle, and subtract(poly, union(triangles))
+// of :160-161 the outline with every broken corner replaced -- no boolean operation is needed.  Anything else returns 0
+// (nothing written): the caller leaves that floe to frac_corner.m itself.
+// polyshape conventions assumed (the reference holds no output of these functions to pin them):
+// area / centroid = the shoelace forms relative to the first vertex (contact.hpp region_area / region_centroid), outlines
+// listed clockwise from the first surviving stored vertex, a new triangle from its first cut point.
+// Monte-Carlo points of the new floes (:124-126,:178-180) are rand: the caller draws them (the step reports floes whose
+// mask is empty: SZ_STEP_NEEDS_MC).
+// ---------------------------------------------------------------------------------------------------------------------
+enum { PIECE_KIND = 0, PIECE_XI, PIECE_YI, PIECE_AREA, PIECE_MASS, PIECE_H, PIECE_INERTIA, PIECE_RMAX, PIECE_ALIVE, PIECE_KSI,
+       PIECE_STRESS_FACTOR, PIECE_NV, PIECE_WORDS = 12 };
+
+SZ_HD double ring_area_abs(const double *x, const double *y, int n) {
+  if (n < 3) return 0;
+  double s = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = (i + 1 == n) ? 0 : i + 1;
+    const double ax = x[i] - x[0], ay = y[i] - y[0], bx = x[k] - x[0], by = y[k] - y[0];
+    s += ax * by - bx * ay;
+  }
+  return absd(0.5 * s);
+}
+SZ_HD void ring_centroid_of(const double *x, const double *y, int n, double &cx, double &cy) {
+  double s = 0, sx = 0, sy = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = (i + 1 == n) ? 0 : i + 1;
+    const double ax = x[i] - x[0], ay = y[i] - y[0], bx = x[k] - x[0], by = y[k] - y[0];
+    const double w = ax * by - bx * ay;
+    s += w; sx += (ax + bx) * w; sy += (ay + by) * w;
+  }
+  cx = x[0] + sx / (3.0 * s); cy = y[0] + sy / (3.0 * s);
+}
+// PolygonMoments.m:14-32 on the closed ring (rows v1..vn, v1; the function appends v1 once more)
+SZ_HD double polygon_moment(const double *cx, const double *cy, int nclosed, double h) {
+  double ixx = 0, iyy = 0;
+  for (int i = 0; i < nclosed; ++i) {
+    const int k = (i + 1 == nclosed) ? 0 : i + 1;          // (the appended row is v1 again: row nclosed + 1 = row 1)
+    const double x0 = cx[i], y0 = cy[i], x1 = (i + 1 == nclosed) ? cx[0] : cx[k], y1 = (i + 1 == nclosed) ? cy[0] : cy[k];
+    const double wi = x0 * y1 - x1 * y0;
+    ixx += wi * ((y0 + y1) * (y0 + y1) - y0 * y1);
+    iyy += wi * ((x0 + x1) * (x0 + x1) - x0 * x1);
+  }
+  return absd(1.0 / 12 * ixx + 1.0 / 12 * iyy) * h * 920.0;
+}
+// do the closed segments a-b and c-d meet (touching counts)?
+SZ_HD bool segments_meet(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
+  const double d1 = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax), d2 = (bx - ax) * (dy - ay) - (by - ay) * (dx - ax);
+  const double d3 = (dx - cx) * (ay - cy) - (dy - cy) * (ax - cx), d4 = (dx - cx) * (by - cy) - (dy - cy) * (bx - cx);
+  if (((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0))) return true;
+  auto on = [](double px, double py, double qx, double qy, double rx, double ry) {   // r on segment p-q, given collinear
+    return mind(px, qx) <= rx && rx <= maxd(px, qx) && mind(py, qy) <= ry && ry <= maxd(py, qy);
+  };
+  if (d1 == 0 && on(ax, ay, bx, by, cx, cy)) return true;
+  if (d2 == 0 && on(ax, ay, bx, by, dx, dy)) return true;
+  if (d3 == 0 && on(cx, cy, dx, dy, ax, ay)) return true;
+  if (d4 == 0 && on(cx, cy, dx, dy, bx, by)) return true;
+  return false;
+}
+// one piece into the output: scalars of frac_corner.m:104-136 / :163-185 and the closed c_alpha ring
+SZ_HD void put_piece(double kind, const double *px, const double *py, int m, double mass, double floe_area_field, double floe_ksi,
+                     double stress_factor, double fx, double fy, double *rec, double *rx, double *ry) {
+  double cx, cy;
+  ring_centroid_of(px, py, m, cx, cy);
+  const double area = ring_area_abs(px, py, m);
+  double r2 = 0;
+  for (int k = 0; k < m; ++k) { const double dx = px[k] - cx, dy = py[k] - cy; rx[k] = dx; ry[k] = dy; r2 = maxd(r2, dx * dx + dy * dy); }
+  rx[m] = px[0] - cx; ry[m] = py[0] - cy;
+  const double h = mass / (920.0 * area);
+  rec[PIECE_KIND] = kind; rec[PIECE_XI] = fx + cx; rec[PIECE_YI] = fy + cy; rec[PIECE_AREA] = area; rec[PIECE_MASS] = mass; rec[PIECE_H] = h;
+  rec[PIECE_INERTIA] = polygon_moment(rx, ry, m + 1, h); rec[PIECE_RMAX] = ::sqrt(r2); rec[PIECE_ALIVE] = (area < 1e4) ? 0.0 : 1.0;
+  rec[PIECE_KSI] = area / floe_area_field * floe_ksi; rec[PIECE_STRESS_FACTOR] = stress_factor; rec[PIECE_NV] = (double)(m + 1);
+}
+
+// x, y[n]: the floe's outline without its closing copy (corners.m:63-68), grind[n] (modified: the quirk of :12-14).
+// tmpx / tmpy: n + 2 * n doubles of scratch.  Output: rec[(1 + ng) * PIECE_WORDS], rings at rx / ry (capacity
+// n + 1 + 5 ng), ring_off[2 + ng].  -> number of pieces (main first, then the triangles in vertex order), 0: not plain.
+template <class Acos>
+SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned char *grind, double mass, double area_field, double ksi,
+                            double fx, double fy, double *tmpx, double *tmpy, double *rec, double *rx, double *ry, int *ring_off, Acos acos_fn) {
+  if (n < 3) return 0;
+  // :9-15
+  double alph = 1e300;
+  int ng = 0;
+  bool equal_angles = false;
+  for (int k = 0; k < n; ++k) {
+    const double a = interior_angle(k, x, y, n, acos_fn);
+    tmpx[k] = a;
+    alph = mind(alph, a);
+  }
+  for (int k = 0; k < n; ++k) if (grind[k]) { ++ng; for (int m = 0; m < k; ++m) if (grind[m] && tmpx[m] == tmpx[k]) equal_angles = true; }
+  if (equal_angles && grind[0] && grind[n - 1]) { grind[n - 1] = 0; --ng; }
+  if (ng == 0) return 0;
+  const double Anorm = 180.0 - 360.0 / n;
+  const double poly_area = ring_area_abs(x, y, n);
+  if (!(poly_area > 0)) return 0;
+  // cut points of every ground corner (:20-52)
+  double *c1x = tmpx, *c1y = tmpy, *c2x = tmpx + n, *c2y = tmpy + n;
+  for (int k = 0; k < n; ++k) {
+    if (!grind[k]) continue;
+    if (interior_angle(k, x, y, n, acos_fn) >= 180) return 0;                   // (a reflex corner: the cut would add ice)
+    const int kp = (k == 0) ? n - 1 : k - 1, kn = (k + 1 == n) ? 0 : k + 1;
+    const double X1 = x[kp], Y1 = y[kp], X2 = x[k], Y2 = y[k], X3 = x[kn], Y3 = y[kn];
+    const double d1 = ::sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2)), d2 = ::sqrt((X3 - X2) * (X3 - X2) + (Y3 - Y2) * (Y3 - Y2));
+    const double d = mind(d1, d2);
+    double x1, y1, x2, y2;
+    if (absd(X1 - X2) < 120 && absd(Y1 - Y2) < 120) return 0;                 // (the cut would take the whole edge: not plain)
+    else if (absd(d * alph / Anorm / 5) < 120) { x1 = X2 + 120 / d1 * (X1 - X2); y1 = Y2 + 120 / d1 * (Y1 - Y2); }
+    else { x1 = X2 + d / d1 * alph / Anorm * (X1 - X2) / 5; y1 = Y2 + d / d1 * alph / Anorm * (Y1 - Y2) / 5; }
+    if (absd(X3 - X2) < 120 && absd(Y3 - Y2) < 120) return 0;
+    else if (absd(d * alph / Anorm / 5) < 120) { x2 = X2 + 120 / d2 * (X3 - X2); y2 = Y2 + 120 / d2 * (Y3 - Y2); }
+    else { x2 = X2 + d / d2 * alph / Anorm * (X3 - X2) / 5; y2 = Y2 + d / d2 * alph / Anorm * (Y3 - Y2) / 5; }
+    if (absd(x1 - x2) < 0.1) x1 = x1 + 1;                                       // :50-52
+    c1x[k] = x1; c1y[k] = y1; c2x[k] = x2; c2y[k] = y2;
+    // the cut must stay inside its two edges and meet no other edge of the outline
+    const double t1 = ::sqrt((x1 - X2) * (x1 - X2) + (y1 - Y2) * (y1 - Y2)), t2 = ::sqrt((x2 - X2) * (x2 - X2) + (y2 - Y2) * (y2 - Y2));
+    if (!(t1 > 0 && t1 < d1 && t2 > 0 && t2 < d2)) return 0;
+    for (int e = 0; e < n; ++e) {
+      const int e1 = (e + 1 == n) ? 0 : e + 1;
+      if (e == kp || e == k) continue;                                          // the two edges at the corner
+      if (segments_meet(x1, y1, x2, y2, x[e], y[e], x[e1], y[e1])) return 0;
+    }
+  }
+  // neighbouring corners: their cuts on the shared edge must not meet
+  for (int k = 0; k < n; ++k) {
+    const int kn = (k + 1 == n) ? 0 : k + 1;
+    if (!(grind[k] && grind[kn])) continue;
+    const double L = ::sqrt((x[kn] - x[k]) * (x[kn] - x[k]) + (y[kn] - y[k]) * (y[kn] - y[k]));
+    const double ta = ::sqrt((c2x[k] - x[k]) * (c2x[k] - x[k]) + (c2y[k] - y[k]) * (c2y[k] - y[k]));
+    const double tb = ::sqrt((c1x[kn] - x[kn]) * (c1x[kn] - x[kn]) + (c1y[kn] - y[kn]) * (c1y[kn] - y[kn]));
+    if (!(ta + tb < L)) return 0;
+  }
+  // the main piece: every ground corner replaced by its two cut points (:159-185)
+  double *mx = rx, *my = ry;                       // built in place at the head of the ring output, then re-centred
+  int m = 0;
+  double *bx = tmpx + 2 * n, *by = tmpy + 2 * n;   // (scratch beyond the cut points: n + ng values)
+  for (int k = 0; k < n; ++k) {
+    if (grind[k]) { bx[m] = c1x[k]; by[m] = c1y[k]; ++m; bx[m] = c2x[k]; by[m] = c2y[k]; ++m; }
+    else { bx[m] = x[k]; by[m] = y[k]; ++m; }
+  }
+  const double new_area = ring_area_abs(bx, by, m);
+  if (!(new_area > 0)) return 0;
+  int np = 0, at = 0;
+  ring_off[0] = 0;
+  put_piece(0.0, bx, by, m, mass * new_area / poly_area, area_field, ksi, new_area / poly_area, fx, fy, rec, mx, my);
+  at += m + 1; ++np; ring_off[np] = at;
+  // the triangles (:66-136), each with the Atot of ITS single cut
+  for (int k = 0; k < n; ++k) {
+    if (!grind[k]) continue;
+    double tx[3] = {c1x[k], c2x[k], x[k]}, ty[3] = {c1y[k], c2y[k], y[k]};
+    const double ta = ring_area_abs(tx, ty, 3);
+    if (!(ta > 0)) return 0;
+    // area of poly1: the outline with this one corner replaced = the outline less the triangle (the corner is convex)
+    double *px = bx + m, *py = by + m;              // scratch for poly1 (n + 1 vertices)
+    int q = 0;
+    for (int v = 0; v < n; ++v) {
+      if (v == k) { px[q] = c1x[k]; py[q] = c1y[k]; ++q; px[q] = c2x[k]; py[q] = c2y[k]; ++q; }
+      else { px[q] = x[v]; py[q] = y[v]; ++q; }
+    }
+    const double a1 = ring_area_abs(px, py, q);
+    double Atot = 0;
+    if (a1 > 10) Atot += a1;
+    if (ta > 10) Atot += ta;
+    if (!(Atot > 0)) return 0;
+    const double Mtot = mass * Atot / poly_area;
+    // clockwise, from the first cut point
+    const double sgn_area = (tx[1] - tx[0]) * (ty[2] - ty[0]) - (tx[2] - tx[0]) * (ty[1] - ty[0]);
+    if (sgn_area > 0) { const double sx = tx[1], sy = ty[1]; tx[1] = tx[2]; ty[1] = ty[2]; tx[2] = sx; ty[2] = sy; }
+    put_piece(1.0, tx, ty, 3, Mtot * ta / Atot, area_field, ksi, ta / Atot, fx, fy, rec + (size_t)np * PIECE_WORDS, rx + at, ry + at);
+    at += 4; ++np; ring_off[np] = at;
+  }
+  return np;
+}
+
 } // namespace szk

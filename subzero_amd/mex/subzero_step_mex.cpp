@@ -442,6 +442,50 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     }
     return;
   }
+  if (!strcmp(cmd, "cuts")) {
+    // K = subzero_step('cuts', ids, grind): frac_corner.m for the plain case (szCornerCuts).  grind: the `grind` vectors
+    // of corners.m:91 of the listed floes one after the other (each as long as the floe's outline without its closing
+    // copy, or with it: a trailing entry is ignored).  K(q).pieces: P x 12 (0 rows: leave the floe to frac_corner.m),
+    // K(q).rings: 2 x M, the closed c_alpha rings of the P pieces side by side, K(q).ring_off: 1 x (P + 1) (0-based)
+    if (nrhs < 4) mexErrMsgTxt("K = subzero_step('cuts', ids, grind, lengths)   (grind: the floes' grind vectors one after the other, lengths: of each)");
+    const std::vector<int32_t> ids = parse_ids(prhs[1], n);
+    const int nsel = (int)ids.size();
+    if ((int)mxGetNumberOfElements(prhs[3]) != nsel || !mxIsDouble(prhs[3])) mexErrMsgTxt("subzero_step('cuts'): lengths must hold one number per listed floe");
+    if (!(mxIsDouble(prhs[2]) || mxIsLogical(prhs[2]))) mexErrMsgTxt("subzero_step('cuts'): grind must be logical or double");
+    std::vector<int32_t> off((size_t)nsel + 1, 0);
+    for (int q = 0; q < nsel; ++q) off[(size_t)q + 1] = off[q] + (g_soa.vert_off[ids[q]] - g_soa.vert_off[ids[q] - 1]);
+    std::vector<uint8_t> grind((size_t)off[nsel] + 1, 0);
+    int64_t ng = 0, at = 0;
+    const int64_t total = (int64_t)mxGetNumberOfElements(prhs[2]);
+    for (int q = 0; q < nsel; ++q) {
+      const int m = (int)mxGetPr(prhs[3])[q];
+      if (m < 0 || m > off[(size_t)q + 1] - off[q] || at + m > total) fail("subzero_step('cuts'): lengths(%d) = %d does not fit the floe (%d vertices) or the grind vector", q + 1, m, off[(size_t)q + 1] - off[q]);
+      for (int k = 0; k < m; ++k) {
+        const bool on = mxIsLogical(prhs[2]) ? ((const unsigned char *)mxGetData(prhs[2]))[at + k] != 0 : mxGetPr(prhs[2])[at + k] != 0;
+        grind[(size_t)off[q] + k] = on ? 1 : 0; ng += on;
+      }
+      at += m;
+    }
+    const int64_t cap_p = nsel + ng + 1, cap_r = off[nsel] + nsel + 5 * ng + 8;
+    std::vector<int32_t> npieces((size_t)nsel + 1), poff((size_t)nsel + 1), roff((size_t)cap_p + 1);
+    std::vector<double> pieces((size_t)cap_p * 12), rx((size_t)cap_r), ry((size_t)cap_r);
+    check(szCornerCuts(g_ctx, ids.data(), nsel, off.data(), grind.data(), npieces.data(), poff.data(), pieces.data(), cap_p, roff.data(), rx.data(), ry.data(), cap_r, nullptr));
+    const char *names[] = {"pieces", "rings", "ring_off"};
+    plhs[0] = mxCreateStructMatrix(1, (size_t)nsel, 3, names);
+    for (int q = 0; q < nsel; ++q) {
+      const int P = poff[(size_t)q + 1] - poff[q];
+      mxArray *pm = mxCreateDoubleMatrix((size_t)P, P ? 12 : 0, mxREAL);
+      const int r0 = roff[(size_t)poff[q]], M = roff[(size_t)poff[q] + P] - r0;
+      mxArray *rings = mxCreateDoubleMatrix(M ? 2 : 0, (size_t)M, mxREAL), *ro = mxCreateDoubleMatrix(1, (size_t)P + 1, mxREAL);
+      for (int k = 0; k < P; ++k) for (int w = 0; w < 12; ++w) mxGetPr(pm)[(size_t)w * P + k] = pieces[((size_t)poff[q] + k) * 12 + w];
+      for (int v = 0; v < M; ++v) { mxGetPr(rings)[2 * v] = rx[(size_t)r0 + v]; mxGetPr(rings)[2 * v + 1] = ry[(size_t)r0 + v]; }
+      for (int k = 0; k <= P; ++k) mxGetPr(ro)[k] = roff[(size_t)poff[q] + k] - r0;
+      mxSetFieldByNumber(plhs[0], (size_t)q, 0, pm);
+      mxSetFieldByNumber(plhs[0], (size_t)q, 1, rings);
+      mxSetFieldByNumber(plhs[0], (size_t)q, 2, ro);
+    }
+    return;
+  }
   if (!strcmp(cmd, "deform")) {
     if (nrhs < 2) mexErrMsgTxt("D = subzero_step('deform', ids)");
     const std::vector<int32_t> ids = parse_ids(prhs[1], n);

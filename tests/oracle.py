@@ -243,6 +243,28 @@ def polyangles(x, y):
     return out
 
 
+def frac_corner(S, ids, offsets, grind):
+    """frac_corner.m:1-189 restated (oracle) for the plain case, for the floes ids (1-based) with the grind flags laid
+    out at `offsets` -> (npieces per floe, piece_off, pieces [P x 12], rings: list of 2 x m closed c_alpha)."""
+    L = lib()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    L.or_frac_corner.argtypes = [ctypes.POINTER(CFloes), ip, ctypes.c_int, ip, u8, ip, ip, _dp, ctypes.c_longlong, ip, _dp, _dp, ctypes.c_longlong]
+    ids = np.ascontiguousarray(ids, np.int32); offsets = np.ascontiguousarray(offsets, np.int32); grind = np.ascontiguousarray(grind, np.uint8)
+    nsel = len(ids)
+    cap_p = int(nsel + grind.sum() + 1); cap_r = int(offsets[-1] + nsel + 5 * grind.sum() + 8)
+    npieces = np.zeros(max(nsel, 1), np.int32); poff = np.zeros(nsel + 1, np.int32)
+    pieces = np.zeros((cap_p, 12)); roff = np.zeros(cap_p + 1, np.int32); rx = np.zeros(cap_r); ry = np.zeros(cap_r)
+    cf = pack_floes(S)
+    rc = L.or_frac_corner(ctypes.byref(cf), ids.ctypes.data_as(ip), nsel, offsets.ctypes.data_as(ip), grind.ctypes.data_as(u8),
+                          npieces.ctypes.data_as(ip), poff.ctypes.data_as(ip), _p(pieces), cap_p, roff.ctypes.data_as(ip), _p(rx), _p(ry), cap_r)
+    if rc != 0:
+        raise RuntimeError("or_frac_corner failed: %d" % rc)
+    P = int(poff[nsel])
+    rings = [np.stack([rx[roff[q]:roff[q + 1]], ry[roff[q]:roff[q + 1]]]) for q in range(P)]
+    return npieces[:nsel], poff, pieces[:P], rings
+
+
 def corner_candidates(S, inter_off, inter, ids, Nb, c2_boundary):
     """corners.m:13-92 restated (oracle) for the floes ids (1-based, Floe(~keep) order) ->
     (offsets, count, angles, da, N0)."""

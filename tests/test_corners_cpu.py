@@ -122,3 +122,66 @@ def test_selection_rule_and_grind_flags():
     assert list(frac) == [False, False]
     grind, frac = corners.grind_flags(offsets, count, np.array([30.0, 30, 30, 30, 0, 0, 0, 0, 0]), da, draws)
     assert list(grind[:4]) == [True, True, False, True] and list(frac) == [True, False]
+
+
+def test_frac_corner_known_answer_on_a_square():
+    """frac_corner.m:20-52 on a 10 km square with one corner broken: every angle 90, Anorm = 90, alph = 90, so the cut
+    points lie a fifth of the side from the corner -- a 2000 x 2000 m right triangle (2e6 m^2) comes off, the floe keeps
+    1e8 - 2e6 m^2, masses and the Stress factors in proportion (:98-108, :166-172)."""
+    import scenes
+    S, P = scenes.pack(6, periodic=False)
+    i = 2
+    a, b = int(S.vert_off[i]), int(S.vert_off[i + 1])
+    # overwrite floe i's outline by a square of the same vertex count?  -- build a one-floe state instead
+    from subzero_amd import synth
+    h = 5e3
+    ring = np.array([[-h, h], [h, h], [h, -h], [-h, -h], [-h, h]])
+    T = S.subset([i]) if hasattr(S, "subset") else None
+    if T is None:
+        T = S.copy()
+        T.n = 1
+        T.vert_off = np.array([0, 5], np.int32)
+        T.cax = ring[:, 0].copy(); T.cay = ring[:, 1].copy(); T.c0x = ring[:, 0].copy(); T.c0y = ring[:, 1].copy()
+        for k in ("Xi", "Yi", "mass", "area", "ksi_ice", "alive", "h"):
+            setattr(T, k, np.asarray(getattr(S, k))[:1].copy())
+        T.Xi[:] = 500.0; T.Yi[:] = -200.0; T.area[:] = 1e8; T.mass[:] = 920.0 * 1e8 * 0.5; T.ksi_ice[:] = 2e-6
+    grind = np.array([0, 1, 0, 0], np.uint8)             # the top-right corner
+    npieces, poff, pieces, rings = oracle.frac_corner(T, [1], [0, 4], grind)
+    assert npieces[0] == 2 and len(pieces) == 2
+    main, tri = pieces
+    assert main[0] == 0 and tri[0] == 1
+    assert abs(tri[3] - 2e6) < 1e-3 and abs(main[3] - (1e8 - 2e6)) < 1e-3
+    assert abs(main[4] - T.mass[0] * (1e8 - 2e6) / 1e8) < 1e-3 and abs(tri[4] - T.mass[0] * 2e6 / 1e8) < 1e-3
+    assert abs(main[10] - (1 - 0.02)) < 1e-12 and abs(tri[10] - 0.02) < 1e-12
+    assert abs(main[5] - 0.5) < 1e-12 and abs(tri[5] - 0.5) < 1e-12          # h = mass / (rho area): unchanged
+    assert main[8] == 1 and tri[8] == 1 and main[11] == 6 and tri[11] == 4   # both alive; closed rings of 5 + 1 and 3 + 1
+    # the triangle's centroid: a third of the way from the corner (5000, 5000) to the two cut points
+    assert abs(tri[1] - (500 + 5e3 - 2e3 / 3)) < 1e-6 and abs(tri[2] - (-200 + 5e3 - 2e3 / 3)) < 1e-6
+    assert abs(tri[7] - np.hypot(2e3 / 3, 4e3 / 3)) < 1e-6                   # rmax: the centroid to a cut point
+    # two equal angles with the first and the last vertex both marked: the last one is left alone (:11-14)
+    grind = np.array([1, 0, 0, 1], np.uint8)
+    npieces, poff, pieces, rings = oracle.frac_corner(T, [1], [0, 4], grind)
+    assert npieces[0] == 2 and abs(pieces[1][3] - 2e6) < 1e-3
+    # both neighbours of one edge broken: cuts of 2000 m each on a 10 km edge stay apart -> three pieces
+    grind = np.array([0, 1, 1, 0], np.uint8)
+    npieces, poff, pieces, rings = oracle.frac_corner(T, [1], [0, 4], grind)
+    assert npieces[0] == 3 and abs(pieces[0][3] - (1e8 - 4e6)) < 1e-3
+    # a sliver whose short edges are under 120 m: the whole edge would go -> not the plain case
+    T.cax[:] = np.array([-50, 50, 50, -50, -50.0]); T.c0x[:] = T.cax
+    npieces, poff, pieces, rings = oracle.frac_corner(T, [1], [0, 4], np.array([0, 1, 0, 0], np.uint8))
+    assert npieces[0] == 0 and len(pieces) == 0
+
+
+def test_generated_outlines_have_no_collinear_vertices():
+    """polyshape's default KeepCollinearPoints = false would drop a collinear vertex and shift the indices of `angles` and
+    `grind` (corners.m:63-71): the restatement takes poly.Vertices to be the stored outline, which is only right when no
+    stored vertex is collinear with its neighbours.  Checked for the outlines the scene generators produce."""
+    import scenes
+    for S, _ in (scenes.pack(400, periodic=True), scenes.concave(60), scenes.many_sided(64)):
+        for i in range(S.n):
+            a, b = int(S.vert_off[i]), int(S.vert_off[i + 1]) - 1          # without the closing copy
+            x, y = S.c0x[a:b], S.c0y[a:b]
+            px, py, nx, ny = np.roll(x, 1), np.roll(y, 1), np.roll(x, -1), np.roll(y, -1)
+            cross = (x - px) * (ny - y) - (y - py) * (nx - x)
+            scale = np.hypot(x - px, y - py) * np.hypot(nx - x, ny - y)
+            assert (np.abs(cross) > 1e-9 * scale).all(), i

@@ -57,6 +57,34 @@ def test_corner_candidates_match_the_oracle(ctx, scene, periodic):
     assert (cnt > 0).sum() > 10 and da.sum() > 20 and grind.sum() > 0
     print("corners %s periodic=%d: %d selected, %d eligible, %d vertices flagged, %d ground, %d floes to reshape, %.3f ms"
           % (scene, periodic, len(ids), (cnt > 0).sum(), da.sum(), grind.sum(), frac.sum(), ms))
+    # frac_corner.m for the floes to reshape (corners.m:94-98): the pieces of the plain case, device against oracle
+    # (the oracle works on the downloaded state: the same floes the device holds)
+    sel = np.nonzero(frac)[0]
+    fids = ids[sel]
+    foff = np.zeros(len(sel) + 1, np.int32)
+    fgrind = []
+    for k, q in enumerate(sel):
+        n = int(G.vert_off[ids[q]] - G.vert_off[ids[q] - 1])
+        g = np.zeros(n, np.uint8); g[:cnt[q]] = grind[off[q]:off[q] + cnt[q]]
+        fgrind.append(g); foff[k + 1] = foff[k] + n
+    fgrind = np.concatenate(fgrind) if fgrind else np.zeros(0, np.uint8)
+    onp, opoff, opieces, orings = oracle.frac_corner(G, fids, foff, fgrind)
+    gnp, gpoff, gpieces, grings, cms = sim.corner_cuts(fids, foff, fgrind)
+    assert np.array_equal(onp, gnp) and np.array_equal(opoff, gpoff)
+    assert np.array_equal(opieces, gpieces), float(np.abs(opieces - gpieces).max())
+    assert len(orings) == len(grings) and all(np.array_equal(a, b) for a, b in zip(orings, grings))
+    cut = (gnp > 0).sum()
+    assert cut > 0 and (gpieces[:, 0] == 1).sum() >= cut
+    # what every cut conserves: the pieces of a floe add up to its area and mass (no boolean operation lost or made ice)
+    for k in np.nonzero(gnp > 0)[0]:
+        i = fids[k] - 1
+        a, b = int(G.vert_off[i]), int(G.vert_off[i + 1])
+        x, y = G.cax[a:b - 1], G.cay[a:b - 1]
+        area0 = 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(np.roll(x, -1), y))
+        pc = gpieces[gpoff[k]:gpoff[k + 1]]
+        assert abs(pc[:, 3].sum() - area0) <= 1e-9 * area0
+        assert abs(pc[:, 4].sum() - G.mass[i]) <= 1e-9 * G.mass[i]
+    print("frac_corner: %d floes to reshape, %d cut on the device (%d pieces), %d left to frac_corner.m, %.3f ms" % (len(sel), cut, len(gpieces), (gnp == 0).sum(), cms))
 
 
 def test_corner_candidates_argument_errors(ctx):

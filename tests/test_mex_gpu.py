@@ -195,6 +195,28 @@ def test_step_gateway_corners_and_eulerian_commands(stepgw):
         a = mx.to_numpy(mx.get_field(C, q, "angles")).ravel(); d = mx.to_numpy(mx.get_field(C, q, "da")).ravel()
         assert len(a) == cnt[q] == len(d)
         assert np.array_equal(a, ang[off[q]:off[q] + cnt[q]]) and np.array_equal(d, da[off[q]:off[q] + cnt[q]].astype(float))
+    # 'cuts': frac_corner.m for the plain case, the pieces as the oracle restates them (two corners of every eligible floe
+    # marked: the vertices with the largest `da`-free choice do not matter here, only that both sides see the same flags)
+    sel = [q for q in range(len(ids)) if cnt[q] >= 4][:12]
+    glist = []
+    for q in sel:
+        g = np.zeros(cnt[q]); g[1] = 1; g[cnt[q] // 2 + 1 if cnt[q] // 2 + 1 < cnt[q] else 0] = 1
+        glist.append(g)
+    K, = stepgw.call(1, mx.string("cuts"), mx.row(ids[sel]), mx.numeric(np.concatenate(glist)), mx.row([len(g) for g in glist]))
+    foff = np.zeros(len(sel) + 1, np.int32); fg = []
+    for k, q in enumerate(sel):
+        nst = int(G.vert_off[ids[q]] - G.vert_off[ids[q] - 1])
+        gg = np.zeros(nst, np.uint8); gg[:cnt[q]] = glist[k]; fg.append(gg); foff[k + 1] = foff[k] + nst
+    onp, opoff, opieces, orings = oracle.frac_corner(G, ids[sel].astype(np.int32), foff, np.concatenate(fg))
+    assert mx.numel(K) == len(sel) and (onp > 0).sum() >= 1
+    for k in range(len(sel)):
+        pm = mx.to_numpy(mx.get_field(K, k, "pieces"))
+        assert pm.shape[0] == onp[k]
+        if onp[k]:
+            assert np.array_equal(pm, opieces[opoff[k]:opoff[k + 1]])
+            rings = mx.to_numpy(mx.get_field(K, k, "rings")); ro = mx.to_numpy(mx.get_field(K, k, "ring_off")).ravel().astype(int)
+            for t in range(onp[k]):
+                assert np.array_equal(rings[:, ro[t]:ro[t + 1]], orings[opoff[k] + t])
     E, = stepgw.call(1, mx.string("eulerian"), mx.scalar(6), mx.scalar(4), mx.scalar(0), cb, mx.scalar(1))
     # (Stress: the device's exact mean of the history against the reference's rounded one, see hoststep.check_stress;
     # the history itself stays on the device in this protocol)
