@@ -116,6 +116,39 @@ def clip_kernel_line(ctx, with_cpu, n_pairs=20000, cpu_pairs=3000):
     return out
 
 
+def post_step_line(sim, S, P, reps=3):
+    """Call-level milliseconds (wall clock around the C-ABI call: kernels, transfers, host work) of the post-step entries
+    of SURVEY.md 8(f) on the resident field, next to the cadence the reference driver calls them at."""
+    from subzero_amd import capi, corners
+    rng = np.random.default_rng(7)
+    keep = corners.keep_mask(rng.uniform(size=S.n), S.OverlapArea, S.area, 0)
+    ids = (np.nonzero(~keep)[0] + 1).astype(np.int32)                     # Subzero.m:341-348: ~70 % of the floes
+
+    def timed(fn):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+    ms_c, (off, cnt, ang, da, n0, k_c) = timed(lambda: sim.corner_candidates(ids, 0, P.c2_boundary))
+    grind, frac = corners.grind_flags(off, cnt, ang, da, rng.uniform(size=corners.draws_needed(cnt)))
+    sel = np.nonzero(frac)[0]
+    foff = np.zeros(len(sel) + 1, np.int32); fg = []
+    for k, q in enumerate(sel):
+        n = int(S.vert_off[ids[q]] - S.vert_off[ids[q] - 1])
+        g = np.zeros(n, np.uint8); g[:cnt[q]] = grind[off[q]:off[q] + cnt[q]]; fg.append(g); foff[k + 1] = foff[k] + n
+    fg = np.concatenate(fg) if fg else np.zeros(0, np.uint8)
+    ms_k, (npieces, poff, pieces, rings, k_k) = timed(lambda: sim.corner_cuts(ids[sel], foff, fg))
+    ms_e, (eul, k_e) = timed(lambda: sim.eulerian_data(40, 40, 0, P.c2_boundary, True))
+    fids = ids[:max(1, len(ids) // 20)]
+    ms_d, _ = timed(lambda: sim.fracture_deform(fids))
+    return {"corner_candidates": {"call_ms": ms_c, "kernel_ms": k_c, "floes": int(len(ids)), "cadence": "every 10th step, ~70 % of the floes (Subzero.m:339-352)"},
+            "corner_cuts": {"call_ms": ms_k, "kernel_ms": k_k, "floes": int(len(sel)), "cut_on_device": int((npieces > 0).sum()), "pieces": int(len(pieces)),
+                            "cadence": "with corner_candidates, the floes with more than one corner to break (corners.m:94-98)"},
+            "eulerian_data": {"call_ms": ms_e, "kernel_ms": k_e, "grid": "40 x 40", "cadence": "every 150th step, or every step with AVERAGE (Subzero.m:304-314)"},
+            "fracture_deform": {"call_ms": ms_d, "floes": int(len(fids)), "cadence": "every 75th step, the floes picked by fracture.m:51-55 (Subzero.m:220)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +243,8 @@ def main():
                      "limiter": "FP64 / int64 vector issue of irregular geometry (16 lanes per pair, ~5.4e3 vector instructions per wave of four pairs), not HBM",
                      "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
     }
+    if not args.no_clip_line:
+        out["post_step_calls"] = post_step_line(sim, S, P)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, P)
     if not args.no_clip_line:

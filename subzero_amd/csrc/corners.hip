@@ -106,9 +106,9 @@ extern "C" int szCornerCuts(szContext *ctx, const int32_t *ids, int nsel, const 
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t nvt = (size_t)offsets[nsel];
-  DevBuf d_ids, d_voff, d_g, d_gt, d_sp, d_sr, d_st, d_tx, d_ty, d_np, d_rec, d_ro, d_rx, d_ry;
+  DevBuf &d_ids = S->post[0]; DevBuf &d_voff = S->post[1]; DevBuf &d_g = S->post[2]; DevBuf &d_gt = S->post[3]; DevBuf &d_sp = S->post[4]; DevBuf &d_sr = S->post[5]; DevBuf &d_st = S->post[6]; DevBuf &d_tx = S->post[7]; DevBuf &d_ty = S->post[8]; DevBuf &d_np = S->post[9]; DevBuf &d_rec = S->post[10]; DevBuf &d_ro = S->post[11]; DevBuf &d_rx = S->post[12]; DevBuf &d_ry = S->post[13];
   DevBuf *all[] = {&d_ids, &d_voff, &d_g, &d_gt, &d_sp, &d_sr, &d_st, &d_tx, &d_ty, &d_np, &d_rec, &d_ro, &d_rx, &d_ry};
-  auto cleanup = [&]() { for (DevBuf *b : all) sz_release(*b); };
+  auto cleanup = [&]() { (void)all; };
   int rc;
   if ((rc = sz_reserve(ctx, d_ids, (size_t)nsel * 4)) || (rc = sz_reserve(ctx, d_voff, ((size_t)nsel + 1) * 4)) || (rc = sz_reserve(ctx, d_g, nvt + 8)) ||
       (rc = sz_reserve(ctx, d_gt, nvt + 8)) || (rc = sz_reserve(ctx, d_sp, ((size_t)nsel + 1) * 4)) || (rc = sz_reserve(ctx, d_sr, ((size_t)nsel + 1) * 4)) ||
@@ -176,8 +176,8 @@ extern "C" int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, 
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   int rc;
-  DevBuf d_ext, d_ent, d_ids, d_off, d_cnt, d_ang, d_da;
-  auto cleanup = [&]() { sz_release(d_ext); sz_release(d_ent); sz_release(d_ids); sz_release(d_off); sz_release(d_cnt); sz_release(d_ang); sz_release(d_da); };
+  DevBuf &d_ext = S->post[14]; DevBuf &d_ent = S->post[15]; DevBuf &d_ids = S->post[16]; DevBuf &d_off = S->post[17]; DevBuf &d_cnt = S->post[18]; DevBuf &d_ang = S->post[19]; DevBuf &d_da = S->post[20];
+  auto cleanup = [&]() { (void)d_ext; (void)d_ent; (void)d_ids; (void)d_off; (void)d_cnt; (void)d_ang; (void)d_da; };
   if ((rc = sz_reserve(ctx, d_ext, (size_t)n * 16 + 16))) return rc;
   hipLaunchKernelGGL(k_corner_extent, grid_for(n, 256), dim3(256), 0, st, S->F, (double *)d_ext.p);
   std::vector<double> ext((size_t)2 * n), x((size_t)n), y((size_t)n);

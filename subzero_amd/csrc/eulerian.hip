@@ -123,8 +123,8 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   hipStream_t st = ctx->stream;
   const int n = S->n;
   int rc;
-  DevBuf d_ext, d_ent, d_grid, d_out, d_flag;
-  auto cleanup = [&]() { sz_release(d_ext); sz_release(d_ent); sz_release(d_grid); sz_release(d_out); sz_release(d_flag); };
+  DevBuf &d_ext = S->post[24]; DevBuf &d_ent = S->post[25]; DevBuf &d_grid = S->post[26]; DevBuf &d_out = S->post[27]; DevBuf &d_flag = S->post[28];
+  auto cleanup = [&]() { (void)d_ext; (void)d_ent; (void)d_grid; (void)d_out; (void)d_flag; };
   if ((rc = sz_reserve(ctx, d_ext, (size_t)n * 16 + 16))) return rc;
   hipLaunchKernelGGL(k_eul_extent, grid_for(n, 256), dim3(256), 0, st, S->F, (double *)d_ext.p);
   std::vector<double> ext((size_t)2 * n), x((size_t)n), y((size_t)n);
@@ -167,8 +167,8 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   // ---- cells that meet the topography (Nb > 0): box = subtract(box, boundaries), overlap = intersect(box, poly) (:141-154)
   // through the clip kernel (szClipPathsBatch: the polyshape operations restated by the fixed-point clip, as polyclip.m
   // uses it).  Only a cell whose rectangle meets the bounding box of a topography floe can lose anything.
-  DevBuf d_ovc, d_ovo, d_ove, d_ova, d_ovb;
-  auto cleanup2 = [&]() { sz_release(d_ovc); sz_release(d_ovo); sz_release(d_ove); sz_release(d_ova); sz_release(d_ovb); };
+  DevBuf &d_ovc = S->post[29]; DevBuf &d_ovo = S->post[30]; DevBuf &d_ove = S->post[31]; DevBuf &d_ova = S->post[32]; DevBuf &d_ovb = S->post[33];
+  auto cleanup2 = [&]() { (void)d_ovc; (void)d_ovo; (void)d_ove; (void)d_ova; (void)d_ovb; };
   EulOverride ov = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (!topo.empty() && M > 0) {
     const size_t nvt = (size_t)S->nverts;

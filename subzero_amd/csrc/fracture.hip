@@ -122,9 +122,9 @@ extern "C" int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, in
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   int rc = SZ_OK;
-  DevBuf d_ids, d_pick, d_aoff, d_boff, d_stage, d_ooff, d_chg, d_sc, d_len, d_ox, d_oy;
-  auto cleanup = [&]() { sz_release(d_ids); sz_release(d_pick); sz_release(d_aoff); sz_release(d_boff); sz_release(d_stage); sz_release(d_ooff);
-                         sz_release(d_chg); sz_release(d_sc); sz_release(d_len); sz_release(d_ox); sz_release(d_oy); };
+  DevBuf &d_ids = S->post[40]; DevBuf &d_pick = S->post[41]; DevBuf &d_aoff = S->post[42]; DevBuf &d_boff = S->post[43]; DevBuf &d_stage = S->post[44]; DevBuf &d_ooff = S->post[45]; DevBuf &d_chg = S->post[46]; DevBuf &d_sc = S->post[47]; DevBuf &d_len = S->post[48]; DevBuf &d_ox = S->post[49]; DevBuf &d_oy = S->post[50];
+  auto cleanup = [&]() { (void)d_ids; (void)d_pick; (void)d_aoff; (void)d_boff; (void)d_stage; (void)d_ooff;
+                         (void)d_chg; (void)d_sc; (void)d_len; (void)d_ox; (void)d_oy; };
 #define FR_TRY(expr) do { if ((rc = (expr))) { cleanup(); return rc; } } while (0)
 #define FR_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szFractureDeform: %s", hipGetErrorString(e_)); } } while (0)
   FR_TRY(sz_reserve(ctx, d_ids, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_pick, (size_t)nsel * sizeof(Pick)));
@@ -233,8 +233,8 @@ extern "C" int szPotentialInteractions(szContext *ctx, const int32_t *ids, int n
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   int cap_each = 64, rc;
-  DevBuf d_ids, d_cnt, d_list;
-  auto cleanup = [&]() { sz_release(d_ids); sz_release(d_cnt); sz_release(d_list); };
+  DevBuf &d_ids = S->post[51]; DevBuf &d_cnt = S->post[52]; DevBuf &d_list = S->post[53];
+  auto cleanup = [&]() { (void)d_ids; (void)d_cnt; (void)d_list; };
   if ((rc = sz_reserve(ctx, d_ids, (size_t)nsel * 4)) || (rc = sz_reserve(ctx, d_cnt, (size_t)nsel * 4))) { cleanup(); return rc; }
   std::vector<int> cnt((size_t)nsel), h;
   for (;;) {      // (a floe with more neighbours than the room per floe: once more with what it needs)

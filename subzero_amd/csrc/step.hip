@@ -821,7 +821,6 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   const bool convex = S->convex_fast != 0 && S->fast_path == 0;
   const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
   if (hi > lo) {
-    const unsigned long long *dev_np = S->speculating ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr;
     if (convex && S->team) {
       // the team pass over every pair, then the lane-per-pair fast path over what it handed on (a device-side list: the
       // launch covers the pair count and its workgroups beyond the list return at once)

@@ -97,6 +97,7 @@ void destroy_state(StepState *S) {
                     &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->pot_list, &S->inc_list,
                     &S->stage_d, &S->stage_i, &S->stage_ids, &S->sp_masks, &S->sp_edges_dev, &S->sp_counts};
   for (DevBuf *b : more) sz_release(*b);
+  for (DevBuf &b : S->post) sz_release(b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
   if (S->c) (void)hipHostFree(S->c);
   if (S->sp_hdr) (void)hipHostFree(S->sp_hdr);
