@@ -14,6 +14,7 @@
 #include <vector>
 #include "clip_batch.hpp"
 #include "offset.hpp"
+#include "trim.hpp"
 
 using szb::ClipArgs;
 
@@ -123,7 +124,23 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
     st = szv::clip_rings(a.ws + woff, (int)nv, ra, na, rb, nb, a.method, a.fill_s, a.fill_c, sink);
   } else {
     RingI64 ra = {a.ax + a0, a.ay + a0}, rb = {a.bx + b0, a.by + b0};
-    st = szv::clip_rings(a.ws + woff, (int)nv, ra, na, rb, nb, a.method, a.fill_s, a.fill_c, sink);
+    int ta = na, tb = nb, cap = (int)nv;
+    // An intersection sees only what lies in the box the two rings share (trim.hpp: the reference's Clipper returns the
+    // same rings vertex for vertex on the trimmed input; the step's general path has used it since round 1): real floe
+    // outlines that overlap in part lose most of their vertices before the sweep.  The trimmed copies sit at the end of
+    // the pair's workspace, which the sweep of fewer vertices leaves idle; when the cut is too small to make that room
+    // (or a tie forbids it) the rings go in whole.
+    if (a.method == szv::OP_INTERSECTION && a.fill_s == szv::FILL_EVENODD && a.fill_c == szv::FILL_EVENODD && na + nb >= 24) {
+      i64 *tx = (i64 *)(a.ws + woff + wbytes - 16 * (i64)(na + nb)), *ty = tx + (na + nb);
+      for (int k = 0; k < na; ++k) { tx[k] = ra.x[k]; ty[k] = ra.y[k]; }
+      for (int k = 0; k < nb; ++k) { tx[na + k] = rb.x[k]; ty[na + k] = rb.y[k]; }
+      if (szt::trim_pair(tx, ty, ta, tx + na, ty + na, tb) &&
+          (i64)szv::WS_PER_VERTEX * (i64)(ta + tb) * a.mult + szv::WS_PER_CLIP + 16 * (i64)(na + nb) <= wbytes) {
+        RingI64 sa = {tx, ty}, sb = {tx + na, ty + na};
+        ra = sa; rb = sb; cap = (ta + tb) * a.mult;
+      } else { ta = na; tb = nb; }
+    }
+    st = szv::clip_rings(a.ws + woff, cap, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
   }
   a.ov_base[p] = voff;
   a.or_base[p] = roff;

@@ -30,10 +30,15 @@ __device__ inline double nz(double v) { return v != v ? 0.0 : v; }
 struct EulOverride { const int *cell, *off, *ent; const double *area, *abox; };
 
 __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int M, int Nx, int Ny, const double *xg, const double *yg,
-                                                  double r_max, double *out, int *overflow, EulOverride ov) {
-  __shared__ int hit_e[EUL_CAP];
-  __shared__ double hit_a[EUL_CAP];
+                                                  double r_max, double *out, int *overflow, EulOverride ov, int *spill_e, double *spill_a, int spill_len) {
+  // the cell's potential floes and their overlaps: EUL_CAP of them in LDS -- or, in the second launch that a cell with
+  // more provokes (a coarse grid over a large field: the reference has no such limit), in the cell's slice of HBM
+  __shared__ int lds_e[EUL_CAP];
+  __shared__ double lds_a[EUL_CAP];
   __shared__ int npot;
+  int *hit_e = spill_e ? spill_e + (size_t)blockIdx.x * spill_len : lds_e;
+  double *hit_a = spill_a ? spill_a + (size_t)blockIdx.x * spill_len : lds_a;
+  const int cap = spill_e ? spill_len : (int)EUL_CAP;
   const int ii = blockIdx.x / Ny, jj = blockIdx.x % Ny;
   if (threadIdx.x == 0) npot = 0;
   __syncthreads();
@@ -42,7 +47,7 @@ __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int
   const int ovc = ov.cell ? ov.cell[blockIdx.x] : -1;
   if (ovc >= 0) {
     const int o0 = ov.off[ovc], cnt = ov.off[ovc + 1] - o0;
-    if (cnt > EUL_CAP) { if (threadIdx.x == 0) atomicAdd(overflow, 1); return; }
+    if (cnt > cap) { if (threadIdx.x == 0) atomicAdd(overflow, 1); return; }
     for (int q = threadIdx.x; q < cnt; q += blockDim.x) { hit_e[q] = ov.ent[o0 + q]; hit_a[q] = ov.area[o0 + q]; }
     if (threadIdx.x == 0) npot = cnt;
   }
@@ -52,11 +57,11 @@ __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int
     const double pint = ::sqrt(ddx * ddx + ddy * ddy) - (F.rmax[en.src] + r_max);   // :123
     if (!(pint < 0)) continue;
     int k = atomicAdd(&npot, 1);
-    if (k >= EUL_CAP) continue;
+    if (k >= cap) continue;
     hit_e[k] = e;
   }
   __syncthreads();
-  if (npot > EUL_CAP) { if (threadIdx.x == 0) atomicAdd(overflow, 1); return; }
+  if (npot > cap) { if (threadIdx.x == 0) atomicAdd(overflow, 1); return; }
   const int np = npot;
   // Mtot of :136 (any positive mass among the potential floes lets the cell through); then the overlaps
   for (int q = threadIdx.x; q < np && ovc < 0; q += blockDim.x) {
@@ -67,9 +72,22 @@ __global__ void __launch_bounds__(256) k_eul_cells(Floes F, const EulEnt *E, int
     hit_a[q] = sze::ring_box_area(F.cax + v0, F.cay + v0, nv, en.x, en.y, xl, xh, yl, yh);
   }
   __syncthreads();
+  if (spill_e && np > (int)EUL_CAP) {
+    // long lists (HBM): rank every entry by all threads (entries are distinct), scatter into the second half of the slice
+    int *se = hit_e + spill_len / 2; double *sa = hit_a + spill_len / 2;
+    for (int q = threadIdx.x; q < np; q += blockDim.x) {
+      const int e = hit_e[q];
+      int rank = 0;
+      for (int m = 0; m < np; ++m) rank += (hit_e[m] < e) ? 1 : 0;
+      se[rank] = e; sa[rank] = hit_a[q];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < np; q += blockDim.x) { hit_e[q] = se[q]; hit_a[q] = sa[q]; }
+    __syncthreads();
+  }
   if (threadIdx.x != 0) return;
   // ascending floe order (the potential list was filled by atomics)
-  for (int a = 1; a < np; ++a) {
+  for (int a = 1; a < np && !(spill_e && np > (int)EUL_CAP); ++a) {
     int e = hit_e[a]; double ar = hit_a[a]; int b = a;
     while (b > 0 && hit_e[b - 1] > e) { hit_e[b] = hit_e[b - 1]; hit_a[b] = hit_a[b - 1]; --b; }
     hit_e[b] = e; hit_a[b] = ar;
@@ -308,11 +326,31 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
   if (he == hipSuccess && M > 0)
     hipLaunchKernelGGL(k_eul_cells, dim3((unsigned)cells), dim3(256), 0, st, S->F, (const EulEnt *)d_ent.p, M, Nx, Ny,
-                       (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p, ov);
+                       (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p, ov,
+                       (int *)nullptr, (double *)nullptr, 0);
   if (he == hipSuccess) he = hipEventRecord(ctx->ev1, st);
   int over = 0;
-  if (he == hipSuccess) he = hipMemcpyAsync(out, d_out.p, EUL_FIELDS * cells * 8, hipMemcpyDeviceToHost, st);
   if (he == hipSuccess) he = hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he == hipSuccess && over) {
+    // a cell holds more potential floes than the LDS lists: once more with the lists in HBM (the reference
+    // has no limit; a 1 x 1 grid over 1e4 floes is a legitimate domain average).  Twice M entries per cell: list + sort room.
+    const size_t per = 2 * (size_t)(M + 8);
+    if (cells * per * 12 > ((size_t)2 << 30)) { cleanup(); cleanup2(); return sz_fail(ctx, SZ_ERR_WORKSPACE, "szEulerianData: a grid cell has more than %d potential floes and the lists of all %zu cells would not fit 2 GB", (int)EUL_CAP, cells); }
+    DevBuf &d_se = S->post[34]; DevBuf &d_sa = S->post[35];
+    if ((rc = sz_reserve(ctx, d_se, cells * per * 4)) || (rc = sz_reserve(ctx, d_sa, cells * per * 8))) { cleanup(); cleanup2(); return rc; }
+    he = hipMemsetAsync(d_out.p, 0, EUL_FIELDS * cells * 8, st);
+    if (he == hipSuccess) he = hipMemsetAsync(d_flag.p, 0, 16, st);
+    if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
+    if (he == hipSuccess)
+      hipLaunchKernelGGL(k_eul_cells, dim3((unsigned)cells), dim3(256), 0, st, S->F, (const EulEnt *)d_ent.p, M, Nx, Ny,
+                         (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p, ov,
+                         (int *)d_se.p, (double *)d_sa.p, (int)per);
+    if (he == hipSuccess) he = hipEventRecord(ctx->ev1, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+  }
+  if (he == hipSuccess) he = hipMemcpyAsync(out, d_out.p, EUL_FIELDS * cells * 8, hipMemcpyDeviceToHost, st);
   if (he == hipSuccess) he = hipStreamSynchronize(st);
   float ms = 0;
   if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);

@@ -222,6 +222,50 @@ __global__ void k_cell_count(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < dev_next(W)) cell_count(e, F, W);
 }
+// The records and staged rings of the entries (step_core.hpp ext_record) with 16 lanes per entry: lane l forms vertex l
+// of the ring where the entry lies and word l of the record, so that the 128-byte lines the team pass loads are written
+// whole; the bounding box is a minimum / maximum over the lanes (exact whatever the order), the same values as the
+// one-thread form.
+__global__ void __launch_bounds__(256) k_ext_records(Floes F, Work W) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, e = t >> 4, l = t & 15;
+  if (e >= dev_next(W)) return;                         // (whole groups of 16 lanes leave together)
+  const int s = W.ext_src[e];
+  const int v0 = F.vert_off[s], n = F.vert_off[s + 1] - v0;
+  const double ox = W.ext_x[e], oy = W.ext_y[e];
+  double x0 = SZC_INF, x1 = -SZC_INF, y0 = SZC_INF, y1 = -SZC_INF;
+  for (int k = l; k < n; k += 16) {
+    const double X = F.cax[v0 + k] + ox, Y = F.cay[v0 + k] + oy;
+    x0 = szc::mind(x0, X); x1 = szc::maxd(x1, X); y0 = szc::mind(y0, Y); y1 = szc::maxd(y1, Y);
+  }
+  for (int d = 1; d < 16; d <<= 1) {
+    x0 = szc::mind(x0, __shfl_xor(x0, d, 16)); x1 = szc::maxd(x1, __shfl_xor(x1, d, 16));
+    y0 = szc::mind(y0, __shfl_xor(y0, d, 16)); y1 = szc::maxd(y1, __shfl_xor(y1, d, 16));
+  }
+  int nstage = n;
+  if (n == (int)RING_SLOTS + 1) {
+    const double fx = F.cax[v0] + ox, fy = F.cay[v0] + oy, lx = F.cax[v0 + n - 1] + ox, ly = F.cay[v0 + n - 1] + oy;
+    const double px = F.cax[v0 + n - 2] + ox, py = F.cay[v0 + n - 2] + oy;
+    if (lx == fx && ly == fy && szc::hyp(fx - px, fy - py) > 1) --nstage;
+  }
+  if (nstage > (int)RING_SLOTS || nstage < 1) nstage = -1;
+  const double safe = SZX_FIXED_SAFE_METRES - 2;
+  bool ok = true;
+  double X = 0, Y = 0;
+  if (l < nstage) { X = F.cax[v0 + l] + ox; Y = F.cay[v0 + l] + oy; ok = szc::absd(X) < safe && szc::absd(Y) < safe; }
+  const unsigned long long bad = __ballot(!ok);
+  const bool in_range = ((bad >> ((threadIdx.x & 63) & ~15)) & 0xffffULL) == 0;
+  double *rx = W.ext_ring + 2 * (size_t)RING_SLOTS * e;
+  if (l < nstage) { rx[l] = X; rx[RING_SLOTS + l] = Y; }
+  double w = 0;
+  switch (l) {
+    case REC_X: w = ox; break; case REC_Y: w = oy; break; case REC_UI: w = F.Ui[s]; break; case REC_VI: w = F.Vi[s]; break;
+    case REC_KSI: w = F.ksi_ice[s]; break; case REC_H: w = F.h[s]; break; case REC_AREA: w = F.area[s]; break;
+    case REC_BX0: w = x0; break; case REC_BX1: w = x1; break; case REC_BY0: w = y0; break; case REC_BY1: w = y1; break;
+    case REC_NSTAGE: w = (double)nstage; break; case REC_NSTORED: w = (double)n; break; case REC_INRANGE: w = in_range ? 1.0 : 0.0; break;
+    default: break;
+  }
+  W.ext_rec[(size_t)REC_WORDS * e + l] = w;
+}
 __global__ void k_cell_fill(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < dev_next(W)) cell_fill(e, F, W);
@@ -753,6 +797,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     }
     {
       hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
+      hipLaunchKernelGGL(k_ext_records, grid_for(16 * (i64)cap, 256), dim3(256), 0, st, F, W);
       launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
       hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
     }

@@ -359,6 +359,9 @@ SZ_HD int cell_of(int e, const Floes &F, const Work &W) {
 SZ_HD bool in_grid(int e, const Floes &F, const Work &W) { const int s = W.ext_src[e]; return F.alive[s] && e >= F.nb && is_present(s, W); }
 SZ_HD void cell_count(int e, const Floes &F, Work &W) {
   if (in_grid(e, F, W)) atomic_add(&W.cell_cnt[cell_of(e, F, W)], 1);
+}
+// (one thread per entry: the host build and small fields; the GPU uses k_ext_records, 16 lanes per entry, same values)
+SZ_HD void ext_record(int e, const Floes &F, Work &W) {
   // what the narrow phase's team pass needs of the entry, once per step instead of once per pair: the ring where the
   // entry lies (ghosts: their own position) -- c_alpha + position, the sums every pair would otherwise form again --
   // its bounding box (contact.hpp ring_box), the scalars of floe_interactions.m:10-21,170-183

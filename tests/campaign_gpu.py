@@ -42,6 +42,17 @@ while time.time() - t0 < budget:
             g = sim.corner_candidates(ids, int(S.nb), P.c2_boundary)
             if not (all(np.array_equal(a, b) for a, b in zip(w[:4], g[:4])) and w[4] == g[4]):
                 print("MISMATCH corners", seed, flush=True); ok = False
+            # frac_corner.m (plain case) with random corners marked
+            cnt_w = w[1]; cid = [q for q in range(len(ids)) if cnt_w[q] >= 3][:40]
+            if cid:
+                foff = np.zeros(len(cid) + 1, np.int32); fg = []
+                for k, q in enumerate(cid):
+                    nst = int(A.vert_off[ids[q]] - A.vert_off[ids[q] - 1])
+                    gq = np.zeros(nst, np.uint8); gq[:cnt_w[q]] = rng.uniform(size=cnt_w[q]) < 0.35; fg.append(gq); foff[k + 1] = foff[k] + nst
+                fg = np.concatenate(fg)
+                wo = oracle.frac_corner(G, ids[cid], foff, fg); go = sim.corner_cuts(ids[cid], foff, fg)
+                if not (np.array_equal(wo[0], go[0]) and np.array_equal(wo[2], go[2]) and all(np.array_equal(a, b) for a, b in zip(wo[3], go[3]))):
+                    print("MISMATCH cuts", seed, flush=True); ok = False
             w = oracle.fracture_deform(A, ra.inter_off, ra.inter, ids); g = sim.fracture_deform(ids)
             if not (all(np.array_equal(a, b) for a, b in zip(w[:4], g[:4])) and all(np.array_equal(a, b) for a, b in zip(w[4], g[4]))):
                 print("MISMATCH deform", seed, flush=True); ok = False

@@ -265,7 +265,7 @@ struct Sim {
       const int nc = W.lvl_base[W.n_levels];
       W.cell_cnt = alloc<int>(pool, nc + 1); W.cell_off = alloc<int>(pool, nc + 1); W.cell_fill = alloc<int>(pool, nc + 1);
       W.cell_item = alloc<CellItem>(pool, cap);
-      for (int e = 0; e < N; ++e) cell_count(e, F, W);
+      for (int e = 0; e < N; ++e) { cell_count(e, F, W); ext_record(e, F, W); }
       int acc = 0;
       for (int c = 0; c < nc; ++c) { W.cell_off[c] = acc; acc += W.cell_cnt[c]; }
       W.cell_off[nc] = acc;

@@ -70,3 +70,24 @@ def test_eulerian_fields_with_topography(ctx, scene, grid):
         assert np.array_equal(want[k], got[k], equal_nan=True), (k, float(np.nanmax(np.abs(want[k] - got[k]))))
     assert (want["c"] != plain["c"]).any() and want["Mtot"].sum() < plain["Mtot"].sum()      # the topography was taken out
     print("eulerian with topography %s %dx%d: %.3f ms in the cell kernel, %d cells changed" % (scene, Nx, Ny, ms, int((want["c"] != plain["c"]).sum())))
+
+
+def test_a_cell_with_more_floes_than_the_lds_lists_hold(ctx):
+    """the reference has no limit on the floes of a cell -- a 1 x 1 grid (a domain average) and a 2 x 1 grid over
+    2600 floes put more than 2048 potential floes into a cell; the lists then live in HBM, same sums in the same order."""
+    S, P = scenes.pack(2600, periodic=True)
+    P.set_reference_ocean()
+    S.Xi += 300.0
+    A, G = S.copy(), S.copy()
+    sim = capi.FloeInteractions(ctx, G)
+    for it in range(3):
+        P.doInt = int(it == 0)
+        oracle.step(A, P, threads=8); sim.step(P)
+    sim.download(capi.SYNC_ALL)
+    A.Stress[:] = G.Stress
+    for Nx, Ny in ((1, 1), (2, 1), (9, 7)):
+        want = oracle.eulerian_data(A, Nx, Ny, 0, P.c2_boundary, True)
+        got, ms = sim.eulerian_data(Nx, Ny, 0, P.c2_boundary, True)
+        for k in oracle.EULERIAN_FIELDS:
+            assert np.array_equal(want[k], got[k]), (Nx, Ny, k, float(np.abs(want[k] - got[k]).max()))
+    assert want["c"].max() > 0.5
