@@ -89,13 +89,13 @@ __global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned
   const i64 n = dev_count ? (i64)*dev_count : count;
   const int cls = (p < n && p < count) ? pair_classify(p, prev_n, P, W) : (int)PC_DONE;
   const int lane = threadIdx.x & 63;
-  for (int c = PC_LIVE; c <= PC_COLD; ++c) {
+  for (int c = PC_LIVE; c <= PC_GENERAL; ++c) {
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
     unsigned long long base = 0;
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : c == PC_COLD ? C_COLD : C_TEAM], (unsigned long long)__popcll(m));
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : c == PC_COLD ? C_COLD : c == PC_GENERAL ? C_RETRY : C_TEAM], (unsigned long long)__popcll(m));
     base = __shfl(base, __builtin_ctzll(m));
-    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : c == PC_COLD ? W.cold_list : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
+    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : c == PC_COLD ? W.cold_list : c == PC_GENERAL ? W.retry_list : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
   }
 }
 }

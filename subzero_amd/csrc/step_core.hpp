@@ -719,7 +719,7 @@ SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P
 //              and waves of like pairs waste no lanes.  A hint only: a wrong guess costs time, never a result.
 //   team_list  the lane-per-pair kernels (walls, rings too long for the block, coordinates out of the fast range)
 // The order inside a list is arbitrary (every pair writes its own words).  Returns the class; the caller appends.
-enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3, PC_COLD = 4 };
+enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3, PC_COLD = 4, PC_GENERAL = 5 };   // PC_GENERAL: straight to the general sweep (a floe at a wall: the box has horizontal edges, no fast path takes it)
 SZ_HD int pair_classify(i64 p, int prev_n, const Params &P, Work &W) {
   const int i = W.pair_i[p], j = W.pair_j[p];
   const bool boundary = (j == WALL);
@@ -733,7 +733,8 @@ SZ_HD int pair_classify(i64 p, int prev_n, const Params &P, Work &W) {
   if (boundary) {
     const double gap = 1e-6;
     if (n1 > 0 && P.bnd_rect && b1.x0 > P.bnd_xmin + gap && b1.x1 < P.bnd_xmax - gap && b1.y0 > P.bnd_ymin + gap && b1.y1 < P.bnd_ymax - gap) return PC_DONE;
-    return PC_OTHER;
+    W.pair_status[p] = szc::ST_DEFER;
+    return PC_GENERAL;
   }
   const szc::Box b2 = {rj[REC_BX0], rj[REC_BX1], rj[REC_BY0], rj[REC_BY1]};
   const bool apart = szc::boxes_apart(b1, b2);
@@ -756,6 +757,7 @@ SZ_HD void pair_classified(i64 p, int cls, Work &W) {   // (the kernel appends a
   else if (cls == PC_COLD) W.cold_list[atomic_add(&W.counters[C_COLD], 1ULL)] = (int)p;
   else if (cls == PC_WIDE) W.wide_list[atomic_add(&W.counters[C_WIDE], 1ULL)] = (int)p;
   else if (cls == PC_OTHER) W.team_list[atomic_add(&W.counters[C_TEAM], 1ULL)] = (int)p;
+  else if (cls == PC_GENERAL) W.retry_list[atomic_add(&W.counters[C_RETRY], 1ULL)] = (int)p;
 }
 
 // The pair by a TEAM of lanes (teamcontact.hpp): the first pass of the default path.  Two dependent rounds of loads:
