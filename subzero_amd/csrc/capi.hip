@@ -35,10 +35,15 @@ int szDestroy(szContext *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   sz_step_destroy(ctx);
   DevBuf *bufs[] = {&ctx->ws, &ctx->ovx, &ctx->ovy, &ctx->oroff, &ctx->ov_base, &ctx->or_base,
-                    &ctx->nrings, &ctx->status, &ctx->retry_list, &ctx->counters,
+                    &ctx->nrings, &ctx->status, &ctx->retry_list, &ctx->counters, &ctx->clip_meta, &ctx->clip_lists,
                     &ctx->in_ax, &ctx->in_ay, &ctx->in_aoff, &ctx->in_bx, &ctx->in_by, &ctx->in_boff,
                     &ctx->in_fax, &ctx->in_fay, &ctx->in_fbx, &ctx->in_fby};
   for (DevBuf *b : bufs) sz_release(*b);
+  for (int k = 0; k < 4; ++k) {
+    if (ctx->clip_streams[k]) (void)hipStreamDestroy(ctx->clip_streams[k]);
+    if (ctx->clip_join[k]) (void)hipEventDestroy(ctx->clip_join[k]);
+  }
+  if (ctx->clip_fork) (void)hipEventDestroy(ctx->clip_fork);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

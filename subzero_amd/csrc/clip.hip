@@ -2,8 +2,11 @@
 // (replaces /root/reference/private/mexclipper.cpp:204-305 as called from polyclip.m:73).
 //
 // Mapping to the hardware (irregular integer/FP64 geometry, no dense contraction, so no MFMA):
-//  * one lane per ring pair; a wave's 64 lanes run 64 independent sweeps (szv::Sweep, vatti.hpp);
-//  * every sweep works in its own workspace slice of one HBM arena; slice and result-slot offsets
+//  * single rings in fixed point (szClipBatch): k_clip_front, a wave per pair (staging, boxes, boxes-apart answers,
+//    trimming, slice class), then k_clip_sweep per slice class side by side: one sweep (szv::Sweep, vatti.hpp) per
+//    wave with its records in 20-160 KB of LDS -- see the comment in front of k_clip_front;
+//  * everything else (several contours, double input, retries): k_clip, one lane per ring pair, a few pairs per wave;
+//  * every pair owns a workspace slice of one HBM arena; slice and result-slot offsets
 //    follow in closed form from the CSR offsets of the input rings (no scan, no allocator);
 //  * pairs whose lists outgrow their slice (only heavily self-intersecting input does) are appended to
 //    a retry list with one wave-aggregated atomic and re-run at 8x / 64x capacity -- on the GPU.
@@ -12,6 +15,16 @@
 #include <algorithm>
 #include <cmath>
 #include <vector>
+#if defined(SZ_CLIP_CLOCKS)
+// diagnostic build: time per part of the sweep (vatti.hpp SZV_PHASE), one pair per workgroup
+#include <hip/hip_runtime.h>
+__device__ unsigned long long sz_ph_t[1 << 16], sz_ph_acc[(1 << 16) * 8];
+__device__ int sz_ph_k[1 << 16];
+#endif
+#if defined(SZ_CLIP_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
+#define SZV_PHASE(k) do { const unsigned b_ = blockIdx.x; if (b_ < 65536u) { const unsigned long long now_ = wall_clock64(); \
+  sz_ph_acc[b_ * 8 + sz_ph_k[b_]] += now_ - sz_ph_t[b_]; sz_ph_t[b_] = now_; sz_ph_k[b_] = (k) - 12; } } while (0)
+#endif
 #include "clip_batch.hpp"
 #include "offset.hpp"
 #include "trim.hpp"
@@ -73,12 +86,34 @@ struct SlotSink {
 };
 
 
+// the even-odd sweep with its records in a slice of LDS (a function of its own, so that the compiler specialises this
+// copy of the sweep for ds_ addressing)
+__device__ __attribute__((noinline, flatten)) int clip_in_slice(void *slice, const szv::Caps &caps, const RingI64 &ra, int na,
+                                                       const RingI64 &rb, int nb, int method, int fill_s, int fill_c,
+                                                       SlotSink &sink) {
+  __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
+  return szv::clip_rings_t<szv::WideLds>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
+}
+
+#if defined(SZ_CLIP_CLOCKS)
+// diagnostic build (make diag_clip): per pair the 100 MHz clock at start, after trimming and at the end, the trimmed
+// size and where the records were
+__device__ unsigned long long sz_clip_clocks[5 * (1 << 16)];
+#define SZ_CLIP_CLOCK(k, v) do { if (t < (1 << 16)) sz_clip_clocks[5 * t + (k)] = (v); } while (0)
+#else
+#define SZ_CLIP_CLOCK(k, v) ((void)0)
+#endif
 __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char clip_lds[];
   if ((int)threadIdx.x >= a.lanes) return;
   int t = blockIdx.x * a.lanes + threadIdx.x;
   int n = a.list ? a.nlist : a.npairs;
   if (t >= n) return;
   int p = a.list ? a.list[t] : t;
+  SZ_CLIP_CLOCK(0, wall_clock64());
+#if defined(SZ_CLIP_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
+  if (blockIdx.x < 65536u) { sz_ph_t[blockIdx.x] = wall_clock64(); sz_ph_k[blockIdx.x] = 0; for (int k = 0; k < 8; ++k) sz_ph_acc[blockIdx.x * 8 + k] = 0; }
+#endif
   int a0 = a.aoff[p], na = a.aoff[p + 1] - a0;
   int b0 = a.boff[p], nb = a.boff[p + 1] - b0;
   const int ra0 = a0, nra = na, rb0 = b0, nrb = nb;   // (ring ranges when the operands have several contours)
@@ -140,10 +175,228 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
         ra = sa; rb = sb; cap = (ta + tb) * a.mult;
       } else { ta = na; tb = nb; }
     }
-    st = szv::clip_rings(a.ws + woff, cap, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
+    // The sweep is a chain of dependent reads and writes of its records: with the records in the lane's slice of LDS
+    // (ds_ addressing, a fraction of the latency of the HBM workspace) when the trimmed rings fit it at capacities cut
+    // to what simple outlines use (vatti.hpp caps_budget); a sweep that outgrows the slice is repeated in HBM.
+    st = szv::ST_WORKSPACE;
+    SZ_CLIP_CLOCK(1, wall_clock64());
+    SZ_CLIP_CLOCK(3, (unsigned long long)(ta + tb));
+    SZ_CLIP_CLOCK(4, 0ULL);
+    szv::Caps lc;
+    if (a.lds_per_lane > 0 && a.mult == 1 && szv::caps_budget<szv::WideLds>(ta + tb, (size_t)a.lds_per_lane, lc) &&
+        lc.pts >= ta + tb + 8) {
+      st = clip_in_slice((void *)(clip_lds + (size_t)threadIdx.x * a.lds_per_lane), lc, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
+      SZ_CLIP_CLOCK(4, st == szv::ST_WORKSPACE ? 2ULL : 1ULL);
+      if (st == szv::ST_WORKSPACE) { sink.nv = 0; sink.nr = 0; sink.roff[0] = 0; atomicAdd(&a.counters[8], 1ULL); }
+    }
+    if (st == szv::ST_WORKSPACE)
+      st = szv::clip_rings(a.ws + woff, cap, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
   }
+  SZ_CLIP_CLOCK(2, wall_clock64());
+#if defined(SZ_CLIP_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
+  SZV_PHASE(12);
+#endif
   a.ov_base[p] = voff;
   a.or_base[p] = roff;
+  a.status[p] = st;
+  if (st == szv::ST_OK) {
+    a.nrings[p] = sink.nr;
+    atomicAdd(&a.counters[4], (unsigned long long)sink.nr);
+    atomicAdd(&a.counters[5], (unsigned long long)sink.nv);
+  } else {
+    a.nrings[p] = 0;
+    if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
+      unsigned long long k = atomicAdd(&a.counters[0], 1ULL);
+      if (k < (unsigned long long)a.retry_cap) a.retry[k] = p;
+    } else {
+      atomicAdd(&a.counters[6], 1ULL);
+    }
+  }
+}
+
+
+// ---- the main pass over single rings in fixed point: a front pass and a sweep pass per slice class -------------------
+// The sweep itself is one lane's chain of dependent accesses; what comes before it is not.  In the front pass the 64
+// lanes of a wave stage both rings of a pair in LDS (coalesced), reduce their boxes, and -- for an intersection --
+//   * find rings whose boxes are apart (trim.hpp: nothing in common, no sweep), or
+//   * cut the rings down to the common box: lane 0 runs trim_ring on the staged copy (a serial scan, now of LDS), the
+//     wave checks the heights of what is kept (the O(n^2) part) and writes the short rings to the end of the pair's HBM
+//     workspace, where the serial path puts them too.
+// The sweep pass then runs one launch per slice class, concurrently: most pairs sweep in 20 KB of LDS, eight to a CU;
+// the few long ones get 40, 80 or all 160 KB (a batch lasts as long as its longest sweep: those start at once and
+// run in LDS too); what fits no slice keeps its records in HBM.
+__device__ bool wave_heights_distinct(const i64 *y1, int n1, const i64 *y2, int n2) {
+  const int total = n1 + n2;
+  bool same = false;
+  for (int r = (int)threadIdx.x; r < total; r += 64) {
+    const i64 v = r < n1 ? y1[r] : y2[r - n1];
+    for (int b = r + 1; b < n1; ++b) same |= (v == y1[b]);
+    for (int b = (r + 1 > n1 ? r + 1 - n1 : 0); b < n2; ++b) same |= (v == y2[b]);
+  }
+  return __ballot(same) == 0ULL;
+}
+__device__ i64 wave_min(i64 v) {
+  for (int d = 32; d >= 1; d >>= 1) { const i64 o = __shfl_xor(v, d); v = o < v ? o : v; }
+  return v;
+}
+__device__ i64 wave_max(i64 v) {
+  for (int d = 32; d >= 1; d >>= 1) { const i64 o = __shfl_xor(v, d); v = o > v ? o : v; }
+  return v;
+}
+__device__ void wave_box(const i64 *x, const i64 *y, int n, szt::Box &b) {
+  const i64 big = 0x7FFFFFFFFFFFFFFFLL;
+  i64 x0 = big, x1 = -big - 1, y0 = big, y1 = -big - 1;
+  for (int k = (int)threadIdx.x; k < n; k += 64) {
+    const i64 vx = x[k], vy = y[k];
+    x0 = vx < x0 ? vx : x0; x1 = vx > x1 ? vx : x1; y0 = vy < y0 ? vy : y0; y1 = vy > y1 ? vy : y1;
+  }
+  b.xmin = wave_min(x0); b.xmax = wave_max(x1); b.ymin = wave_min(y0); b.ymax = wave_max(y1);
+}
+
+// slice classes of the sweep pass: bytes of LDS per pair; class CLASS_HBM keeps its records in the HBM workspace
+enum { CLIP_CLASSES = 4, CLASS_HBM = 4, META_TAIL = 1 << 30 };
+__device__ __constant__ int clip_class_bytes[CLIP_CLASSES] = {20 * 1024, 40 * 1024, 80 * 1024, 160 * 1024};
+__device__ int slice_class(int nv) {
+  szv::Caps c;
+  for (int k = 0; k < CLIP_CLASSES; ++k)
+    if (szv::caps_budget<szv::WideLds>(nv, (size_t)clip_class_bytes[k], c) && c.pts >= nv + 8) return k;
+  return CLASS_HBM;
+}
+struct PairSlots { i64 nv, wbytes, cv, cr, woff, voff, roff; };
+__device__ bool pair_slots(const ClipArgs &a, int p, int a0, int na, int b0, int nb, PairSlots &s) {
+  s.nv = (i64)(na + nb);
+  s.wbytes = (i64)szv::WS_PER_VERTEX * s.nv + szv::WS_PER_CLIP;
+  s.cv = slot_verts(s.nv); s.cr = slot_rings(s.nv);
+  const i64 before = (i64)a0 + b0;
+  s.woff = (i64)szv::WS_PER_VERTEX * before + (i64)szv::WS_PER_CLIP * p;
+  s.voff = 2 * before + 8 * (i64)p; s.roff = before + 5 * (i64)p;
+  return !(s.woff + s.wbytes > a.ws_cap || s.voff + s.cv > a.ov_cap || s.roff + s.cr + 1 > a.or_cap || s.nv > 0x3FFFFFFF);
+}
+
+// Front pass, one pair per wave: staging, boxes, the pairs that are apart (finished here), trimming; every other pair is
+// appended to the list of the smallest slice class that holds the records of its (trimmed) rings.
+__global__ void __launch_bounds__(64) k_clip_front(ClipArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char clip_lds[];
+  const int t = blockIdx.x, p = t, lane = (int)threadIdx.x;
+  if (t >= a.npairs) return;
+  if (lane == 0) SZ_CLIP_CLOCK(0, wall_clock64());
+  const int a0 = a.aoff[p], na = a.aoff[p + 1] - a0;
+  const int b0 = a.boff[p], nb = a.boff[p + 1] - b0;
+  PairSlots s;
+  if (!pair_slots(a, p, a0, na, b0, nb, s)) {
+    if (lane == 0) { a.nrings[p] = 0; a.status[p] = szv::ST_WORKSPACE; atomicAdd(&a.counters[7], 1ULL); }
+    return;
+  }
+  const i64 nv = s.nv;
+  RingI64 ra = {a.ax + a0, a.ay + a0}, rb = {a.bx + b0, a.by + b0};
+  i64 *tx = (i64 *)(a.ws + s.woff + s.wbytes - 16 * nv), *ty = tx + (na + nb);
+  int ta = na, tb = nb;
+  bool apart = false, tail = false;
+  const bool evenodd = a.fill_s == szv::FILL_EVENODD && a.fill_c == szv::FILL_EVENODD;
+  const bool staged = a.method == szv::OP_INTERSECTION && na > 0 && nb > 0 && 16 * nv <= (i64)a.lds_per_lane;
+  if (staged) {
+    i64 *sx = (i64 *)clip_lds, *sy = sx + (na + nb);
+    for (int k = lane; k < na; k += 64) { sx[k] = ra.x[k]; sy[k] = ra.y[k]; }
+    for (int k = lane; k < nb; k += 64) { sx[na + k] = rb.x[k]; sy[na + k] = rb.y[k]; }
+    __syncthreads();
+    szt::Box A, B, q;
+    wave_box(sx, sy, na, A); wave_box(sx + na, sy + na, nb, B);
+    szt::common_box(A, B, q);
+    if (szt::box_empty(q)) {
+      // apart: no sweep when neither ring can raise the reference's errors on its own -- in range, and in general
+      // position as far as the trimming asks it of the vertices it keeps (no two vertices of a height)
+      if (szt::box_in_range(A) && szt::box_in_range(B)) {
+        const int ea = (na > 1 && sx[na - 1] == sx[0] && sy[na - 1] == sy[0]) ? na - 1 : na;
+        const int eb = (nb > 1 && sx[na + nb - 1] == sx[na] && sy[na + nb - 1] == sy[na]) ? nb - 1 : nb;
+        apart = wave_heights_distinct(sy, ea, sy + na, eb);
+      }
+    } else if (evenodd && na + nb >= 24) {
+      if (lane == 0) {
+        ta = szt::trim_ring(sx, sy, na, q);
+        tb = szt::trim_ring(sx + na, sy + na, nb, q);
+      }
+      ta = __shfl(ta, 0); tb = __shfl(tb, 0);
+      __syncthreads();
+      if (ta != na || tb != nb) {
+        // (an untouched ring may still carry its closing duplicate: not a tie -- trim_pair)
+        const int ea = (ta == na && na > 1 && sx[na - 1] == sx[0] && sy[na - 1] == sy[0]) ? na - 1 : ta;
+        const int eb = (tb == nb && nb > 1 && sx[na + nb - 1] == sx[na] && sy[na + nb - 1] == sy[na]) ? nb - 1 : tb;
+        const bool room = (i64)szv::WS_PER_VERTEX * (i64)(ta + tb) + szv::WS_PER_CLIP + 16 * nv <= s.wbytes;
+        if (room && wave_heights_distinct(sy, ea, sy + na, eb)) {
+          for (int k = lane; k < ta; k += 64) { tx[k] = sx[k]; ty[k] = sy[k]; }
+          for (int k = lane; k < tb; k += 64) { tx[na + k] = sx[na + k]; ty[na + k] = sy[na + k]; }
+          tail = true;
+        } else { ta = na; tb = nb; }
+      }
+    }
+  }
+  if (lane != 0) return;
+  if (!staged && a.method == szv::OP_INTERSECTION && evenodd && na + nb >= 24) {
+    // rings too long to stage in the slice: the serial trimming of k_clip
+    for (int k = 0; k < na; ++k) { tx[k] = ra.x[k]; ty[k] = ra.y[k]; }
+    for (int k = 0; k < nb; ++k) { tx[na + k] = rb.x[k]; ty[na + k] = rb.y[k]; }
+    if (szt::trim_pair(tx, ty, ta, tx + na, ty + na, tb) &&
+        (i64)szv::WS_PER_VERTEX * (i64)(ta + tb) + szv::WS_PER_CLIP + 16 * nv <= s.wbytes) tail = true;
+    else { ta = na; tb = nb; }
+  }
+  SZ_CLIP_CLOCK(1, wall_clock64());
+  SZ_CLIP_CLOCK(3, (unsigned long long)(apart ? 0 : ta + tb));
+  SZ_CLIP_CLOCK(4, apart ? 3ULL : 0ULL);
+  if (apart) {
+    a.oroff[s.roff] = 0;
+    a.ov_base[p] = s.voff; a.or_base[p] = s.roff;
+    a.status[p] = szv::ST_OK; a.nrings[p] = 0;
+    SZ_CLIP_CLOCK(2, wall_clock64());
+    return;
+  }
+  a.meta[2 * p] = ta | (tail ? META_TAIL : 0);
+  a.meta[2 * p + 1] = tb;
+  const int c = slice_class(ta + tb);
+  const unsigned long long k = atomicAdd(&a.counters[9 + c], 1ULL);
+  a.class_list[(size_t)c * a.npairs + k] = p;
+}
+
+// Sweep pass over one class list: lane 0 of each wave sweeps one pair with its records in `slice` bytes of LDS
+// (clip_in_slice), or in the pair's HBM workspace (slice 0, or a sweep that outgrew the slice after all).
+__global__ void __launch_bounds__(64) k_clip_sweep(ClipArgs a, const int *list, int count, int slice) {
+  extern __shared__ __attribute__((aligned(16))) char clip_lds[];
+  const int t = blockIdx.x;
+  if (t >= count || threadIdx.x != 0) return;
+  const int p = list[t];
+  const int a0 = a.aoff[p], na = a.aoff[p + 1] - a0;
+  const int b0 = a.boff[p], nb = a.boff[p + 1] - b0;
+  PairSlots s;
+  pair_slots(a, p, a0, na, b0, nb, s);
+  const int m0 = a.meta[2 * p], ta = m0 & ~META_TAIL, tb = a.meta[2 * p + 1];
+  RingI64 ra = {a.ax + a0, a.ay + a0}, rb = {a.bx + b0, a.by + b0};
+  if (m0 & META_TAIL) {
+    i64 *tx = (i64 *)(a.ws + s.woff + s.wbytes - 16 * s.nv), *ty = tx + (na + nb);
+    RingI64 sa = {tx, ty}, sb = {tx + na, ty + na};
+    ra = sa; rb = sb;
+  }
+  SlotSink sink;
+  sink.ox = a.ovx + s.voff; sink.oy = a.ovy + s.voff; sink.roff = a.oroff + s.roff;
+  sink.cap_v = (int)s.cv; sink.cap_r = (int)s.cr; sink.nv = 0; sink.nr = 0;
+  sink.roff[0] = 0;
+  int st = szv::ST_WORKSPACE;
+  szv::Caps lc;
+#if defined(SZ_CLIP_CLOCKS)
+  const unsigned long long t_in = wall_clock64();
+#endif
+  if (slice > 0 && szv::caps_budget<szv::WideLds>(ta + tb, (size_t)slice, lc) && lc.pts >= ta + tb + 8) {
+    st = clip_in_slice((void *)clip_lds, lc, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
+#if defined(SZ_CLIP_CLOCKS)
+    if (p < (1 << 16)) sz_clip_clocks[5 * p + 4] = st == szv::ST_WORKSPACE ? 2ULL : 1ULL;
+#endif
+    if (st == szv::ST_WORKSPACE) { sink.nv = 0; sink.nr = 0; sink.roff[0] = 0; atomicAdd(&a.counters[8], 1ULL); }
+  }
+  if (st == szv::ST_WORKSPACE)
+    st = szv::clip_rings(a.ws + s.woff, ta + tb, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
+#if defined(SZ_CLIP_CLOCKS)
+  if (p < (1 << 16)) { sz_clip_clocks[5 * p + 1] = t_in; sz_clip_clocks[5 * p + 2] = wall_clock64(); }
+#endif
+  a.ov_base[p] = s.voff;
+  a.or_base[p] = s.roff;
   a.status[p] = st;
   if (st == szv::ST_OK) {
     a.nrings[p] = sink.nr;
@@ -179,10 +432,11 @@ int szb::prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
   if ((rc = sz_reserve(ctx, ctx->nrings, (size_t)npairs * 4 + 4))) return rc;
   if ((rc = sz_reserve(ctx, ctx->status, (size_t)npairs * 4 + 4))) return rc;
   if ((rc = sz_reserve(ctx, ctx->retry_list, (size_t)npairs * 4 + 4))) return rc;
-  if ((rc = sz_reserve(ctx, ctx->counters, 64))) return rc;
+  if ((rc = sz_reserve(ctx, ctx->counters, 128))) return rc;
   a.npairs = npairs;
   a.list = nullptr; a.nlist = 0;
   a.mult = 1;
+  a.lds_per_lane = 0;
   a.ws = (char *)ctx->ws.p; a.ws_cap = (i64)ctx->ws.cap;
   a.ovx = (i64 *)ctx->ovx.p; a.ovy = (i64 *)ctx->ovy.p;
   a.ov_cap = (i64)(ctx->ovx.cap < ctx->ovy.cap ? ctx->ovx.cap : ctx->ovy.cap) / 8;
@@ -192,8 +446,8 @@ int szb::prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
   a.retry = (int *)ctx->retry_list.p; a.retry_cap = npairs;
   a.counters = (unsigned long long *)ctx->counters.p;
   // bump pointers of the retry region start behind the closed-form region
-  unsigned long long init[8] = {0, (unsigned long long)ws_main, (unsigned long long)ov_main,
-                                (unsigned long long)or_main, 0, 0, 0, 0};
+  unsigned long long init[16] = {0, (unsigned long long)ws_main, (unsigned long long)ov_main,
+                                 (unsigned long long)or_main, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   SZ_HIP(ctx, hipMemcpy(ctx->counters.p, init, sizeof(init), hipMemcpyHostToDevice));
   return SZ_OK;
 }
@@ -203,6 +457,63 @@ static int clip_lanes(int npairs) {
   const int want = (npairs + 2047) / 2048;
   return want < 1 ? 1 : want > 64 ? 64 : want;
 }
+// bytes of LDS per lane for the sweep records (0: HBM only)
+static int clip_lds_per_lane() {
+  if (const char *v = getenv("SUBZERO_CLIP_LDS")) { const int b = atoi(v); if (b >= 0 && b <= 160 * 1024) return b & ~15; }
+  return 20 * 1024;
+}
+static void clip_launch(szContext *ctx, int n, const ClipArgs &a) {
+  hipLaunchKernelGGL(k_clip, dim3((n + a.lanes - 1) / a.lanes), dim3(64), (size_t)a.lds_per_lane * a.lanes, ctx->stream, a);
+}
+// The main pass as a front pass and one sweep pass per slice class (k_clip_front / k_clip_sweep): the sweep launches
+// run side by side on streams of their own, forked from and joined to the context's stream.
+static int clip_main_in_classes(szContext *ctx, ClipArgs &a) {
+  static const int class_bytes[CLIP_CLASSES] = {20 * 1024, 40 * 1024, 80 * 1024, 160 * 1024};
+  int rc;
+  if ((rc = sz_reserve(ctx, ctx->clip_meta, (size_t)a.npairs * 8 + 8))) return rc;
+  if ((rc = sz_reserve(ctx, ctx->clip_lists, (size_t)a.npairs * 4 * (CLIP_CLASSES + 1) + 8))) return rc;
+  a.meta = (int *)ctx->clip_meta.p;
+  a.class_list = (int *)ctx->clip_lists.p;
+  if (!ctx->clip_fork) {
+    SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->clip_fork, hipEventDisableTiming));
+    for (int k = 0; k < 4; ++k) {
+      SZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->clip_streams[k], hipStreamNonBlocking));
+      SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->clip_join[k], hipEventDisableTiming));
+    }
+  }
+  a.lds_per_lane = class_bytes[0];
+  hipLaunchKernelGGL(k_clip_front, dim3(a.npairs), dim3(64), (size_t)class_bytes[0], ctx->stream, a);
+  SZ_HIP(ctx, hipGetLastError());
+  unsigned long long c[16];
+  SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SZ_HIP(ctx, hipEventRecord(ctx->clip_fork, ctx->stream));
+  // longest sweeps first: the 160 KB class down to 40 KB on the side streams, then the short ones and what stays in HBM
+  for (int k = CLIP_CLASSES - 1; k >= 1; --k) {
+    const int count = (int)c[9 + k];
+    if (count == 0) continue;
+    hipStream_t st = ctx->clip_streams[k];
+    SZ_HIP(ctx, hipStreamWaitEvent(st, ctx->clip_fork, 0));
+    hipLaunchKernelGGL(k_clip_sweep, dim3(count), dim3(64), (size_t)class_bytes[k], st, a, (const int *)a.class_list + (size_t)k * a.npairs, count, class_bytes[k]);
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipEventRecord(ctx->clip_join[k], st));
+  }
+  if (c[9 + CLASS_HBM] > 0) {
+    hipStream_t st = ctx->clip_streams[0];
+    SZ_HIP(ctx, hipStreamWaitEvent(st, ctx->clip_fork, 0));
+    hipLaunchKernelGGL(k_clip_sweep, dim3((int)c[9 + CLASS_HBM]), dim3(64), 0, st, a, (const int *)a.class_list + (size_t)CLASS_HBM * a.npairs, (int)c[9 + CLASS_HBM], 0);
+    SZ_HIP(ctx, hipGetLastError());
+    SZ_HIP(ctx, hipEventRecord(ctx->clip_join[0], st));
+  }
+  if (c[9] > 0) {
+    hipLaunchKernelGGL(k_clip_sweep, dim3((int)c[9]), dim3(64), (size_t)class_bytes[0], ctx->stream, a, (const int *)a.class_list, (int)c[9], class_bytes[0]);
+    SZ_HIP(ctx, hipGetLastError());
+  }
+  for (int k = CLIP_CLASSES - 1; k >= 1; --k)
+    if (c[9 + k] > 0) SZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->clip_join[k], 0));
+  if (c[9 + CLASS_HBM] > 0) SZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->clip_join[0], 0));
+  return SZ_OK;
+}
 
 // Runs the main pass and the retry tiers.  On return the per-pair arrays on the device are final.
 int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
@@ -210,12 +521,28 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
     if (stats) memset(stats, 0, sizeof(*stats));
     return SZ_OK;
   }
-  // One sweep per lane, and a wave lasts as long as the sum of its lanes' divergent paths: as few pairs per wave as
-  // still give each of the 1024 SIMDs its two waves (252 VGPRs) -- a batch of 2e4 pairs runs 10 per wave.
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void *)k_clip, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_clip_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  // Single rings in fixed point (szClipBatch and what the fracture entries build on it): front pass + sweep classes,
+  // one pair per wave.  Everything else (several contours, double input, SUBZERO_CLIP_LANES set): k_clip, one sweep
+  // per lane, as few pairs per wave as still give each of the 1024 SIMDs its two waves (252 VGPRs).
   a.lanes = clip_lanes(a.npairs);
+  a.lds_per_lane = clip_lds_per_lane();
+  const bool classes = a.lds_per_lane > 0 && !getenv("SUBZERO_CLIP_LANES") && !a.aring && !a.fax;
+  if (!classes && !getenv("SUBZERO_CLIP_LDS")) a.lds_per_lane = 0;
+  if ((i64)a.lds_per_lane * a.lanes > 160 * 1024) a.lds_per_lane = (160 * 1024 / a.lanes) & ~15;
   SZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_clip, dim3((a.npairs + a.lanes - 1) / a.lanes), dim3(64), 0, ctx->stream, a);
-  SZ_HIP(ctx, hipGetLastError());
+  if (classes) {
+    const int rc = clip_main_in_classes(ctx, a);
+    if (rc) return rc;
+  } else {
+    clip_launch(ctx, a.npairs, a);
+    SZ_HIP(ctx, hipGetLastError());
+  }
   SZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   unsigned long long c[8];
   SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
@@ -244,7 +571,8 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
     b.nlist = nlist;
     b.mult = mult;
     b.lanes = clip_lanes(nlist);
-    hipLaunchKernelGGL(k_clip, dim3((nlist + b.lanes - 1) / b.lanes), dim3(64), 0, ctx->stream, b);
+    b.lds_per_lane = 0;
+    clip_launch(ctx, nlist, b);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
     SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -520,3 +848,12 @@ int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation) {
 }
 
 } // extern "C"
+
+#if defined(SZ_CLIP_CLOCKS)
+extern "C" int szDebugClipPhases(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_ph_acc), sizeof(unsigned long long) * 8 * (size_t)(n < (1 << 16) ? n : (1 << 16)));
+}
+extern "C" int szDebugClipClocks(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_clip_clocks), sizeof(unsigned long long) * 5 * (size_t)(n < (1 << 16) ? n : (1 << 16)));
+}
+#endif

@@ -19,14 +19,17 @@ struct ClipArgs {
   int method, fill_s, fill_c;
   int mult;
   int lanes;                    // pairs per 64-lane wave (the rest of the lanes idle: fewer divergent sweeps per wave)
+  int lds_per_lane;             // bytes of LDS per lane for the sweep's records (0: the HBM workspace only)
   char *ws; i64 ws_cap;         // workspace arena
   i64 *ovx, *ovy; i64 ov_cap;   // result vertices
   int *oroff; i64 or_cap;       // result ring offsets (local to the pair's vertex slot)
   i64 *ov_base, *or_base;       // per pair: where its slots start
   int *nrings, *status;
   int *retry; int retry_cap;    // pairs to re-run with a larger workspace
+  int *meta;                    // front pass -> sweep pass, per pair: trimmed sizes (bit 30 of the first: rings at the workspace tail)
+  int *class_list;              // 5 lists of npairs: the pairs of each slice class
   unsigned long long *counters; // [0] retry count, [1] ws bump, [2] ov bump, [3] or bump,
-                                // [4] rings out, [5] verts out, [6] failed, [7] arena exhausted
+                                // [4] rings out, [5] verts out, [6] failed, [7] arena exhausted, [8] outgrew the LDS slice, [9..13] class list lengths
 };
 
 // sizes and (re)allocates the context's clip buffers for a batch of npairs pairs with `total` input vertices; fills the

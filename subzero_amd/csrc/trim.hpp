@@ -101,13 +101,36 @@ SZ_HD bool heights_distinct(const i64 *y1, int n1, const i64 *y2, int n2) {
 // Both rings of an INTERSECTION, in place.  Returns false when the rings must be handed over as they were
 // (the caller restores them: the arrays may have been compacted); true with the new counts otherwise
 // (which equal the old ones when there was nothing to cut).
+SZ_HD void common_box(const Box &A, const Box &B, Box &q) {
+  q.xmin = A.xmin > B.xmin ? A.xmin : B.xmin; q.xmax = A.xmax < B.xmax ? A.xmax : B.xmax;
+  q.ymin = A.ymin > B.ymin ? A.ymin : B.ymin; q.ymax = A.ymax < B.ymax ? A.ymax : B.ymax;
+}
+SZ_HD bool box_empty(const Box &q) { return q.xmin > q.xmax || q.ymin > q.ymax; }
+// Two rings whose boxes have nothing in common (strictly apart along x or along y) have an empty INTERSECTION under
+// every fill rule: at no scanline does an edge of one have an odd number -- or any non-zero winding sum -- of the
+// other's edges to its left (they are never active together, or all of them are on one side), so IsContributing
+// (clipper.cpp:1740-1790) never holds and Execute returns no paths.  The caller still owes the reference's range
+// error (clipper.cpp:883-896), which `in_range` of both boxes rules out, and its "Clipper Error." for a ring that is
+// degenerate on its own (a lone lattice polygon with coincident vertices and edges can fail DoMaxima or the crossing
+// order, clipper.cpp:2841,3005): clip.hip answers without a sweep only when no two vertices of the pair share a
+// height, the condition under which this file trims at all.
+SZ_HD bool box_in_range(const Box &b) {
+  const i64 hi = 0x3FFFFFFFFFFFFFFFLL;
+  return !(b.xmax > hi || b.ymax > hi || -b.xmin > hi || -b.ymin > hi);
+}
+
+SZ_HD bool trim_pair_in(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb, const Box &q);
 SZ_HD bool trim_pair(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb) {
   if (na < 1 || nb < 1 || (na < MIN_RING && nb < MIN_RING)) return true;
   Box A, B, q;
   box_of(ax, ay, na, A); box_of(bx, by, nb, B);
-  q.xmin = A.xmin > B.xmin ? A.xmin : B.xmin; q.xmax = A.xmax < B.xmax ? A.xmax : B.xmax;
-  q.ymin = A.ymin > B.ymin ? A.ymin : B.ymin; q.ymax = A.ymax < B.ymax ? A.ymax : B.ymax;
-  if (q.xmin > q.xmax || q.ymin > q.ymax) return true;       // nothing in common: left to the sweep as it is
+  common_box(A, B, q);
+  return trim_pair_in(ax, ay, na, bx, by, nb, q);
+}
+// (the same with the common box already known)
+SZ_HD bool trim_pair_in(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb, const Box &q) {
+  if (na < 1 || nb < 1 || (na < MIN_RING && nb < MIN_RING)) return true;
+  if (box_empty(q)) return true;                              // nothing in common: left to the sweep as it is
   const int ta = trim_ring(ax, ay, na, q), tb = trim_ring(bx, by, nb, q);
   if (ta == na && tb == nb) return true;
   // (an untouched ring may still carry its closing duplicate: not a tie)

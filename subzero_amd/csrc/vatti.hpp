@@ -306,6 +306,30 @@ SZ_HD size_t workspace_bytes_caps(const Caps &c) {
          align16(sizeof(typename Rec::Join) * c.ghosts) + align16(sizeof(typename Rec::Cross) * c.crosses);
 }
 SZ_HD size_t workspace_bytes(int nv) { return workspace_bytes_caps<Wide>(caps_for(nv)); }
+// Capacities for nv input vertices inside a budget of `bytes` (a slice of LDS): the lists whose length the input fixes
+// (edges, minima, scanlines) in full, the lists of the output side (rings, points, joins, crossings) in caps_for's
+// proportions from what is left.  Simple outlines use a fraction of caps_for's worst case; a sweep that outgrows the
+// slice reports ST_WORKSPACE like any other and the caller repeats it in the HBM workspace.  False: nv does not fit.
+template <class Rec>
+SZ_HD bool caps_budget(int nv, size_t bytes, Caps &c) {
+  Caps in;
+  in.edges = nv + 2; in.minima = nv / 2 + 2; in.beams = nv + 2;
+  in.rings = in.pts = in.joins = in.ghosts = in.crosses = 0;
+  const size_t fixed = workspace_bytes_caps<Rec>(in) + 5 * 16;
+  Caps one = caps_for(1), two = caps_for(2);                  // (every list is linear in nv)
+  one.edges = one.minima = one.beams = two.edges = two.minima = two.beams = 0;
+  const size_t b1 = workspace_bytes_caps<Rec>(one), b2 = workspace_bytes_caps<Rec>(two);
+  const size_t per = b2 > b1 ? b2 - b1 : 1;
+  if (bytes < fixed + b1 + 4 * per) return false;
+  size_t u = (bytes - fixed - b1) / per;
+  while (u > 4) {                                             // (alignment padding: settle on a u that really fits)
+    c = caps_for((int)u);
+    c.edges = in.edges; c.minima = in.minima; c.beams = in.beams;
+    if (workspace_bytes_caps<Rec>(c) <= bytes) return true;
+    --u;
+  }
+  return false;
+}
 SZ_HD size_t workspace_bytes_compact() { return workspace_bytes_caps<Compact>(caps_compact()); }
 // Linear upper bound of workspace_bytes(nv), so that per-pair workspace offsets follow in closed form
 // from the CSR offsets of the inputs: offset(p) = WS_PER_VERTEX * (verts before p) + WS_PER_CLIP * p.
@@ -1288,11 +1312,25 @@ struct SweepT {
     if (ael == NIL) return;
     int e = ael;
     sel = e;
+    // (most beams hold no crossing: the edges come out in order at top_y, which this first walk already sees -- then
+    // the bubble pass below would compare every neighbour pair once more, find nothing, cut the last link and stop)
+    bool in_order = true;
+    int before = NIL;
+    i64 x_before = 0;
     while (e != NIL) {
       E[e].sprev = E[e].aprev;
-      E[e].snext = E[e].anext;
-      E[e].cur.x = x_at(e, top_y);
-      e = E[e].anext;
+      const int en = E[e].anext;
+      E[e].snext = en;
+      const i64 x = x_at(e, top_y);
+      E[e].cur.x = x;
+      if (before != NIL && x_before > x) in_order = false;
+      if (en == NIL && in_order) {
+        if (before != NIL) E[before].snext = NIL;
+        sel = NIL;
+        return;
+      }
+      before = e; x_before = x;
+      e = en;
     }
     bool modified;
     do {
@@ -1379,8 +1417,10 @@ struct SweepT {
 
   SZ_HD void do_top_of_beam(i64 top_y) {
     int e = ael;
+    bool promote = false;     // an edge ends at top_y with a successor: the second walk below has work
     while (e != NIL) {
       if (err) return;
+      if (E[e].top.y == top_y && E[e].up != NIL) promote = true;
       bool is_max = (E[e].top.y == top_y && E[e].up == NIL);
       if (is_max) {
         int mp = maxima_pair_in_ael(e);
@@ -1396,14 +1436,17 @@ struct SweepT {
           if (E[e].ring >= 0) emit(e, E[e].bot);
           sel_push(e);
         } else {
-          E[e].cur.x = x_at(e, top_y);
+          // (cur.x is x_at(e, top_y) already: build_crossings set it for every active edge of this beam -- clipper.cpp
+          // computes TopX a second time here, to the same value)
           E[e].cur.y = top_y;
         }
         e = E[e].anext;
       }
     }
+    if (sel != NIL) promote = true;           // (horizontals bring edges of their own into the list)
     do_horizontals();
     // promote intermediate vertices
+    if (!promote) return;
     e = ael;
     while (e != NIL) {
       if (err) return;

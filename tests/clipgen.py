@@ -264,6 +264,30 @@ def monotone_pairs(n, seed=0):
     return ps
 
 
+def star_pairs(n, seed=0, sizes=(40, 150, 300, 600, 1400), apart_every=5):
+    """Pairs of long star-shaped outlines (radius noise around a circle: simple polygons in general position) that
+    overlap in part, every `apart_every`-th pair moved until the boxes are apart: the sizes are chosen to fall into
+    every slice class of the clip kernel's sweep pass, the HBM one included (clip.hip)."""
+    rng = np.random.default_rng(seed)
+    ps = PairSet()
+
+    def star(m):
+        th = np.sort(rng.uniform(0, 2 * np.pi, m))
+        r = 1.0 + 0.15 * np.sin(3 * th + rng.uniform(0, 6)) + rng.uniform(-0.04, 0.04, m)
+        return np.stack([r * np.cos(th), r * np.sin(th)], 1) * rng.uniform(0.5, 2.0)
+
+    for k in range(n):
+        a = star(int(sizes[k % len(sizes)] * rng.uniform(0.5, 1.0)))
+        b = star(int(sizes[(k // 2) % len(sizes)] * rng.uniform(0.5, 1.0)))
+        d = rng.uniform(0.4, 1.6) * _rot(np.array([[1.0, 0.0]]), rng.uniform(0, 2 * np.pi))[0]
+        if apart_every and k % apart_every == apart_every - 1:
+            d = np.array([a[:, 0].max() - b[:, 0].min() + rng.uniform(0.01, 1.0), rng.uniform(-1, 1)])
+            if k % 2:
+                d = np.array([rng.uniform(-1, 1), a[:, 1].min() - b[:, 1].max() - rng.uniform(0.01, 1.0)])
+        ps.add(a, b + d)
+    return ps
+
+
 def lattice_pairs(n, seed=0, grid=6, max_verts=9):
     """Small polygons on a coarse integer lattice: shared edges, horizontal edges, touching vertices,
     collinear runs, self-intersections -- the degenerate paths of the sweep (joins, horizontals)."""

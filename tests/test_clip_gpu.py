@@ -24,6 +24,7 @@ def test_gpu_matches_golden(ctx, name):
     (g.lattice_pairs, 1500, {"grid": 10, "max_verts": 30}),  # exercises the 8x retry tier
     (g.lattice_pairs, 4000, {"grid": 3, "max_verts": 12}),
     (g.rect_pairs, 4000, {}),
+    (g.star_pairs, 400, {}),      # long outlines: every slice class of the sweep pass, and pairs whose boxes are apart
 ])
 def test_gpu_matches_cpu_checkers(ctx, gen, n, kw):
     ps = gen(n, seed=777, **kw)
