@@ -11,7 +11,7 @@
 //                                                             a team of 16 (32) lanes per pair, four (two) pairs per wave
 //   k_narrow_convex / k_narrow / k_narrow_lds                 one lane per pair: the single-minimum fast path for what the team pass
 //                                                             hands on, the general sweep for what that defers
-//   k_incoming / k_row_count / k_row_fill / k_transfer_*      per pair / per extended floe
+//   k_incoming / k_row_count / k_row_fill                     per pair / per extended floe (the transfer marks ride along)
 //   k_integrate_pre / k_integrate_post                        one thread per real floe
 //   k_forcing                                                 one 256-thread workgroup per real floe (Monte-Carlo forcing)
 // Host read-backs per step: one, of the counters at its end (k_publish into a pinned host buffer), in a steady step --
@@ -99,6 +99,8 @@ __global__ void k_ext_clear(Floes F, Params P, Work W) {   // (and the cells of 
   if (e >= F.nb && e < F.n) mc_precheck(e, F, P, W);
 }
 // ---- exclusive scans: two launches of <= 256 workgroups (one per CU), no spinning --------------------------
+// (one launch with a look-back wait between the halves was measured in round 3: 2 us SLOWER per scan than the kernel
+// boundary it removes -- a back-to-back launch costs about 2 us here, a cross-XCD hand-off of a flag more)
 // k_scan_reduce: workgroup b sums its tile of the input -> agg[b]; k_scan_write: workgroup b adds up the
 // aggregates before it, scans its tile (coalesced 1024-element slabs, wave shuffles + 16 LDS words) and writes;
 // the last workgroup stores the total.  A Job names the arrays: n(), first(ch, k) (the value, read or produced in
@@ -514,24 +516,16 @@ __global__ void k_row_fill(Floes F, Params P, Work W) {
   if (!W.counters[C_GO]) return;
   int N = dev_next(W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) row_fill(i, N, F, P, W);
+  // (the kill mark of floe i is its own row_fill's: the first half of the transfer resolution rides along; the second
+  // half, which needs every floe's first half, rides with k_integrate_pre -- two launches fewer)
+  if (i < N) { row_fill(i, N, F, P, W); transfer_collect(i, F, W); }
 }
-__global__ void k_transfer_collect(Floes F, Work W) {
+__global__ void k_integrate_pre(Floes F, Params P, Work W) {   // grid: max(n, cap_ext) threads
   if (!W.counters[C_GO]) return;
-  int N = dev_next(W);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) transfer_collect(i, F, W);
-}
-__global__ void k_transfer_apply(Floes F, Work W) {
-  if (!W.counters[C_GO]) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < W.cap_ext) transfer_apply(i, F, W);
-}
-__global__ void k_integrate_pre(Floes F, Params P, Work W) {
-  if (!W.counters[C_GO]) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x + F.nb;
-  if (i < F.n) integrate_pre(i, F, P, W);
   int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z < W.cap_ext) transfer_apply(z, F, W);
+  int i = z + F.nb;
+  if (i < F.n) integrate_pre(i, F, P, W);
   if (z < F.nb) { F.collision_force[2 * z] = 0; F.collision_force[2 * z + 1] = 0; F.collision_torque[z] = 0; F.OverlapArea[z] = 0; }
 }
 __global__ void k_integrate_post(Floes F, Params P, Work W) {
@@ -1048,10 +1042,8 @@ static int step_back_a(szContext *ctx, StepState *S) {
   if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)nr_cap))) return rc;
   W.rows = (double *)S->rows.p; W.cap_rows = nr_cap;
   hipLaunchKernelGGL(k_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
-  hipLaunchKernelGGL(k_transfer_collect, grid_for(cap, 256), dim3(256), 0, st, F, W);
-  hipLaunchKernelGGL(k_transfer_apply, grid_for(cap, 256), dim3(256), 0, st, F, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
-  hipLaunchKernelGGL(k_integrate_pre, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  hipLaunchKernelGGL(k_integrate_pre, grid_for(n > cap ? n : cap, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
