@@ -93,9 +93,11 @@ __global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
     unsigned long long base = 0;
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : c == PC_COLD ? C_COLD : c == PC_GENERAL ? C_RETRY : C_TEAM], (unsigned long long)__popcll(m));
+    const bool walls = c == PC_GENERAL && W.wall_list != nullptr;     // (a list of their own when the step sweeps them beside the team pass)
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : c == PC_COLD ? C_COLD : c == PC_GENERAL ? (walls ? C_WALLS : C_RETRY) : C_TEAM], (unsigned long long)__popcll(m));
+    if (c == PC_GENERAL && !walls && lane == __builtin_ctzll(m)) atomicAdd(&W.counters[C_WALLS], (unsigned long long)__popcll(m));   // (counted either way: the next step sizes its wall launch from it)
     base = __shfl(base, __builtin_ctzll(m));
-    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : c == PC_COLD ? W.cold_list : c == PC_GENERAL ? W.retry_list : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
+    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : c == PC_COLD ? W.cold_list : c == PC_GENERAL ? (walls ? W.wall_list : W.retry_list) : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
   }
 }
 }

@@ -432,6 +432,16 @@ __global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, i
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   if (t < count) narrow_lds(t, list, mult, F, P, W, (void *)(smem + (size_t)threadIdx.x * lds_per_lane), lds_per_lane);
 }
+// The floes at the walls (k_pair_classify's list of their own): the general sweep of each against the domain box, one
+// pair per wave with the sweep workspace in LDS, launched beside the team pass on a stream of its own -- the box has
+// horizontal edges, so no fast path takes these pairs, and queued behind the team pass (as deferred pairs are) their
+// quarter of a millisecond came on top of the step.  The waves stride over the list: any grid size is correct.
+__global__ void __launch_bounds__(64) k_narrow_walls(int lds_per_wave, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (threadIdx.x != 0) return;
+  const i64 n = (i64)W.counters[C_WALLS];
+  for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_lds(t, W.wall_list, 1, F, P, W, (void *)smem, lds_per_wave);
+}
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
 // Pairs it does not cover are appended to the retry list and redone by k_narrow.
@@ -670,6 +680,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_NARROW_LDS")) { int b = atoi(v); if (b >= 0 && (size_t)b * S->narrow_lanes <= 160 * 1024) S->narrow_lds = b; }
   if (const char *v = getenv("SUBZERO_CONVEX_FAST")) S->convex_fast = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_TEAM")) S->team = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_WALLS_EARLY")) S->walls_early = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_CONVEX_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->convex_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->retry_lanes = l; }
   if (const char *v = getenv("SUBZERO_RETRY_LDS")) { int b = atoi(v); if (b >= 0 && b <= 40 * 1024) S->retry_lds = b; }
@@ -683,6 +694,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   (void)hipFuncSetAttribute((const void *)k_narrow_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)k_narrow_walls, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)k_narrow_convex_big, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CONVEX_BIG_STRIDE);
   if (const char *v = getenv("SUBZERO_BIG_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->big_lanes = l; }
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -756,6 +768,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
         (rc = sz_reserve(ctx, S->pair_mult, npa * 4)) || (rc = sz_reserve(ctx, S->pair_nrows, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_status, npa * 4)) || (rc = sz_reserve(ctx, S->pair_flag, npa * 4)) ||
         (rc = sz_reserve(ctx, S->retry_list, npa * 4)) || (rc = sz_reserve(ctx, S->retry_copy, npa * 4)) ||
+        (rc = sz_reserve(ctx, S->wall_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) || (rc = sz_reserve(ctx, S->wide_list, npa * 4)) || (rc = sz_reserve(ctx, S->live_list, npa * 4)) || (rc = sz_reserve(ctx, S->cold_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
@@ -766,6 +779,10 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     W.pair_i = (int *)S->pair_i.p; W.pair_j = (int *)S->pair_j.p; W.pair_nvoff = (i64 *)S->pair_nvoff.p;
     W.pair_scr = (i64 *)S->pair_scr.p; W.pair_mult = (int *)S->pair_mult.p; W.pair_nrows = (int *)S->pair_nrows.p;
     W.pair_status = (int *)S->pair_status.p; W.pair_flag = (int *)S->pair_flag.p; W.retry_list = (int *)S->retry_list.p;
+    // (a list of their own for the floes at the walls when the step before had any: step_narrow_first)
+    // (... and deferred no other pair: a general pass after the read-back then sweeps the wall pairs in the time it
+    // takes anyway -- uniaxial200, whose six many-sided pairs a step go that way)
+    W.wall_list = (S->walls_early && S->classified && S->retry_lds > 0 && S->stepped && S->last_walls > 0 && S->last_deferred == 0) ? (int *)S->wall_list.p : nullptr;
     W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p; W.wide_list = (int *)S->wide_list.p; W.live_list = (int *)S->live_list.p; W.cold_list = (int *)S->cold_list.p;
     W.pair_rowoff = (i64 *)S->pair_rowoff.p;
     W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
@@ -840,10 +857,10 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
   const i64 np = speculative ? S->spec_np : (i64)c[C_NPAIRS], nvt = speculative ? S->spec_nvt : (i64)c[C_NVTOT];
   S->np = np; S->nvt = nvt; S->N = (int)c[C_NEXT]; S->retried = 0;
 
-  if ((rc = bind_pairs(np, nvt))) return rc;
-  hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W, (unsigned long long)main_bytes);
   // the pairs sorted for the team pass (narrow_team.hip): boxes apart -> answered, the others onto their kernel's list
   S->classified = classify && S->team != 0 && S->convex_fast != 0 && S->fast_path == 0;
+  if ((rc = bind_pairs(np, nvt))) return rc;
+  hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W, (unsigned long long)main_bytes);
   if (S->classified)
     sz_launch_pair_classify(st, np, speculative ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr,
                             (S->stepped && getenv("SUBZERO_NO_HINT") == nullptr) ? S->last_next : 0, P, W);
@@ -861,15 +878,49 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   const bool fast = S->fast_path != 0 || convex;   // a first pass that defers its leftovers to the 1x general tier
   if (hi > lo) {
     if (convex && S->team) {
+      // The wall pairs first, on this stream, and the team pass beside them on a stream of its own: a wall pair's
+      // sweep is one wave of 368 registers for a quarter of a millisecond, which finds no room once the team pass has
+      // filled every SIMD -- started first it takes one SIMD each and the team pass the rest.
+      hipStream_t ts = st;
+      if (W.wall_list) {
+        if (!S->wall_stream) {
+          SZ_HIP(ctx, hipStreamCreateWithFlags(&S->wall_stream, hipStreamNonBlocking));
+          SZ_HIP(ctx, hipEventCreateWithFlags(&S->wall_fork, hipEventDisableTiming));
+          SZ_HIP(ctx, hipEventCreateWithFlags(&S->wall_join, hipEventDisableTiming));
+        }
+        // (a fork and a join between two streams cost some tens of microseconds: a team pass shorter than that follows
+        // the wall pairs on this stream instead -- which still spares such a field the host round trips of the deferred
+        // pairs: uniaxial200)
+        if (S->last_hot + S->last_cold >= 4096) {
+          ts = S->wall_stream;
+          SZ_HIP(ctx, hipEventRecord(S->wall_fork, st));
+          SZ_HIP(ctx, hipStreamWaitEvent(ts, S->wall_fork, 0));
+        }
+        // (sized from the last step's list; a 16-64 KB slice of LDS per wave while every workgroup still finds a place
+        // at once; the waves stride over the list)
+        i64 wg = S->last_walls + S->last_walls / 4 + 16;
+        if (wg > 1024) wg = 1024;
+        const i64 per_cu = (wg + 255) / 256;
+        i64 room = ((i64)160 * 1024 / per_cu) & ~(i64)1023;
+        if (room > S->retry_lds_max) room = S->retry_lds_max;
+        if (room < S->retry_lds) room = S->retry_lds;
+        hipLaunchKernelGGL(k_narrow_walls, dim3((unsigned)wg), dim3(64), (size_t)room, st, (int)room, F, P, W);
+        SZ_HIP(ctx, hipGetLastError());
+        SZ_HIP(ctx, hipEventRecord(S->ev[2], ts));
+      }
       // the team pass over every pair, then the lane-per-pair fast path over what it handed on (a device-side list: the
       // launch covers the pair count and its workgroups beyond the list return at once)
-      if (S->classified) sz_launch_narrow_team(st, hi - lo, S->stepped ? S->last_hot : -1, S->last_cold, S->last_wide, F, P, W);
-      else sz_launch_narrow_team_range(st, lo, hi - lo, F, P, W);
-      SZ_HIP(ctx, hipEventRecord(S->ev[3], st));   // narrow_ms = the team pass alone (the kernel bench.py prices)
+      if (S->classified) sz_launch_narrow_team(ts, hi - lo, S->stepped ? S->last_hot : -1, S->last_cold, S->last_wide, F, P, W);
+      else sz_launch_narrow_team_range(ts, lo, hi - lo, F, P, W);
+      SZ_HIP(ctx, hipEventRecord(S->ev[3], ts));   // narrow_ms = the team pass alone (the kernel bench.py prices)
       team_timed = true;
       const int L = 16;
-      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, (i64)0, hi - lo,
+      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, ts, (i64)0, hi - lo,
                          (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
+      if (ts != st) {
+        SZ_HIP(ctx, hipEventRecord(S->wall_join, ts));
+        SZ_HIP(ctx, hipStreamWaitEvent(st, S->wall_join, 0));
+      }
     } else if (convex) {
       // one wave per SIMD is all this kernel can use (it is bound by the path of its longest lane): as few pairs
       // per wave as still give every one of the 1024 SIMDs at most one wave -- fewer lanes, less divergence
@@ -1074,7 +1125,8 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
   const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
-  S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE];
+  S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS];
+  S->last_deferred = S->retried - (W.wall_list ? 0 : S->last_walls) + (i64)c[C_BIG];   // pairs of this step that waited for the host besides the floes at the walls
   if (getenv("SUBZERO_DEBUG_LISTS")) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS]);
   if (stats) {
     float ms;
@@ -1084,7 +1136,8 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[3], S->ev[4])); stats->rows_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[4], S->ev[5])); stats->integrate_ms = ms;
     stats->n_ext = S->N; stats->n_pairs = np; stats->n_rows = S->nr; stats->pair_vertices = S->nvt;
-    stats->retried = S->retried; stats->pair_rows = S->pair_rows_local;
+    stats->retried = S->retried + (W.wall_list ? S->last_walls : 0);   // (pairs through the general sweep: deferred ones and the floes at the walls)
+    stats->pair_rows = S->pair_rows_local;
   }
   return SZ_OK;
 }

@@ -102,7 +102,7 @@ static_assert((int)RING_SLOTS == (int)sztm::T_NV, "the staged rings are what the
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COLD, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COLD, C_WALLS, C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -136,6 +136,7 @@ struct Work {
   int *pair_mult;               // [cap_pairs] capacity tier used
   int *pair_nrows, *pair_status, *pair_flag; // flag: 1 sentinel +Inf, 2 sentinel -Inf, 4 contributes rows
   int *retry_list;
+  int *wall_list;               // floes at the walls (PC_GENERAL), when the step runs them beside the team pass (null: they go on retry_list)
   int *big_list;                // pairs the first pass hands to the fast path on the 32-vertex block (C_BIG of them)
   int *team_list;               // pairs the team pass hands to the lane-per-pair fast path (C_TEAM of them)
   int *wide_list;               // pairs with more vertices than a 16-lane team has lanes: 32 lanes each (C_WIDE of them)

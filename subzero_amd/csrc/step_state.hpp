@@ -25,7 +25,7 @@ struct StepState {
   double xo_max = 0, xo_min = 0, yo_max = 0, yo_min = 0; // extent of the uploaded grid axes
   bool have_ocean = false;
   // grow-only per-step buffers
-  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy, big_list, team_list, wide_list, live_list, cold_list;
+  DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy, big_list, team_list, wide_list, live_list, cold_list, wall_list;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_item;
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
@@ -75,6 +75,12 @@ struct StepState {
   bool back_spec_ok = false, no_back_speculation = false;   // ... when the previous step deferred no pair (SUBZERO_SPECULATE_BACK=0: never)
   bool counters_clean = false;    // the last step ended by resetting the device counters (k_publish with reset)
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // the floes at the walls are swept on a stream of their own beside the team pass (step.hip step_narrow_first)
+  hipStream_t wall_stream = nullptr;
+  hipEvent_t wall_fork = nullptr, wall_join = nullptr;
+  long long last_walls = 0;       // pairs on the wall list in the step before (sizes the launch)
+  long long last_deferred = 0;    // pairs the step before handed to the general pass after its read-back, the wall pairs not counted
+  int walls_early = 1;            // SUBZERO_WALLS_EARLY=0: the wall pairs wait for the general pass after the read-back
 };
 
 

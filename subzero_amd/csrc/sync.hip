@@ -93,12 +93,15 @@ void destroy_state(StepState *S) {
   for (DevBuf &b : S->bufs) sz_release(b);
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
-                    &S->retry_copy, &S->big_list, &S->team_list, &S->wide_list, &S->live_list, &S->cold_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
+                    &S->retry_copy, &S->big_list, &S->team_list, &S->wide_list, &S->live_list, &S->cold_list, &S->wall_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
                     &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->pot_list, &S->inc_list,
                     &S->stage_d, &S->stage_i, &S->stage_ids, &S->sp_masks, &S->sp_edges_dev, &S->sp_counts};
   for (DevBuf *b : more) sz_release(*b);
   for (DevBuf &b : S->post) sz_release(b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
+  if (S->wall_stream) (void)hipStreamDestroy(S->wall_stream);
+  if (S->wall_fork) (void)hipEventDestroy(S->wall_fork);
+  if (S->wall_join) (void)hipEventDestroy(S->wall_join);
   if (S->c) (void)hipHostFree(S->c);
   if (S->sp_hdr) (void)hipHostFree(S->sp_hdr);
   delete S;
