@@ -149,6 +149,37 @@ def post_step_line(sim, S, P, reps=3):
             "fracture_deform": {"call_ms": ms_d, "floes": int(len(fids)), "cadence": "every 75th step, the floes picked by fracture.m:51-55 (Subzero.m:220)"}}
 
 
+def other_fields_line(ctx):
+    """ms/step of the same step on other fields (not the headline workload): floes between walls, the reference's evolved
+    outlines, two BASELINE.json configs and a larger field; a few tens of steps each."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    from subzero_amd import capi, synth
+    out = {}
+
+    def run(name, S, P, warm, steps):
+        sim = capi.FloeInteractions(ctx, S)
+        it = 0
+        for _ in range(warm):
+            P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+        t = time.perf_counter(); general = 0
+        for _ in range(steps):
+            P.doInt = int(it % 10 == 0); st = sim.step(P); it += 1; general += st.retried
+        el = time.perf_counter() - t
+        out[name] = {"floes": int(S.n), "candidate_pairs": int(st.n_pairs), "ms_per_step": el / steps * 1e3,
+                     "floe_timesteps_per_s": S.n * steps / el, "pairs_through_the_general_sweep_per_step": general / steps}
+        del sim
+
+    S, P0 = build_workload(10000)
+    P = synth.StepParams(dt=10.0, Lx=1e5, Ly=1e5, periodic=False); P.Modulus = P0.Modulus
+    run("pack10000 between walls", S, P, 12, 20)
+    S, P = scenes.concave(2500, periodic=True); run("2500 evolved outlines (FloeShapes.mat), periodic", S, P, 3, 10)
+    S, P = synth.config("uniaxial200"); run("uniaxial200 (BASELINE.json configs[2])", S, P, 5, 20)
+    S, P = synth.config("convex1000"); run("convex1000 (BASELINE.json configs[1])", S, P, 12, 30)
+    S, P = build_workload(40000); run("pack40000 periodic", S, P, 12, 10)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +188,7 @@ def main():
     ap.add_argument("--floes", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clip-line", action="store_true")
+    ap.add_argument("--no-other-fields", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,6 +281,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(S, P)
     if not args.no_clip_line:
         out["clip_kernel"] = clip_kernel_line(ctx, not args.no_cpu_baseline)
+    if not args.no_other_fields and not args.no_clip_line:
+        del sim
+        out["other_fields"] = other_fields_line(ctx)
     ctx.close()
     print(json.dumps(out), flush=True)
 
