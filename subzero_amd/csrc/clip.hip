@@ -225,33 +225,8 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
 // The sweep pass then runs one launch per slice class, concurrently: most pairs sweep in 20 KB of LDS, eight to a CU;
 // the few long ones get 40, 80 or all 160 KB (a batch lasts as long as its longest sweep: those start at once and
 // run in LDS too); what fits no slice keeps its records in HBM.
-__device__ bool wave_heights_distinct(const i64 *y1, int n1, const i64 *y2, int n2) {
-  const int total = n1 + n2;
-  bool same = false;
-  for (int r = (int)threadIdx.x; r < total; r += 64) {
-    const i64 v = r < n1 ? y1[r] : y2[r - n1];
-    for (int b = r + 1; b < n1; ++b) same |= (v == y1[b]);
-    for (int b = (r + 1 > n1 ? r + 1 - n1 : 0); b < n2; ++b) same |= (v == y2[b]);
-  }
-  return __ballot(same) == 0ULL;
-}
-__device__ i64 wave_min(i64 v) {
-  for (int d = 32; d >= 1; d >>= 1) { const i64 o = __shfl_xor(v, d); v = o < v ? o : v; }
-  return v;
-}
-__device__ i64 wave_max(i64 v) {
-  for (int d = 32; d >= 1; d >>= 1) { const i64 o = __shfl_xor(v, d); v = o > v ? o : v; }
-  return v;
-}
-__device__ void wave_box(const i64 *x, const i64 *y, int n, szt::Box &b) {
-  const i64 big = 0x7FFFFFFFFFFFFFFFLL;
-  i64 x0 = big, x1 = -big - 1, y0 = big, y1 = -big - 1;
-  for (int k = (int)threadIdx.x; k < n; k += 64) {
-    const i64 vx = x[k], vy = y[k];
-    x0 = vx < x0 ? vx : x0; x1 = vx > x1 ? vx : x1; y0 = vy < y0 ? vy : y0; y1 = vy > y1 ? vy : y1;
-  }
-  b.xmin = wave_min(x0); b.xmax = wave_max(x1); b.ymin = wave_min(y0); b.ymax = wave_max(y1);
-}
+using szt::wave_box;
+using szt::wave_heights_distinct;
 
 // slice classes of the sweep pass: bytes of LDS per pair; class CLASS_HBM keeps its records in the HBM workspace
 enum { CLIP_CLASSES = 4, CLASS_HBM = 4, META_TAIL = 1 << 30 };

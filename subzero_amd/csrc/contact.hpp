@@ -210,6 +210,8 @@ struct PairScratch {
   int cap_v, cap_r;               // capacity of each region slot
   double *px, *py; int cap_p;     // crossings P
   double *rows; int cap_rows;     // output: 5 doubles per contact row [Fx, Fy, Px, Py, overlap]
+  int wave;                       // 1: all 64 lanes of the wave run this pair alike and the fixed-point rings are in LDS --
+                                  // the conversion and the trimming then spread over the lanes (step_core.hpp narrow_t)
 };
 
 struct PairOut {
@@ -519,6 +521,54 @@ SZ_HD int crossings_long(const Ring &c1, const Ring &c2, double *px, double *py,
   }
   return np;
 }
+#if defined(__HIPCC__)
+// The same set found by the 64 lanes of a wave that all hold the same pair (step_core.hpp narrow_t, WAVE; the rings and
+// px / py in LDS): lane l takes the edges l, l + 64, ... of ring 1 against every edge of ring 2 -- the arithmetic of
+// each (i, j) is InterX's, unchanged -- and the lanes that found a point take turns to insert it, every lane
+// performing the same insertion.  The result is a sorted set: the order of discovery does not matter.
+template <class Ring>
+__device__ inline int crossings_wave(const Ring &c1, const Ring &c2, double *px, double *py, int cap) {
+  const int m1 = c1.len() - 1, m2 = c2.len() - 1;
+  int np = 0;
+  if (m1 <= 0 || m2 <= 0) return 0;
+  const int lane = (int)(threadIdx.x & 63);
+  for (int ib = 0; ib < m1; ib += 64) {
+    const int i = ib + lane;
+    const bool live = i < m1;
+    const int ii = live ? i : 0;
+    const double x1a = c1.X(ii), y1a = c1.Y(ii), x1b = c1.X(ii + 1), y1b = c1.Y(ii + 1);
+    const double dx1 = x1b - x1a, dy1 = y1b - y1a;
+    const double S1 = dx1 * y1a - dy1 * x1a;
+    double x2b = c2.X(0), y2b = c2.Y(0);
+    double b = dx1 * y2b - dy1 * x2b;
+    for (int j = 0; j < m2; ++j) {
+      const double x2a = x2b, y2a = y2b, a = b;
+      x2b = c2.X(j + 1); y2b = c2.Y(j + 1);
+      b = dx1 * y2b - dy1 * x2b;
+      bool hit = live && (((a - S1) * (b - S1)) <= 0);
+      double X = 0, Y = 0;
+      if (hit) {
+        const double dx2 = x2b - x2a, dy2 = y2b - y2a;
+        const double S2 = dx2 * y2a - dy2 * x2a;
+        const double c = y1a * dx2 - x1a * dy2;
+        const double d = y1b * dx2 - x1b * dy2;
+        const double L = dy2 * dx1 - dy1 * dx2;
+        hit = (((c - S2) * (d - S2)) <= 0) && L != 0;
+        if (hit) { X = (dx2 * S1 - dx1 * S2) / L; Y = (dy2 * S1 - dy1 * S2) / L; }
+      }
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const double Xl = __shfl(X, l), Yl = __shfl(Y, l);
+        np = crossing_insert(px, py, np, cap, Xl, Yl);
+        if (np < 0) return -1;
+      }
+    }
+  }
+  return np;
+}
+#endif
 // (rings held in LDS by the fast path are short: nothing to prune)
 SZ_HD int crossings_any(const RingL &c1, const RingL &c2, double *px, double *py, int cap, double *, double *) {
   return crossings(c1, c2, px, py, cap);
@@ -545,21 +595,37 @@ struct ViaArrays {
   SZ_HD int first(const Ring &ring1, const Ring &ring2, bool boundary, PairScratch &S, RegionSink *sink) const {   // :29 / :34
     int n1 = ring1.n, n2 = ring2.n;
     SZC_PHASE(10);
-    fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y);
-    fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y);
+    fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y, S.wave);
+    fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y, S.wave);
     SZC_PHASE(11);
     // an intersection sees only what lies in the box the two rings share (trim.hpp); on a tie the rings go in whole
-    if (!boundary && !SZC_TRIM_OFF && !szt::trim_pair(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2)) {
+    if (!boundary && !SZC_TRIM_OFF && !trim(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, S.wave)) {
       n1 = ring1.n; n2 = ring2.n;
-      fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y);
-      fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y);
+      fill(ring1, n1, false, 0.0, 0.0, S.f1x, S.f1y, S.wave);
+      fill(ring2, n2, false, 0.0, 0.0, S.f2x, S.f2y, S.wave);
     }
     SZC_TRIM_PROBE(ring1.n + ring2.n, n1 + n2);
     SZC_PHASE(1);
     return sweep(S.f1x, S.f1y, n1, S.f2x, S.f2y, n2, boundary ? szv::OP_DIFFERENCE : szv::OP_INTERSECTION, sink);
   }
+  SZ_HD static bool trim(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wave) return szt::trim_pair_wave(ax, ay, na, bx, by, nb);
+#endif
+    return szt::trim_pair(ax, ay, na, bx, by, nb);
+  }
   template <class Ring>
-  SZ_HD static void fill(const Ring &r, int n, bool shifted, double dx, double dy, i64 *fx, i64 *fy) {
+  SZ_HD static void fill(const Ring &r, int n, bool shifted, double dx, double dy, i64 *fx, i64 *fy, int wave = 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wave) {   // a vertex per lane (the conversion is ~100 instructions of FP64 / int64 emulation a coordinate)
+      for (int k = (int)(threadIdx.x & 63); k < n; k += 64) {
+        if (!shifted) { fx[k] = to_fixed(r.X(k)); fy[k] = to_fixed(r.Y(k)); }
+        else { fx[k] = to_fixed(r.X(k) + dx); fy[k] = to_fixed(r.Y(k) + dy); }
+      }
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
+#endif
 #pragma unroll 4
     for (int k = 0; k < n; ++k) {
       if (!shifted) { fx[k] = to_fixed(r.X(k)); fy[k] = to_fixed(r.Y(k)); }
@@ -572,13 +638,13 @@ struct ViaArrays {
     int nc1 = c1.len(), nc2 = c2.len();
     // (both rings closed here, :62-70; ring 2 is converted again: clip 1 may have trimmed its copy)
     SZC_PHASE(10);
-    fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy);
-    fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y);
+    fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy, S.wave);
+    fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y, S.wave);
     SZC_PHASE(11);
-    if (op == szv::OP_INTERSECTION && !SZC_TRIM_OFF && !szt::trim_pair(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2)) {
+    if (op == szv::OP_INTERSECTION && !SZC_TRIM_OFF && !trim(S.fsx, S.fsy, nc1, S.f2x, S.f2y, nc2, S.wave)) {
       nc1 = c1.len(); nc2 = c2.len();
-      fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy);
-      fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y);
+      fill(c1, nc1, shifted, fdx, fdy, S.fsx, S.fsy, S.wave);
+      fill(c2, nc2, false, 0.0, 0.0, S.f2x, S.f2y, S.wave);
     }
     SZC_TRIM_PROBE(c1.len() + c2.len(), nc1 + nc2);
     SZC_PHASE(6);
@@ -705,7 +771,11 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
     const int len2 = c2.len(), nx = len2 + 4 * (len2 / (int)CROSS_CHUNK + 1);
     if (blk && 8 * (nx + len2) <= room) { lay_x = blk; lay_y = blk + nx; }
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  int np = S.wave ? crossings_wave(c1, c2, S.px, S.py, S.cap_p) : crossings_any(c1, c2, S.px, S.py, S.cap_p, lay_x, lay_y);   // :70
+#else
   int np = crossings_any(c1, c2, S.px, S.py, S.cap_p, lay_x, lay_y);                   // :70
+#endif
   SZC_PHASE(4);
   if (np < 0) return szv::ST_WORKSPACE;
 #if defined(SZ_ABLATE) && SZ_ABLATE == 3

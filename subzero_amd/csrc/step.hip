@@ -432,6 +432,14 @@ __global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, i
   i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
   if (t < count) narrow_lds(t, list, mult, F, P, W, (void *)(smem + (size_t)threadIdx.x * lds_per_lane), lds_per_lane);
 }
+// k_narrow_lds with one pair per wave and ALL 64 lanes on it (step_core.hpp narrow_t, WAVE): the lanes run the pair's
+// serial parts alike and share the loops over vertices in front of every clip -- the conversion to fixed point and the
+// trimming, a quarter of a long pair's time when one lane does them.  Deferred lists at the 1x tier.
+__global__ void __launch_bounds__(64) k_narrow_wave(i64 count, const int *list, int lds_per_wave, Floes F, Params P, Work W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const i64 t = blockIdx.x;
+  if (t < count) narrow_wave(t, list, F, P, W, (void *)smem, lds_per_wave);
+}
 // The floes at the walls (k_pair_classify's list of their own): the general sweep of each against the domain box, one
 // pair per wave with the sweep workspace in LDS, launched beside the team pass on a stream of its own -- the box has
 // horizontal edges, so no fast path takes these pairs, and queued behind the team pass (as deferred pairs are) their
@@ -695,6 +703,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   (void)hipFuncSetAttribute((const void *)k_narrow_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)k_narrow_walls, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)k_narrow_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)k_narrow_convex_big, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CONVEX_BIG_STRIDE);
   if (const char *v = getenv("SUBZERO_BIG_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->big_lanes = l; }
   if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1037,7 +1046,10 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
       room = (room > S->retry_lds_max ? S->retry_lds_max : room) & ~(i64)1023;
       if (room > retry_lds) retry_lds = (int)room;
     }
-    if (retry_lds > 0)
+    static const bool wave_off = getenv("SUBZERO_WAVE_GENERAL") != nullptr && atoi(getenv("SUBZERO_WAVE_GENERAL")) == 0;
+    if (retry_lds > 0 && RL == 1 && mult == 1 && !wave_off)
+      hipLaunchKernelGGL(k_narrow_wave, dim3((unsigned)nl), dim3(64), (size_t)retry_lds, st, nl, (const int *)S->retry_copy.p, retry_lds, F, P, W);
+    else if (retry_lds > 0)
       hipLaunchKernelGGL(k_narrow_lds, grid_for(nl, RL), dim3(64), (size_t)retry_lds * RL, st, nl, (const int *)S->retry_copy.p, mult, RL, retry_lds, F, P, W);
     else
       hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);

@@ -587,14 +587,25 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
   point_small(p, L, S); p += L.end;
   S.cap_rows = S.cap_r;
   S.rows = (double *)p; p += up16(40 * (size_t)S.cap_rows);
+  S.wave = 0;
   return p <= end;
 }
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
-template <bool CONVEX_ONLY, class Blk, bool LDS_WS = false>
+// (WAVE: all 64 lanes of the wave are here with the same arguments -- k_narrow_wave, mult 1 -- and run the pair alike:
+// same reads, same plain stores; one lane speaks for the wave where a counter or a list is touched, and the loops that
+// split over vertices -- staging, conversion to fixed point, trimming -- spread over the lanes)
+template <bool CONVEX_ONLY, class Blk, bool LDS_WS = false, bool WAVE = false>
 SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
                     void *fast_ws, int fast_ws_bytes, Blk *fast_blk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool speaker = !WAVE || (threadIdx.x & 63) == 0;
+  const int lane0 = WAVE ? (int)(threadIdx.x & 63) : 0, lanes = WAVE ? 64 : 1;
+#else
+  const bool speaker = true;
+  const int lane0 = 0, lanes = 1;
+#endif
   i64 p = list ? (i64)list[t] : t;
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
@@ -631,7 +642,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   szc::PairScratch S;
   if (off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, n1, n2, mult, S)) {
     W.pair_status[p] = szv::ST_WORKSPACE;
-    atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
+    if (speaker) atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
     return;
   }
   W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);   // where row_fill / export_pair find the rows
@@ -648,9 +659,12 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
       lds_ws_bytes = fast_ws_bytes - ring_bytes;
       double *lx1 = (double *)((char *)fast_ws + lds_ws_bytes), *ly1 = lx1 + n1, *lx2 = ly1 + n1, *ly2 = lx2 + n2;
 #pragma unroll 4
-      for (int k = 0; k < n1; ++k) { lx1[k] = ring1.X(k); ly1[k] = ring1.Y(k); }
+      for (int k = lane0; k < n1; k += lanes) { lx1[k] = ring1.X(k); ly1[k] = ring1.Y(k); }
 #pragma unroll 4
-      for (int k = 0; k < n2; ++k) { lx2[k] = ring2.X(k); ly2[k] = ring2.Y(k); }
+      for (int k = lane0; k < n2; k += lanes) { lx2[k] = ring2.X(k); ly2[k] = ring2.Y(k); }
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (WAVE) __builtin_amdgcn_wave_barrier();
+#endif
       szc::RingD s1 = {lx1, ly1, -0.0, -0.0, n1, 0}, s2 = {lx2, ly2, -0.0, -0.0, n2, 0};
       ring1 = s1; ring2 = s2;
       // ... and, while the sweep still keeps room for 24 vertices, the rings in fixed point, the region slots and
@@ -660,6 +674,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
       if ((i64)L.end + (i64)szv::WS_PER_CLIP + 24 * (i64)szv::WS_PER_VERTEX <= (i64)lds_ws_bytes) {
         lds_ws_bytes -= (int)L.end;
         point_small((char *)fast_ws + lds_ws_bytes, L, S);
+        S.wave = WAVE ? 1 : 0;
       }
     }
   }
@@ -675,16 +690,14 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   SZC_PHASE(0);
   W.pair_status[p] = st;
   if (st == szc::ST_DEFER_BIG) {
-    unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL);
-    W.big_list[k] = (int)p;
+    if (speaker) { unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL); W.big_list[k] = (int)p; }
     return;
   }
   if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY || st == szc::ST_DEFER) {
-    unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL);
-    W.retry_list[k] = (int)p;
+    if (speaker) { unsigned long long k = atomic_add(&W.counters[C_RETRY], 1ULL); W.retry_list[k] = (int)p; }
     return;
   }
-  if (st != szv::ST_OK) { atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
+  if (st != szv::ST_OK) { if (speaker) atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
   int flag = 0;
   double sabs = 0;
   for (int r = 0; r < out.nrows; ++r) sabs += absd(S.rows[5 * r]) + absd(S.rows[5 * r + 1]);
@@ -692,7 +705,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
-  if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+  if ((flag & 4) && speaker) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
 }
 // the general sweep for every clip of the pair
 SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
@@ -702,6 +715,10 @@ SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params
 // the general sweep with its workspace in the lane's slice of LDS when that is large enough (k_narrow_lds)
 SZ_HD void narrow_lds(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W, void *lds_ws, int lds_stride) {
   narrow_t<false, szx::FastBlock, true>(t, list, mult, F, P, W, lds_ws, lds_stride, nullptr);
+}
+// ... by a whole wave per pair (k_narrow_wave; list at the 1x tier only: no allocation from the bump counter)
+SZ_HD void narrow_wave(i64 t, const int *list, const Floes &F, const Params &P, Work &W, void *lds_ws, int lds_bytes) {
+  narrow_t<false, szx::FastBlock, true, true>(t, list, 1, F, P, W, lds_ws, lds_bytes, nullptr);
 }
 // the single-minimum fast path only (convex.hpp); pairs it does not cover go to the retry list for narrow()
 template <class Blk>

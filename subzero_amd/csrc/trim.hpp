@@ -141,4 +141,53 @@ SZ_HD bool trim_pair_in(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb, co
   return true;
 }
 
+#if defined(__HIPCC__)
+// ---- the same by the 64 lanes of a wave that all hold the same pair (clip.hip k_clip_front, step_core.hpp narrow_t in
+// its wave form): the reductions and the O(n^2) height check spread over the lanes, the serial scan of trim_ring run
+// by every lane alike (same reads, same writes).  The arrays must be in LDS (or otherwise coherent inside a wave).
+__device__ inline i64 wave_min(i64 v) {
+  for (int d = 32; d >= 1; d >>= 1) { const i64 o = __shfl_xor(v, d); v = o < v ? o : v; }
+  return v;
+}
+__device__ inline i64 wave_max(i64 v) {
+  for (int d = 32; d >= 1; d >>= 1) { const i64 o = __shfl_xor(v, d); v = o > v ? o : v; }
+  return v;
+}
+__device__ inline void wave_box(const i64 *x, const i64 *y, int n, Box &b) {
+  const i64 big = 0x7FFFFFFFFFFFFFFFLL;
+  i64 x0 = big, x1 = -big - 1, y0 = big, y1 = -big - 1;
+  for (int k = (int)(threadIdx.x & 63); k < n; k += 64) {
+    const i64 vx = x[k], vy = y[k];
+    x0 = vx < x0 ? vx : x0; x1 = vx > x1 ? vx : x1; y0 = vy < y0 ? vy : y0; y1 = vy > y1 ? vy : y1;
+  }
+  b.xmin = wave_min(x0); b.xmax = wave_max(x1); b.ymin = wave_min(y0); b.ymax = wave_max(y1);
+}
+__device__ inline bool wave_heights_distinct(const i64 *y1, int n1, const i64 *y2, int n2) {
+  const int total = n1 + n2;
+  bool same = false;
+  for (int r = (int)(threadIdx.x & 63); r < total; r += 64) {
+    const i64 v = r < n1 ? y1[r] : y2[r - n1];
+    for (int b = r + 1; b < n1; ++b) same |= (v == y1[b]);
+    for (int b = (r + 1 > n1 ? r + 1 - n1 : 0); b < n2; ++b) same |= (v == y2[b]);
+  }
+  return __ballot(same) == 0ULL;
+}
+// trim_pair by a whole wave (every lane returns the same)
+__device__ inline bool trim_pair_wave(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb) {
+  if (na < 1 || nb < 1 || (na < MIN_RING && nb < MIN_RING)) return true;
+  Box A, B, q;
+  wave_box(ax, ay, na, A); wave_box(bx, by, nb, B);
+  common_box(A, B, q);
+  if (box_empty(q)) return true;
+  const int ta = trim_ring(ax, ay, na, q), tb = trim_ring(bx, by, nb, q);
+  if (ta == na && tb == nb) return true;
+  __builtin_amdgcn_wave_barrier();
+  const int ea = (ta == na && na > 1 && ax[na - 1] == ax[0] && ay[na - 1] == ay[0]) ? na - 1 : ta;
+  const int eb = (tb == nb && nb > 1 && bx[nb - 1] == bx[0] && by[nb - 1] == by[0]) ? nb - 1 : tb;
+  if (!wave_heights_distinct(ay, ea, by, eb)) return false;
+  na = ta; nb = tb;
+  return true;
+}
+#endif
+
 } // namespace szt
