@@ -18,12 +18,12 @@
 #if defined(SZ_CLIP_CLOCKS)
 // diagnostic build: time per part of the sweep (vatti.hpp SZV_PHASE), one pair per workgroup
 #include <hip/hip_runtime.h>
-__device__ unsigned long long sz_ph_t[1 << 16], sz_ph_acc[(1 << 16) * 8];
+__device__ unsigned long long sz_ph_t[1 << 16], sz_ph_acc[(1 << 16) * 16];
 __device__ int sz_ph_k[1 << 16];
 #endif
 #if defined(SZ_CLIP_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
 #define SZV_PHASE(k) do { const unsigned b_ = blockIdx.x; if (b_ < 65536u) { const unsigned long long now_ = wall_clock64(); \
-  sz_ph_acc[b_ * 8 + sz_ph_k[b_]] += now_ - sz_ph_t[b_]; sz_ph_t[b_] = now_; sz_ph_k[b_] = (k) - 12; } } while (0)
+  sz_ph_acc[b_ * 16 + sz_ph_k[b_]] += now_ - sz_ph_t[b_]; sz_ph_t[b_] = now_; sz_ph_k[b_] = (k) - 12; } } while (0)
 #endif
 #include "clip_batch.hpp"
 #include "offset.hpp"
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) k_clip(ClipArgs a) {
   int p = a.list ? a.list[t] : t;
   SZ_CLIP_CLOCK(0, wall_clock64());
 #if defined(SZ_CLIP_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
-  if (blockIdx.x < 65536u) { sz_ph_t[blockIdx.x] = wall_clock64(); sz_ph_k[blockIdx.x] = 0; for (int k = 0; k < 8; ++k) sz_ph_acc[blockIdx.x * 8 + k] = 0; }
+  if (blockIdx.x < 65536u) { sz_ph_t[blockIdx.x] = wall_clock64(); sz_ph_k[blockIdx.x] = 0; for (int k = 0; k < 16; ++k) sz_ph_acc[blockIdx.x * 16 + k] = 0; }
 #endif
   int a0 = a.aoff[p], na = a.aoff[p + 1] - a0;
   int b0 = a.boff[p], nb = a.boff[p + 1] - b0;
@@ -826,7 +826,7 @@ int szOrientation(const int64_t *x, const int64_t *y, int n, int *orientation) {
 
 #if defined(SZ_CLIP_CLOCKS)
 extern "C" int szDebugClipPhases(unsigned long long *out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_ph_acc), sizeof(unsigned long long) * 8 * (size_t)(n < (1 << 16) ? n : (1 << 16)));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_ph_acc), sizeof(unsigned long long) * 16 * (size_t)(n < (1 << 16) ? n : (1 << 16)));
 }
 extern "C" int szDebugClipClocks(unsigned long long *out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_clip_clocks), sizeof(unsigned long long) * 5 * (size_t)(n < (1 << 16) ? n : (1 << 16)));

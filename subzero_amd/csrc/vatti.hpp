@@ -441,10 +441,20 @@ struct SweepT {
   }
 
   // ---- pending scanlines: ascending unique array, largest y popped first ----
+  // (the place by bisection: a new edge's top lies below every vertex between it and the scanline, tens to hundreds of
+  // pending heights for a long outline, and walking down to it is a chain of dependent loads -- the reference keeps a
+  // binary heap and drops duplicates when it pops, clipper.cpp:1332-1349; the heights come out the same)
   SZ_HD void push_beam(i64 y) {
     int k = nB;
-    while (k > 0 && B[k - 1] > y) --k;
-    if (k > 0 && B[k - 1] == y) return;
+    if (k > 0 && !(B[k - 1] < y)) {
+      int lo = 0;
+      --k;                                  // B[k] >= y: the first such index lies in [lo, k]
+      while (lo < k) {
+        const int mid = (lo + k) >> 1;
+        if (B[mid] < y) lo = mid + 1; else k = mid;
+      }
+      if (B[k] == y) return;
+    }
     if (nB >= cap.beams) { fail(ST_WORKSPACE); return; }
     for (int j = nB; j > k; --j) B[j] = B[j - 1];
     B[k] = y;
@@ -1376,6 +1386,7 @@ struct SweepT {
     build_crossings(top_y);
     if (err) return false;
     if (nX == 0) return true;
+    SZV_PHASE(23);
     if (nX == 1 || order_crossings()) {
       for (int i = 0; i < nX; ++i) {
         if (err) break;
@@ -1415,12 +1426,34 @@ struct SweepT {
     } else fail(ST_CLIP_ERROR);
   }
 
+  // an edge that ends at the scanline with a successor: the vertex goes out, the successor takes its place (and a join is
+  // recorded where it starts on a neighbour's edge that runs parallel); returns the successor
+  SZ_HD int promote_vertex(int e) {
+    int op = NIL;
+    if (E[e].ring >= 0) op = emit(e, E[e].top);
+    e = ael_advance(e);
+    int ep = E[e].aprev, en = E[e].anext;
+    if (ep != NIL && E[ep].cur.x == E[e].bot.x && E[ep].cur.y == E[e].bot.y && op != NIL &&
+        E[ep].ring >= 0 && E[ep].cur.y > E[ep].top.y &&
+        parallel4(E[e].cur, E[e].top, E[ep].cur, E[ep].top) && E[e].wdelta != 0 && E[ep].wdelta != 0) {
+      int op2 = emit(ep, E[e].bot);
+      add_join(op, op2, E[e].top);
+    } else if (en != NIL && E[en].cur.x == E[e].bot.x && E[en].cur.y == E[e].bot.y && op != NIL &&
+               E[en].ring >= 0 && E[en].cur.y > E[en].top.y &&
+               parallel4(E[e].cur, E[e].top, E[en].cur, E[en].top) && E[e].wdelta != 0 && E[en].wdelta != 0) {
+      int op2 = emit(en, E[e].bot);
+      add_join(op, op2, E[e].top);
+    }
+    return e;
+  }
   SZ_HD void do_top_of_beam(i64 top_y) {
     int e = ael;
-    bool promote = false;     // an edge ends at top_y with a successor: the second walk below has work
+    // (the second walk below looks for the edges that end at top_y with a successor; the first walk has seen them:
+    // when it met a single one and no horizontal -- the common scanline, one vertex of one ring -- that edge is promoted
+    // without walking again)
+    int ending = NIL, n_ending = 0;
     while (e != NIL) {
       if (err) return;
-      if (E[e].top.y == top_y && E[e].up != NIL) promote = true;
       bool is_max = (E[e].top.y == top_y && E[e].up == NIL);
       if (is_max) {
         int mp = maxima_pair_in_ael(e);
@@ -1428,7 +1461,9 @@ struct SweepT {
       }
       if (is_max) {
         int ep = E[e].aprev;
+        SZV_PHASE(20);
         do_maxima(e);
+        SZV_PHASE(17);
         e = (ep == NIL) ? ael : E[ep].anext;
       } else {
         if (E[e].top.y == top_y && E[e].up != NIL && horiz(E[e].up)) {
@@ -1436,6 +1471,7 @@ struct SweepT {
           if (E[e].ring >= 0) emit(e, E[e].bot);
           sel_push(e);
         } else {
+          if (E[e].top.y == top_y && E[e].up != NIL) { ending = e; ++n_ending; }
           // (cur.x is x_at(e, top_y) already: build_crossings set it for every active edge of this beam -- clipper.cpp
           // computes TopX a second time here, to the same value)
           E[e].cur.y = top_y;
@@ -1443,30 +1479,19 @@ struct SweepT {
         e = E[e].anext;
       }
     }
-    if (sel != NIL) promote = true;           // (horizontals bring edges of their own into the list)
+    const bool had_horizontals = sel != NIL;      // (horizontals bring edges of their own into the list)
+    SZV_PHASE(21);
     do_horizontals();
+    SZV_PHASE(22);
     // promote intermediate vertices
-    if (!promote) return;
+    if (!had_horizontals) {                         // (maxima remove edges and move others past them, they make none)
+      if (n_ending == 0) return;
+      if (n_ending == 1) { (void)promote_vertex(ending); return; }
+    }
     e = ael;
     while (e != NIL) {
       if (err) return;
-      if (E[e].top.y == top_y && E[e].up != NIL) {
-        int op = NIL;
-        if (E[e].ring >= 0) op = emit(e, E[e].top);
-        e = ael_advance(e);
-        int ep = E[e].aprev, en = E[e].anext;
-        if (ep != NIL && E[ep].cur.x == E[e].bot.x && E[ep].cur.y == E[e].bot.y && op != NIL &&
-            E[ep].ring >= 0 && E[ep].cur.y > E[ep].top.y &&
-            parallel4(E[e].cur, E[e].top, E[ep].cur, E[ep].top) && E[e].wdelta != 0 && E[ep].wdelta != 0) {
-          int op2 = emit(ep, E[e].bot);
-          add_join(op, op2, E[e].top);
-        } else if (en != NIL && E[en].cur.x == E[e].bot.x && E[en].cur.y == E[e].bot.y && op != NIL &&
-                   E[en].ring >= 0 && E[en].cur.y > E[en].top.y &&
-                   parallel4(E[e].cur, E[e].top, E[en].cur, E[en].top) && E[e].wdelta != 0 && E[en].wdelta != 0) {
-          int op2 = emit(en, E[e].bot);
-          add_join(op, op2, E[e].top);
-        }
-      }
+      if (E[e].top.y == top_y && E[e].up != NIL) e = promote_vertex(e);
       e = E[e].anext;
     }
   }
