@@ -361,6 +361,15 @@ struct SweepT {
   int op, fill_s, fill_c;
   int err;
   int reverse_out;   // Clipper::ReverseSolution (clipper.cpp:1478,1598,3721,3734); only ClipperOffset sets it
+  // Curr.Y of the reference's active edges is one value at any moment: the scanline the sweep stands on (every edge
+  // gets it at the top of each beam, clipper.cpp:3020-3038, and an edge that comes in starts there).  It is kept here,
+  // once, instead of in every edge -- the walk that stored it per edge and beam is gone; cur.x stays per edge.
+  i64 y_now;
+  // build_crossings notes the edges that end at the top of the beam, in list order, for do_top_of_beam -- in the
+  // memory of the crossing list, which is empty exactly when the note is valid (a beam without crossings: the active
+  // list is then unchanged in between); note[0] their number, note[1..4] the first four
+  bool beam_in_order;
+  SZ_HD int *end_note() const { return (int *)X; }
 
   SZ_HD void bind(void *buf, int nv) { bind_caps(buf, caps_for(nv)); }
   SZ_HD void bind_caps(void *buf, const Caps &c) {
@@ -379,6 +388,7 @@ struct SweepT {
     cur_lm = 0;
     err = ST_OK;
     reverse_out = 0;
+    y_now = 0; beam_in_order = false;
   }
   SZ_HD void fail(int code) { if (err == ST_OK) err = code; }
 
@@ -393,6 +403,7 @@ struct SweepT {
     const Edge &g = E[e];
     return (y == g.top.y) ? g.top.x : g.bot.x + rnd(g.slope * (double)(y - g.bot.y));
   }
+  SZ_HD Pt cur_of(int e) const { Pt p; p.x = E[e].cur.x; p.y = y_now; return p; }   // Curr of an active edge
   SZ_HD void flip_horizontal(int e) {
     i64 t = E[e].top.x; E[e].top.x = E[e].bot.x; E[e].bot.x = t;
   }
@@ -401,7 +412,7 @@ struct SweepT {
     const Edge &a = E[i1], &b = E[i2];
     Pt ip;
     if (a.slope == b.slope) {
-      ip.y = a.cur.y;
+      ip.y = y_now;
       ip.x = x_at(i1, ip.y);
       return ip;
     } else if (a.slope == 0) {
@@ -432,8 +443,8 @@ struct SweepT {
       else ip.x = x_at(i2, ip.y);
     }
     // never below the bottom of the scanbeam
-    if (ip.y > a.cur.y) {
-      ip.y = a.cur.y;
+    if (ip.y > y_now) {
+      ip.y = y_now;
       if (dabs(a.slope) > dabs(b.slope)) ip.x = x_at(i2, ip.y);
       else ip.x = x_at(i1, ip.y);
     }
@@ -1189,14 +1200,14 @@ struct SweepT {
       }
       int lp = E[lb].aprev;
       if (E[lb].ring >= 0 && lp != NIL && E[lp].cur.x == E[lb].bot.x && E[lp].ring >= 0 &&
-          parallel4(E[lp].bot, E[lp].top, E[lb].cur, E[lb].top) && E[lb].wdelta != 0 && E[lp].wdelta != 0) {
+          parallel4(E[lp].bot, E[lp].top, cur_of(lb), E[lb].top) && E[lb].wdelta != 0 && E[lp].wdelta != 0) {
         int op2 = emit(lp, E[lb].bot);
         add_join(op1, op2, E[lb].top);
       }
       if (E[lb].anext != rb) {
         int rp = E[rb].aprev;
         if (E[rb].ring >= 0 && E[rp].ring >= 0 &&
-            parallel4(E[rp].cur, E[rp].top, E[rb].cur, E[rb].top) && E[rb].wdelta != 0 && E[rp].wdelta != 0) {
+            parallel4(cur_of(rp), E[rp].top, cur_of(rb), E[rb].top) && E[rb].wdelta != 0 && E[rp].wdelta != 0) {
           int op2 = emit(rp, E[rb].bot);
           add_join(op1, op2, E[rb].top);
         }
@@ -1204,7 +1215,7 @@ struct SweepT {
         if (e != NIL) {
           while (e != rb) {
             if (err) return;
-            cross_edges(rb, e, E[lb].cur);
+            cross_edges(rb, e, cur_of(lb));
             e = E[e].anext;
           }
         }
@@ -1254,7 +1265,7 @@ struct SweepT {
         if (E[e].cur.x == E[h].top.x && E[h].up != NIL && E[e].slope < E[E[h].up].slope) break;
 
         if (E[h].ring >= 0) {
-          op1 = emit(h, E[e].cur);
+          op1 = emit(h, cur_of(e));
           join_with_pending_horizontals(h, op1);
           add_ghost(op1, E[h].bot);
         }
@@ -1290,13 +1301,13 @@ struct SweepT {
         h = ael_advance(h);
         // h is no longer horizontal
         int ep = E[h].aprev, en = E[h].anext;
-        if (ep != NIL && E[ep].cur.x == E[h].bot.x && E[ep].cur.y == E[h].bot.y && E[ep].wdelta != 0 &&
-            E[ep].ring >= 0 && E[ep].cur.y > E[ep].top.y &&
+        if (ep != NIL && E[ep].cur.x == E[h].bot.x && y_now == E[h].bot.y && E[ep].wdelta != 0 &&
+            E[ep].ring >= 0 && y_now > E[ep].top.y &&
             mul_eq(E[h].top.y - E[h].bot.y, E[ep].top.x - E[ep].bot.x, E[h].top.x - E[h].bot.x, E[ep].top.y - E[ep].bot.y)) {
           int op2 = emit(ep, E[h].bot);
           add_join(op1, op2, E[h].top);
-        } else if (en != NIL && E[en].cur.x == E[h].bot.x && E[en].cur.y == E[h].bot.y && E[en].wdelta != 0 &&
-                   E[en].ring >= 0 && E[en].cur.y > E[en].top.y &&
+        } else if (en != NIL && E[en].cur.x == E[h].bot.x && y_now == E[h].bot.y && E[en].wdelta != 0 &&
+                   E[en].ring >= 0 && y_now > E[en].top.y &&
                    mul_eq(E[h].top.y - E[h].bot.y, E[en].top.x - E[en].bot.x, E[h].top.x - E[h].bot.x, E[en].top.y - E[en].bot.y)) {
           int op2 = emit(en, E[h].bot);
           add_join(op1, op2, E[h].top);
@@ -1327,16 +1338,21 @@ struct SweepT {
     bool in_order = true;
     int before = NIL;
     i64 x_before = 0;
+    int end_n = 0;
+    int *note = end_note();
     while (e != NIL) {
       E[e].sprev = E[e].aprev;
       const int en = E[e].anext;
       E[e].snext = en;
       const i64 x = x_at(e, top_y);
       E[e].cur.x = x;
+      if (E[e].top.y == top_y) { if (end_n < 4) note[1 + end_n] = e; ++end_n; }   // (for do_top_of_beam, see there)
       if (before != NIL && x_before > x) in_order = false;
       if (en == NIL && in_order) {
         if (before != NIL) E[before].snext = NIL;
         sel = NIL;
+        note[0] = end_n;
+        beam_in_order = true;
         return;
       }
       before = e; x_before = x;
@@ -1382,6 +1398,7 @@ struct SweepT {
     return true;
   }
   SZ_HD bool do_crossings(i64 top_y) {
+    beam_in_order = false;
     if (ael == NIL) return true;
     build_crossings(top_y);
     if (err) return false;
@@ -1433,28 +1450,41 @@ struct SweepT {
     if (E[e].ring >= 0) op = emit(e, E[e].top);
     e = ael_advance(e);
     int ep = E[e].aprev, en = E[e].anext;
-    if (ep != NIL && E[ep].cur.x == E[e].bot.x && E[ep].cur.y == E[e].bot.y && op != NIL &&
-        E[ep].ring >= 0 && E[ep].cur.y > E[ep].top.y &&
-        parallel4(E[e].cur, E[e].top, E[ep].cur, E[ep].top) && E[e].wdelta != 0 && E[ep].wdelta != 0) {
+    if (ep != NIL && E[ep].cur.x == E[e].bot.x && y_now == E[e].bot.y && op != NIL &&
+        E[ep].ring >= 0 && y_now > E[ep].top.y &&
+        parallel4(cur_of(e), E[e].top, cur_of(ep), E[ep].top) && E[e].wdelta != 0 && E[ep].wdelta != 0) {
       int op2 = emit(ep, E[e].bot);
       add_join(op, op2, E[e].top);
-    } else if (en != NIL && E[en].cur.x == E[e].bot.x && E[en].cur.y == E[e].bot.y && op != NIL &&
-               E[en].ring >= 0 && E[en].cur.y > E[en].top.y &&
-               parallel4(E[e].cur, E[e].top, E[en].cur, E[en].top) && E[e].wdelta != 0 && E[en].wdelta != 0) {
+    } else if (en != NIL && E[en].cur.x == E[e].bot.x && y_now == E[e].bot.y && op != NIL &&
+               E[en].ring >= 0 && y_now > E[en].top.y &&
+               parallel4(cur_of(e), E[e].top, cur_of(en), E[en].top) && E[e].wdelta != 0 && E[en].wdelta != 0) {
       int op2 = emit(en, E[e].bot);
       add_join(op, op2, E[e].top);
     }
     return e;
   }
   SZ_HD void do_top_of_beam(i64 top_y) {
-    int e = ael;
-    // (the second walk below looks for the edges that end at top_y with a successor; the first walk has seen them:
-    // when it met a single one and no horizontal -- the common scanline, one vertex of one ring -- that edge is promoted
-    // without walking again)
+    y_now = top_y;
+    // The reference walks the whole list here (clipper.cpp:3006-3040): Curr of every edge, the maxima, the edges whose
+    // successor is horizontal.  Curr needs no walk (cur.x is x_at(e, top_y) since build_crossings, the height is
+    // y_now); the edges that END at top_y are the ones with anything to do, and when the beam held no crossing
+    // build_crossings has met them in list order on its own walk -- they are then taken from its note, in that order
+    // (one loop for both ways: the noted edges, or the whole list).
+    // The second walk below looks for the ending edges with a successor; when there is a single one and no horizontal
+    // -- the common scanline, one vertex of one ring -- that edge is promoted without walking again.
     int ending = NIL, n_ending = 0;
+    const int *note = end_note();
+    const int end_n = beam_in_order ? note[0] : 5;
+    const bool noted = end_n <= 4;
+    beam_in_order = false;
+    int k = 0;
+    int e = noted ? (end_n > 0 ? note[1] : NIL) : ael;
     while (e != NIL) {
       if (err) return;
-      bool is_max = (E[e].top.y == top_y && E[e].up == NIL);
+      int next;
+      // (a noted edge may have left the list with its maxima partner)
+      const bool here = (!noted || !(E[e].aprev == NIL && E[e].anext == NIL && e != ael)) && E[e].top.y == top_y;
+      bool is_max = here && E[e].up == NIL;
       if (is_max) {
         int mp = maxima_pair_in_ael(e);
         is_max = (mp == NIL || !horiz(mp));
@@ -1464,20 +1494,17 @@ struct SweepT {
         SZV_PHASE(20);
         do_maxima(e);
         SZV_PHASE(17);
-        e = (ep == NIL) ? ael : E[ep].anext;
+        next = (ep == NIL) ? ael : E[ep].anext;
       } else {
-        if (E[e].top.y == top_y && E[e].up != NIL && horiz(E[e].up)) {
+        if (here && E[e].up != NIL && horiz(E[e].up)) {
           e = ael_advance(e);
           if (E[e].ring >= 0) emit(e, E[e].bot);
           sel_push(e);
-        } else {
-          if (E[e].top.y == top_y && E[e].up != NIL) { ending = e; ++n_ending; }
-          // (cur.x is x_at(e, top_y) already: build_crossings set it for every active edge of this beam -- clipper.cpp
-          // computes TopX a second time here, to the same value)
-          E[e].cur.y = top_y;
-        }
-        e = E[e].anext;
+        } else if (here && E[e].up != NIL) { ending = e; ++n_ending; }
+        next = E[e].anext;
       }
+      if (noted) { ++k; next = k < end_n ? note[1 + k] : NIL; }
+      e = next;
     }
     const bool had_horizontals = sel != NIL;      // (horizontals bring edges of their own into the list)
     SZV_PHASE(21);
@@ -1769,6 +1796,7 @@ struct SweepT {
     bool ok = true;
     i64 bot_y, top_y = 0;
     if (!pop_beam(bot_y)) return false;
+    y_now = bot_y;
     SZV_PHASE(14);
     insert_minima(bot_y);
     for (;;) {
