@@ -39,7 +39,7 @@ int szDestroy(szContext *ctx) {
                     &ctx->in_ax, &ctx->in_ay, &ctx->in_aoff, &ctx->in_bx, &ctx->in_by, &ctx->in_boff,
                     &ctx->in_fax, &ctx->in_fay, &ctx->in_fbx, &ctx->in_fby};
   for (DevBuf *b : bufs) sz_release(*b);
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 5; ++k) {
     if (ctx->clip_streams[k]) (void)hipStreamDestroy(ctx->clip_streams[k]);
     if (ctx->clip_join[k]) (void)hipEventDestroy(ctx->clip_join[k]);
   }

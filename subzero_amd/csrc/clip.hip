@@ -94,6 +94,21 @@ __device__ __attribute__((noinline, flatten)) int clip_in_slice(void *slice, con
   __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
   return szv::clip_rings_t<szv::WideLds>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
 }
+// (for the sweep pass, where all 64 lanes of the wave run the sweep alike: vatti.hpp WideLdsWave)
+__device__ __attribute__((noinline, flatten)) int clip_in_slice_wave(void *slice, const szv::Caps &caps, const RingI64 &ra, int na,
+                                                            const RingI64 &rb, int nb, int method, int fill_s, int fill_c,
+                                                            SlotSink &sink) {
+  __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
+  return szv::clip_rings_t<szv::WideLdsWave>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
+}
+// (the same inlined into its caller: k_clip_sweep_small, a kernel compiled for four waves per SIMD -- a function of its
+// own is compiled for all 256 registers whatever its caller asks for)
+__device__ __attribute__((always_inline)) int clip_in_slice_inlined(void *slice, const szv::Caps &caps, const RingI64 &ra, int na,
+                                                                    const RingI64 &rb, int nb, int method, int fill_s, int fill_c,
+                                                                    SlotSink &sink) {
+  __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
+  return szv::clip_rings_t<szv::WideLdsWave>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
+}
 
 #if defined(SZ_CLIP_CLOCKS)
 // diagnostic build (make diag_clip): per pair the 100 MHz clock at start, after trimming and at the end, the trimmed
@@ -229,8 +244,8 @@ using szt::wave_box;
 using szt::wave_heights_distinct;
 
 // slice classes of the sweep pass: bytes of LDS per pair; class CLASS_HBM keeps its records in the HBM workspace
-enum { CLIP_CLASSES = 4, CLASS_HBM = 4, META_TAIL = 1 << 30 };
-__device__ __constant__ int clip_class_bytes[CLIP_CLASSES] = {20 * 1024, 40 * 1024, 80 * 1024, 160 * 1024};
+enum { CLIP_CLASSES = 5, CLASS_HBM = 5, META_TAIL = 1 << 30 };
+__device__ __constant__ int clip_class_bytes[CLIP_CLASSES] = {10 * 1024, 20 * 1024, 40 * 1024, 80 * 1024, 160 * 1024};
 __device__ int slice_class(int nv) {
   szv::Caps c;
   for (int k = 0; k < CLIP_CLASSES; ++k)
@@ -333,10 +348,14 @@ __global__ void __launch_bounds__(64) k_clip_front(ClipArgs a) {
 
 // Sweep pass over one class list: lane 0 of each wave sweeps one pair with its records in `slice` bytes of LDS
 // (clip_in_slice), or in the pair's HBM workspace (slice 0, or a sweep that outgrew the slice after all).
-__global__ void __launch_bounds__(64) k_clip_sweep(ClipArgs a, const int *list, int count, int slice) {
+template <bool SMALL>
+__device__ __attribute__((always_inline)) void clip_sweep_body(const ClipArgs &a, const int *list, int count, int slice) {
   extern __shared__ __attribute__((aligned(16))) char clip_lds[];
+  // (all 64 lanes run the pair alike -- same reads, same plain stores -- so that the sweep in LDS can hand its walk
+  // over the active edges to them; lane 0 alone touches counters and lists)
   const int t = blockIdx.x;
-  if (t >= count || threadIdx.x != 0) return;
+  if (t >= count) return;
+  const bool speaker = threadIdx.x == 0;
   const int p = list[t];
   const int a0 = a.aoff[p], na = a.aoff[p + 1] - a0;
   const int b0 = a.boff[p], nb = a.boff[p + 1] - b0;
@@ -359,13 +378,16 @@ __global__ void __launch_bounds__(64) k_clip_sweep(ClipArgs a, const int *list, 
   const unsigned long long t_in = wall_clock64();
 #endif
   if (slice > 0 && szv::caps_budget<szv::WideLds>(ta + tb, (size_t)slice, lc) && lc.pts >= ta + tb + 8) {
-    st = clip_in_slice((void *)clip_lds, lc, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
+    st = SMALL ? clip_in_slice_inlined((void *)clip_lds, lc, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink)
+               : clip_in_slice_wave((void *)clip_lds, lc, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
 #if defined(SZ_CLIP_CLOCKS)
     if (p < (1 << 16)) sz_clip_clocks[5 * p + 4] = st == szv::ST_WORKSPACE ? 2ULL : 1ULL;
 #endif
-    if (st == szv::ST_WORKSPACE) { sink.nv = 0; sink.nr = 0; sink.roff[0] = 0; atomicAdd(&a.counters[8], 1ULL); }
+    if (st == szv::ST_WORKSPACE) { sink.nv = 0; sink.nr = 0; sink.roff[0] = 0; if (speaker) atomicAdd(&a.counters[8], 1ULL); }
   }
-  if (st == szv::ST_WORKSPACE)
+  // (a sweep that outgrew its slice: again in the pair's HBM workspace -- in the small-class kernel it goes to the retry
+  // tier instead, which keeps the second copy of the sweep, and its registers, out of that kernel)
+  if (st == szv::ST_WORKSPACE && !SMALL)
     st = szv::clip_rings(a.ws + s.woff, ta + tb, ra, ta, rb, tb, a.method, a.fill_s, a.fill_c, sink);
 #if defined(SZ_CLIP_CLOCKS)
   if (p < (1 << 16)) { sz_clip_clocks[5 * p + 1] = t_in; sz_clip_clocks[5 * p + 2] = wall_clock64(); }
@@ -375,17 +397,30 @@ __global__ void __launch_bounds__(64) k_clip_sweep(ClipArgs a, const int *list, 
   a.status[p] = st;
   if (st == szv::ST_OK) {
     a.nrings[p] = sink.nr;
-    atomicAdd(&a.counters[4], (unsigned long long)sink.nr);
-    atomicAdd(&a.counters[5], (unsigned long long)sink.nv);
+    if (speaker) {
+      atomicAdd(&a.counters[4], (unsigned long long)sink.nr);
+      atomicAdd(&a.counters[5], (unsigned long long)sink.nv);
+    }
   } else {
     a.nrings[p] = 0;
     if (st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
-      unsigned long long k = atomicAdd(&a.counters[0], 1ULL);
-      if (k < (unsigned long long)a.retry_cap) a.retry[k] = p;
+      if (speaker) {
+        unsigned long long k = atomicAdd(&a.counters[0], 1ULL);
+        if (k < (unsigned long long)a.retry_cap) a.retry[k] = p;
+      }
     } else {
-      atomicAdd(&a.counters[6], 1ULL);
+      if (speaker) atomicAdd(&a.counters[6], 1ULL);
     }
   }
+}
+
+__global__ void __launch_bounds__(64) k_clip_sweep(ClipArgs a, const int *list, int count, int slice) {
+  clip_sweep_body<false>(a, list, count, slice);
+}
+// the 10 KB class: 128 registers, four waves per SIMD, sixteen sweeps per CU (the sweep is a chain of LDS round trips:
+// what a SIMD gets done grows with the waves it can switch between)
+__global__ void __launch_bounds__(64) __attribute__((flatten, amdgpu_waves_per_eu(4, 4))) k_clip_sweep_small(ClipArgs a, const int *list, int count, int slice) {
+  clip_sweep_body<true>(a, list, count, slice);
 }
 
 } // namespace
@@ -443,7 +478,7 @@ static void clip_launch(szContext *ctx, int n, const ClipArgs &a) {
 // The main pass as a front pass and one sweep pass per slice class (k_clip_front / k_clip_sweep): the sweep launches
 // run side by side on streams of their own, forked from and joined to the context's stream.
 static int clip_main_in_classes(szContext *ctx, ClipArgs &a) {
-  static const int class_bytes[CLIP_CLASSES] = {20 * 1024, 40 * 1024, 80 * 1024, 160 * 1024};
+  static const int class_bytes[CLIP_CLASSES] = {10 * 1024, 20 * 1024, 40 * 1024, 80 * 1024, 160 * 1024};
   int rc;
   if ((rc = sz_reserve(ctx, ctx->clip_meta, (size_t)a.npairs * 8 + 8))) return rc;
   if ((rc = sz_reserve(ctx, ctx->clip_lists, (size_t)a.npairs * 4 * (CLIP_CLASSES + 1) + 8))) return rc;
@@ -451,19 +486,19 @@ static int clip_main_in_classes(szContext *ctx, ClipArgs &a) {
   a.class_list = (int *)ctx->clip_lists.p;
   if (!ctx->clip_fork) {
     SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->clip_fork, hipEventDisableTiming));
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
       SZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->clip_streams[k], hipStreamNonBlocking));
       SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->clip_join[k], hipEventDisableTiming));
     }
   }
-  a.lds_per_lane = class_bytes[0];
-  hipLaunchKernelGGL(k_clip_front, dim3(a.npairs), dim3(64), (size_t)class_bytes[0], ctx->stream, a);
+  a.lds_per_lane = class_bytes[1];
+  hipLaunchKernelGGL(k_clip_front, dim3(a.npairs), dim3(64), (size_t)class_bytes[1], ctx->stream, a);
   SZ_HIP(ctx, hipGetLastError());
   unsigned long long c[16];
   SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SZ_HIP(ctx, hipEventRecord(ctx->clip_fork, ctx->stream));
-  // longest sweeps first: the 160 KB class down to 40 KB on the side streams, then the short ones and what stays in HBM
+  // longest sweeps first: the 160 KB class down to 20 KB on the side streams, then what stays in HBM and the short ones
   for (int k = CLIP_CLASSES - 1; k >= 1; --k) {
     const int count = (int)c[9 + k];
     if (count == 0) continue;
@@ -481,7 +516,7 @@ static int clip_main_in_classes(szContext *ctx, ClipArgs &a) {
     SZ_HIP(ctx, hipEventRecord(ctx->clip_join[0], st));
   }
   if (c[9] > 0) {
-    hipLaunchKernelGGL(k_clip_sweep, dim3((int)c[9]), dim3(64), (size_t)class_bytes[0], ctx->stream, a, (const int *)a.class_list, (int)c[9], class_bytes[0]);
+    hipLaunchKernelGGL(k_clip_sweep_small, dim3((int)c[9]), dim3(64), (size_t)class_bytes[0], ctx->stream, a, (const int *)a.class_list, (int)c[9], class_bytes[0]);
     SZ_HIP(ctx, hipGetLastError());
   }
   for (int k = CLIP_CLASSES - 1; k >= 1; --k)
@@ -500,6 +535,7 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
   if (!once) {
     (void)hipFuncSetAttribute((const void *)k_clip, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_clip_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_clip_sweep_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
   // Single rings in fixed point (szClipBatch and what the fracture entries build on it): front pass + sweep classes,

@@ -29,7 +29,7 @@ struct ClipArgs {
   int *meta;                    // front pass -> sweep pass, per pair: trimmed sizes (bit 30 of the first: rings at the workspace tail)
   int *class_list;              // 5 lists of npairs: the pairs of each slice class
   unsigned long long *counters; // [0] retry count, [1] ws bump, [2] ov bump, [3] or bump,
-                                // [4] rings out, [5] verts out, [6] failed, [7] arena exhausted, [8] outgrew the LDS slice, [9..13] class list lengths
+                                // [4] rings out, [5] verts out, [6] failed, [7] arena exhausted, [8] outgrew the LDS slice, [9..14] class list lengths
 };
 
 // sizes and (re)allocates the context's clip buffers for a batch of npairs pairs with `total` input vertices; fills the

@@ -26,8 +26,8 @@ struct szContext {
   // clip path buffers
   DevBuf ws, ovx, ovy, oroff, ov_base, or_base, nrings, status, retry_list, counters;
   DevBuf clip_meta, clip_lists;      // front pass -> sweep pass (clip.hip)
-  hipStream_t clip_streams[4] = {nullptr, nullptr, nullptr, nullptr};   // the sweep passes of the slice classes run side by side
-  hipEvent_t clip_fork = nullptr, clip_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t clip_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the sweep passes of the slice classes run side by side
+  hipEvent_t clip_fork = nullptr, clip_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   DevBuf in_ax, in_ay, in_aoff, in_bx, in_by, in_boff;
   DevBuf in_fax, in_fay, in_fbx, in_fby; // double inputs of szPolyclipBatch
 };

@@ -72,6 +72,7 @@ enum { KIND_SUBJECT = 0, KIND_CLIP = 1 };
 // (64 lanes x 2.3 KB < 160 KB per CU).  The algorithm is written once against the field names.
 template <class Ix, class Wn>
 struct Records {
+  static const bool kWave = false;   // (see WideLdsWave)
   struct Edge {
     Pt bot, cur, top;
     double slope; // dx/dy, SZV_HORIZONTAL for dy == 0
@@ -112,6 +113,9 @@ typedef Records<signed char, signed char> Compact; // at most 127 entries per li
 // Wide records again under a name of their own: the sweep instantiated on it is a separate set of functions, so a
 // caller that keeps the workspace in LDS gets its own copy, specialised for ds_ addressing (contact.hpp clip_fixed_lds)
 struct WideLds : Records<int, int> {};
+// ... and for a sweep that ALL 64 lanes of a wave run alike (clip.hip k_clip_sweep): the one walk over the active edges
+// per beam (build_crossings) then spreads over the lanes -- lane k takes the k-th edge
+struct WideLdsWave : Records<int, int> { static const bool kWave = true; };
 
 // ---- numeric kernels ----------------------------------------------------------------------
 
@@ -1333,6 +1337,43 @@ struct SweepT {
     if (ael == NIL) return;
     int e = ael;
     sel = e;
+    bool walked = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kWave) {
+      // lane k <- the k-th active edge (a chain of one load per edge), then every lane its edge: the links of the sorted
+      // list, x at the top of the beam, whether it ends there; neighbours compare by shuffle
+      const int lane = (int)(threadIdx.x & 63);
+      int mine = NIL, n = 0;
+      for (int q = ael; q != NIL && n <= 64; q = E[q].anext, ++n) if (n == lane) mine = q;
+      if (n <= 64) {
+        i64 x = 0;
+        bool ends = false;
+        if (mine != NIL) {
+          E[mine].sprev = E[mine].aprev;
+          E[mine].snext = E[mine].anext;
+          x = x_at(mine, top_y);
+          E[mine].cur.x = x;
+          ends = E[mine].top.y == top_y;
+        }
+        const i64 xb = __shfl_up(x, 1);
+        const bool out_of_order = lane > 0 && lane < n && xb > x;
+        const unsigned long long m_end = __ballot(ends);
+        int *note = end_note();
+        const int rank = __popcll(m_end & ((1ULL << lane) - 1ULL));
+        if (ends && rank < 4) note[1 + rank] = mine;
+        if (__ballot(out_of_order) == 0ULL) {
+          if (n >= 2 && lane == n - 2) E[mine].snext = NIL;       // (what the bubble pass leaves behind, see below)
+          if (lane == 0) note[0] = __popcll(m_end);
+          __builtin_amdgcn_wave_barrier();
+          sel = NIL;
+          beam_in_order = true;
+          return;
+        }
+        __builtin_amdgcn_wave_barrier();
+        walked = true;                                              // links and cur.x are set: the bubble passes as they are
+      }
+    }
+#endif
     // (most beams hold no crossing: the edges come out in order at top_y, which this first walk already sees -- then
     // the bubble pass below would compare every neighbour pair once more, find nothing, cut the last link and stop)
     bool in_order = true;
@@ -1340,7 +1381,7 @@ struct SweepT {
     i64 x_before = 0;
     int end_n = 0;
     int *note = end_note();
-    while (e != NIL) {
+    while (e != NIL && !walked) {
       E[e].sprev = E[e].aprev;
       const int en = E[e].anext;
       E[e].snext = en;
