@@ -92,6 +92,17 @@ SZ_HD_NOINLINE int clip_fixed_lds(void *lds_ws, int cap_nv, const i64 *ax, const
   return szv::clip_rings_lds(lds_ws, cap_nv, a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
 }
 
+// ... for a wave whose 64 lanes all run the pair alike (k_narrow_wave): the sweep's walk over the active edges spreads
+// over them (vatti.hpp WideLdsWave)
+SZ_HD_NOINLINE int clip_fixed_lds_wave(void *lds_ws, int cap_nv, const i64 *ax, const i64 *ay, int na, const i64 *bx,
+                                       const i64 *by, int nb, int op, RegionSink *sink) {
+  FixedRing a = {ax, ay}, b = {bx, by};
+  sink->nv = 0; sink->nr = 0;
+  if (sink->ox != nullptr) sink->roff[0] = 0;
+  SZ_ASSUME_LDS(lds_ws);
+  if (cap_nv < na + nb) return szv::ST_WORKSPACE;
+  return szv::clip_rings_t<szv::WideLdsWave>(lds_ws, szv::caps_for(cap_nv), a, na, b, nb, op, szv::FILL_EVENODD, szv::FILL_EVENODD, *sink);
+}
 // compact-record form (inlined: the workspace pointer then stays provably in LDS for the GPU compiler)
 SZ_HD int clip_fixed_compact(void *ws, const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb,
                              int op, RegionSink *sink) {
@@ -138,7 +149,8 @@ struct ClipWide {
 };
 // k_narrow_lds: each clip takes the lane's slice of LDS when its (trimmed) rings fit it, the pair's HBM slice
 // otherwise -- or when the records of the clip outgrow the slice after all
-struct ClipWideLds {
+template <bool WAVE>
+struct ClipWideLdsT {
   void *host_ws; void *lds_ws; int lds_ws_bytes, cap_nv;    // HBM slice / the lane's slice of LDS and what of it the sweep may use; cap_nv: what the HBM slice holds
   // the sweep's part of the slice, free between two clips (device only)
   SZ_HD double *idle(int &bytes) const {
@@ -159,13 +171,16 @@ struct ClipWideLds {
   SZ_HD int operator()(const i64 *ax, const i64 *ay, int na, const i64 *bx, const i64 *by, int nb, int op, RegionSink *sink) const {
     const int lc = lds_cap();
     if (na + nb <= lc) {
-      int st = clip_fixed_lds(lds_ws, lc, ax, ay, na, bx, by, nb, op, sink);
+      int st = WAVE ? clip_fixed_lds_wave(lds_ws, lc, ax, ay, na, bx, by, nb, op, sink)
+                    : clip_fixed_lds(lds_ws, lc, ax, ay, na, bx, by, nb, op, sink);
       if (st != szv::ST_WORKSPACE || lc >= cap_nv) return st;
     }
     return clip_fixed(host_ws, cap_nv, ax, ay, na, bx, by, nb, op, sink);
   }
   SZ_HD bool fits(int nv) const { return nv <= cap_nv; }
 };
+typedef ClipWideLdsT<false> ClipWideLds;
+typedef ClipWideLdsT<true> ClipWideLdsWave;
 struct ClipCompact {
   void *ws;
   SZ_HD double *idle(int &bytes) const { bytes = 0; return nullptr; }
@@ -941,9 +956,10 @@ SZ_HD bool well_inside_box(const Box &b, const double *c2b) {
 }
 
 // Both parts with Wide records in the pair's HBM slice (the general path).
-SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
-                       const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
-                       PairScratch &S, PairOut &out, void *lds_ws = nullptr, int lds_ws_bytes = 0) {
+template <class LdsClip>
+SZ_HD int pair_contact_t(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+                         const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
+                         PairScratch &S, PairOut &out, void *lds_ws = nullptr, int lds_ws_bytes = 0) {
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   {
     Box b1, b2;
@@ -958,9 +974,9 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
   int nreg = 0;
   if (lds_ws != nullptr) {   // the sweep workspace of this lane is its slice of LDS (k_narrow_lds)
 #if defined(__HIP_DEVICE_COMPILE__)
-    ViaArrays<ClipWideLds> clip = {{S.ws, lds_ws, lds_ws_bytes, S.cap_nv}};
+    ViaArrays<LdsClip> clip = {{S.ws, lds_ws, lds_ws_bytes, S.cap_nv}};
 #else
-    ViaArrays<ClipWideLds> clip = {{S.ws, S.ws, lds_ws_bytes, S.cap_nv}};   // (no LDS on the host: the pair's own workspace stands in)
+    ViaArrays<LdsClip> clip = {{S.ws, S.ws, lds_ws_bytes, S.cap_nv}};   // (no LDS on the host: the pair's own workspace stands in)
 #endif
     int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
     if (st != szv::ST_OK) return st;
@@ -970,6 +986,11 @@ SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, c
   int st = pair_clip1(ring1, ring2, boundary, S, clip, nreg);
   if (st != szv::ST_OK) return st;
   return pair_finish(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, nreg, clip, out);
+}
+SZ_HD int pair_contact(const RingD &ring1, const Body &f1, const RingD &ring2, const Body &f2, bool boundary,
+                       const double *c2b, bool periodic, double Modulus, double dt, double mu, double nu,
+                       PairScratch &S, PairOut &out, void *lds_ws = nullptr, int lds_ws_bytes = 0) {
+  return pair_contact_t<ClipWideLds>(ring1, f1, ring2, f2, boundary, c2b, periodic, Modulus, dt, mu, nu, S, out, lds_ws, lds_ws_bytes);
 }
 // Both parts through the single-minimum fast path only, with both rings staged in the lane's block (so the
 // contact model reads them from LDS as well); ST_DEFER = redo this pair with pair_contact.

@@ -684,6 +684,9 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   if (CONVEX_ONLY)
     st = szc::pair_contact_fast(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                                 P.mu, P.nu, S, out, fast_blk);
+  else if (WAVE)
+    st = szc::pair_contact_t<szc::ClipWideLdsWave>(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
+                                                   P.mu, P.nu, S, out, (LDS_WS && fast_ws) ? fast_ws : nullptr, lds_ws_bytes);
   else
     st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                            P.mu, P.nu, S, out, (LDS_WS && fast_ws) ? fast_ws : nullptr, lds_ws_bytes);
