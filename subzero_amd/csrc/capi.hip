@@ -39,11 +39,11 @@ int szDestroy(szContext *ctx) {
                     &ctx->in_ax, &ctx->in_ay, &ctx->in_aoff, &ctx->in_bx, &ctx->in_by, &ctx->in_boff,
                     &ctx->in_fax, &ctx->in_fay, &ctx->in_fbx, &ctx->in_fby};
   for (DevBuf *b : bufs) sz_release(*b);
-  for (int k = 0; k < 5; ++k) {
-    if (ctx->clip_streams[k]) (void)hipStreamDestroy(ctx->clip_streams[k]);
-    if (ctx->clip_join[k]) (void)hipEventDestroy(ctx->clip_join[k]);
+  for (int k = 0; k < 3; ++k) {
+    if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+    if (ctx->side_join[k]) (void)hipEventDestroy(ctx->side_join[k]);
   }
-  if (ctx->clip_fork) (void)hipEventDestroy(ctx->clip_fork);
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

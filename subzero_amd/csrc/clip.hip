@@ -484,44 +484,36 @@ static int clip_main_in_classes(szContext *ctx, ClipArgs &a) {
   if ((rc = sz_reserve(ctx, ctx->clip_lists, (size_t)a.npairs * 4 * (CLIP_CLASSES + 1) + 8))) return rc;
   a.meta = (int *)ctx->clip_meta.p;
   a.class_list = (int *)ctx->clip_lists.p;
-  if (!ctx->clip_fork) {
-    SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->clip_fork, hipEventDisableTiming));
-    for (int k = 0; k < 5; ++k) {
-      SZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->clip_streams[k], hipStreamNonBlocking));
-      SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->clip_join[k], hipEventDisableTiming));
-    }
-  }
+  if ((rc = sz_side_streams(ctx))) return rc;
   a.lds_per_lane = class_bytes[1];
   hipLaunchKernelGGL(k_clip_front, dim3(a.npairs), dim3(64), (size_t)class_bytes[1], ctx->stream, a);
   SZ_HIP(ctx, hipGetLastError());
   unsigned long long c[16];
   SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  SZ_HIP(ctx, hipEventRecord(ctx->clip_fork, ctx->stream));
-  // longest sweeps first: the 160 KB class down to 20 KB on the side streams, then what stays in HBM and the short ones
-  for (int k = CLIP_CLASSES - 1; k >= 1; --k) {
+  SZ_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+  // Six launches on four streams (context.hpp: no more than the hardware queues), the longest sweeps first:
+  //   side 0: the 160 KB class, then what stays in HBM      side 1: the 80 KB class
+  //   side 2: the 40 KB class          the context's stream: the 20 KB class, then the 10 KB class (the many short ones)
+  auto launch = [&](hipStream_t st, int k) {
     const int count = (int)c[9 + k];
-    if (count == 0) continue;
-    hipStream_t st = ctx->clip_streams[k];
-    SZ_HIP(ctx, hipStreamWaitEvent(st, ctx->clip_fork, 0));
-    hipLaunchKernelGGL(k_clip_sweep, dim3(count), dim3(64), (size_t)class_bytes[k], st, a, (const int *)a.class_list + (size_t)k * a.npairs, count, class_bytes[k]);
+    if (count == 0) return;
+    const int bytes = k < CLIP_CLASSES ? class_bytes[k] : 0;
+    const int *list = (const int *)a.class_list + (size_t)k * a.npairs;
+    if (k == 0) hipLaunchKernelGGL(k_clip_sweep_small, dim3(count), dim3(64), (size_t)bytes, st, a, list, count, bytes);
+    else hipLaunchKernelGGL(k_clip_sweep, dim3(count), dim3(64), (size_t)bytes, st, a, list, count, bytes);
+  };
+  static const int plan[3][2] = {{4, CLASS_HBM}, {3, -1}, {2, -1}};
+  for (int q = 0; q < 3; ++q) {
+    SZ_HIP(ctx, hipStreamWaitEvent(ctx->side[q], ctx->side_fork, 0));
+    for (int j = 0; j < 2; ++j) if (plan[q][j] >= 0) launch(ctx->side[q], plan[q][j]);
     SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipEventRecord(ctx->clip_join[k], st));
+    SZ_HIP(ctx, hipEventRecord(ctx->side_join[q], ctx->side[q]));
   }
-  if (c[9 + CLASS_HBM] > 0) {
-    hipStream_t st = ctx->clip_streams[0];
-    SZ_HIP(ctx, hipStreamWaitEvent(st, ctx->clip_fork, 0));
-    hipLaunchKernelGGL(k_clip_sweep, dim3((int)c[9 + CLASS_HBM]), dim3(64), 0, st, a, (const int *)a.class_list + (size_t)CLASS_HBM * a.npairs, (int)c[9 + CLASS_HBM], 0);
-    SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipEventRecord(ctx->clip_join[0], st));
-  }
-  if (c[9] > 0) {
-    hipLaunchKernelGGL(k_clip_sweep_small, dim3((int)c[9]), dim3(64), (size_t)class_bytes[0], ctx->stream, a, (const int *)a.class_list, (int)c[9], class_bytes[0]);
-    SZ_HIP(ctx, hipGetLastError());
-  }
-  for (int k = CLIP_CLASSES - 1; k >= 1; --k)
-    if (c[9 + k] > 0) SZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->clip_join[k], 0));
-  if (c[9 + CLASS_HBM] > 0) SZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->clip_join[0], 0));
+  launch(ctx->stream, 1);
+  launch(ctx->stream, 0);
+  SZ_HIP(ctx, hipGetLastError());
+  for (int q = 0; q < 3; ++q) SZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join[q], 0));
   return SZ_OK;
 }
 

@@ -26,8 +26,11 @@ struct szContext {
   // clip path buffers
   DevBuf ws, ovx, ovy, oroff, ov_base, or_base, nrings, status, retry_list, counters;
   DevBuf clip_meta, clip_lists;      // front pass -> sweep pass (clip.hip)
-  hipStream_t clip_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the sweep passes of the slice classes run side by side
-  hipEvent_t clip_fork = nullptr, clip_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // Three side streams for everything in the library that runs kernels side by side (the sweep passes of the clip batch,
+  // the wall pairs of a step): with the context's own stream that makes four, the number of hardware queues a process
+  // gets by default (GPU_MAX_HW_QUEUES) -- a fifth stream shares a queue with another and silently runs behind it.
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t side_fork = nullptr, side_join[3] = {nullptr, nullptr, nullptr};
   DevBuf in_ax, in_ay, in_aoff, in_bx, in_by, in_boff;
   DevBuf in_fax, in_fay, in_fbx, in_fby; // double inputs of szPolyclipBatch
 };
@@ -61,6 +64,15 @@ inline int sz_reserve(szContext *ctx, DevBuf &b, size_t bytes) {
   size_t want = bytes + bytes / 4 + 256;
   SZ_HIP(ctx, hipMalloc(&b.p, want));
   b.cap = want;
+  return SZ_OK;
+}
+inline int sz_side_streams(szContext *ctx) {
+  if (ctx->side_fork) return SZ_OK;
+  SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+  for (int k = 0; k < 3; ++k) {
+    SZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+    SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[k], hipEventDisableTiming));
+  }
   return SZ_OK;
 }
 inline void sz_release(DevBuf &b) {

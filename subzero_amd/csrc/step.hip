@@ -892,8 +892,8 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
       // filled every SIMD -- started first it takes one SIMD each and the team pass the rest.
       hipStream_t ts = st;
       if (W.wall_list) {
-        if (!S->wall_stream) {
-          SZ_HIP(ctx, hipStreamCreateWithFlags(&S->wall_stream, hipStreamNonBlocking));
+        { const int rcs = sz_side_streams(ctx); if (rcs) return rcs; }
+        if (!S->wall_fork) {
           SZ_HIP(ctx, hipEventCreateWithFlags(&S->wall_fork, hipEventDisableTiming));
           SZ_HIP(ctx, hipEventCreateWithFlags(&S->wall_join, hipEventDisableTiming));
         }
@@ -901,7 +901,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
         // the wall pairs on this stream instead -- which still spares such a field the host round trips of the deferred
         // pairs: uniaxial200)
         if (S->last_hot + S->last_cold >= 4096) {
-          ts = S->wall_stream;
+          ts = ctx->side[0];
           SZ_HIP(ctx, hipEventRecord(S->wall_fork, st));
           SZ_HIP(ctx, hipStreamWaitEvent(ts, S->wall_fork, 0));
         }
@@ -1139,7 +1139,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
   S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS];
   S->last_deferred = S->retried - (W.wall_list ? 0 : S->last_walls) + (i64)c[C_BIG];   // pairs of this step that waited for the host besides the floes at the walls
-  if (getenv("SUBZERO_DEBUG_LISTS")) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS]);
+  if (getenv("SUBZERO_DEBUG_LISTS")) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld | walls %lld (%s) deferred besides %lld big %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS], (long long)c[C_WALLS], W.wall_list ? "beside the team pass" : "on the retry list", (long long)S->last_deferred, (long long)c[C_BIG]);
   if (stats) {
     float ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;

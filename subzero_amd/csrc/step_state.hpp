@@ -76,7 +76,6 @@ struct StepState {
   bool counters_clean = false;    // the last step ended by resetting the device counters (k_publish with reset)
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // the floes at the walls are swept on a stream of their own beside the team pass (step.hip step_narrow_first)
-  hipStream_t wall_stream = nullptr;
   hipEvent_t wall_fork = nullptr, wall_join = nullptr;
   long long last_walls = 0;       // pairs on the wall list in the step before (sizes the launch)
   long long last_deferred = 0;    // pairs the step before handed to the general pass after its read-back, the wall pairs not counted

@@ -99,7 +99,6 @@ void destroy_state(StepState *S) {
   for (DevBuf *b : more) sz_release(*b);
   for (DevBuf &b : S->post) sz_release(b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
-  if (S->wall_stream) (void)hipStreamDestroy(S->wall_stream);
   if (S->wall_fork) (void)hipEventDestroy(S->wall_fork);
   if (S->wall_join) (void)hipEventDestroy(S->wall_join);
   if (S->c) (void)hipHostFree(S->c);
