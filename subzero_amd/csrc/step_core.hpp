@@ -769,7 +769,10 @@ SZ_HD int pair_classify(i64 p, int prev_n, const Params &P, Work &W) {
     if (r1 > r0 + 64) r1 = r0 + 64;
     if (r1 > W.cap_rows) r1 = W.cap_rows;
     const double want = (double)(j + 1);
-    for (i64 r = r0; r < r1; ++r) if (W.rows[7 * r] == want) return PC_LIVE;
+    bool live = false;                      // (no early exit: the loads of the rows then overlap)
+#pragma unroll 4
+    for (i64 r = r0; r < r1; ++r) live |= (W.rows[7 * r] == want);
+    if (live) return PC_LIVE;
   }
   return PC_COLD;
 }
