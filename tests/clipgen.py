@@ -403,14 +403,17 @@ def run_ref(ps, method):
     return ClipResult(ox, oy, roff, proff, st)
 
 
-def run_host(ps, method, fill_s=0, fill_c=0, fast=0, trim=0):
+def run_host(ps, method, fill_s=0, fill_c=0, fast=0, trim=0, budget=0):
     """fast = 1 / 2: try the single-minimum fast path (convex.hpp) first, from int64 rings / from rings in metres
     as the step hands them over; what it declines goes to the general sweep.  r.fast = clips it completed.
     trim = 1: the rings of an intersection are first cut down to their common box (trim.hpp), as the step's general
-    path does; r.trim = (vertices before, after, pairs handed over untrimmed because of a tie)."""
+    path does; r.trim = (vertices before, after, pairs handed over untrimmed because of a tie).
+    budget = bytes: the sweep's records inside that many bytes first (caps_budget: the slice classes of the clip
+    batch), in a buffer of exactly that size; r.budget = (clips completed there, clips that outgrew it)."""
     L = host_lib()
     L.host_clip_set_fast(int(fast))
     L.host_clip_set_trim(int(trim))
+    L.host_clip_set_budget(int(budget))
     ax, ay, aoff, bx, by, boff, ox, oy, cap_v, roff, cap_r, proff, st = _alloc(ps)
     rc = L.host_clip_batch(len(ps), ax, ay, aoff, bx, by, boff, method, fill_s, fill_c,
                            ox, oy, cap_v, roff, cap_r, proff, st)
@@ -420,8 +423,12 @@ def run_host(ps, method, fill_s=0, fill_c=0, fast=0, trim=0):
     c = [ctypes.c_longlong() for _ in range(3)]
     L.host_clip_trim_counts(*[ctypes.byref(v) for v in c])
     r.trim = tuple(int(v.value) for v in c)
+    c = [ctypes.c_longlong() for _ in range(2)]
+    L.host_clip_budget_counts(*[ctypes.byref(v) for v in c])
+    r.budget = tuple(int(v.value) for v in c)
     L.host_clip_set_fast(0)
     L.host_clip_set_trim(0)
+    L.host_clip_set_budget(0)
     return r
 
 

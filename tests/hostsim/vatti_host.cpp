@@ -38,6 +38,13 @@ extern "C" void host_clip_trim_counts(long long *before, long long *after, long 
   *before = g_trim_before; *after = g_trim_after; *declined = g_trim_declined;
 }
 
+// the records of the sweep inside a byte budget first (vatti.hpp caps_budget: the LDS slice classes of the clip batch's
+// sweep pass), in a buffer of exactly that size with a canary behind it
+static int g_budget = 0;
+static long long g_budget_done = 0, g_budget_outgrown = 0;
+extern "C" void host_clip_set_budget(int bytes) { g_budget = bytes; g_budget_done = g_budget_outgrown = 0; }
+extern "C" void host_clip_budget_counts(long long *done, long long *outgrown) { *done = g_budget_done; *outgrown = g_budget_outgrown; }
+
 extern "C" int host_clip_batch(int npairs,
                    const int64_t *ax, const int64_t *ay, const int32_t *aoff,
                    const int64_t *bx, const int64_t *by, const int32_t *boff,
@@ -101,6 +108,20 @@ extern "C" int host_clip_batch(int npairs,
       void *w = (void *)(((uintptr_t)ws.data() + 15) & ~(uintptr_t)15);
       st = szv::clip_rings_compact(w, a, na, b, nb, method, s);
       if (st != szv::ST_WORKSPACE && st != szv::ST_OUT_CAPACITY) ++g_compact_done;
+    }
+    if (st == szv::ST_WORKSPACE && g_budget > 0) {
+      szv::Caps c;
+      if (szv::caps_budget<szv::WideLdsWave>(na + nb, (size_t)g_budget, c) && c.pts >= na + nb + 8) {
+        std::vector<char> slice((size_t)g_budget + 16 + 64);
+        char *w = (char *)(((uintptr_t)slice.data() + 15) & ~(uintptr_t)15);
+        for (int k = 0; k < 64; ++k) w[g_budget + k] = (char)0x5A;
+        if (szv::workspace_bytes_caps<szv::WideLdsWave>(c) > (size_t)g_budget) return 7;      // the capacities must fit the slice
+        s.nv = nv0; s.nr = nr0;
+        st = szv::clip_rings_t<szv::WideLdsWave>((void *)w, c, a, na, b, nb, method, fill_s, fill_c, s);
+        for (int k = 0; k < 64; ++k) if (w[g_budget + k] != (char)0x5A) return 8;             // ... and the sweep stay inside it
+        if (st == szv::ST_WORKSPACE) { ++g_budget_outgrown; s.nv = nv0; s.nr = nr0; }
+        else ++g_budget_done;
+      }
     }
     // capacity tiers, as the GPU path retries overflowing pairs with a larger workspace
     for (int cap = na + nb, tier = 0; (st == szv::ST_WORKSPACE) && tier < 4; ++tier, cap *= 8) {

@@ -175,3 +175,20 @@ def test_trim_rules_on_hand_made_rings():
     for m in (0, 2, 3):
         h = g.run_host(ps, m, trim=1)
         assert g.compare(g.run_ref(ps, m), h, 1) == [] and h.trim == (0, 0, 0)
+
+
+@pytest.mark.parametrize("budget", [10 * 1024, 20 * 1024, 40 * 1024, 160 * 1024])
+def test_sweep_inside_a_byte_budget(budget):
+    """The slice classes of the clip batch's sweep pass (clip.hip): capacities cut to a byte budget (vatti.hpp caps_budget)
+    fit the budget, the sweep stays inside it (canary), what completes there equals the reference, and what outgrows it
+    is reported and redone with full capacities."""
+    ref = g.ref_lib()
+    total = done = 0
+    for gen, n, kw in ((g.shape_pairs, 1500, {}), (g.lattice_pairs, 1500, {"grid": 8, "max_verts": 24}), (g.star_pairs, 60, {"apart_every": 0})):
+        ps = gen(n, seed=4242, **kw)
+        for m in (0, 1, 3):
+            h = g.run_host(ps, m, trim=1, budget=budget)
+            base = g.run_ref(ps, m) if ref is not None else g.run_host(ps, m)
+            assert g.compare(base, h, len(ps)) == []
+            total += len(ps); done += h.budget[0]
+    assert done > 0.2 * total          # (the small classes hold the short rings; the large ones nearly everything)
