@@ -234,3 +234,14 @@ def test_back_half_queued_behind_the_narrow_phase_falls_back_when_pairs_are_defe
         finally:
             if env is not None:
                 os.environ.pop("SUBZERO_SPECULATE_BACK", None)
+
+
+@pytest.mark.parametrize("early", ["1", "0"])
+def test_wall_pairs_beside_the_team_pass(ctx, monkeypatch, early):
+    """A field between walls large enough for the team pass to move to the side stream (step.hip step_narrow_first: the
+    wall pairs' general sweeps are launched first, on the step's stream): every step against the oracle, with the wall
+    list of its own and -- SUBZERO_WALLS_EARLY=0 -- with the wall pairs on the retry list behind the read-back."""
+    monkeypatch.setenv("SUBZERO_WALLS_EARLY", early)
+    S, P = scenes.pack(2500, periodic=False, seed=17, vel_seed=18, sigma=0.2, n_stress=4, n_mc=120)
+    A, G, exact = lockstep(ctx, S, P, 8)
+    assert exact
