@@ -145,6 +145,12 @@ __global__ void __launch_bounds__(1024) k_scan_write(Job job, int tile, const lo
   const int n = job.n();
   const long long lo = (long long)blockIdx.x * tile;
   long long totals[Job::CH];
+  long long all[Job::CH];          // the sums over ALL tiles, for a job whose store needs them (ScanGhosts)
+  if (Job::NEEDS_TOTALS)
+    for (int ch = 0; ch < Job::CH; ++ch) {
+      const long long one = ((int)threadIdx.x < (int)gridDim.x) ? agg[ch * 256 + threadIdx.x] : 0;
+      (void)block_scan_incl(one, lds16, &all[ch]);
+    }
   for (int ch = 0; ch < Job::CH; ++ch) {
     long long mine = ((int)threadIdx.x < (int)blockIdx.x) ? agg[ch * 256 + threadIdx.x] : 0, carry;
     (void)block_scan_incl(mine, lds16, &carry);
@@ -153,7 +159,7 @@ __global__ void __launch_bounds__(1024) k_scan_write(Job job, int tile, const lo
       const long long v = (k < n) ? job.load(ch, (int)k) : 0;
       long long tot;
       const long long inc = block_scan_incl(v, lds16, &tot);
-      if (k < n) job.store(ch, (int)k, carry + inc - v);
+      if (k < n) { if (Job::NEEDS_TOTALS) job.store_with_totals(ch, (int)k, carry + inc - v, all); else job.store(ch, (int)k, carry + inc - v); }
       carry += tot;
     }
     totals[ch] = carry;
@@ -161,7 +167,8 @@ __global__ void __launch_bounds__(1024) k_scan_write(Job job, int tile, const lo
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) job.finish(totals);
 }
 struct ScanGhost { // ghost creation of one dimension fused into its scan: flags in the first launch, ghosts in the second
-  enum { CH = 1 };
+  enum { CH = 1, NEEDS_TOTALS = 0 };
+  __device__ void store_with_totals(int, int, long long, const long long *) const {}
   int dim; Floes F; Params P; Work W;
   __device__ int n() const { return (dim == 0) ? F.n : F.n + (int)W.counters[C_GX]; }
   __device__ long long first(int, int k) const { Work w = W; ghost_flag(k, dim, F, P, w); return W.flag[k]; }
@@ -172,8 +179,53 @@ struct ScanGhost { // ghost creation of one dimension fused into its scan: flags
     W.counters[C_NEXT] = (unsigned long long)(n() + t[0]);
   }
 };
+// Both periodic dimensions in one scan (the reference makes the x ghosts of every floe, then the y ghosts of every floe AND
+// x ghost, ghost_images.m:33-37,54-58): the y test of an x ghost is its parent's (same ring, same y), so the three
+// prefix sums over the real floes -- x ghosts, y ghosts, both -- give every slot: x ghost of k at N + px, y ghost of k at
+// N + GX + py, y ghost of k's x ghost at N + GX + GYreal + pxy (the order the two passes produce).  Two launches instead
+// of four, over n entries instead of n + 2n.
+struct ScanGhosts {
+  enum { CH = 3, NEEDS_TOTALS = 1 };
+  Floes F; Params P; Work W;
+  __device__ int n() const { return F.n; }
+  __device__ long long first(int ch, int k) const {
+    if (ch == 0) {
+      Work w = W;
+      ghost_flag(k, 0, F, P, w); const int fx = W.flag[k];
+      ghost_flag(k, 1, F, P, w); const int fy = W.flag[k];
+      W.flag[k] = fx | (fy << 1);
+    }
+    return load(ch, k);
+  }
+  __device__ long long load(int ch, int k) const { const int f = W.flag[k]; return ch == 0 ? (f & 1) : ch == 1 ? ((f >> 1) & 1) : ((f & 3) == 3); }
+  __device__ void store(int, int, long long) const {}
+  __device__ void entry(int g, int parent, int k, bool sx, bool sy) const {
+    if (g >= W.cap_ext) return; // cannot happen: cap_ext = 4 n
+    W.ext_src[g] = W.ext_src[k]; W.ext_nv[g] = W.ext_nv[k];
+    W.ext_x[g] = sx ? W.ext_x[k] - 2 * P.Lx * sgn(W.ext_x[k]) : W.ext_x[k];
+    W.ext_y[g] = sy ? W.ext_y[k] - 2 * P.Ly * sgn(W.ext_y[k]) : W.ext_y[k];
+    W.ext_num[g] = -iabs(W.ext_num[k]);
+    W.ext_parent[g] = parent;
+  }
+  __device__ void store_with_totals(int ch, int k, long long v, const long long *all) const {
+    if (ch == 0) { W.scan[k] = (int)v; return; }
+    if (ch == 1) { W.yg_of[k] = (int)v; return; }          // (kept there until the last channel comes by)
+    const int f = W.flag[k], N = F.n, GX = (int)all[0], GYr = (int)all[1];
+    const int px = W.scan[k], py = W.yg_of[k];
+    W.yg_of[k] = -1;
+    if (f & 1) { const int g = N + px; entry(g, k, k, true, false); W.xg_of[k] = g; }
+    if (f & 2) { const int g = N + GX + py; entry(g, k, k, false, true); W.yg_of[k] = g; }
+    if ((f & 3) == 3) { const int gx = N + px, g = N + GX + GYr + (int)v; entry(g, gx, k, true, true); if (gx < W.cap_ext) W.yg_of[gx] = g; }
+  }
+  __device__ void finish(const long long *t) const {
+    W.counters[C_GX] = (unsigned long long)t[0];
+    W.counters[C_GY] = (unsigned long long)(t[1] + t[2]);
+    W.counters[C_NEXT] = (unsigned long long)(F.n + t[0] + t[1] + t[2]);
+  }
+};
 struct ScanPairs { // pair counts -> pair_base, pair vertex counts -> nv_base
-  enum { CH = 2 };
+  enum { CH = 2, NEEDS_TOTALS = 0 };
+  __device__ void store_with_totals(int, int, long long, const long long *) const {}
   Work W;
   __device__ int n() const { return dev_next(W); }
   __device__ long long first(int ch, int k) const { if (ch == 0) { Work w = W; pair_room(k, w); } return load(ch, k); }
@@ -186,7 +238,8 @@ struct ScanPairs { // pair counts -> pair_base, pair vertex counts -> nv_base
   }
 };
 struct ScanRows {
-  enum { CH = 1 };
+  enum { CH = 1, NEEDS_TOTALS = 0 };
+  __device__ void store_with_totals(int, int, long long, const long long *) const {}
   Work W;
   __device__ int n() const { return dev_next(W); }
   __device__ long long first(int ch, int k) const { return load(ch, k); }
@@ -195,7 +248,8 @@ struct ScanRows {
   __device__ void finish(const long long *t) const { W.counters[C_NROWS] = (unsigned long long)t[0]; W.row_off[n()] = t[0]; }
 };
 struct ScanCells {
-  enum { CH = 1 };
+  enum { CH = 1, NEEDS_TOTALS = 0 };
+  __device__ void store_with_totals(int, int, long long, const long long *) const {}
   Work W;
   __device__ int n() const { return W.lvl_base[W.n_levels]; }
   __device__ long long first(int ch, int k) const { return load(ch, k); }
@@ -204,7 +258,8 @@ struct ScanCells {
   __device__ void finish(const long long *t) const { W.cell_off[n()] = (int)t[0]; }
 };
 struct ScanSegment {
-  enum { CH = 1 };
+  enum { CH = 1, NEEDS_TOTALS = 0 };
+  __device__ void store_with_totals(int, int, long long, const long long *) const {}
   const int *in; i64 *out; int count; unsigned long long *total;
   __device__ int n() const { return count; }
   __device__ long long first(int ch, int k) const { return load(ch, k); }
@@ -810,10 +865,13 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     W.cell_cnt = (int *)S->cell_cnt.p; W.cell_off = (int *)S->cell_off.p; W.cell_fill = (int *)S->cell_fill.p;
     hipLaunchKernelGGL(k_ext_clear, grid_for(cap, 256), dim3(256), 0, st, F, P, W);   // (clears the cells as well)
     if (P.PERIODIC) {
-      for (int dim = 0; dim < 2; ++dim) {
-        int bound = (dim == 0) ? n : 2 * n;
-        launch_scan(st, S->scan_agg, bound, ScanGhost{dim, F, P, W});   // flags, slots and the ghosts themselves
-      }
+      static const bool two_passes = getenv("SUBZERO_GHOST_TWO_PASSES") != nullptr;
+      if (two_passes) {
+        for (int dim = 0; dim < 2; ++dim) {
+          int bound = (dim == 0) ? n : 2 * n;
+          launch_scan(st, S->scan_agg, bound, ScanGhost{dim, F, P, W});   // flags, slots and the ghosts themselves
+        }
+      } else launch_scan(st, S->scan_agg, n, ScanGhosts{F, P, W});      // both dimensions: flags, slots and the ghosts themselves
     }
     {
       hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);

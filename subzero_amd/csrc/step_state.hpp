@@ -31,7 +31,7 @@ struct StepState {
   DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
   DevBuf post[64];                // device buffers of the post-step entries (corners.hip, eulerian.hip, fracture.hip): grow-only, kept between calls
   std::vector<long long> hdr;     // segment headers of all ranks (szStepShardFinish)
-  long long *scan_agg = nullptr;  // 2 x 256 workgroup aggregates of the scan in flight (launch_scan)
+  long long *scan_agg = nullptr;  // up to 4 x 256 workgroup aggregates of the scan in flight (launch_scan)
   int fast_path = 0;              // two-stage LDS path for small rings (opt-in: SUBZERO_FAST_PATH=1)
   int fast_lanes = 64;            // pairs per workgroup on the fast path (SUBZERO_FAST_LANES)
   double rmax_max = 0, rmax_p90 = 0; // over the floes that can be candidates (i >= Nb)

@@ -117,7 +117,7 @@ int build_state(szContext *ctx, const szFloeState *h, StepState *old, const int3
   StepState *S = new StepState();
   *out = S;
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
-  { int rc0 = dev_alloc(ctx, S, S->scan_agg, 512); if (rc0) return rc0; }
+  { int rc0 = dev_alloc(ctx, S, S->scan_agg, 1024); if (rc0) return rc0; }
   SZ_HIP(ctx, hipHostMalloc((void **)&S->c, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
   memset(S->c, 0, C_COUNT * sizeof(unsigned long long));
   SZ_HIP(ctx, hipHostGetDevicePointer((void **)&S->c_dev, S->c, 0));
