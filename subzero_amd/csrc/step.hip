@@ -275,10 +275,6 @@ __global__ void k_broad(int lo_is_real, Floes F, Params P, Work W) {
   else { i += F.n; if (i >= N) return; }
   broad(i, N, F, P, W);
 }
-__global__ void k_cell_count(Floes F, Work W) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < dev_next(W)) cell_count(e, F, W);
-}
 // The records and staged rings of the entries (step_core.hpp ext_record) with 16 lanes per entry: lane l forms vertex l
 // of the ring where the entry lies and word l of the record, so that the 128-byte lines the team pass loads are written
 // whole; the bounding box is a minimum / maximum over the lanes (exact whatever the order), the same values as the
@@ -322,6 +318,7 @@ __global__ void __launch_bounds__(256) k_ext_records(Floes F, Work W) {
     default: break;
   }
   W.ext_rec[(size_t)REC_WORDS * e + l] = w;
+  if (l == 0) cell_count(e, F, W);      // (the entry's cell of the broad-phase grid: one launch fewer than as a kernel of its own)
 }
 __global__ void k_cell_fill(Floes F, Work W) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,8 +871,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
       } else launch_scan(st, S->scan_agg, n, ScanGhosts{F, P, W});      // both dimensions: flags, slots and the ghosts themselves
     }
     {
-      hipLaunchKernelGGL(k_cell_count, grid_for(cap, 256), dim3(256), 0, st, F, W);
-      hipLaunchKernelGGL(k_ext_records, grid_for(16 * (i64)cap, 256), dim3(256), 0, st, F, W);
+      hipLaunchKernelGGL(k_ext_records, grid_for(16 * (i64)cap, 256), dim3(256), 0, st, F, W);   // (counts the cells as well)
       launch_scan(st, S->scan_agg, (i64)nc - 1, ScanCells{W});
       hipLaunchKernelGGL(k_cell_fill, grid_for(cap, 256), dim3(256), 0, st, F, W);
     }
