@@ -448,7 +448,7 @@ __global__ void k_pair_expand(Floes F, Params P, Work W, unsigned long long scra
 // (go: what the back half of the step -- contact rows, calc_trajectory -- is to do, see GoRule.  A back half queued
 // behind the narrow phase without a host round trip runs only if the narrow phase left nothing for the host to do;
 // its kernels return at once otherwise, and so does the reset of the counters.)
-struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; };   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
+struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; int team_pending; };   // team_pending: pairs on team_list have not had their pass   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
 enum { GO_LEAVE = 0, GO_SET = 1, GO_IF_CLEAN = 2 };
 __global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go) {
   const unsigned e = threadIdx.x;
@@ -457,7 +457,7 @@ __global__ void k_publish(unsigned long long *counters, unsigned long long *host
   if (rule.mode == GO_SET) go = 1;
   else if (rule.mode == GO_IF_CLEAN)
     go = !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
-           counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] ||
+           counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) ||
            2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap) ? 1ULL : 0ULL;
   const unsigned long long v = (e == C_GO) ? go : counters[e];
   host_copy[e] = v;
@@ -895,7 +895,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
     if (speculative) break;   // no read-back here: the counts are checked with those of the narrow phase (step_narrow)
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
     if (c[C_NEED_MC]) {   // nothing of the floe array has been touched yet: the caller regenerates the points and steps again
@@ -977,9 +977,15 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
       else sz_launch_narrow_team_range(ts, lo, hi - lo, F, P, W);
       SZ_HIP(ctx, hipEventRecord(S->ev[3], ts));   // narrow_ms = the team pass alone (the kernel bench.py prices)
       team_timed = true;
-      const int L = 16;
-      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, ts, (i64)0, hi - lo,
-                         (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
+      // (the pass over what the team pass handed on: in a steady field that list is empty step after step -- when the
+      // last one was and the back half is queued behind this launch, the pass is not launched; a pair that does turn up
+      // on the list keeps the back half from running (GoRule) and the pass is made up for after the read-back)
+      S->convex_skipped = queue_back && S->stepped && S->last_team == 0 && S->classified;
+      if (!S->convex_skipped) {
+        const int L = 16;
+        hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, ts, (i64)0, hi - lo,
+                           (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
+      }
       if (ts != st) {
         SZ_HIP(ctx, hipEventRecord(S->wall_join, ts));
         SZ_HIP(ctx, hipStreamWaitEvent(st, S->wall_join, 0));
@@ -1035,7 +1041,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   if (!team_timed) SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
   // the counters for the host -- and for the back half of the step, which runs only once the narrow phase is complete:
   // queued right behind this launch (queue_back) it goes ahead if nothing was deferred and everything fitted
-  const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows} : GoRule{GO_SET, 0, 0, 0};
+  const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows, S->convex_skipped ? 1 : 0} : GoRule{GO_SET, 0, 0, 0, 0};
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
@@ -1057,6 +1063,19 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
       return STEP_RETRY_EXACT;
     S->np = (i64)c[C_NPAIRS]; S->nvt = (i64)c[C_NVTOT]; S->N = (int)c[C_NEXT];
   }
+  if (S->convex_skipped) {
+    S->convex_skipped = false;
+    if (c[C_TEAM] > 0) {    // pairs the team pass handed on after all: their pass now, then the counters again
+      const i64 nt = (i64)c[C_TEAM];
+      const int L = 16;
+      hipLaunchKernelGGL(k_narrow_convex, grid_for(nt, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, (i64)0, nt,
+                         (const unsigned long long *)nullptr, L, F, P, W, (const int *)W.team_list);
+      SZ_HIP(ctx, hipGetLastError());
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
+      SZ_HIP(ctx, hipGetLastError());
+      SZ_HIP(ctx, hipStreamSynchronize(st));
+    }
+  }
   if (convex && c[C_BIG] > 0) {
     // rings of 17-32 vertices: the fast path again, on the larger block; its leftovers join the general kernel's list
     const i64 nb = (i64)c[C_BIG];
@@ -1069,7 +1088,7 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
       SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->bump, 8, hipMemcpyHostToDevice, st));
     }
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -1108,7 +1127,7 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     else
       hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -1173,7 +1192,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0}, S->back_queued ? 1 : 0);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0}, S->back_queued ? 1 : 0);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (S->back_queued) {
@@ -1191,7 +1210,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
   const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
-  S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS];
+  S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS]; S->last_team = (i64)c[C_TEAM];
   S->last_deferred = S->retried - (W.wall_list ? 0 : S->last_walls) + (i64)c[C_BIG];   // pairs of this step that waited for the host besides the floes at the walls
   if (getenv("SUBZERO_DEBUG_LISTS")) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld | walls %lld (%s) deferred besides %lld big %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS], (long long)c[C_WALLS], W.wall_list ? "beside the team pass" : "on the retry list", (long long)S->last_deferred, (long long)c[C_BIG]);
   if (stats) {
@@ -1248,7 +1267,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
         return rc;
       }
       ++S->back_misses;
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0}, 0);   // from here on the host decides
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0, 0}, 0);   // from here on the host decides
       SZ_HIP(ctx, hipGetLastError());
     }
     SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

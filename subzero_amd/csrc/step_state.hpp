@@ -77,6 +77,8 @@ struct StepState {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // the floes at the walls are swept on a stream of their own beside the team pass (step.hip step_narrow_first)
   hipEvent_t wall_fork = nullptr, wall_join = nullptr;
+  long long last_team = 0;        // pairs the team pass handed on to the lane-per-pair fast pass in the step before
+  bool convex_skipped = false;    // ... whose launch this step left out (step_narrow_first)
   long long last_walls = 0;       // pairs on the wall list in the step before (sizes the launch)
   long long last_deferred = 0;    // pairs the step before handed to the general pass after its read-back, the wall pairs not counted
   int walls_early = 1;            // SUBZERO_WALLS_EARLY=0: the wall pairs wait for the general pass after the read-back
