@@ -448,8 +448,15 @@ __global__ void k_pair_expand(Floes F, Params P, Work W, unsigned long long scra
 // (go: what the back half of the step -- contact rows, calc_trajectory -- is to do, see GoRule.  A back half queued
 // behind the narrow phase without a host round trip runs only if the narrow phase left nothing for the host to do;
 // its kernels return at once otherwise, and so does the reset of the counters.)
-struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; int team_pending; };   // team_pending: pairs on team_list have not had their pass   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
-enum { GO_LEAVE = 0, GO_SET = 1, GO_IF_CLEAN = 2 };
+// what k_publish will make of C_GO, for a kernel that runs in its place (k_incoming_go): no side effect
+__device__ inline bool go_by_rule(const unsigned long long *counters, const GoRule &rule) {
+  if (rule.mode == GO_SET) return true;
+  if (rule.mode == GO_IF_CLEAN)
+    return !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
+             counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) ||
+             2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap);
+  return counters[C_GO] != 0;
+}
 __global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go) {
   const unsigned e = threadIdx.x;
   if (e >= (unsigned)C_COUNT) return;
@@ -566,6 +573,19 @@ __global__ void k_export(i64 ns, i64 p_lo, const i64 *off, Floes F, Work W, Xfer
 __global__ void k_import(i64 np, int world, i64 seg_max, i64 rows_max, char *recv, Work W) {
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np) import_pair(p, np, world, seg_max, rows_max, recv, W);
+}
+// k_publish (the counters after the narrow phase, C_GO by the rule) and k_incoming in one launch, for the step whose
+// back half is queued behind its narrow phase: every workgroup works the rule out for itself from the counters -- which
+// nothing changes meanwhile but the first workgroup's C_GO, and that one they do not read -- and the first one publishes
+__global__ void __launch_bounds__(256) k_incoming_go(i64 np, Work W, unsigned long long *host_copy, GoRule rule) {
+  const bool go = go_by_rule(W.counters, rule);
+  const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (go && p < np && p < (i64)W.counters[C_NPAIRS]) incoming(p, W);
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)C_COUNT) {
+    const unsigned e = threadIdx.x;
+    host_copy[e] = (e == C_GO) ? (go ? 1ULL : 0ULL) : W.counters[e];
+    if (e == C_GO) W.counters[C_GO] = go ? 1ULL : 0ULL;
+  }
 }
 __global__ void k_incoming(i64 np, Work W) {   // (np may be a capacity: the pairs are those of C_NPAIRS)
   if (!W.counters[C_GO]) return;
@@ -1042,7 +1062,9 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   // the counters for the host -- and for the back half of the step, which runs only once the narrow phase is complete:
   // queued right behind this launch (queue_back) it goes ahead if nothing was deferred and everything fitted
   const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows, S->convex_skipped ? 1 : 0} : GoRule{GO_SET, 0, 0, 0, 0};
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0);
+  S->go_rule = rule;
+  S->publish_with_incoming = queue_back && S->spec_np > 0;      // (step_back_a's first kernel then does both)
+  if (!S->publish_with_incoming) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -1164,7 +1186,10 @@ static int step_back_a(szContext *ctx, StepState *S) {
   const i64 np = S->back_queued ? S->spec_np : S->np;     // (queued behind the narrow phase: a capacity, the device knows the count)
   const int n = S->n, cap = W.cap_ext;
   int rc;
-  if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
+  if (S->publish_with_incoming) {
+    S->publish_with_incoming = false;
+    hipLaunchKernelGGL(k_incoming_go, grid_for(np > 0 ? np : 1, 256), dim3(256), 0, st, np, W, S->c_dev, S->go_rule);
+  } else if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
   {
     int lanes; size_t lds; int *spill = nullptr;
     if ((rc = filter_launch_shape(ctx, S, (i64)cap + 64, lanes, lds, spill))) return rc;
