@@ -89,16 +89,27 @@ __global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned
   const i64 n = dev_count ? (i64)*dev_count : count;
   const int cls = (p < n && p < count) ? pair_classify(p, prev_n, P, W) : (int)PC_DONE;
   const int lane = threadIdx.x & 63;
+  // the five lists are appended to a wave at a time: the ballots first, then ONE atomic per list, all of them issued by
+  // one instruction (lane c takes list c), so that a wave waits for one round trip to the counters, not five
+  const bool walls = W.wall_list != nullptr;      // (a list of their own when the step sweeps them beside the team pass)
+  unsigned long long mine = 0;                    // lane c: the ballot of class c
+  unsigned long long m_own = 0;                   // every lane: the ballot of its own class
+#pragma unroll
   for (int c = PC_LIVE; c <= PC_GENERAL; ++c) {
     const unsigned long long m = __ballot(cls == c);
-    if (!m) continue;
-    unsigned long long base = 0;
-    const bool walls = c == PC_GENERAL && W.wall_list != nullptr;     // (a list of their own when the step sweeps them beside the team pass)
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&W.counters[c == PC_LIVE ? C_LIVE : c == PC_WIDE ? C_WIDE : c == PC_COLD ? C_COLD : c == PC_GENERAL ? (walls ? C_WALLS : C_RETRY) : C_TEAM], (unsigned long long)__popcll(m));
-    if (c == PC_GENERAL && !walls && lane == __builtin_ctzll(m)) atomicAdd(&W.counters[C_WALLS], (unsigned long long)__popcll(m));   // (counted either way: the next step sizes its wall launch from it)
-    base = __shfl(base, __builtin_ctzll(m));
-    if (cls == c) (c == PC_LIVE ? W.live_list : c == PC_WIDE ? W.wide_list : c == PC_COLD ? W.cold_list : c == PC_GENERAL ? (walls ? W.wall_list : W.retry_list) : W.team_list)[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)p;
+    if (lane == c) mine = m;
+    if (cls == c) m_own = m;
   }
+  unsigned long long base = 0;
+  if (lane >= PC_LIVE && lane <= PC_GENERAL && mine) {
+    const int ctr = lane == PC_LIVE ? C_LIVE : lane == PC_WIDE ? C_WIDE : lane == PC_COLD ? C_COLD : lane == PC_GENERAL ? (walls ? C_WALLS : C_RETRY) : C_TEAM;
+    base = atomicAdd(&W.counters[ctr], (unsigned long long)__popcll(mine));
+    if (lane == PC_GENERAL && !walls) atomicAdd(&W.counters[C_WALLS], (unsigned long long)__popcll(mine));   // (counted either way: the next step sizes its wall launch from it)
+  }
+  const int src = (cls >= PC_LIVE && cls <= PC_GENERAL) ? cls : 0;
+  base = __shfl(base, src);
+  if (cls >= PC_LIVE && cls <= PC_GENERAL)
+    (cls == PC_LIVE ? W.live_list : cls == PC_WIDE ? W.wide_list : cls == PC_COLD ? W.cold_list : cls == PC_GENERAL ? (walls ? W.wall_list : W.retry_list) : W.team_list)[base + __popcll(m_own & ((1ULL << lane) - 1ULL))] = (int)p;
 }
 }
 
