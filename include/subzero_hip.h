@@ -228,6 +228,21 @@ int szFloesFetch(szContext *ctx, szFloeState *host, const int32_t *ids, int32_t 
 int szFloesResync(szContext *ctx, const szFloeState *host, const int32_t *src);
 /* One timestep on the device-resident floes.  SZ_OK, an error, or SZ_STEP_NEEDS_MC (nothing changed; see above). */
 int szStep(szContext *ctx, const szStepParams *params, szStepStats *stats);
+/* How the steps of this floe array have run so far (bench.py, tests): out[k] for k < n, slots SZ_DIAG_*.  The three lists
+ * are those of the pair-interaction kernel (k_narrow_team): what its roofline is priced on. */
+enum {
+  SZ_DIAG_STEPS = 0,        /* completed steps */
+  SZ_DIAG_STEPS_FUSED,      /* ... whose front and back stages ran as the fused launch chain */
+  SZ_DIAG_SPEC_MISSES,      /* steps redone because a capacity taken from the step before did not hold */
+  SZ_DIAG_BACK_MISSES,      /* steps whose queued back half waited for the host after all */
+  SZ_DIAG_LIST_HOT, SZ_DIAG_LIST_COLD, SZ_DIAG_LIST_WIDE,   /* last step: pairs on the team pass's three lists */
+  SZ_DIAG_LIST_HANDED_ON,   /* last step: pairs the team pass or the classification left to the lane-per-pair kernels */
+  SZ_DIAG_LIST_WALLS,       /* last step: floes against the domain box (general sweep) */
+  SZ_DIAG_TEAM_VERTICES,    /* last step: stored ring vertices (both rings) summed over the pairs of the three lists */
+  SZ_DIAG_CELL_CAP, SZ_DIAG_POT_CAP,   /* slots per grid cell / candidates per floe the lists hold now */
+  SZ_DIAG_COUNT
+};
+int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n);
 /* floes (1-based, ascending) for which the last szStep returned SZ_STEP_NEEDS_MC */
 int szMcEmptyDownload(szContext *ctx, int32_t *ids, int64_t cap, int64_t *count);
 int szFloesDownload(szContext *ctx, szFloeState *host, int what);

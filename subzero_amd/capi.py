@@ -144,7 +144,7 @@ class ParamPacker:
 EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
-    "szFloesUpload", "szStep", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
+    "szFloesUpload", "szStep", "szStepDiagnostics", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
     "szEulerianData", "szCornerCandidates", "szCornerCuts", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
@@ -184,6 +184,7 @@ def load():
     L.szOrientation.argtypes = [_i64p, _i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.szFloesUpload.argtypes = [_vp, ctypes.POINTER(FloeStateC)]
     L.szStep.argtypes = [_vp, ctypes.POINTER(StepParamsC), ctypes.POINTER(StepStats)]
+    L.szStepDiagnostics.argtypes = [_vp, _i64p, ctypes.c_int32]
     L.szFloesDownload.argtypes = [_vp, ctypes.POINTER(FloeStateC), ctypes.c_int]
     L.szInteractionsDownload.argtypes = [_vp, _ip, _dp, ctypes.c_int64]
     L.szPairsDownload.argtypes = [_vp, _ip, _ip, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _ip]
@@ -340,6 +341,15 @@ class FloeInteractions:
             raise NeedsMc(self.mc_empty())
         self.ctx.check(rc, "szStep")
         return st
+
+    DIAG = ("steps", "steps_fused", "spec_misses", "back_misses", "list_hot", "list_cold", "list_wide", "list_handed_on",
+            "list_walls", "team_vertices", "cell_cap", "pot_cap")
+
+    def diagnostics(self):
+        """How the steps of this array have run (szStepDiagnostics): a dict over DIAG."""
+        out = np.zeros(len(self.DIAG), np.int64)
+        self.ctx.check(self.ctx.L.szStepDiagnostics(self.ctx.h, out, len(out)), "szStepDiagnostics")
+        return dict(zip(self.DIAG, (int(v) for v in out)))
 
     def mc_empty(self):
         """Floes (1-based) the last step asked new Monte-Carlo points for."""

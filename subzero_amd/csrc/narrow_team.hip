@@ -89,6 +89,12 @@ __global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned
   const i64 n = dev_count ? (i64)*dev_count : count;
   const int cls = (p < n && p < count) ? pair_classify(p, prev_n, P, W) : (int)PC_DONE;
   const int lane = threadIdx.x & 63;
+  {   // ring vertices of the pairs the team pass will take (its algorithmic bytes: bench.py)
+    long long tv = 0;
+    if (cls == PC_LIVE || cls == PC_COLD || cls == PC_WIDE) tv = W.ext_nv[W.pair_i[p]] + W.ext_nv[W.pair_j[p]];
+    for (int d = 32; d > 0; d >>= 1) tv += __shfl_xor(tv, d);
+    if (lane == 0 && tv) atomicAdd(&W.counters[C_TEAMV], (unsigned long long)tv);
+  }
   // the five lists are appended to a wave at a time: the ballots first, then ONE atomic per list, all of them issued by
   // one instruction (lane c takes list c), so that a wave waits for one round trip to the counters, not five
   const bool walls = W.wall_list != nullptr;      // (a list of their own when the step sweeps them beside the team pass)

@@ -453,19 +453,14 @@ __device__ inline bool go_by_rule(const unsigned long long *counters, const GoRu
   if (rule.mode == GO_SET) return true;
   if (rule.mode == GO_IF_CLEAN)
     return !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
-             counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) ||
+             counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) || counters[C_ERR_CELL] ||
              2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap);
   return counters[C_GO] != 0;
 }
 __global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go) {
   const unsigned e = threadIdx.x;
   if (e >= (unsigned)C_COUNT) return;
-  unsigned long long go = counters[C_GO];
-  if (rule.mode == GO_SET) go = 1;
-  else if (rule.mode == GO_IF_CLEAN)
-    go = !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
-           counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) ||
-           2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap) ? 1ULL : 0ULL;
+  const unsigned long long go = go_by_rule(counters, rule) ? 1ULL : 0ULL;
   const unsigned long long v = (e == C_GO) ? go : counters[e];
   host_copy[e] = v;
   const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
@@ -592,7 +587,8 @@ __global__ void k_incoming(i64 np, Work W) {   // (np may be a capacity: the pai
   i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < np && p < (i64)W.counters[C_NPAIRS]) incoming(p, W);
 }
-__global__ void __launch_bounds__(64) k_row_count(int lanes, Work W, int *spill) { // slices of LDS (or of `spill`) as in k_broad_filter
+// (agg: the fused chain -- the count also goes into its tile's sum, from which kf_row_fill places the rows)
+__global__ void __launch_bounds__(64) k_row_count(int lanes, Work W, int *spill, int agg) { // slices of LDS (or of `spill`) as in k_broad_filter
   extern __shared__ int filter_lds[];
   if (!W.counters[C_GO]) return;
   int N = dev_next(W);
@@ -600,7 +596,10 @@ __global__ void __launch_bounds__(64) k_row_count(int lanes, Work W, int *spill)
   int i = blockIdx.x * lanes + threadIdx.x;
   const size_t stride = 2 * (size_t)W.pot_cap + 1;
   int *tmp = spill ? spill + ((size_t)blockIdx.x * lanes + threadIdx.x) * stride : filter_lds + threadIdx.x * stride;
-  if (i < N) row_count(i, W, tmp);
+  if (i < N) {
+    row_count(i, W, tmp);
+    if (agg) { const int c = W.row_cnt[i]; if (c) atomicAdd(&W.row_agg[i >> 6], (unsigned long long)c); }
+  }
 }
 __global__ void k_row_fill(Floes F, Params P, Work W) {
   if (!W.counters[C_GO]) return;
@@ -648,13 +647,9 @@ static_assert(MC_PARTS == 256, "k_forcing folds exactly 256 partials");
 #define SZ_FORCING_WAVES 5
 #endif
 #define SZ_FORCING_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SZ_FORCING_WAVES, SZ_FORCING_WAVES)))
-__global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first, int last, Floes F, Params P, Work W) {
-  __shared__ double fold[256];
-  __shared__ double red[3];
-  __shared__ int scnt;
-  const int i = blockIdx.x + first;
-  if (i >= last || !W.counters[C_GO]) return;
-  if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
+// the forcing of floe i by the 256 threads of the workgroup (every thread is here with the same i); false: the floe's
+// Monte-Carlo mask is empty (reported, st_flag cleared)
+__device__ inline bool forcing_block(int i, const Floes &F, const Params &P, Work &W, double *fold, double *red, int *scnt) {
   const int t = threadIdx.x;
   const int nmc = F.n_mc;
   const double *mx = F.mcX + i * F.mc_si, *my = F.mcY + i * F.mc_si;
@@ -667,7 +662,8 @@ __global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first
   // sampled again in pass 2)
   enum { KEEP = 4 };
   McPoint kept[KEEP];
-  if (t == 0) scnt = 0;
+  __syncthreads();                                              // (scnt / red of the floe before are done with)
+  if (t == 0) *scnt = 0;
   __syncthreads();
   const bool keep = nmc <= 256 * KEEP;
   double a0 = 0.0, a1 = 0.0;
@@ -687,14 +683,14 @@ __global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first
     wind_point(c, P, mx[q * sq], my[q * sq], uw, vw);
     a0 += uw; a1 += vw; ++mine;
   }
-  if (mine) atomicAdd(&scnt, mine);
+  if (mine) atomicAdd(scnt, mine);
   const double su = mc_fold_block(a0, fold), sv = mc_fold_block(a1, fold);
   if (t == 0) { red[0] = su; red[1] = sv; }
   __syncthreads();
-  const int cnt = scnt;
+  const int cnt = *scnt;
   if (cnt == 0) { // calc_trajectory.m:100-110 would regenerate the points with rand()
     if (t == 0) { atomicAdd(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; }
-    return;
+    return false;
   }
   wind_stress(c, red[0], red[1], cnt);
   // pass 2: stresses and torque
@@ -718,7 +714,51 @@ __global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first
   }
   const double sFx = mc_fold_block(a0, fold), sFy = mc_fold_block(a1, fold), sT = mc_fold_block(a2, fold);
   if (t == 0) { F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt; }
+  return true;
 }
+__global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first, int last, Floes F, Params P, Work W) {
+  __shared__ double fold[256];
+  __shared__ double red[3];
+  __shared__ int scnt;
+  const int i = blockIdx.x + first;
+  if (i >= last || !W.counters[C_GO]) return;
+  if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
+  (void)forcing_block(i, F, P, W, fold, red, &scnt);
+}
+// The fused back half (step_fused.hpp).  kf_integrate: a thread per real floe -- the transfer marks, integrate_pre and,
+// for the floes whose forcing is not due, integrate_post at once (the three parts of calc_trajectory touch one floe
+// only).  On a step that refreshes the forcing every live floe waits for k_forcing and k_integrate_post; on the others
+// the few floes thinner than 0.1 m (calc_trajectory.m:94,121) go on a list that a handful of workgroups stride.
+__global__ void __launch_bounds__(64) kf_integrate(Floes F, Params P, Work W) {   // grid: max(n, cap_ext) threads
+  if (!W.counters[C_GO]) return;
+  const int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z < W.cap_ext) transfer_apply(z, F, W);
+  const int i = z + F.nb;
+  if (i < F.n) {
+    integrate_pre(i, F, P, W);
+    const int fl = W.st_flag[i];
+    if ((fl & ST_GO) && !(fl & ST_FORCE)) integrate_post(i, F, P, W);
+    else if ((fl & ST_GO) && !P.doInt) W.force_list[atomicAdd(&W.counters[C_FORCE], 1ULL)] = i;
+  }
+  if (z < F.nb) { F.collision_force[2 * z] = 0; F.collision_force[2 * z + 1] = 0; F.collision_torque[z] = 0; F.OverlapArea[z] = 0; }
+}
+// The floes of force_list (kf_integrate; a step that does not refresh the forcing for everybody): forcing, then
+// integrate_post, a few workgroups striding the list.  (No register cap here, unlike k_forcing: with integrate_post
+// inlined under 96 registers the kernel spills and every launch -- nearly always over an empty list -- sets up scratch.)
+__global__ void __launch_bounds__(256) kf_forcing_post_list(int first, int last, Floes F, Params P, Work W) {
+  __shared__ double fold[256];
+  __shared__ double red[3];
+  __shared__ int scnt;
+  if (!W.counters[C_GO]) return;
+  const int n = (int)W.counters[C_FORCE];
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    const int i = W.force_list[k];
+    if (i < first || i >= last) continue;
+    (void)forcing_block(i, F, P, W, fold, red, &scnt);
+    if (threadIdx.x == 0) integrate_post(i, F, P, W);
+  }
+}
+#include "step_fused.hpp"
 // sharded forcing: FxOA, FyOA, torqueOA of a floe range leave / arrive as three packed arrays of `cnt_max`
 __global__ void k_force_export(int first, int count, int cnt_max, Floes F, double *dst) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,6 +816,10 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_SPECULATE")) S->no_speculation = atoi(v) == 0;
   if (const char *v = getenv("SUBZERO_SPECULATE_BACK")) S->no_back_speculation = atoi(v) == 0;
   if (const char *v = getenv("SUBZERO_BROAD_WAVE")) S->broad_wave = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_FUSED")) S->fused_on = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_CELL_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->cell_cap = l; }
+  S->no_hint = getenv("SUBZERO_NO_HINT") != nullptr;
+  S->debug_lists = getenv("SUBZERO_DEBUG_LISTS") != nullptr;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
   SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
@@ -797,7 +841,8 @@ extern "C" {
 // narrow: pair_contact on the pairs [lo, hi) + capacity-tier retries       (one segment per rank)
 // back  : mirror lists, contact rows, sums, calc_trajectory                (every rank, identical results)
 enum { STEP_RETRY_EXACT = 1000, STEP_BACK_NOGO = 1001 };   // internal: the speculative step did not fit its capacities; run it again the exact way
-static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool speculative = false, bool classify = true) {
+// the step's parameters on the device side: ocean / wind grids, Params
+static int step_params(szContext *ctx, StepState *S, const szStepParams *hp) {
   hipStream_t st = ctx->stream;
   int rc;
   // ocean / wind grids: uploaded on the first step and whenever the forcing is refreshed
@@ -836,19 +881,14 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     if (P.c2_boundary[2 * k + 1] > P.Ly) P.Ly = P.c2_boundary[2 * k + 1];
   }
   boundary_summary(P);
-  Floes &F = S->F;
+  return SZ_OK;
+}
+// per-pair buffers and scratch for np pairs with nvt ring vertices in all (grow-only); -> bytes of the closed-form
+// part of the scratch arena (the retry tiers allocate behind it)
+static int bind_pairs(szContext *ctx, StepState *S, i64 np, i64 nvt, i64 &main_bytes) {
   Work &W = S->W;
-  const int n = S->n;
-  const int cap = W.cap_ext;
-  W.g_rows = nullptr;
-
-  SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
-  unsigned long long *c = S->c;
-  S->mc_empty.clear();
-  // per-pair buffers and scratch for np pairs with nvt ring vertices in all (grow-only); -> bytes of the closed-form
-  // part of the scratch arena (the retry tiers allocate behind it)
-  i64 main_bytes = 0;
-  auto bind_pairs = [&](i64 np, i64 nvt) -> int {
+  int rc;
+  {
     const size_t npa = (size_t)np + 1;
     if ((rc = sz_reserve(ctx, S->pair_i, npa * 4)) || (rc = sz_reserve(ctx, S->pair_j, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_nvoff, npa * 8)) || (rc = sz_reserve(ctx, S->pair_scr, npa * 8)) ||
@@ -875,7 +915,25 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
     W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
     return SZ_OK;
-  };
+  }
+}
+static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool speculative = false, bool classify = true) {
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = step_params(ctx, S, hp))) return rc;
+  Params &P = S->P;
+  Floes &F = S->F;
+  Work &W = S->W;
+  const int n = S->n;
+  const int cap = W.cap_ext;
+  W.g_rows = nullptr;
+  W.cell_cap = 0;
+  S->fused = false;
+
+  SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
+  unsigned long long *c = S->c;
+  S->mc_empty.clear();
+  i64 main_bytes = 0;
   for (int attempt = 0;; ++attempt) {
     if (attempt > 0 || !S->counters_clean) hipLaunchKernelGGL(k_counters_clear, dim3(1), dim3(64), 0, st, F, W);
     S->counters_clean = false;
@@ -948,11 +1006,65 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
 
   // the pairs sorted for the team pass (narrow_team.hip): boxes apart -> answered, the others onto their kernel's list
   S->classified = classify && S->team != 0 && S->convex_fast != 0 && S->fast_path == 0;
-  if ((rc = bind_pairs(np, nvt))) return rc;
+  if ((rc = bind_pairs(ctx, S, np, nvt, main_bytes))) return rc;
   hipLaunchKernelGGL(k_pair_expand, grid_for(cap, 256), dim3(256), 0, st, F, P, W, (unsigned long long)main_bytes);
   if (S->classified)
     sz_launch_pair_classify(st, np, speculative ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr,
-                            (S->stepped && getenv("SUBZERO_NO_HINT") == nullptr) ? S->last_next : 0, P, W);
+                            (S->stepped && !S->no_hint) ? S->last_next : 0, P, W);
+  SZ_HIP(ctx, hipGetLastError());
+  return SZ_OK;
+}
+
+// Can this step run the fused launch chain (step_fused.hpp)?  One grid level, lists of at most 64 candidates, the team
+// pass first, counts that fit the packed tile sums, a cell array of bearable size.
+static bool fused_eligible(StepState *S, const szStepParams *hp) {
+  if (!S->fused_on || !(S->team != 0 && S->convex_fast != 0 && S->fast_path == 0) || S->pot_cap > 64 || !S->broad_wave) return false;
+  if (S->n >= (1 << 21) || S->spec_np >= (1 << 24) || S->world > 1) return false;
+  double Lx = hp->c2_boundary[0], Ly = hp->c2_boundary[1];
+  for (int k = 1; k < 5; ++k) { if (hp->c2_boundary[2 * k] > Lx) Lx = hp->c2_boundary[2 * k]; if (hp->c2_boundary[2 * k + 1] > Ly) Ly = hp->c2_boundary[2 * k + 1]; }
+  Work tmp = S->W;
+  grid_levels(S->rmax_max, S->rmax_p90, Lx, Ly, tmp);
+  if (tmp.n_levels != 1) return false;
+  return (size_t)tmp.lvl_base[1] * (size_t)S->cell_cap * sizeof(CellItem) <= ((size_t)512 << 20);
+}
+// The front stages and the pair records of a speculative step as four launches (step_fused.hpp); capacities from the step
+// before, no read-back.
+static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp) {
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = step_params(ctx, S, hp))) return rc;
+  Params &P = S->P;
+  Floes &F = S->F;
+  Work &W = S->W;
+  const int n = S->n, cap = W.cap_ext;
+  W.g_rows = nullptr;
+  SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
+  S->mc_empty.clear();
+  if (!S->counters_clean) hipLaunchKernelGGL(k_counters_clear, dim3(1), dim3(64), 0, st, F, W);
+  S->counters_clean = false;
+  grid_levels(S->rmax_max, S->rmax_p90, P.Lx, P.Ly, W);
+  const size_t nc = (size_t)W.lvl_base[W.n_levels] + 1;
+  const int ntiles = (n + 63) / 64, ntiles_ext = (cap + 63) / 64;
+  if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, nc * (size_t)S->cell_cap * sizeof(CellItem))) ||
+      (rc = sz_reserve(ctx, S->gh_mask, 16 * (size_t)ntiles)) || (rc = sz_reserve(ctx, S->gh_agg, 8 * (size_t)ntiles)) ||
+      (rc = sz_reserve(ctx, S->pair_agg, 8 * (size_t)ntiles_ext)) || (rc = sz_reserve(ctx, S->row_agg, 8 * (size_t)ntiles_ext)) ||
+      (rc = sz_reserve(ctx, S->rel_mask, 8 * (size_t)cap)) || (rc = sz_reserve(ctx, S->pot_nvpre, 4 * (size_t)cap * S->pot_cap)) ||
+      (rc = sz_reserve(ctx, S->force_list, 4 * (size_t)n))) return rc;
+  W.cell_item = (CellItem *)S->cell_item.p; W.cell_cnt = (int *)S->cell_cnt.p; W.cell_cap = S->cell_cap;
+  W.gh_mask = (unsigned long long *)S->gh_mask.p; W.gh_agg = (unsigned long long *)S->gh_agg.p;
+  W.pair_agg = (unsigned long long *)S->pair_agg.p; W.row_agg = (unsigned long long *)S->row_agg.p;
+  W.rel_mask = (unsigned long long *)S->rel_mask.p; W.pot_nvpre = (int *)S->pot_nvpre.p; W.force_list = (int *)S->force_list.p;
+  S->speculating = true; S->fused = true;
+  const i64 np = S->spec_np, nvt = S->spec_nvt;
+  S->np = np; S->nvt = nvt; S->N = (int)S->c[C_NEXT]; S->retried = 0;
+  S->classified = true;
+  i64 main_bytes = 0;
+  if ((rc = bind_pairs(ctx, S, np, nvt, main_bytes))) return rc;
+  hipLaunchKernelGGL(kf_front_a, grid_for(cap, 256), dim3(256), 0, st, (int)nc - 1, ntiles_ext, F, P, W);
+  hipLaunchKernelGGL(kf_front_b, dim3((unsigned)ntiles), dim3(1024), 0, st, ntiles, F, P, W);
+  hipLaunchKernelGGL(kf_broad, dim3((unsigned)n), dim3(64), 0, st, F, P, W);
+  SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
+  hipLaunchKernelGGL(kf_pairs, dim3((unsigned)ntiles_ext), dim3(512), 0, st, (S->stepped && !S->no_hint) ? S->last_next : 0, (unsigned long long)main_bytes, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -1087,6 +1199,10 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     // has been changed so far (the narrow phase writes its own buffers only), so whatever does not fit is simply done
     // again the exact way.
     S->speculating = false;
+    if (c[C_ERR_CELL]) {   // fused front: a grid cell was full -- more slots from the next step on, this one the scan-based way
+      while ((unsigned long long)S->cell_cap < c[C_NEED_CELL] && S->cell_cap < (1 << 20)) S->cell_cap *= 2;
+      return STEP_RETRY_EXACT;
+    }
     if (c[C_NEED_MC] || c[C_ERR_POT] || (i64)c[C_NPAIRS] > S->spec_np || (i64)c[C_NVTOT] > S->spec_nvt || c[C_ERR_ARENA])
       return STEP_RETRY_EXACT;
     S->np = (i64)c[C_NPAIRS]; S->nvt = (i64)c[C_NVTOT]; S->N = (int)c[C_NEXT];
@@ -1175,6 +1291,14 @@ static int step_narrow(szContext *ctx, StepState *S, i64 lo, i64 hi) {
 
 static int step_forcing(szContext *ctx, StepState *S, int first, int last) {
   if (last <= first) return SZ_OK;
+  if (S->fused) {   // forcing and integrate_post of the floes kf_integrate left for it
+    // (a step that refreshes the forcing: every live floe, a workgroup each, then integrate_post -- the scan-based chain's two kernels)
+    if (!S->P.doInt) {
+      hipLaunchKernelGGL(kf_forcing_post_list, dim3(32), dim3(256), 0, ctx->stream, first, last, S->F, S->P, S->W);
+      SZ_HIP(ctx, hipGetLastError());
+      return SZ_OK;
+    }
+  }
   hipLaunchKernelGGL(k_forcing, dim3(last - first), dim3(256), 0, ctx->stream, first, last, S->F, S->P, S->W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
@@ -1199,15 +1323,22 @@ static int step_back_a(szContext *ctx, StepState *S) {
   {
     int lanes; size_t lds; int *spill = nullptr;
     if ((rc = filter_launch_shape(ctx, S, (i64)cap + 64, lanes, lds, spill))) return rc;
-    hipLaunchKernelGGL(k_row_count, grid_for(cap, lanes), dim3(64), lds, st, lanes, W, spill);
+    hipLaunchKernelGGL(k_row_count, grid_for(cap, lanes), dim3(64), lds, st, lanes, W, spill, S->fused ? 1 : 0);
   }
-  launch_scan(st, S->scan_agg, cap, ScanRows{W});
   // No host round trip here: every contact row of a pair appears at most twice in the CSR (once for each floe
   // of the pair), so the pair rows counted by the narrow phase bound it; the exact count and the overflow flag
   // of the mirror lists are read with the counters at the end of the step.
   const i64 nr_cap = S->back_queued ? S->spec_rows : 2 * S->pair_rows_total + 1;
   if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)nr_cap))) return rc;
   W.rows = (double *)S->rows.p; W.cap_rows = nr_cap;
+  if (S->fused) {
+    hipLaunchKernelGGL(kf_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
+    SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
+    hipLaunchKernelGGL(kf_integrate, grid_for(n > cap ? n : cap, 64), dim3(64), 0, st, F, P, W);
+    SZ_HIP(ctx, hipGetLastError());
+    return SZ_OK;
+  }
+  launch_scan(st, S->scan_agg, cap, ScanRows{W});
   hipLaunchKernelGGL(k_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
   hipLaunchKernelGGL(k_integrate_pre, grid_for(n > cap ? n : cap, 64), dim3(64), 0, st, F, P, W);
@@ -1220,7 +1351,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
   unsigned long long *c = S->c;
   const int n = S->n;
-  hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
+  if (!S->fused || P.doInt) hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0}, S->back_queued ? 1 : 0);
@@ -1241,9 +1372,11 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     return sz_fail(ctx, SZ_ERR_STATE, "integrate: %llu floe(s) have an empty Monte-Carlo mask; regenerating it needs MATLAB's rand (calc_trajectory.m:100-110)", c[C_ERR_MC]);
   const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
+  ++S->steps_done; if (S->fused) ++S->steps_fused;
+  S->last_team_vertices = (i64)c[C_TEAMV];
   S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS]; S->last_team = (i64)c[C_TEAM];
   S->last_deferred = S->retried - (W.wall_list ? 0 : S->last_walls) + (i64)c[C_BIG];   // pairs of this step that waited for the host besides the floes at the walls
-  if (getenv("SUBZERO_DEBUG_LISTS")) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld | walls %lld (%s) deferred besides %lld big %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS], (long long)c[C_WALLS], W.wall_list ? "beside the team pass" : "on the retry list", (long long)S->last_deferred, (long long)c[C_BIG]);
+  if (S->debug_lists) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld | walls %lld (%s) deferred besides %lld big %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS], (long long)c[C_WALLS], W.wall_list ? "beside the team pass" : "on the retry list", (long long)S->last_deferred, (long long)c[C_BIG]);
   if (stats) {
     float ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;
@@ -1284,7 +1417,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   // Steady state: the front stages and the narrow phase are queued back to back, sized by the last step's counts plus
   // a margin, and validated at the one read-back after the narrow phase (one host round trip fewer per step).
   if (S->spec_np > 0 && !S->no_speculation && S->convex_fast && !S->fast_path) {
-    if ((rc = step_front(ctx, S, hp, true))) return rc;
+    if ((rc = fused_eligible(S, hp) ? step_front_fused(ctx, S, hp) : step_front(ctx, S, hp, true))) return rc;
     const bool queue_back = S->back_spec_ok;
     if ((rc = step_narrow_first(ctx, S, 0, S->spec_np, queue_back))) return rc;
     if (queue_back) {
@@ -1410,6 +1543,16 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
   }
   if ((rc = step_forcing(ctx, S, S->nb, S->n))) return rc;
   return step_back_b(ctx, S, stats);
+}
+
+int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n) {
+  if (!ctx || !out || n < 0) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepDiagnostics: no floes uploaded");
+  const int64_t v[SZ_DIAG_COUNT] = {S->steps_done, S->steps_fused, S->spec_misses, S->back_misses, S->last_hot, S->last_cold, S->last_wide,
+                                    S->last_team, S->last_walls, S->last_team_vertices, S->cell_cap, S->pot_cap};
+  for (int k = 0; k < n && k < (int)SZ_DIAG_COUNT; ++k) out[k] = v[k];
+  return SZ_OK;
 }
 
 int64_t szShardForcingBytes(szContext *ctx, int world) {

@@ -102,7 +102,12 @@ static_assert((int)RING_SLOTS == (int)sztm::T_NV, "the staged rings are what the
 // counters living in device memory
 enum {
   C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COLD, C_WALLS, C_COUNT
+  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COLD, C_WALLS,
+  C_ERR_CELL,   // fused front: entries that found their grid cell full (Work::cell_cap slots) -- the step is then done again by the scan-based chain
+  C_NEED_CELL,  // ... and the fullest cell's demand
+  C_TEAMV,      // ring vertices (stored lengths, both rings) of the pairs on the team pass's three lists: what that kernel's roofline is priced on
+  C_FORCE,      // fused back half: floes on force_list (forcing due on a step that does not refresh it for everybody: h < 0.1)
+  C_COUNT
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -174,6 +179,14 @@ struct Work {
   // sharded narrow-phase (multi-GPU): contact rows of all pairs gathered from the ranks that computed them
   double *g_rows;    // null on one GPU: rows are read from the pair's scratch slice
   i64 *pair_rowoff;  // [cap_pairs] offset (in doubles) of pair p's rows inside g_rows (sharded step) or inside scratch
+  // ---- the fused launch chain of the steady step (step_fused.hpp): tiles of 64 consecutive floes / entries ----
+  int cell_cap;                          // > 0: cell c owns the slots [c * cell_cap, (c + 1) * cell_cap) of cell_item, filled by atomic append (no cell scan); 0: CSR by cell_off
+  unsigned long long *gh_mask, *gh_agg;  // [2 * tiles] ballots of the x / y ghost flags of a tile's floes; [tiles] their counts packed x | y << 21 | both << 42
+  unsigned long long *pair_agg;          // [tiles of entries] pairs (low 24 bits) and pair vertices (<< 24) of a tile's entries
+  unsigned long long *row_agg;           // [tiles of entries] contact rows of a tile's entries
+  unsigned long long *rel_mask;          // [cap_ext] bit k: candidate k of the entry is a pair this rank evaluates (pair_relevant)
+  int *pot_nvpre;                        // [cap_ext * pot_cap] ring vertices of the entry's pairs before candidate k
+  int *force_list;                       // [n] floes whose forcing is due though the step does not refresh it for all (C_FORCE of them)
 };
 
 // per-pair scratch slice: linear bound so that offsets follow from prefix sums (see carve())
@@ -235,23 +248,24 @@ SZ_HD void ext_clear(int e, Work &W) { // e < cap_ext
   W.cf_ext[2 * e] = 0; W.cf_ext[2 * e + 1] = 0; W.ct_ext[e] = 0; W.ov_ext[e] = 0;
 }
 SZ_HD void marks_clear(int e, const Floes &F) { F.kill[e] = 0; F.transfer[e] = 0; } // e < 4 n (:123)
-// flag[e] = alive and the translated ring reaches beyond the box in dimension dim (:31,:52)
-SZ_HD void ghost_flag(int e, int dim, const Floes &F, const Params &P, Work &W) {
-  int s = W.ext_src[e], v0 = F.vert_off[s], nv = F.vert_off[s + 1] - v0;
-  if (!is_present(s, W)) { W.flag[e] = 0; return; }   // (sharded step: not a floe this rank knows this step)
+// alive and the translated ring reaches beyond the box in dimension dim (:31,:52); s = the entry's floe, c = its
+// coordinate in that dimension
+SZ_HD int ghost_flag_of(int s, double c, int dim, const Floes &F, const Params &P, const Work &W) {
+  const int v0 = F.vert_off[s], nv = F.vert_off[s + 1] - v0;
+  if (!is_present(s, W)) return 0;   // (sharded step: not a floe this rank knows this step)
   // no vertex is farther from the floe position than rmax (initialize_floe_values.m:26 defines it so, and the
   // rotation of c0 into c_alpha keeps the distances): a floe well inside the box needs no look at its ring
   // (the 1e-9 relative margin is far above the rounding of the rotated ring and of the sums below)
-  {
-    const double L = (dim == 0) ? P.Lx : P.Ly, c = (dim == 0) ? W.ext_x[e] : W.ext_y[e];
-    if (absd(c) + F.rmax[s] < L * (1 - 1e-9)) { W.flag[e] = 0; return; }
-  }
+  const double L = (dim == 0) ? P.Lx : P.Ly;
+  if (absd(c) + F.rmax[s] < L * (1 - 1e-9)) return 0;
   double m = 0;
-  for (int k = 0; k < nv; ++k) {
-    double v = (dim == 0) ? F.cax[v0 + k] + W.ext_x[e] : F.cay[v0 + k] + W.ext_y[e];
-    m = szc::maxd(m, absd(v));
-  }
-  W.flag[e] = (F.alive[s] && m > (dim == 0 ? P.Lx : P.Ly)) ? 1 : 0;
+  const double *ca = (dim == 0) ? F.cax : F.cay;
+  for (int k = 0; k < nv; ++k) m = szc::maxd(m, absd(ca[v0 + k] + c));
+  return (F.alive[s] && m > L) ? 1 : 0;
+}
+// flag[e] = that, for entry e
+SZ_HD void ghost_flag(int e, int dim, const Floes &F, const Params &P, Work &W) {
+  W.flag[e] = ghost_flag_of(W.ext_src[e], (dim == 0) ? W.ext_x[e] : W.ext_y[e], dim, F, P, W);
 }
 // e's ghost goes to slot base + scan[e] (:33-37, :54-58)
 SZ_HD void ghost_emit(int e, int dim, int base, const Floes &F, const Params &P, Work &W) {
@@ -741,12 +755,16 @@ SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P
 //   team_list  the lane-per-pair kernels (walls, rings too long for the block, coordinates out of the fast range)
 // The order inside a list is arbitrary (every pair writes its own words).  Returns the class; the caller appends.
 enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3, PC_COLD = 4, PC_GENERAL = 5 };   // PC_GENERAL: straight to the general sweep (a floe at a wall: the box has horizontal edges, no fast path takes it)
+SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Params &P, Work &W);
 SZ_HD int pair_classify(i64 p, int prev_n, const Params &P, Work &W) {
-  const int i = W.pair_i[p], j = W.pair_j[p];
+  return pair_classify_ij(p, W.pair_i[p], W.pair_j[p], W.pair_nvoff[p], prev_n, P, W);
+}
+// (the pair's words passed in: the fused chain classifies a pair in the thread that has just written them)
+SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Params &P, Work &W) {
   const bool boundary = (j == WALL);
   const double *ri = W.ext_rec + (size_t)REC_WORDS * i, *rj = boundary ? ri : W.ext_rec + (size_t)REC_WORDS * j;
   const int n1 = (int)ri[REC_NSTORED], n2 = boundary ? 4 : (int)rj[REC_NSTORED];
-  const i64 off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;
+  const i64 off = (i64)SCR_PER_V * (nvoff + 2 * p) + (i64)SCR_PER_PAIR * p;
   W.pair_scr[p] = off; W.pair_mult[p] = 1; W.pair_nrows[p] = 0; W.pair_flag[p] = 0; W.pair_rowoff[p] = off / 8;
   if (off + scratch_bytes_for((i64)n1 + n2, 1) > W.scratch_bytes) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); return PC_DONE; }
   W.pair_status[p] = szv::ST_OK;

@@ -1,0 +1,394 @@
+// step_fused.hpp -- the steady step's launch chain with its global scans folded into the kernels on either side
+// (included by step.hip inside its anonymous namespace; the bodies are those of step_core.hpp).
+//
+// Round 3 ended with ~22 launches of 5-20 us around the team kernel: every prefix sum of the step was two launches of
+// its own between two per-floe kernels, and 1e4 floes are 157 waves on a chip of 1024 SIMDs -- each of those launches
+// is latency.  A kernel boundary is the cheapest grid-wide hand-off on this chip (a look-back or a ticket between
+// workgroups on different XCDs costs more than the ~2 us of a back-to-back launch: measured in round 3), so the chain
+// below keeps one boundary per TRUE dependency and nothing else:
+//
+//   kf_front_a   per entry    clears, ext_init, mc_precheck, ghost flags -> a ballot and a packed count per TILE of 64 floes
+//   kf_front_b   16 lanes / floe  sums the tile counts before its tile (<= a few hundred words), places the floe's ghosts
+//                             (:33-37,:54-58 in the order of the reference's two passes), writes the records and staged
+//                             rings of the floe and of its ghosts, appends each to its grid cell (fixed slots per cell:
+//                             no count -> scan -> fill)
+//   kf_broad     wave / floe  candidate list of the floe (k_broad_wave) and then of its ghosts, whose `mems` start from the
+//                             floe's finished list (:94-99) -- which this wave has just made; pair counts per entry and, by
+//                             one atomic, per tile of 64 entries
+//   kf_pairs     tile of 64 entries   sums the tile counts before its tile, scans its own, writes the pair records and
+//                             classifies each pair in the thread that wrote it (pair_classify)
+//   [team pass]
+//   k_incoming_go, k_row_count (+ tile counts)
+//   kf_row_fill  tile of 64 entries   row offsets from the tile counts, then row_fill
+//   kf_integrate per floe     transfer marks, integrate_pre and -- where no forcing is due -- integrate_post
+//   kf_forcing_post  workgroup / floe   forcing + integrate_post of the floes whose forcing is due
+//   k_publish
+// Same arrays, same values as the scan-based chain (which stays: first steps, grids of several levels, lists beyond 64
+// entries, the exact re-run of a step that outgrew its capacities); tests/test_fused_gpu.py compares the two word by word.
+#pragma once
+
+// ---- kf_front_a ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kf_front_a(int ncells, int ntiles_ext, Floes F, Params P, Work W) {
+  const int e = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  for (int c = e; c < ncells; c += stride) W.cell_cnt[c] = 0;
+  for (int t = e; t < ntiles_ext; t += stride) { W.pair_agg[t] = 0; W.row_agg[t] = 0; }
+  if (e < W.cap_ext) { ext_clear(e, W); marks_clear(e, F); }
+  int fx = 0, fy = 0;
+  if (e < F.n) {
+    ext_init(e, F, W);
+    if (P.PERIODIC) {
+      fx = ghost_flag_of(e, F.Xi[e], 0, F, P, W);
+      fy = ghost_flag_of(e, F.Yi[e], 1, F, P, W);
+      W.flag[e] = fx | (fy << 1);
+    }
+  }
+  if (e >= F.nb && e < F.n) mc_precheck(e, F, P, W);
+  if (P.PERIODIC && (e & ~63) < F.n) {                // (whole waves: a tile is a wave)
+    const unsigned long long mx = __ballot(fx != 0), my = __ballot(fy != 0);
+    if ((threadIdx.x & 63) == 0) {
+      const int t = e >> 6;
+      W.gh_mask[2 * t] = mx; W.gh_mask[2 * t + 1] = my;
+      W.gh_agg[t] = (unsigned long long)__popcll(mx) | ((unsigned long long)__popcll(my) << 21) | ((unsigned long long)__popcll(mx & my) << 42);
+    }
+  }
+}
+
+// ---- kf_front_b ----------------------------------------------------------------------------------------------------
+// entry e into its cell of the one-level grid (fixed slots per cell)
+__device__ inline void cell_insert(int e, int s, double x, double y, const Floes &F, Work &W) {
+  if (!(F.alive[s] && e >= F.nb && is_present(s, W))) return;       // in_grid
+  const int c = cell_at(0, x, y, W);
+  const int k = atomicAdd(&W.cell_cnt[c], 1);
+  if (k < W.cell_cap) {
+    CellItem it; it.x = x; it.y = y; it.r = F.rmax[s]; it.e = e; it.pad = 0;
+    W.cell_item[(size_t)c * W.cell_cap + k] = it;
+  } else {
+    atomicAdd(&W.counters[C_ERR_CELL], 1ULL); atomicMax(&W.counters[C_NEED_CELL], (unsigned long long)(k + 1));
+  }
+}
+// record and staged ring of entry e (floe s at (ox, oy)) by the 16 lanes of a group, lane l: k_ext_records' body
+__device__ inline void ext_record_lanes(int e, int s, double ox, double oy, int l, const Floes &F, Work &W) {
+  const int v0 = F.vert_off[s], n = F.vert_off[s + 1] - v0;
+  double x0 = SZC_INF, x1 = -SZC_INF, y0 = SZC_INF, y1 = -SZC_INF;
+  for (int k = l; k < n; k += 16) {
+    const double X = F.cax[v0 + k] + ox, Y = F.cay[v0 + k] + oy;
+    x0 = szc::mind(x0, X); x1 = szc::maxd(x1, X); y0 = szc::mind(y0, Y); y1 = szc::maxd(y1, Y);
+  }
+  for (int d = 1; d < 16; d <<= 1) {
+    x0 = szc::mind(x0, __shfl_xor(x0, d, 16)); x1 = szc::maxd(x1, __shfl_xor(x1, d, 16));
+    y0 = szc::mind(y0, __shfl_xor(y0, d, 16)); y1 = szc::maxd(y1, __shfl_xor(y1, d, 16));
+  }
+  int nstage = n;
+  if (n == (int)RING_SLOTS + 1) {
+    const double fx = F.cax[v0] + ox, fy = F.cay[v0] + oy, lx = F.cax[v0 + n - 1] + ox, ly = F.cay[v0 + n - 1] + oy;
+    const double px = F.cax[v0 + n - 2] + ox, py = F.cay[v0 + n - 2] + oy;
+    if (lx == fx && ly == fy && szc::hyp(fx - px, fy - py) > 1) --nstage;
+  }
+  if (nstage > (int)RING_SLOTS || nstage < 1) nstage = -1;
+  const double safe = SZX_FIXED_SAFE_METRES - 2;
+  bool ok = true;
+  double X = 0, Y = 0;
+  if (l < nstage) { X = F.cax[v0 + l] + ox; Y = F.cay[v0 + l] + oy; ok = szc::absd(X) < safe && szc::absd(Y) < safe; }
+  const unsigned long long bad = __ballot(!ok);
+  const bool in_range = ((bad >> ((threadIdx.x & 63) & ~15)) & 0xffffULL) == 0;
+  double *rx = W.ext_ring + 2 * (size_t)RING_SLOTS * e;
+  if (l < nstage) { rx[l] = X; rx[RING_SLOTS + l] = Y; }
+  double w = 0;
+  switch (l) {
+    case REC_X: w = ox; break; case REC_Y: w = oy; break; case REC_UI: w = F.Ui[s]; break; case REC_VI: w = F.Vi[s]; break;
+    case REC_KSI: w = F.ksi_ice[s]; break; case REC_H: w = F.h[s]; break; case REC_AREA: w = F.area[s]; break;
+    case REC_BX0: w = x0; break; case REC_BX1: w = x1; break; case REC_BY0: w = y0; break; case REC_BY1: w = y1; break;
+    case REC_NSTAGE: w = (double)nstage; break; case REC_NSTORED: w = (double)n; break; case REC_INRANGE: w = in_range ? 1.0 : 0.0; break;
+    default: break;
+  }
+  W.ext_rec[(size_t)REC_WORDS * e + l] = w;
+}
+// One workgroup per tile of 64 floes, 16 lanes per floe.  Ghost slots as ScanGhosts places them: x ghost of k at N + px,
+// y ghost of k at N + GX + py, y ghost of k's x ghost at N + GX + GYreal + pxy, the p's = exclusive counts over the
+// floes before k.
+__global__ void __launch_bounds__(1024) kf_front_b(int ntiles, Floes F, Params P, Work W) {
+  __shared__ unsigned long long red[2][16];
+  const int w = blockIdx.x, t = threadIdx.x;
+  unsigned long long before = 0, all = 0;
+  if (P.PERIODIC) {
+    for (int u = t; u < ntiles; u += 1024) { const unsigned long long a = W.gh_agg[u]; all += a; if (u < w) before += a; }
+    for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+    if ((t & 63) == 0) { red[0][t >> 6] = before; red[1][t >> 6] = all; }
+    __syncthreads();
+    before = 0; all = 0;
+    for (int q = 0; q < 16; ++q) { before += red[0][q]; all += red[1][q]; }
+  }
+  const int N = F.n;
+  const unsigned FLD = (1u << 21) - 1;
+  const int GX = (int)(all & FLD), GYr = (int)((all >> 21) & FLD), GXY = (int)((all >> 42) & FLD);
+  if (P.PERIODIC && w == ntiles - 1 && t == 0) {
+    W.counters[C_GX] = (unsigned long long)GX; W.counters[C_GY] = (unsigned long long)(GYr + GXY);
+    W.counters[C_NEXT] = (unsigned long long)(N + GX + GYr + GXY);
+  }
+  const int f = 64 * w + (t >> 4), l = t & 15;
+  if (f >= N) return;
+  const double ox = F.Xi[f], oy = F.Yi[f];
+  int gx = -1, gy = -1, gxy = -1;
+  double gxx = ox, gyy = oy;
+  if (P.PERIODIC) {
+    const unsigned long long mx = W.gh_mask[2 * w], my = W.gh_mask[2 * w + 1];
+    const int bit = f & 63;
+    const unsigned long long below = (1ULL << bit) - 1ULL;
+    const bool fx = (mx >> bit) & 1ULL, fy = (my >> bit) & 1ULL;
+    if (fx) { gx = N + (int)(before & FLD) + __popcll(mx & below); gxx = ox - 2 * P.Lx * sgn(ox); }
+    if (fy) { gy = N + GX + (int)((before >> 21) & FLD) + __popcll(my & below); gyy = oy - 2 * P.Ly * sgn(oy); }
+    if (fx && fy) gxy = N + GX + GYr + (int)((before >> 42) & FLD) + __popcll(mx & my & below);
+    if (gx >= W.cap_ext) gx = -1;       // (cannot happen: cap_ext = 4 n)
+    if (gy >= W.cap_ext) gy = -1;
+    if (gxy >= W.cap_ext || gx < 0) gxy = -1;
+    if (l == 0) {
+      const int nvf = F.vert_off[f + 1] - F.vert_off[f], num = -(f + 1);
+      if (gx >= 0) { W.ext_src[gx] = f; W.ext_nv[gx] = nvf; W.ext_x[gx] = gxx; W.ext_y[gx] = oy; W.ext_num[gx] = num; W.ext_parent[gx] = f; W.xg_of[f] = gx; }
+      if (gy >= 0) { W.ext_src[gy] = f; W.ext_nv[gy] = nvf; W.ext_x[gy] = ox; W.ext_y[gy] = gyy; W.ext_num[gy] = num; W.ext_parent[gy] = f; W.yg_of[f] = gy; }
+      if (gxy >= 0) { W.ext_src[gxy] = f; W.ext_nv[gxy] = nvf; W.ext_x[gxy] = gxx; W.ext_y[gxy] = gyy; W.ext_num[gxy] = num; W.ext_parent[gxy] = gx; W.yg_of[gx] = gxy; }
+    }
+  }
+  ext_record_lanes(f, f, ox, oy, l, F, W);
+  if (gx >= 0) ext_record_lanes(gx, f, gxx, oy, l, F, W);
+  if (gy >= 0) ext_record_lanes(gy, f, ox, gyy, l, F, W);
+  if (gxy >= 0) ext_record_lanes(gxy, f, gxx, gyy, l, F, W);
+  // (one lane each: the four appends go out side by side)
+  if (l == 0) cell_insert(f, f, ox, oy, F, W);
+  if (l == 1 && gx >= 0) cell_insert(gx, f, gxx, oy, F, W);
+  if (l == 2 && gy >= 0) cell_insert(gy, f, ox, gyy, F, W);
+  if (l == 3 && gxy >= 0) cell_insert(gxy, f, gxx, gyy, F, W);
+}
+
+// ---- kf_broad ------------------------------------------------------------------------------------------------------
+struct BroadLds { int hit[64], sorted[64], init[64], relf[64], s_end[9], s_c0[9], s_cn[9]; };
+// The candidate list of entry i by the wave (k_broad_wave's body, cells with fixed slots).  ninit > 0: `mems` starts from
+// L.init (the finished list of the floe a ghost is an image of, :94-99).  keep_init: leave the list in L.init.  -> kept
+__device__ inline int broad_entry_wave(int i, int ninit, bool keep_init, int N, BroadLds &L, const Floes &F, const Params &P, Work &W) {
+  const int lane = threadIdx.x & 63;
+  const int si = W.ext_src[i];
+  const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
+  int H = 0;
+  __syncthreads();                                    // (the arrays of the entry before are done with)
+  if (F.alive[si] && !(xi != xi) && P.COLLISION && is_present(si, W)) {
+    const int gx0 = cell_coord(xi, W.lvl_x0[0], W.lvl_cs[0], W.lvl_cx[0]), gy0 = cell_coord(yi, W.lvl_y0[0], W.lvl_cs[0], W.lvl_cy[0]);
+    int c0 = 0, cn = 0;
+    if (lane < 9) {
+      const int gx = gx0 + (lane % 3) - 1, gy = gy0 + (lane / 3) - 1;
+      if (gx >= 0 && gx < W.lvl_cx[0] && gy >= 0 && gy < W.lvl_cy[0]) {
+        const int c = W.lvl_base[0] + gy * W.lvl_cx[0] + gx;
+        cn = W.cell_cnt[c]; if (cn > W.cell_cap) cn = W.cell_cap;
+        c0 = c * W.cell_cap;
+      }
+    }
+    int pre = cn;
+    for (int d = 1; d < 16; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+    if (lane < 9) { L.s_end[lane] = pre; L.s_c0[lane] = c0; L.s_cn[lane] = cn; }
+    __syncthreads();
+    const int T = L.s_end[8];
+    for (int base = 0; base < T; base += 64) {
+      const int t = base + lane;
+      bool ok = false;
+      int j = 0;
+      if (t < T) {
+        int cell = 0;
+        for (int c = 0; c < 8; ++c) if (t >= L.s_end[c]) cell = c + 1;
+        const int q = L.s_c0[cell] + (t - (L.s_end[cell] - L.s_cn[cell]));
+        const CellItem it = W.cell_item[q];
+        j = it.e;
+        if (j > i) {
+          const double dx = xi - it.x, dy = yi - it.y, R = ri + it.r, d2 = dx * dx + dy * dy;
+          ok = !(d2 > R * R * 1.000001) && (::sqrt(d2) < R);       // :103
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) { const int r = H + __popcll(m & ((1ULL << lane) - 1ULL)); if (r < 64) L.hit[r] = j; }
+      H += __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (H > W.pot_cap || H > 64) {
+    if (lane == 0) { atomicAdd(&W.counters[C_ERR_POT], 1ULL); atomicMax(&W.counters[C_NEED_POT], (unsigned long long)H); }
+    H = 0;
+  }
+  const int mine = lane < H ? L.hit[lane] : 0x7fffffff;
+  int rank = 0;
+  for (int k = 0; k < H; ++k) rank += (L.hit[k] < mine) ? 1 : 0;
+  if (lane < H) L.sorted[rank] = mine;
+  __syncthreads();
+  const int j = lane < H ? L.sorted[lane] : 0;
+  const int num = lane < H ? W.ext_num[j] : 0;
+  const int key = iabs(num);
+  bool keep = lane < H;
+  if (P.PERIODIC) {
+    bool dup = false;
+    for (int k = 0; k < H; ++k) { const int nk = __shfl(num, k); if (k < lane && lane < H && nk == key) dup = true; }
+    for (int q = 0; q < ninit; ++q) if (L.init[q] == key) dup = true;          // (:94-99)
+    if (keep && dup) {
+      const double lim = szc::mind(2 * P.Lx, 2 * P.Ly), R = ri + F.rmax[W.ext_src[j]];
+      keep = 2 * R > lim;
+    }
+  }
+  const unsigned long long km = __ballot(keep);
+  const int K = __popcll(km);
+  const int idx = __popcll(km & ((1ULL << lane) - 1ULL));
+  if (keep) W.pot_list[(size_t)i * W.pot_cap + idx] = j + 1;
+  __syncthreads();                                    // (L.init has been read by every lane)
+  if (keep && keep_init) L.init[idx] = j + 1;
+  // the pairs of this entry (pair_count), which of its candidates they are, the ring vertices before each
+  const bool rel = keep && i >= F.nb && pair_relevant(i, j, W);
+  const int ni = W.ext_nv[i];
+  const int nvj = rel ? ni + W.ext_nv[j] : 0;
+  if (rel) (void)__hip_atomic_fetch_add(&W.inc_pre[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int inc = nvj;
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+  if (keep) W.pot_nvpre[(size_t)i * W.pot_cap + idx] = inc - nvj;
+  long long nv = __shfl(inc, 63);
+  unsigned long long relm;
+  if (W.owned) {
+    if (keep) L.relf[idx] = rel ? 1 : 0;
+    __syncthreads();
+    relm = __ballot(lane < K && L.relf[lane] != 0);
+  } else relm = (i >= F.nb) ? ((K >= 64) ? ~0ULL : ((1ULL << K) - 1ULL)) : 0ULL;
+  int cnt = __popcll(__ballot(rel));
+  if (lane == 0) {
+    if (has_wall_pair(i, N, F, P, W)) { ++cnt; nv += ni + 4; }
+    W.pot_cnt[i] = K; W.pair_cnt[i] = cnt; W.pair_nv[i] = nv; W.rel_mask[i] = relm;
+    if (cnt) atomicAdd(&W.pair_agg[i >> 6], (unsigned long long)cnt | ((unsigned long long)nv << 24));
+  }
+  return K;
+}
+// a wave per real floe: its own list, then those of its ghosts (the x ghost, the y ghost, the y ghost of the x ghost)
+__global__ void __launch_bounds__(64) kf_broad(Floes F, Params P, Work W) {
+  __shared__ BroadLds L;
+  const int i = blockIdx.x;
+  if (i >= F.n) return;
+  const int N = dev_next(W);
+  int K = 0;
+  if (i >= F.nb) K = broad_entry_wave(i, 0, P.PERIODIC != 0, N, L, F, P, W);
+  if (!P.PERIODIC) return;
+  const int gx = W.xg_of[i], gy = W.yg_of[i];
+  if (gx >= 0) {
+    (void)broad_entry_wave(gx, K, false, N, L, F, P, W);
+    const int gxy = W.yg_of[gx];
+    if (gxy >= 0) (void)broad_entry_wave(gxy, K, false, N, L, F, P, W);
+  }
+  if (gy >= 0) (void)broad_entry_wave(gy, K, false, N, L, F, P, W);
+}
+
+// ---- kf_pairs ------------------------------------------------------------------------------------------------------
+__device__ inline int nth_set_bit(unsigned long long m, int q) {   // position of the q-th (0-based) set bit of m
+  int pos = 0;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const int c = __popcll(m & ((1ULL << s) - 1ULL));
+    if (q >= c) { q -= c; m >>= s; pos += s; }
+  }
+  return pos;
+}
+// One workgroup per tile of 64 entries: ScanPairs + pair_expand + pair_classify.  The pairs of entry i are its relevant
+// candidates in list order, then the wall (has_wall_pair) -- pair p = pair_base[i] + rank.
+__global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long scratch_bump, Floes F, Params P, Work W) {
+  __shared__ unsigned long long red[8];
+  __shared__ long long s_base[65], s_nvb[64];
+  __shared__ int s_cnt[64];
+  const int T = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const int N = dev_next(W);
+  const int ntiles = (N + 63) >> 6;
+  if (T == 0 && t == 0) W.counters[C_SCR_BUMP] = scratch_bump;
+  if (T >= ntiles) return;
+  unsigned long long before = 0;
+  for (int u = t; u < T; u += 512) before += W.pair_agg[u];
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  if (lane == 0) red[t >> 6] = before;
+  __syncthreads();
+  before = 0;
+  for (int q = 0; q < 8; ++q) before += red[q];
+  const long long base_p = (long long)(before & 0xffffffULL), base_nv = (long long)(before >> 24);
+  if (t < 64) {
+    const int e = 64 * T + t;
+    long long cnt = 0, nv = 0;
+    if (e < N) { cnt = W.pair_cnt[e]; nv = W.pair_nv[e]; pair_room(e, W); }
+    long long ic = cnt, iv = nv;
+    for (int d = 1; d < 64; d <<= 1) { const long long a = __shfl_up(ic, d), b = __shfl_up(iv, d); if (lane >= d) { ic += a; iv += b; } }
+    s_base[t] = ic - cnt; s_nvb[t] = iv - nv; s_cnt[t] = (int)cnt;
+    if (t == 63) s_base[64] = ic;
+    if (e < N) { W.pair_base[e] = base_p + ic - cnt; W.nv_base[e] = base_nv + iv - nv; }
+    if (T == ntiles - 1 && t == 63) {
+      W.counters[C_NPAIRS] = (unsigned long long)(base_p + ic); W.pair_base[N] = base_p + ic;
+      W.counters[C_NVTOT] = (unsigned long long)(base_nv + iv); W.nv_base[N] = base_nv + iv;
+    }
+  }
+  __syncthreads();
+  const int tp = (int)s_base[64];
+  const bool walls = W.wall_list != nullptr;
+  for (int pl0 = 0; pl0 < tp; pl0 += 512) {
+    const int pl = pl0 + t;
+    int cls = PC_DONE;
+    i64 p = 0;
+    if (pl < tp) {
+      int lo = 0;                                     // the entry whose range holds pl: the last one with s_base <= pl
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) if (lo + s < 64 && s_base[lo + s] <= pl) lo += s;
+      const int i = 64 * T + lo, q = pl - (int)s_base[lo];
+      const unsigned long long rm = W.rel_mask[i];
+      int j; i64 nvo;
+      if (q < __popcll(rm)) {
+        const int k = nth_set_bit(rm, q);
+        j = W.pot_list[(size_t)i * W.pot_cap + k] - 1;
+        nvo = base_nv + s_nvb[lo] + W.pot_nvpre[(size_t)i * W.pot_cap + k];
+      } else {                                        // the wall, after the floe's last candidate
+        j = WALL;
+        nvo = base_nv + s_nvb[lo] + (W.pair_nv[i] - (W.ext_nv[i] + 4));
+      }
+      p = base_p + pl;
+      if (p < W.cap_pairs) {
+        W.pair_i[p] = i; W.pair_j[p] = j; W.pair_nvoff[p] = nvo;
+        cls = pair_classify_ij(p, i, j, nvo, prev_n, P, W);
+      }
+    }
+    {   // ring vertices of the pairs the team pass will take (its algorithmic bytes: bench.py)
+      long long tv = 0;
+      if (cls == PC_LIVE || cls == PC_COLD || cls == PC_WIDE) tv = W.ext_nv[W.pair_i[p]] + W.ext_nv[W.pair_j[p]];
+      for (int d = 32; d > 0; d >>= 1) tv += __shfl_xor(tv, d);
+      if (lane == 0 && tv) atomicAdd(&W.counters[C_TEAMV], (unsigned long long)tv);
+    }
+    // the lists are appended to a wave at a time (k_pair_classify)
+    unsigned long long mine = 0, m_own = 0;
+#pragma unroll
+    for (int c = PC_LIVE; c <= PC_GENERAL; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (lane == c) mine = m;
+      if (cls == c) m_own = m;
+    }
+    unsigned long long base = 0;
+    if (lane >= PC_LIVE && lane <= PC_GENERAL && mine) {
+      const int ctr = lane == PC_LIVE ? C_LIVE : lane == PC_WIDE ? C_WIDE : lane == PC_COLD ? C_COLD : lane == PC_GENERAL ? (walls ? C_WALLS : C_RETRY) : C_TEAM;
+      base = atomicAdd(&W.counters[ctr], (unsigned long long)__popcll(mine));
+      if (lane == PC_GENERAL && !walls) atomicAdd(&W.counters[C_WALLS], (unsigned long long)__popcll(mine));
+    }
+    const int src = (cls >= PC_LIVE && cls <= PC_GENERAL) ? cls : 0;
+    base = __shfl(base, src);
+    if (cls >= PC_LIVE && cls <= PC_GENERAL)
+      (cls == PC_LIVE ? W.live_list : cls == PC_WIDE ? W.wide_list : cls == PC_COLD ? W.cold_list : cls == PC_GENERAL ? (walls ? W.wall_list : W.retry_list) : W.team_list)[base + __popcll(m_own & ((1ULL << lane) - 1ULL))] = (int)p;
+  }
+}
+
+// ---- kf_row_fill -----------------------------------------------------------------------------------------------------
+// One wave per tile of 64 entries: ScanRows from the tile counts (k_row_count has added them up), then k_row_fill.
+__global__ void __launch_bounds__(64) kf_row_fill(Floes F, Params P, Work W) {
+  if (!W.counters[C_GO]) return;
+  const int T = blockIdx.x, lane = threadIdx.x;
+  const int N = dev_next(W);
+  const int ntiles = (N + 63) >> 6;
+  if (T >= ntiles) return;
+  unsigned long long before = 0;
+  for (int u = lane; u < T; u += 64) before += W.row_agg[u];
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  const int i = 64 * T + lane;
+  const long long cnt = i < N ? W.row_cnt[i] : 0;
+  long long inc = cnt;
+  for (int d = 1; d < 64; d <<= 1) { const long long a = __shfl_up(inc, d); if (lane >= d) inc += a; }
+  if (i < N) W.row_off[i] = (i64)before + inc - cnt;
+  if (T == ntiles - 1 && lane == 63) { W.counters[C_NROWS] = before + (unsigned long long)inc; W.row_off[N] = (i64)before + inc; }
+  if (i < N) { row_fill(i, N, F, P, W); transfer_collect(i, F, W); }
+}

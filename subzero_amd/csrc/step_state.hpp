@@ -88,6 +88,13 @@ struct StepState {
   long long last_walls = 0;       // pairs on the wall list in the step before (sizes the launch)
   long long last_deferred = 0;    // pairs the step before handed to the general pass after its read-back, the wall pairs not counted
   int walls_early = 1;            // SUBZERO_WALLS_EARLY=0: the wall pairs wait for the general pass after the read-back
+  // the fused launch chain of the steady step (step_fused.hpp)
+  bool fused_on = true;           // SUBZERO_FUSED=0: the scan-based chain always
+  bool fused = false;             // this step's front ran fused (its back half then does too)
+  int cell_cap = 32;              // slots per grid cell (SUBZERO_CELL_CAP); doubles when a step finds a cell full
+  DevBuf gh_mask, gh_agg, pair_agg, row_agg, rel_mask, pot_nvpre, force_list;
+  long long steps_done = 0, steps_fused = 0, last_team_vertices = 0;   // szStepDiagnostics
+  bool no_hint = false, debug_lists = false;   // SUBZERO_NO_HINT, SUBZERO_DEBUG_LISTS (read once)
 };
 
 
