@@ -22,63 +22,10 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "context.hpp"
-#if defined(SZ_PHASE_PROFILE)
-// Diagnostic build only (make EXTRA=-DSZ_PHASE_PROFILE): wall-clock time of the parts of the contact model per
-// pair of the general kernels, summed and for the slowest pair; read with szDebugPhases.  Not in the product build.
-#include <hip/hip_runtime.h>
-struct SzPhaseState { unsigned long long last, t[20]; int cur, trim[4], ntrim; };
-__device__ unsigned long long sz_phase_acc[20];
-__device__ unsigned long long sz_phase_worst[28];
-__device__ SzPhaseState sz_phase_state[1 << 17];
-static __host__ __device__ inline void sz_phase_mark(int k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  SzPhaseState &s = sz_phase_state[(blockIdx.x * blockDim.x + threadIdx.x) & 0x1ffff];
-  const unsigned long long now = wall_clock64();
-  if (k == 8) { for (int i = 0; i < 20; ++i) s.t[i] = 0; s.ntrim = 0; }
-  else s.t[s.cur < 20 ? s.cur : 9] += now - s.last;
-  s.last = now; s.cur = k;
-  if (k == 0) {
-    unsigned long long tot = 0;
-    for (int i = 1; i < 20; ++i) { tot += s.t[i]; atomicAdd(&sz_phase_acc[i], s.t[i]); }
-    if (atomicMax(&sz_phase_worst[0], tot) < tot) {
-      for (int i = 1; i < 20; ++i) sz_phase_worst[i] = s.t[i];
-      for (int i = 0; i < 4; ++i) sz_phase_worst[20 + i] = i < s.ntrim ? (unsigned long long)s.trim[i] : 0ull;
-      sz_phase_worst[24] = (unsigned long long)s.ntrim;
-    }
-  }
-#endif
-}
-static __host__ __device__ inline void sz_trim_mark(int before, int after) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  SzPhaseState &s = sz_phase_state[(blockIdx.x * blockDim.x + threadIdx.x) & 0x1ffff];
-  if (s.ntrim < 4) { s.trim[s.ntrim] = before; s.trim[s.ntrim + 1] = after; } s.ntrim += 2;
-#endif
-}
-#define SZC_PHASE(k) sz_phase_mark(k)
-#define SZV_PHASE(k) sz_phase_mark(k)
-#define SZC_TRIM_PROBE(before, after) sz_trim_mark(before, after)
-#endif
 #include "step_core.hpp"
-#if defined(SZ_PHASE_PROFILE)
-extern "C" int szDebugPhases(unsigned long long *out26, int reset) {
-  unsigned long long z[28] = {0};
-  if (hipMemcpyFromSymbol(out26, HIP_SYMBOL(sz_phase_acc), sizeof(unsigned long long) * 20) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out26 + 20, HIP_SYMBOL(sz_phase_worst), sizeof(unsigned long long) * 28) != hipSuccess) return -1;
-  if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_acc), z, 160); (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_worst), z, 224); }
-  return 0;
-}
-#endif
-
 #include "step_state.hpp"
 
-#if defined(SZ_WAVE_CYCLES)
-// Diagnostic build only (make EXTRA=-DSZ_WAVE_CYCLES): wall-clock ticks (100 MHz) of every wave of the last fast-pass
-// launch, read with szDebugWaveCycles.  Not in the product build.
-__device__ unsigned long long sz_wave_cycles[1 << 17];
-extern "C" int szDebugWaveCycles(unsigned long long *out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_wave_cycles), sizeof(unsigned long long) * (size_t)(n < (1 << 17) ? n : (1 << 17))) == hipSuccess ? 0 : -1;
-}
-#endif
+#include "narrow_general.hpp"
 
 namespace {
 
@@ -454,7 +401,7 @@ __device__ inline bool go_by_rule(const unsigned long long *counters, const GoRu
   if (rule.mode == GO_IF_CLEAN)
     return !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
              counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) || counters[C_ERR_CELL] ||
-             2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap);
+             (rule.next_cap > 0 && (long long)counters[C_NEXT] > rule.next_cap) || 2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap);
   return counters[C_GO] != 0;
 }
 __global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go) {
@@ -468,96 +415,6 @@ __global__ void k_publish(unsigned long long *counters, unsigned long long *host
   else if (e == C_GO) counters[e] = go;
 }
 static_assert(C_COUNT <= 64, "k_publish is launched with one wave");
-// `lanes` of the 64 lanes of each wave carry a pair (the rest stay idle): with only ~4e4 pairs per step the
-// chip is short of waves, not of lanes; fewer pairs per wave means more waves in flight to overlap the
-// latency of the workspace accesses, and fewer divergent paths per wave.
-__global__ void __launch_bounds__(64) k_narrow(i64 first, i64 count, const int *list, int mult, int lanes, int lds_per_lane, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  void *fast = lds_per_lane ? (void *)(smem + (size_t)threadIdx.x * lds_per_lane) : nullptr;
-  if (t < count) narrow(list ? t : first + t, list, mult, F, P, W, fast, lds_per_lane);
-}
-// k_narrow with the sweep workspace of every lane in LDS (ds_ addressing): for deferred pairs of short rings (ties,
-// floes at the walls), whose general sweeps are chains of dependent accesses to a few KB of records
-__global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, int mult, int lanes, int lds_per_lane, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow_lds(t, list, mult, F, P, W, (void *)(smem + (size_t)threadIdx.x * lds_per_lane), lds_per_lane);
-}
-// k_narrow_lds with one pair per wave and ALL 64 lanes on it (step_core.hpp narrow_t, WAVE): the lanes run the pair's
-// serial parts alike and share the loops over vertices in front of every clip -- the conversion to fixed point and the
-// trimming, a quarter of a long pair's time when one lane does them.  Deferred lists at the 1x tier.
-__global__ void __launch_bounds__(64) k_narrow_wave(i64 count, const int *list, int lds_per_wave, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const i64 t = blockIdx.x;
-  if (t < count) narrow_wave(t, list, F, P, W, (void *)smem, lds_per_wave);
-}
-// The floes at the walls (k_pair_classify's list of their own): the general sweep of each against the domain box, one
-// pair per wave with the sweep workspace in LDS, launched beside the team pass on a stream of its own -- the box has
-// horizontal edges, so no fast path takes these pairs, and queued behind the team pass (as deferred pairs are) their
-// quarter of a millisecond came on top of the step.  The waves stride over the list: any grid size is correct.
-__global__ void __launch_bounds__(64) k_narrow_walls(int lds_per_wave, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (threadIdx.x != 0) return;
-  const i64 n = (i64)W.counters[C_WALLS];
-  for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_lds(t, W.wall_list, 1, F, P, W, (void *)smem, lds_per_wave);
-}
-// First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
-// state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
-// Pairs it does not cover are appended to the retry list and redone by k_narrow.
-#define CONVEX_STRIDE 616
-static_assert(CONVEX_STRIDE % 16 == 8 && CONVEX_STRIDE == sizeof(szx::FastBlock), "lane stride must be 8 x odd and hold a FastBlock");
-// (dev_count: the pair count where the host does not know it yet -- the speculative step launches for a capacity)
-#ifndef SZ_CONVEX_WAVES_ATTR
-#define SZ_CONVEX_WAVES_ATTR
-#endif
-__global__ void __launch_bounds__(64) SZ_CONVEX_WAVES_ATTR k_narrow_convex(i64 first, i64 count, const unsigned long long *dev_count, int lanes, Floes F, Params P, Work W, const int *order) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (dev_count && t >= (i64)*dev_count) return;
-#if defined(SZ_WAVE_CYCLES)
-  const unsigned long long t0 = wall_clock64();
-#endif
-  if (t < count) narrow_convex(order ? t : first + t, order, F, P, W, (szx::FastBlock *)(smem + (size_t)threadIdx.x * CONVEX_STRIDE));
-#if defined(SZ_WAVE_CYCLES)
-  if (threadIdx.x == 0 && blockIdx.x < (1u << 17)) sz_wave_cycles[blockIdx.x] = wall_clock64() - t0;
-#endif
-}
-
-// Second fast pass: the pairs the first one found too long for its 16-vertex blocks but not for 32-vertex ones (many-
-// sided and mildly evolved floes), a few lanes per wave (1128 B of LDS each).  What it does not cover joins the list of
-// the general kernel.
-#define CONVEX_BIG_STRIDE 1128
-static_assert(CONVEX_BIG_STRIDE % 16 == 8 && CONVEX_BIG_STRIDE == sizeof(szx::FastBlockBig), "lane stride must be 8 x odd and hold a FastBlockBig");
-__global__ void __launch_bounds__(64) k_narrow_convex_big(i64 count, const int *list, int lanes, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow_convex(t, list, F, P, W, (szx::FastBlockBig *)(smem + (size_t)threadIdx.x * CONVEX_BIG_STRIDE));
-}
-
-// Two-stage fast path: the sweep workspace of every lane (compact records, 2.3 KB) lives in LDS -- one
-// 64-lane workgroup per CU (64 x 2344 B = 146.5 KB of the 160 KB); the lane stride is 8 x odd bytes so that
-// the same field of neighbouring lanes falls into different banks.  k_narrow_a: first clip of every pair;
-// k_narrow_b: contact model of the pairs that overlap (compacted by one atomic append per pair).
-#define FAST_WS_STRIDE 2344
-static_assert(FAST_WS_STRIDE % 16 == 8, "lane stride must be 8 x odd");
-__global__ void __launch_bounds__(64) k_narrow_a(i64 first, i64 count, int lanes, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow_a(first + t, F, P, W, smem + (size_t)threadIdx.x * FAST_WS_STRIDE);
-}
-__global__ void __launch_bounds__(64) k_narrow_b(int lanes, Floes F, Params P, Work W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)threadIdx.x >= lanes) return;
-  const i64 count = (i64)W.counters[C_TOUCH];
-  i64 t = (i64)blockIdx.x * lanes + threadIdx.x;
-  if (t < count) narrow_b(t, F, P, W, smem + (size_t)threadIdx.x * FAST_WS_STRIDE);
-}
 __global__ void k_export_header(char *base, i64 ns, const unsigned long long *rows, i64 status, i64 rows_max) {
   seg_header(base, ns, status ? 0 : (i64)*rows, status, rows_max);
 }
@@ -821,14 +678,8 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   S->no_hint = getenv("SUBZERO_NO_HINT") != nullptr;
   S->debug_lists = getenv("SUBZERO_DEBUG_LISTS") != nullptr;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
-  SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_a, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
-  SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_narrow_b, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * FAST_WS_STRIDE));
-  (void)hipFuncSetAttribute((const void *)k_narrow_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void *)k_narrow_walls, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void *)k_narrow_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void *)k_narrow_convex_big, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CONVEX_BIG_STRIDE);
   if (const char *v = getenv("SUBZERO_BIG_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->big_lanes = l; }
-  if (S->narrow_lds) (void)hipFuncSetAttribute((const void *)k_narrow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  { const int rcg = sz_narrow_general_configure(ctx, S->narrow_lds != 0); if (rcg) return rcg; }
   (void)hipFuncSetAttribute((const void *)k_broad_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute((const void *)k_row_count, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   return SZ_OK;
@@ -927,7 +778,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
   const int n = S->n;
   const int cap = W.cap_ext;
   W.g_rows = nullptr;
-  W.cell_cap = 0;
+  W.cell_cap = 0; W.reg_rows = 0;
   S->fused = false;
 
   SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
@@ -979,7 +830,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
     if (speculative) break;   // no read-back here: the counts are checked with those of the narrow phase (step_narrow)
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
     if (c[C_NEED_MC]) {   // nothing of the floe array has been touched yet: the caller regenerates the points and steps again
@@ -1055,6 +906,8 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   W.pair_agg = (unsigned long long *)S->pair_agg.p; W.row_agg = (unsigned long long *)S->row_agg.p;
   W.rel_mask = (unsigned long long *)S->rel_mask.p; W.pot_nvpre = (int *)S->pot_nvpre.p; W.force_list = (int *)S->force_list.p;
   S->speculating = true; S->fused = true;
+  W.reg_rows = 1;
+  S->next_cap = S->stepped ? std::min<i64>(cap, (i64)S->last_next + (S->last_next - n) / 4 + 256) : (i64)cap;   // entries the back half's grid covers (GoRule)
   const i64 np = S->spec_np, nvt = S->spec_nvt;
   S->np = np; S->nvt = nvt; S->N = (int)S->c[C_NEXT]; S->retried = 0;
   S->classified = true;
@@ -1105,7 +958,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
         i64 room = ((i64)160 * 1024 / per_cu) & ~(i64)1023;
         if (room > S->retry_lds_max) room = S->retry_lds_max;
         if (room < S->retry_lds) room = S->retry_lds;
-        hipLaunchKernelGGL(k_narrow_walls, dim3((unsigned)wg), dim3(64), (size_t)room, st, (int)room, F, P, W);
+        szl_k_narrow_walls(dim3((unsigned)wg), (size_t)room, st, (int)room, F, P, W);
         SZ_HIP(ctx, hipGetLastError());
         SZ_HIP(ctx, hipEventRecord(S->ev[2], ts));
       }
@@ -1121,7 +974,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
       S->convex_skipped = queue_back && S->stepped && S->last_team == 0 && S->classified;
       if (!S->convex_skipped) {
         const int L = 16;
-        hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, ts, (i64)0, hi - lo,
+        szl_k_narrow_convex(grid_for(hi - lo, L), (size_t)L * CONVEX_STRIDE, ts, (i64)0, hi - lo,
                            (const unsigned long long *)&W.counters[C_TEAM], L, F, P, W, (const int *)W.team_list);
       }
       if (ts != st) {
@@ -1164,22 +1017,22 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
         SZ_HIP(ctx, hipEventRecord(S->ev[2], st));
       }
 #endif
-      hipLaunchKernelGGL(k_narrow_convex, grid_for(hi - lo, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo,
+      szl_k_narrow_convex(grid_for(hi - lo, L), (size_t)L * CONVEX_STRIDE, st, lo, hi - lo,
                          S->speculating ? (const unsigned long long *)&W.counters[C_NPAIRS] : (const unsigned long long *)nullptr, L, F, P, W, order);
     } else if (fast) {
       const int L = S->fast_lanes;
       const size_t lds = (size_t)L * FAST_WS_STRIDE;
-      hipLaunchKernelGGL(k_narrow_a, grid_for(hi - lo, L), dim3(64), lds, st, lo, hi - lo, L, F, P, W);
-      hipLaunchKernelGGL(k_narrow_b, grid_for(hi - lo, L), dim3(64), lds, st, L, F, P, W);
+      szl_k_narrow_a(grid_for(hi - lo, L), lds, st, lo, hi - lo, L, F, P, W);
+      szl_k_narrow_b(grid_for(hi - lo, L), lds, st, L, F, P, W);
     } else {
-      hipLaunchKernelGGL(k_narrow, grid_for(hi - lo, S->narrow_lanes), dim3(64), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
+      szl_k_narrow(grid_for(hi - lo, S->narrow_lanes), (size_t)S->narrow_lds * S->narrow_lanes, st, lo, hi - lo, (const int *)nullptr, 1, S->narrow_lanes, S->narrow_lds, F, P, W);
     }
     SZ_HIP(ctx, hipGetLastError());
   }
   if (!team_timed) SZ_HIP(ctx, hipEventRecord(S->ev[3], st));
   // the counters for the host -- and for the back half of the step, which runs only once the narrow phase is complete:
   // queued right behind this launch (queue_back) it goes ahead if nothing was deferred and everything fitted
-  const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows, S->convex_skipped ? 1 : 0} : GoRule{GO_SET, 0, 0, 0, 0};
+  const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows, S->convex_skipped ? 1 : 0, S->fused ? (long long)S->next_cap : 0LL} : GoRule{GO_SET, 0, 0, 0, 0, 0};
   S->go_rule = rule;
   S->publish_with_incoming = queue_back && S->spec_np > 0;      // (step_back_a's first kernel then does both)
   if (!S->publish_with_incoming) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0);
@@ -1212,10 +1065,10 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     if (c[C_TEAM] > 0) {    // pairs the team pass handed on after all: their pass now, then the counters again
       const i64 nt = (i64)c[C_TEAM];
       const int L = 16;
-      hipLaunchKernelGGL(k_narrow_convex, grid_for(nt, L), dim3(64), (size_t)L * CONVEX_STRIDE, st, (i64)0, nt,
+      szl_k_narrow_convex(grid_for(nt, L), (size_t)L * CONVEX_STRIDE, st, (i64)0, nt,
                          (const unsigned long long *)nullptr, L, F, P, W, (const int *)W.team_list);
       SZ_HIP(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
       SZ_HIP(ctx, hipGetLastError());
       SZ_HIP(ctx, hipStreamSynchronize(st));
     }
@@ -1225,14 +1078,14 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     const i64 nb = (i64)c[C_BIG];
     if (S->big_lanes > 0) {
       const int L = S->big_lanes;
-      hipLaunchKernelGGL(k_narrow_convex_big, grid_for(nb, L), dim3(64), (size_t)L * CONVEX_BIG_STRIDE, st, nb, (const int *)S->big_list.p, L, F, P, W);
+      szl_k_narrow_convex_big(grid_for(nb, L), (size_t)L * CONVEX_BIG_STRIDE, st, nb, (const int *)S->big_list.p, L, F, P, W);
     } else {   // (pass switched off: straight to the general kernel, through the same list mechanics)
       SZ_HIP(ctx, hipMemcpyAsync((int *)S->retry_list.p + c[C_RETRY], S->big_list.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
       S->bump = c[C_RETRY] + (unsigned long long)nb;
       SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->bump, 8, hipMemcpyHostToDevice, st));
     }
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -1265,13 +1118,13 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     }
     static const bool wave_off = getenv("SUBZERO_WAVE_GENERAL") != nullptr && atoi(getenv("SUBZERO_WAVE_GENERAL")) == 0;
     if (retry_lds > 0 && RL == 1 && mult == 1 && !wave_off)
-      hipLaunchKernelGGL(k_narrow_wave, dim3((unsigned)nl), dim3(64), (size_t)retry_lds, st, nl, (const int *)S->retry_copy.p, retry_lds, F, P, W);
+      szl_k_narrow_wave(dim3((unsigned)nl), (size_t)retry_lds, st, nl, (const int *)S->retry_copy.p, retry_lds, F, P, W);
     else if (retry_lds > 0)
-      hipLaunchKernelGGL(k_narrow_lds, grid_for(nl, RL), dim3(64), (size_t)retry_lds * RL, st, nl, (const int *)S->retry_copy.p, mult, RL, retry_lds, F, P, W);
+      szl_k_narrow_lds(grid_for(nl, RL), (size_t)retry_lds * RL, st, nl, (const int *)S->retry_copy.p, mult, RL, retry_lds, F, P, W);
     else
-      hipLaunchKernelGGL(k_narrow, grid_for(nl, RL), dim3(64), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
+      szl_k_narrow(grid_for(nl, RL), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -1316,15 +1169,6 @@ static int step_back_a(szContext *ctx, StepState *S) {
   const i64 np = S->back_queued ? S->spec_np : S->np;     // (queued behind the narrow phase: a capacity, the device knows the count)
   const int n = S->n, cap = W.cap_ext;
   int rc;
-  if (S->publish_with_incoming) {
-    S->publish_with_incoming = false;
-    hipLaunchKernelGGL(k_incoming_go, grid_for(np > 0 ? np : 1, 256), dim3(256), 0, st, np, W, S->c_dev, S->go_rule);
-  } else if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
-  {
-    int lanes; size_t lds; int *spill = nullptr;
-    if ((rc = filter_launch_shape(ctx, S, (i64)cap + 64, lanes, lds, spill))) return rc;
-    hipLaunchKernelGGL(k_row_count, grid_for(cap, lanes), dim3(64), lds, st, lanes, W, spill, S->fused ? 1 : 0);
-  }
   // No host round trip here: every contact row of a pair appears at most twice in the CSR (once for each floe
   // of the pair), so the pair rows counted by the narrow phase bound it; the exact count and the overflow flag
   // of the mirror lists are read with the counters at the end of the step.
@@ -1332,11 +1176,24 @@ static int step_back_a(szContext *ctx, StepState *S) {
   if ((rc = sz_reserve(ctx, S->rows, 56 * (size_t)nr_cap))) return rc;
   W.rows = (double *)S->rows.p; W.cap_rows = nr_cap;
   if (S->fused) {
-    hipLaunchKernelGGL(kf_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
+    // the pairs have registered their rows as they completed (pair_register): one launch places and writes them
+    const int publish = S->publish_with_incoming ? 1 : 0;
+    S->publish_with_incoming = false;
+    const i64 entries = S->back_queued ? S->next_cap : (i64)S->N;
+    hipLaunchKernelGGL(kf_rows, grid_for(entries > 0 ? entries : 1, 64), dim3(1024), 0, st, publish, S->c_dev, S->go_rule, F, P, W);
     SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
     hipLaunchKernelGGL(kf_integrate, grid_for(n > cap ? n : cap, 64), dim3(64), 0, st, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
     return SZ_OK;
+  }
+  if (S->publish_with_incoming) {
+    S->publish_with_incoming = false;
+    hipLaunchKernelGGL(k_incoming_go, grid_for(np > 0 ? np : 1, 256), dim3(256), 0, st, np, W, S->c_dev, S->go_rule);
+  } else if (np > 0) hipLaunchKernelGGL(k_incoming, grid_for(np, 256), dim3(256), 0, st, np, W);
+  {
+    int lanes; size_t lds; int *spill = nullptr;
+    if ((rc = filter_launch_shape(ctx, S, (i64)cap + 64, lanes, lds, spill))) return rc;
+    hipLaunchKernelGGL(k_row_count, grid_for(cap, lanes), dim3(64), lds, st, lanes, W, spill, 0);
   }
   launch_scan(st, S->scan_agg, cap, ScanRows{W});
   hipLaunchKernelGGL(k_row_fill, grid_for(cap, 64), dim3(64), 0, st, F, P, W);
@@ -1354,7 +1211,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   if (!S->fused || P.doInt) hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0}, S->back_queued ? 1 : 0);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, S->back_queued ? 1 : 0);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (S->back_queued) {
@@ -1431,7 +1288,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
         return rc;
       }
       ++S->back_misses;
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0, 0}, 0);   // from here on the host decides
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0, 0, 0}, 0);   // from here on the host decides
       SZ_HIP(ctx, hipGetLastError());
     }
     SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -186,6 +186,7 @@ struct Work {
   unsigned long long *row_agg;           // [tiles of entries] contact rows of a tile's entries
   unsigned long long *rel_mask;          // [cap_ext] bit k: candidate k of the entry is a pair this rank evaluates (pair_relevant)
   int *pot_nvpre;                        // [cap_ext * pot_cap] ring vertices of the entry's pairs before candidate k
+  int reg_rows;                          // 1: a pair registers its rows with both floes the moment it completes (pair_register) -- no k_incoming / k_row_count
   int *force_list;                       // [n] floes whose forcing is due though the step does not refresh it for all (C_FORCE of them)
 };
 
@@ -606,6 +607,21 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
 }
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
+// (fused chain) The pair p = (i, j) has completed with nrows contact rows: both floes' row counts (per entry and per tile
+// of 64 entries: kf_rows places the rows from them) and p on j's mirror list (:187-214, incoming) -- by the lane that
+// stores the pair's result, whichever kernel that is.
+SZ_HD void pair_register(i64 p, int i, int j, int nrows, Work &W) {
+  if (!W.reg_rows || nrows <= 0) return;
+  (void)atomic_add(&W.row_cnt[i], nrows);
+  atomic_add_noret(&W.row_agg[i >> 6], (unsigned long long)nrows);
+  if (j < 0) return;                                   // the wall: no partner floe
+  const int k = atomic_add(&W.inc_cnt[j], 1);
+  if (k >= W.pot_cap) { atomic_add(&W.counters[C_ERR_INC], 1ULL); return; }
+  W.inc_list[(size_t)j * W.pot_cap + k] = (int)p;
+  (void)atomic_add(&W.row_cnt[j], nrows);
+  atomic_add_noret(&W.row_agg[j >> 6], (unsigned long long)nrows);
+}
+
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
 // (WAVE: all 64 lanes of the wave are here with the same arguments -- k_narrow_wave, mult 1 -- and run the pair alike:
 // same reads, same plain stores; one lane speaks for the wave where a counter or a list is touched, and the loops that
@@ -722,7 +738,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
-  if ((flag & 4) && speaker) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+  if ((flag & 4) && speaker) { atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows); pair_register(p, i, j, out.nrows, W); }
 }
 // the general sweep for every clip of the pair
 SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
@@ -881,6 +897,7 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
     rows[0] = row[0]; rows[1] = row[1]; rows[2] = row[2]; rows[3] = row[3]; rows[4] = row[4];
     W.pair_nrows[p] = out.nrows;
     atomic_add_noret(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+    pair_register(p, i, j, out.nrows, W);
   }
   if (flag) W.pair_flag[p] = flag;
 }
@@ -972,7 +989,7 @@ SZ_HD void narrow_b(i64 t, const Floes &F, const Params &P, Work &W, void *fast_
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
-  if (flag & 4) atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
+  if (flag & 4) { atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows); pair_register(p, W.pair_i[p], W.pair_j[p], out.nrows, W); }
 }
 
 // contact rows of pair p: in the pair's scratch slice, or in the gathered exchange buffer (sharded step)
@@ -1009,6 +1026,41 @@ SZ_HD void row_count(int i, Work &W, int *tmp) { // i < N
   }
   for (int a = 0; a < ninc; ++a) { inc[a] = tmp[a]; cnt += W.pair_nrows[tmp[a]]; }
   W.row_cnt[i] = cnt;
+}
+
+// floe centre outside the box (:152-155): the floe is dead from here on
+SZ_HD void centre_check(int i, double x, double y, const Floes &F, const Params &P, Work &W) {
+  const int N0 = F.n;
+  if (!P.PERIODIC && i >= F.nb && i < N0 && is_present(i, W) && is_owned(i, W)) {
+    const double *c = P.c2_boundary;
+    // inpolygon of one point against the 5-point closed box, inpolygon.m:150-224
+    double mnx = c[0], mxx = c[0], mny = c[1], mxy = c[1];
+    for (int k = 1; k < 5; ++k) { mnx = szc::mind(mnx, c[2 * k]); mxx = szc::maxd(mxx, c[2 * k]); mny = szc::mind(mny, c[2 * k + 1]); mxy = szc::maxd(mxy, c[2 * k + 1]); }
+    bool in = false;
+    if (x >= mnx && x <= mxx && y >= mny && y <= mxy) {
+      double sumdq = 0; bool on = false;
+      for (int m = 0; m < 4; ++m) {
+        double xa = c[2 * m], ya = c[2 * m + 1], xb = c[2 * m + 2], yb = c[2 * m + 3];
+        double avx = absd(0.5 * (xa + xb)), avy = absd(0.5 * (ya + yb));
+        double sf = szc::maxd(avx, avy); sf = szc::maxd(sf, avx * avy);
+        double ax = xa - x, ay = ya - y, bx = xb - x, by = yb - y;
+        int qa, qb;
+        { bool px = ax > 0, py = ay > 0; qa = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+        { bool px = bx > 0, py = by > 0; qb = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
+        double cp = ax * by - bx * ay;
+        double scp = (cp > 0) ? 1 : (cp < 0 ? -1 : 0);
+        if (absd(cp) < sf * SZC_EPS * 3) scp = 0;
+        double dp = ax * bx + ay * by;
+        double dq = qb - qa;
+        if (absd(dq) == 3) dq = -dq / 3;
+        if (absd(dq) == 2) dq = 2 * scp;
+        sumdq += dq;
+        if (scp == 0 && dp <= 0) on = true;
+      }
+      in = (sumdq != 0) || on;
+    }
+    if (!in) F.alive[i] = 0;
+  }
 }
 
 // rows of extended floe i in the reference's order, torques and sums; kill/transfer marks of its pairs
@@ -1069,37 +1121,7 @@ SZ_HD void row_fill(int i, int N, const Floes &F, const Params &P, Work &W) {
   }
   W.ov_ext[i] = ov;
   W.cf_ext[2 * i] = sfx; W.cf_ext[2 * i + 1] = sfy; W.ct_ext[i] = stq;
-  // floe centre outside the box (:152-155)
-  if (!P.PERIODIC && i >= F.nb && i < N0 && is_present(i, W) && is_owned(i, W)) {
-    const double *c = P.c2_boundary;
-    // inpolygon of one point against the 5-point closed box, inpolygon.m:150-224
-    double mnx = c[0], mxx = c[0], mny = c[1], mxy = c[1];
-    for (int k = 1; k < 5; ++k) { mnx = szc::mind(mnx, c[2 * k]); mxx = szc::maxd(mxx, c[2 * k]); mny = szc::mind(mny, c[2 * k + 1]); mxy = szc::maxd(mxy, c[2 * k + 1]); }
-    bool in = false;
-    if (x >= mnx && x <= mxx && y >= mny && y <= mxy) {
-      double sumdq = 0; bool on = false;
-      for (int m = 0; m < 4; ++m) {
-        double xa = c[2 * m], ya = c[2 * m + 1], xb = c[2 * m + 2], yb = c[2 * m + 3];
-        double avx = absd(0.5 * (xa + xb)), avy = absd(0.5 * (ya + yb));
-        double sf = szc::maxd(avx, avy); sf = szc::maxd(sf, avx * avy);
-        double ax = xa - x, ay = ya - y, bx = xb - x, by = yb - y;
-        int qa, qb;
-        { bool px = ax > 0, py = ay > 0; qa = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
-        { bool px = bx > 0, py = by > 0; qb = (!px && py) ? 1 : (!px && !py) ? 2 : (px && !py) ? 3 : 0; }
-        double cp = ax * by - bx * ay;
-        double scp = (cp > 0) ? 1 : (cp < 0 ? -1 : 0);
-        if (absd(cp) < sf * SZC_EPS * 3) scp = 0;
-        double dp = ax * bx + ay * by;
-        double dq = qb - qa;
-        if (absd(dq) == 3) dq = -dq / 3;
-        if (absd(dq) == 2) dq = 2 * scp;
-        sumdq += dq;
-        if (scp == 0 && dp <= 0) on = true;
-      }
-      in = (sumdq != 0) || on;
-    }
-    if (!in) F.alive[i] = 0;
-  }
+  centre_check(i, x, y, F, P, W);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -373,6 +373,152 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
   }
 }
 
+// ---- kf_rows ---------------------------------------------------------------------------------------------------------
+// The contact rows of the step in one launch: k_incoming + k_row_count + ScanRows + k_row_fill.  The pairs have
+// registered their rows with both floes as they completed (pair_register: counts per entry and per tile, mirror
+// lists), so a tile of 64 entries knows where its rows start from the tile sums before it.  16 lanes per entry: lane l
+// takes the entry's l-th ITEM -- its own pairs in list order, then the pairs that name it as partner in ascending order
+// of their source floe (:187) -- loads the pair's words and rows side by side with the other lanes, and the sums of
+// :221-263 are then formed in item order from registers (shuffles), the same additions in the same order as the
+// one-thread loop of row_fill.  More than 16 items or more than two rows in a pair: one lane runs row_fill itself.
+// publish: the workgroups work the go rule out for themselves and the first one publishes the counters (k_incoming_go).
+__global__ void __launch_bounds__(1024) kf_rows(int publish, unsigned long long *host_copy, GoRule rule, Floes F, Params P, Work W) {
+  __shared__ unsigned long long red[16];
+  __shared__ long long s_off[64];
+  const bool go = publish ? go_by_rule(W.counters, rule) : (W.counters[C_GO] != 0);
+  const int T = blockIdx.x, t = threadIdx.x;
+  if (publish && T == 0 && t < (int)C_COUNT) {
+    host_copy[t] = (t == C_GO) ? (go ? 1ULL : 0ULL) : W.counters[t];
+    if (t == C_GO) W.counters[C_GO] = go ? 1ULL : 0ULL;
+  }
+  if (!go) return;
+  const int N = dev_next(W);
+  const int ntiles = (N + 63) >> 6;
+  if (T >= ntiles) return;
+  unsigned long long before = 0;
+  for (int u = t; u < T; u += 1024) before += W.row_agg[u];
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  if ((t & 63) == 0) red[t >> 6] = before;
+  __syncthreads();
+  before = 0;
+  for (int q = 0; q < 16; ++q) before += red[q];
+  if (t < 64) {
+    const int e = 64 * T + t;
+    const long long cnt = e < N ? W.row_cnt[e] : 0;
+    long long inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) { const long long a = __shfl_up(inc, d); if (t >= d) inc += a; }
+    s_off[t] = (long long)before + inc - cnt;
+    if (e < N) W.row_off[e] = (i64)before + inc - cnt;
+    if (T == ntiles - 1 && t == 63) { W.counters[C_NROWS] = before + (unsigned long long)inc; W.row_off[N] = (i64)before + inc; }
+  }
+  __syncthreads();
+  const int e = 64 * T + (t >> 4), l = t & 15;
+  if (e >= N) return;
+  const int N0 = F.n;
+  const int K = W.pair_cnt[e];
+  const i64 pb = W.pair_base[e];
+  int ninc = W.inc_cnt[e]; if (ninc > W.pot_cap) ninc = W.pot_cap;
+  const int items = K + ninc;
+  const double x = W.ext_x[e], y = W.ext_y[e];
+  const unsigned gsh = (threadIdx.x & 63) & ~15u;            // this group's lanes within the wave's ballots
+  // lane l: item l as it lies in memory (own pairs in order, mirrored pairs unsorted)
+  i64 p = -1; int j = 0, fl = 0, nr = 0, src = 0x7fffffff; i64 ro = 0;
+  const bool own = l < K, mir = l >= K && l < items;
+  if (items <= 16) {
+    if (own) { p = pb + l; j = W.pair_j[p]; fl = W.pair_flag[p]; nr = (fl & 4) ? W.pair_nrows[p] : 0; ro = W.pair_rowoff[p]; }
+    else if (mir) { p = W.inc_list[(size_t)e * W.pot_cap + (l - K)]; src = W.pair_i[p]; nr = W.pair_nrows[p]; ro = W.pair_rowoff[p]; fl = 4; }
+  }
+  const bool serial = items > 16 || ((__ballot(nr > 2) >> gsh) & 0xffffULL) != 0;
+  if (serial) {
+    if (l == 0) {
+      int *inc = W.inc_list + (size_t)e * W.pot_cap;          // ascending source floe, in place (row_count's insertion sort)
+      for (int a = 1; a < ninc; ++a) {
+        const int v = inc[a], sv = W.pair_i[v]; int b = a;
+        while (b > 0 && W.pair_i[inc[b - 1]] > sv) { inc[b] = inc[b - 1]; --b; }
+        inc[b] = v;
+      }
+      row_fill(e, N, F, P, W);
+      transfer_collect(e, F, W);
+    }
+    return;
+  }
+  // position of the item in the reference's row order: own pairs keep theirs, mirrored ones are ranked by source floe
+  int pos = l;
+  if (mir) {
+    int rank = 0;
+    for (int b = 0; b < 16; ++b) { const int sb = __shfl(src, b, 16); if (b >= K && b < items && sb < src) ++rank; }
+    pos = K + rank;
+  }
+  int inv = 0;                                               // the lane that holds the item of position l
+  for (int b = 0; b < 16; ++b) { const int pq = __shfl(pos, b, 16); if (pq == l) inv = b; }
+  // ... brought to lane l: from here on lane order is row order
+  {
+    const int p_lo = __shfl((int)(p & 0xffffffffLL), inv, 16), p_hi = __shfl((int)(p >> 32), inv, 16);
+    p = ((i64)p_hi << 32) | (unsigned)p_lo;
+    const int r_lo = __shfl((int)(ro & 0xffffffffLL), inv, 16), r_hi = __shfl((int)(ro >> 32), inv, 16);
+    ro = ((i64)r_hi << 32) | (unsigned)r_lo;
+    j = __shfl(j, inv, 16); fl = __shfl(fl, inv, 16); nr = __shfl(nr, inv, 16); src = __shfl(src, inv, 16);
+  }
+  const bool have = l < items;
+  if (!have) nr = 0;
+  // the rows of my item: up to two, read side by side
+  double fx0 = 0, fy0 = 0, px0 = 0, py0 = 0, o0 = 0, fx1 = 0, fy1 = 0, px1 = 0, py1 = 0, o1 = 0;
+  if (nr > 0) {
+    const double *pr = (const double *)W.scratch + ro;
+    fx0 = pr[0]; fy0 = pr[1]; px0 = pr[2]; py0 = pr[3]; o0 = pr[4];
+    if (nr > 1) { fx1 = pr[5]; fy1 = pr[6]; px1 = pr[7]; py1 = pr[8]; o1 = pr[9]; }
+  }
+  double w0;
+  if (own) {
+    if (j == WALL) {
+      if (absd(py0) == P.Ly) fx0 = 0;                          // :160-162
+      if (absd(px0) == P.Lx) fy0 = 0;                          // :163-165
+      if (absd(py1) == P.Ly) fx1 = 0;
+      if (absd(px1) == P.Lx) fy1 = 0;
+      w0 = SZC_INF;
+    } else w0 = (double)(j + 1);
+  } else { fx0 = -fx0; fy0 = -fy0; fx1 = -fx1; fy1 = -fy1; w0 = (double)(src + 1); }
+  const double tq0 = (px0 - x) * fy0 - (py0 - y) * fx0, tq1 = (px1 - x) * fy1 - (py1 - y) * fx1;
+  int rb = nr;                                               // rows before my item (exclusive scan over the lanes)
+  for (int d = 1; d < 16; d <<= 1) { const int v = __shfl_up(rb, d, 16); if (l >= d) rb += v; }
+  rb -= nr;
+  {
+    const i64 r = s_off[t >> 4] + rb;
+    if (nr > 0 && r < W.cap_rows) { double *w = W.rows + 7 * r; w[0] = w0; w[1] = fx0; w[2] = fy0; w[3] = px0; w[4] = py0; w[5] = tq0; w[6] = o0; }
+    if (nr > 1 && r + 1 < W.cap_rows) { double *w = W.rows + 7 * (r + 1); w[0] = w0; w[1] = fx1; w[2] = fy1; w[3] = px1; w[4] = py1; w[5] = tq1; w[6] = o1; }
+  }
+  // the sums, item by item (:221-239, :251-263; OverlapArea :137,:168,:199)
+  double so = 0;
+  if (own && nr > 0) { so += o0; if (nr > 1) so += o1; }
+  double sfx = 0, sfy = 0, stq = 0, ov = 0;
+  for (int a = 0; a < 16; ++a) {
+    if (a >= items) break;                                   // (uniform over the group)
+    const int na = __shfl(nr, a, 16);
+    const double ax0 = __shfl(fx0, a, 16), ay0 = __shfl(fy0, a, 16), at0 = __shfl(tq0, a, 16);
+    const double ax1 = __shfl(fx1, a, 16), ay1 = __shfl(fy1, a, 16), at1 = __shfl(tq1, a, 16);
+    const double aso = __shfl(so, a, 16), ao0 = __shfl(o0, a, 16), ao1 = __shfl(o1, a, 16);
+    if (na > 0) { sfx += ax0; sfy += ay0; stq += at0; }
+    if (na > 1) { sfx += ax1; sfy += ay1; stq += at1; }
+    if (a < K) { if (na > 0) ov = aso + ov; }
+    else { if (na > 0) ov = ov + ao0; if (na > 1) ov = ov + ao1; }
+  }
+  // kill / transfer marks of the own pairs, the last one in list order that sets each (:138-145)
+  const bool mark = own && !(fl & 4) && (fl & 3) && j != WALL && e + 1 > F.nb;
+  const bool markA = mark && e + 1 <= N0 && (fl & 1), markB = mark && !markA && j + 1 <= N0;
+  const unsigned mk = (unsigned)((__ballot(markA || markB) >> gsh) & 0xffffULL), mt = (unsigned)((__ballot(markA) >> gsh) & 0xffffULL);
+  int kill = 0;
+  if (mk) { const int la = 31 - __clz(mk); const int jj = __shfl(j, la, 16), isA = __shfl((int)markA, la, 16); kill = isA ? e + 1 : jj + 1; }
+  int transfer_to = 0;
+  if (mt) { const int la = 31 - __clz(mt); transfer_to = __shfl(j, la, 16) + 1; }
+  if (l == 0) {
+    W.ov_ext[e] = ov; W.cf_ext[2 * e] = sfx; W.cf_ext[2 * e + 1] = sfy; W.ct_ext[e] = stq;
+    if (mk) F.kill[e] = kill;
+    if (mt) F.transfer[e] = transfer_to;
+    centre_check(e, x, y, F, P, W);
+    if (iabs(kill - (e + 1)) > 0 && kill > 0) atomic_max(&W.tmax[kill - 1], e + 1);     // transfer_collect
+  }
+}
+
 // ---- kf_row_fill -----------------------------------------------------------------------------------------------------
 // One wave per tile of 64 entries: ScanRows from the tile counts (k_row_count has added them up), then k_row_fill.
 __global__ void __launch_bounds__(64) kf_row_fill(Floes F, Params P, Work W) {

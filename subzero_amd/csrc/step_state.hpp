@@ -9,7 +9,7 @@
 using namespace szs;
 
 // what the back half of the step -- contact rows, calc_trajectory -- is to do (step.hip k_publish)
-struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; int team_pending; };   // team_pending: pairs on team_list have not had their pass   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
+struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; int team_pending; long long next_cap; };   // next_cap > 0: entries of the extended list the queued back half covers   // team_pending: pairs on team_list have not had their pass   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
 enum { GO_LEAVE = 0, GO_SET = 1, GO_IF_CLEAN = 2 };
 
 struct StepState {
@@ -82,7 +82,8 @@ struct StepState {
   // the floes at the walls are swept on a stream of their own beside the team pass (step.hip step_narrow_first)
   hipEvent_t wall_fork = nullptr, wall_join = nullptr;
   long long last_team = 0;        // pairs the team pass handed on to the lane-per-pair fast pass in the step before
-  GoRule go_rule = {0, 0, 0, 0, 0};
+  GoRule go_rule = {0, 0, 0, 0, 0, 0};
+  i64 next_cap = 0;               // fused chain: entries of the extended list the queued back half's launches cover
   bool publish_with_incoming = false;   // the counters after the narrow phase are published by the back half's first kernel (k_incoming_go)
   bool convex_skipped = false;    // ... whose launch this step left out (step_narrow_first)
   long long last_walls = 0;       // pairs on the wall list in the step before (sizes the launch)
