@@ -15,7 +15,7 @@ def short(name):
 
 def main():
     d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    f = glob.glob(os.path.join(d, "*", "*kernel_trace.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*kernel_trace.csv")), key=os.path.getmtime)
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(f))]
     rows.sort()
     hot = [k for k, r in enumerate(rows) if r[2] == HOT]

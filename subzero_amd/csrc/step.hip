@@ -35,7 +35,7 @@ namespace {
 __device__ inline int dev_next(const Work &W) { return (int)W.counters[C_NEXT]; }
 
 __global__ void k_counters_clear(Floes F, Work W) {
-  int e = threadIdx.x;
+  const int e = threadIdx.x * C_STRIDE;
   if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
 }
 __global__ void k_ext_clear(Floes F, Params P, Work W) {   // (and the cells of the broad-phase grid: one launch fewer)
@@ -396,25 +396,32 @@ __global__ void k_pair_expand(Floes F, Params P, Work W, unsigned long long scra
 // behind the narrow phase without a host round trip runs only if the narrow phase left nothing for the host to do;
 // its kernels return at once otherwise, and so does the reset of the counters.)
 // what k_publish will make of C_GO, for a kernel that runs in its place (k_incoming_go): no side effect
-__device__ inline bool go_by_rule(const unsigned long long *counters, const GoRule &rule) {
+// (pair_rows: the step's pair rows -- C_PAIRROWS, plus the 64 parts the fused chain keeps them in: pair_rows_total)
+__device__ inline unsigned long long pair_rows_total(const unsigned long long *counters, const unsigned long long *parts) {   // by a whole wave
+  unsigned long long v = parts ? parts[(size_t)AGG_STRIDE * (threadIdx.x & 63)] : 0ULL;
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v + counters[C_PAIRROWS];
+}
+__device__ inline bool go_by_rule(const unsigned long long *counters, const GoRule &rule, unsigned long long pair_rows) {
   if (rule.mode == GO_SET) return true;
   if (rule.mode == GO_IF_CLEAN)
     return !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
              counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) || counters[C_ERR_CELL] ||
-             (rule.next_cap > 0 && (long long)counters[C_NEXT] > rule.next_cap) || 2 * (long long)counters[C_PAIRROWS] + 1 > rule.rows_cap);
+             (rule.next_cap > 0 && (long long)counters[C_NEXT] > rule.next_cap) || 2 * (long long)pair_rows + 1 > rule.rows_cap);
   return counters[C_GO] != 0;
 }
-__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go) {
-  const unsigned e = threadIdx.x;
+__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go, const unsigned long long *parts) {
+  const unsigned long long prows = pair_rows_total(counters, parts);
+  const unsigned e = threadIdx.x * C_STRIDE;
   if (e >= (unsigned)C_COUNT) return;
-  const unsigned long long go = go_by_rule(counters, rule) ? 1ULL : 0ULL;
-  const unsigned long long v = (e == C_GO) ? go : counters[e];
+  const unsigned long long go = go_by_rule(counters, rule, prows) ? 1ULL : 0ULL;
+  const unsigned long long v = (e == C_GO) ? go : (e == C_PAIRROWS) ? prows : counters[e];
   host_copy[e] = v;
   const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
   if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
   else if (e == C_GO) counters[e] = go;
 }
-static_assert(C_COUNT <= 64, "k_publish is launched with one wave");
+static_assert(C_SLOTS <= 64, "k_publish is launched with one wave");
 __global__ void k_export_header(char *base, i64 ns, const unsigned long long *rows, i64 status, i64 rows_max) {
   seg_header(base, ns, status ? 0 : (i64)*rows, status, rows_max);
 }
@@ -430,11 +437,11 @@ __global__ void k_import(i64 np, int world, i64 seg_max, i64 rows_max, char *rec
 // back half is queued behind its narrow phase: every workgroup works the rule out for itself from the counters -- which
 // nothing changes meanwhile but the first workgroup's C_GO, and that one they do not read -- and the first one publishes
 __global__ void __launch_bounds__(256) k_incoming_go(i64 np, Work W, unsigned long long *host_copy, GoRule rule) {
-  const bool go = go_by_rule(W.counters, rule);
+  const bool go = go_by_rule(W.counters, rule, W.counters[C_PAIRROWS]);
   const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (go && p < np && p < (i64)W.counters[C_NPAIRS]) incoming(p, W);
-  if (blockIdx.x == 0 && threadIdx.x < (unsigned)C_COUNT) {
-    const unsigned e = threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)C_SLOTS) {
+    const unsigned e = threadIdx.x * C_STRIDE;
     host_copy[e] = (e == C_GO) ? (go ? 1ULL : 0ULL) : W.counters[e];
     if (e == C_GO) W.counters[C_GO] = go ? 1ULL : 0ULL;
   }
@@ -830,7 +837,7 @@ static int step_front(szContext *ctx, StepState *S, const szStepParams *hp, bool
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
     if (speculative) break;   // no read-back here: the counts are checked with those of the narrow phase (step_narrow)
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
     if (c[C_NEED_MC]) {   // nothing of the floe array has been touched yet: the caller regenerates the points and steps again
@@ -896,14 +903,15 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   grid_levels(S->rmax_max, S->rmax_p90, P.Lx, P.Ly, W);
   const size_t nc = (size_t)W.lvl_base[W.n_levels] + 1;
   const int ntiles = (n + 63) / 64, ntiles_ext = (cap + 63) / 64;
-  if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4)) || (rc = sz_reserve(ctx, S->cell_item, nc * (size_t)S->cell_cap * sizeof(CellItem))) ||
+  if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4 * CELL_STRIDE)) || (rc = sz_reserve(ctx, S->cell_item, nc * (size_t)S->cell_cap * sizeof(CellItem))) ||
       (rc = sz_reserve(ctx, S->gh_mask, 16 * (size_t)ntiles)) || (rc = sz_reserve(ctx, S->gh_agg, 8 * (size_t)ntiles)) ||
-      (rc = sz_reserve(ctx, S->pair_agg, 8 * (size_t)ntiles_ext)) || (rc = sz_reserve(ctx, S->row_agg, 8 * (size_t)ntiles_ext)) ||
+      (rc = sz_reserve(ctx, S->pair_agg, 8 * 4 * (size_t)ntiles_ext)) || (rc = sz_reserve(ctx, S->row_agg, 8 * (size_t)AGG_STRIDE * (ntiles_ext + 64))) ||
       (rc = sz_reserve(ctx, S->rel_mask, 8 * (size_t)cap)) || (rc = sz_reserve(ctx, S->pot_nvpre, 4 * (size_t)cap * S->pot_cap)) ||
       (rc = sz_reserve(ctx, S->force_list, 4 * (size_t)n))) return rc;
   W.cell_item = (CellItem *)S->cell_item.p; W.cell_cnt = (int *)S->cell_cnt.p; W.cell_cap = S->cell_cap;
   W.gh_mask = (unsigned long long *)S->gh_mask.p; W.gh_agg = (unsigned long long *)S->gh_agg.p;
   W.pair_agg = (unsigned long long *)S->pair_agg.p; W.row_agg = (unsigned long long *)S->row_agg.p;
+  W.prow_part = W.row_agg + (size_t)AGG_STRIDE * ntiles_ext;     // (64 more lines of the same buffer)
   W.rel_mask = (unsigned long long *)S->rel_mask.p; W.pot_nvpre = (int *)S->pot_nvpre.p; W.force_list = (int *)S->force_list.p;
   S->speculating = true; S->fused = true;
   W.reg_rows = 1;
@@ -915,7 +923,7 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   if ((rc = bind_pairs(ctx, S, np, nvt, main_bytes))) return rc;
   hipLaunchKernelGGL(kf_front_a, grid_for(cap, 256), dim3(256), 0, st, (int)nc - 1, ntiles_ext, F, P, W);
   hipLaunchKernelGGL(kf_front_b, dim3((unsigned)ntiles), dim3(1024), 0, st, ntiles, F, P, W);
-  hipLaunchKernelGGL(kf_broad, dim3((unsigned)n), dim3(64), 0, st, F, P, W);
+  hipLaunchKernelGGL(kf_broad, grid_for(S->next_cap, 16), dim3(1024), 0, st, F, P, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
   hipLaunchKernelGGL(kf_pairs, dim3((unsigned)ntiles_ext), dim3(512), 0, st, (S->stepped && !S->no_hint) ? S->last_next : 0, (unsigned long long)main_bytes, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
@@ -1035,7 +1043,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
   const GoRule rule = queue_back ? GoRule{GO_IF_CLEAN, (long long)S->spec_np, (long long)S->spec_nvt, (long long)S->spec_rows, S->convex_skipped ? 1 : 0, S->fused ? (long long)S->next_cap : 0LL} : GoRule{GO_SET, 0, 0, 0, 0, 0};
   S->go_rule = rule;
   S->publish_with_incoming = queue_back && S->spec_np > 0;      // (step_back_a's first kernel then does both)
-  if (!S->publish_with_incoming) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0);
+  if (!S->publish_with_incoming) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, rule, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -1056,7 +1064,8 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
       while ((unsigned long long)S->cell_cap < c[C_NEED_CELL] && S->cell_cap < (1 << 20)) S->cell_cap *= 2;
       return STEP_RETRY_EXACT;
     }
-    if (c[C_NEED_MC] || c[C_ERR_POT] || (i64)c[C_NPAIRS] > S->spec_np || (i64)c[C_NVTOT] > S->spec_nvt || c[C_ERR_ARENA])
+    if (c[C_NEED_MC] || c[C_ERR_POT] || (i64)c[C_NPAIRS] > S->spec_np || (i64)c[C_NVTOT] > S->spec_nvt || c[C_ERR_ARENA] ||
+        (S->fused && (i64)c[C_NEXT] > S->next_cap))      // (fused front: its per-entry launches covered next_cap entries)
       return STEP_RETRY_EXACT;
     S->np = (i64)c[C_NPAIRS]; S->nvt = (i64)c[C_NVTOT]; S->N = (int)c[C_NEXT];
   }
@@ -1068,7 +1077,7 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
       szl_k_narrow_convex(grid_for(nt, L), (size_t)L * CONVEX_STRIDE, st, (i64)0, nt,
                          (const unsigned long long *)nullptr, L, F, P, W, (const int *)W.team_list);
       SZ_HIP(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
       SZ_HIP(ctx, hipGetLastError());
       SZ_HIP(ctx, hipStreamSynchronize(st));
     }
@@ -1085,7 +1094,7 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
       SZ_HIP(ctx, hipMemcpyAsync(&W.counters[C_RETRY], &S->bump, 8, hipMemcpyHostToDevice, st));
     }
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -1124,7 +1133,7 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     else
       szl_k_narrow(grid_for(nl, RL), 0, st, (i64)0, nl, (const int *)S->retry_copy.p, mult, RL, 0, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, -1LL, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
     SZ_HIP(ctx, hipGetLastError());
     SZ_HIP(ctx, hipStreamSynchronize(st));
   }
@@ -1211,7 +1220,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   if (!S->fused || P.doInt) hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, S->back_queued ? 1 : 0);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, S->back_queued ? 1 : 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipStreamSynchronize(st));
   if (S->back_queued) {
@@ -1288,7 +1297,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
         return rc;
       }
       ++S->back_misses;
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0, 0, 0}, 0);   // from here on the host decides
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0, 0, 0}, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));   // from here on the host decides
       SZ_HIP(ctx, hipGetLastError());
     }
     SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -24,6 +24,7 @@ namespace szs {
 using szv::i64;
 
 enum { WALL = -2 }; // partner id of the floe-vs-boundary candidate
+enum { AGG_STRIDE = 16 }; // words between two sums that atomics bump: a 128-byte line each (the L2 serves the atomics of one line one by one)
 
 // device image of the Floe struct array (SoA).  Field names follow initialize_floe_values.m:12-52.
 struct Floes {
@@ -99,15 +100,41 @@ enum { REC_X = 0, REC_Y, REC_UI, REC_VI, REC_KSI, REC_H, REC_AREA, REC_BX0, REC_
        REC_WORDS = 16, RING_SLOTS = 16 };
 static_assert((int)RING_SLOTS == (int)sztm::T_NV, "the staged rings are what the team's block holds");
 
-// counters living in device memory
+// counters living in device memory.  Each on a 128-byte line of its own (C_STRIDE words apart): the L2 serves atomics on
+// one line one after the other (~12 ns each, measured: 1e4 waves on one address take 120 us) and the list counters are
+// bumped by hundreds of waves per launch -- side by side in one array they queued behind each other.  The enumerators
+// are the word offsets; slot k (k < C_SLOTS) lives at word k * C_STRIDE, on the device and in the host's pinned copy.
 enum {
-  C_GX = 0, C_GY, C_NEXT, C_NPAIRS, C_NVTOT, C_NROWS, C_ERR_POT, C_ERR_INC, C_RETRY, C_ERR_CLIP, C_ERR_ARENA,
-  C_ERR_MC, C_PAIRROWS, C_TOUCH, C_SCR_BUMP, C_NEED_POT, C_NEED_MC, C_BIG, C_GO, C_TEAM, C_WIDE, C_LIVE, C_COLD, C_WALLS,
-  C_ERR_CELL,   // fused front: entries that found their grid cell full (Work::cell_cap slots) -- the step is then done again by the scan-based chain
-  C_NEED_CELL,  // ... and the fullest cell's demand
-  C_TEAMV,      // ring vertices (stored lengths, both rings) of the pairs on the team pass's three lists: what that kernel's roofline is priced on
-  C_FORCE,      // fused back half: floes on force_list (forcing due on a step that does not refresh it for everybody: h < 0.1)
-  C_COUNT
+  C_STRIDE = 16,
+  C_GX = 0 * C_STRIDE,
+  C_GY = 1 * C_STRIDE,
+  C_NEXT = 2 * C_STRIDE,
+  C_NPAIRS = 3 * C_STRIDE,
+  C_NVTOT = 4 * C_STRIDE,
+  C_NROWS = 5 * C_STRIDE,
+  C_ERR_POT = 6 * C_STRIDE,
+  C_ERR_INC = 7 * C_STRIDE,
+  C_RETRY = 8 * C_STRIDE,
+  C_ERR_CLIP = 9 * C_STRIDE,
+  C_ERR_ARENA = 10 * C_STRIDE,
+  C_ERR_MC = 11 * C_STRIDE,
+  C_PAIRROWS = 12 * C_STRIDE,
+  C_TOUCH = 13 * C_STRIDE,
+  C_SCR_BUMP = 14 * C_STRIDE,
+  C_NEED_POT = 15 * C_STRIDE,
+  C_NEED_MC = 16 * C_STRIDE,
+  C_BIG = 17 * C_STRIDE,
+  C_GO = 18 * C_STRIDE,
+  C_TEAM = 19 * C_STRIDE,
+  C_WIDE = 20 * C_STRIDE,
+  C_LIVE = 21 * C_STRIDE,
+  C_COLD = 22 * C_STRIDE,
+  C_WALLS = 23 * C_STRIDE,
+  C_ERR_CELL = 24 * C_STRIDE,   // fused front: entries that found their grid cell full (Work::cell_cap slots) -- the step is then done again by the scan-based chain
+  C_NEED_CELL = 25 * C_STRIDE,   // ... and the fullest cell's demand
+  C_TEAMV = 26 * C_STRIDE,   // ring vertices (stored lengths, both rings) of the pairs on the team pass's three lists: what that kernel's roofline is priced on
+  C_FORCE = 27 * C_STRIDE,   // fused back half: floes on force_list (forcing due on a step that does not refresh it for everybody: h < 0.1)
+  C_SLOTS = 28, C_COUNT = C_SLOTS * C_STRIDE
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test
@@ -182,11 +209,12 @@ struct Work {
   // ---- the fused launch chain of the steady step (step_fused.hpp): tiles of 64 consecutive floes / entries ----
   int cell_cap;                          // > 0: cell c owns the slots [c * cell_cap, (c + 1) * cell_cap) of cell_item, filled by atomic append (no cell scan); 0: CSR by cell_off
   unsigned long long *gh_mask, *gh_agg;  // [2 * tiles] ballots of the x / y ghost flags of a tile's floes; [tiles] their counts packed x | y << 21 | both << 42
-  unsigned long long *pair_agg;          // [tiles of entries] pairs (low 24 bits) and pair vertices (<< 24) of a tile's entries
-  unsigned long long *row_agg;           // [tiles of entries] contact rows of a tile's entries
+  unsigned long long *pair_agg;          // [groups of 16 entries] pairs (low 24 bits) and pair vertices (<< 24) of the group's entries (kf_broad: a workgroup each)
+  unsigned long long *row_agg;           // [AGG_STRIDE * tiles of 64 entries] contact rows of a tile's entries (a 128-byte line each: bumped by atomics)
+  unsigned long long *prow_part;         // [AGG_STRIDE * 64] C_PAIRROWS in 64 parts (pair p bumps part p & 63), a line each
   unsigned long long *rel_mask;          // [cap_ext] bit k: candidate k of the entry is a pair this rank evaluates (pair_relevant)
   int *pot_nvpre;                        // [cap_ext * pot_cap] ring vertices of the entry's pairs before candidate k
-  int reg_rows;                          // 1: a pair registers its rows with both floes the moment it completes (pair_register) -- no k_incoming / k_row_count
+  int reg_rows;                          // 1: a pair registers its rows with both floes the moment it completes (pair_done) -- no k_incoming / k_row_count
   int *force_list;                       // [n] floes whose forcing is due though the step does not refresh it for all (C_FORCE of them)
 };
 
@@ -607,19 +635,20 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
 }
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
-// (fused chain) The pair p = (i, j) has completed with nrows contact rows: both floes' row counts (per entry and per tile
-// of 64 entries: kf_rows places the rows from them) and p on j's mirror list (:187-214, incoming) -- by the lane that
-// stores the pair's result, whichever kernel that is.
-SZ_HD void pair_register(i64 p, int i, int j, int nrows, Work &W) {
-  if (!W.reg_rows || nrows <= 0) return;
+// The pair p = (i, j) has completed with nrows > 0 contact rows -- by the lane that stores the pair's result, whichever
+// kernel that is.  Scan-based chain: the step's row count.  Fused chain: the count in 64 parts, both floes' row counts
+// (per entry and per tile of 64 entries: kf_rows places the rows from them) and p on j's mirror list (:187-214, incoming).
+SZ_HD void pair_done(i64 p, int i, int j, int nrows, Work &W) {
+  if (!W.reg_rows) { atomic_add_noret(&W.counters[C_PAIRROWS], (unsigned long long)nrows); return; }
+  atomic_add_noret(&W.prow_part[(size_t)AGG_STRIDE * (size_t)(p & 63)], (unsigned long long)nrows);
   (void)atomic_add(&W.row_cnt[i], nrows);
-  atomic_add_noret(&W.row_agg[i >> 6], (unsigned long long)nrows);
+  atomic_add_noret(&W.row_agg[(size_t)AGG_STRIDE * (i >> 6)], (unsigned long long)nrows);
   if (j < 0) return;                                   // the wall: no partner floe
   const int k = atomic_add(&W.inc_cnt[j], 1);
   if (k >= W.pot_cap) { atomic_add(&W.counters[C_ERR_INC], 1ULL); return; }
   W.inc_list[(size_t)j * W.pot_cap + k] = (int)p;
   (void)atomic_add(&W.row_cnt[j], nrows);
-  atomic_add_noret(&W.row_agg[j >> 6], (unsigned long long)nrows);
+  atomic_add_noret(&W.row_agg[(size_t)AGG_STRIDE * (j >> 6)], (unsigned long long)nrows);
 }
 
 // t-th entry of the work list (all pairs when list == nullptr, else the retry list at tier `mult`)
@@ -738,7 +767,7 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
-  if ((flag & 4) && speaker) { atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows); pair_register(p, i, j, out.nrows, W); }
+  if ((flag & 4) && speaker) pair_done(p, i, j, out.nrows, W);
 }
 // the general sweep for every clip of the pair
 SZ_HD void narrow(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
@@ -896,8 +925,7 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
     double *rows = (double *)(W.scratch + off);
     rows[0] = row[0]; rows[1] = row[1]; rows[2] = row[2]; rows[3] = row[3]; rows[4] = row[4];
     W.pair_nrows[p] = out.nrows;
-    atomic_add_noret(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows);
-    pair_register(p, i, j, out.nrows, W);
+    pair_done(p, i, j, out.nrows, W);
   }
   if (flag) W.pair_flag[p] = flag;
 }
@@ -989,7 +1017,7 @@ SZ_HD void narrow_b(i64 t, const Floes &F, const Params &P, Work &W, void *fast_
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   W.pair_nrows[p] = (flag & 4) ? out.nrows : 0;
   W.pair_flag[p] = flag;
-  if (flag & 4) { atomic_add(&W.counters[C_PAIRROWS], (unsigned long long)out.nrows); pair_register(p, W.pair_i[p], W.pair_j[p], out.nrows, W); }
+  if (flag & 4) pair_done(p, W.pair_i[p], W.pair_j[p], out.nrows, W);
 }
 
 // contact rows of pair p: in the pair's scratch slice, or in the gathered exchange buffer (sharded step)

@@ -27,11 +27,13 @@
 // entries, the exact re-run of a step that outgrew its capacities); tests/test_fused_gpu.py compares the two word by word.
 #pragma once
 
+enum { CELL_STRIDE = 8 };   // ints between the fill counts of two grid cells (four cells to a 128-byte line: the appends are atomics)
 // ---- kf_front_a ----------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) kf_front_a(int ncells, int ntiles_ext, Floes F, Params P, Work W) {
   const int e = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
-  for (int c = e; c < ncells; c += stride) W.cell_cnt[c] = 0;
-  for (int t = e; t < ntiles_ext; t += stride) { W.pair_agg[t] = 0; W.row_agg[t] = 0; }
+  for (int c = e; c < ncells; c += stride) W.cell_cnt[CELL_STRIDE * c] = 0;
+  for (int t = e; t < ntiles_ext; t += stride) W.row_agg[(size_t)AGG_STRIDE * t] = 0;
+  if (e < 64) W.prow_part[(size_t)AGG_STRIDE * e] = 0;
   if (e < W.cap_ext) { ext_clear(e, W); marks_clear(e, F); }
   int fx = 0, fy = 0;
   if (e < F.n) {
@@ -55,12 +57,14 @@ __global__ void __launch_bounds__(256) kf_front_a(int ncells, int ntiles_ext, Fl
 
 // ---- kf_front_b ----------------------------------------------------------------------------------------------------
 // entry e into its cell of the one-level grid (fixed slots per cell)
+__device__ inline int item_aux(int num, int nv);
 __device__ inline void cell_insert(int e, int s, double x, double y, const Floes &F, Work &W) {
   if (!(F.alive[s] && e >= F.nb && is_present(s, W))) return;       // in_grid
   const int c = cell_at(0, x, y, W);
-  const int k = atomicAdd(&W.cell_cnt[c], 1);
+  const int k = atomicAdd(&W.cell_cnt[CELL_STRIDE * c], 1);
   if (k < W.cell_cap) {
-    CellItem it; it.x = x; it.y = y; it.r = F.rmax[s]; it.e = e; it.pad = 0;
+    CellItem it; it.x = x; it.y = y; it.r = F.rmax[s]; it.e = e;
+    it.pad = item_aux(e == s ? s + 1 : -(s + 1), F.vert_off[s + 1] - F.vert_off[s]);   // (FloeNum: negative for a ghost; ring length)
     W.cell_item[(size_t)c * W.cell_cap + k] = it;
   } else {
     atomicAdd(&W.counters[C_ERR_CELL], 1ULL); atomicMax(&W.counters[C_NEED_CELL], (unsigned long long)(k + 1));
@@ -160,71 +164,100 @@ __global__ void __launch_bounds__(1024) kf_front_b(int ntiles, Floes F, Params P
 }
 
 // ---- kf_broad ------------------------------------------------------------------------------------------------------
-struct BroadLds { int hit[64], sorted[64], init[64], relf[64], s_end[9], s_c0[9], s_cn[9]; };
-// The candidate list of entry i by the wave (k_broad_wave's body, cells with fixed slots).  ninit > 0: `mems` starts from
-// L.init (the finished list of the floe a ghost is an image of, :94-99).  keep_init: leave the list in L.init.  -> kept
-__device__ inline int broad_entry_wave(int i, int ninit, bool keep_init, int N, BroadLds &L, const Floes &F, const Params &P, Work &W) {
+// A wave per entry of the extended list (real floes from Nb on, then the ghosts): k_broad_wave's body on cells with fixed
+// slots, every item carrying its FloeNum and ring length (CellItem::pad, item_aux), so that nothing about a partner is
+// loaded after its item.  A ghost's `mems` starts from the finished list of the floe it is an image of (:94-99), and an
+// entry is already listed there exactly when its real floe k is a candidate of that root -- k > root, both in the grid,
+// sqrt(dx^2 + dy^2) < r_root + r_k (:103; the root's own filter never drops a real floe: nothing earlier in its list
+// carries that number) -- which this wave works out from the two floes directly: the ghosts do not wait for their roots.
+__device__ inline int item_aux(int num, int nv) { return (int)(((unsigned)(nv < 1023 ? nv : 1023) << 22) | ((unsigned)num & 0x3fffffu)); }
+__device__ inline int aux_num(int aux) { return (aux << 10) >> 10; }
+__device__ inline int aux_nv(int aux) { return (int)((unsigned)aux >> 22); }
+struct BroadWave { int hit[64], haux[64], sj[64], saux[64], relf[64], s_end[9], s_c0[9], s_cn[9]; double hr[64], sr[64]; };
+__device__ inline void wave_sync() {   // LDS writes of the wave's lanes before it are visible to its reads after it (team.hpp)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// one entry by one wave -> its pair count | pair vertices << 24 (0 for an entry without a list)
+__device__ inline unsigned long long broad_entry(int i, BroadWave &L, const Floes &F, const Params &P, Work &W) {
+  int *hit = L.hit, *haux = L.haux, *sj = L.sj, *saux = L.saux, *relf = L.relf, *s_end = L.s_end, *s_c0 = L.s_c0, *s_cn = L.s_cn;
+  double *hr = L.hr, *sr = L.sr;
   const int lane = threadIdx.x & 63;
-  const int si = W.ext_src[i];
-  const double xi = W.ext_x[i], yi = W.ext_y[i], ri = F.rmax[si];
+  if (i < F.nb) return 0ULL;
+  const bool ghost = i >= F.n;
+  // (an entry beyond this step's list reads stale words of the arrays and leaves)
+  const int N = dev_next(W);
+  const int si = ghost ? W.ext_src[i] : i;
+  const double xi = ghost ? W.ext_x[i] : F.Xi[i], yi = ghost ? W.ext_y[i] : F.Yi[i];
+  const int ni = W.ext_nv[i];
+  if (i >= N) return 0ULL;
+  const double ri = F.rmax[si];
+  const int alive_i = F.alive[si];
+  const bool present_i = is_present(si, W);
+  const double rx = F.Xi[si], ry = F.Yi[si];          // (a ghost's root: the floe it copies)
   int H = 0;
-  __syncthreads();                                    // (the arrays of the entry before are done with)
-  if (F.alive[si] && !(xi != xi) && P.COLLISION && is_present(si, W)) {
+  if (alive_i && !(xi != xi) && P.COLLISION && present_i) {
     const int gx0 = cell_coord(xi, W.lvl_x0[0], W.lvl_cs[0], W.lvl_cx[0]), gy0 = cell_coord(yi, W.lvl_y0[0], W.lvl_cs[0], W.lvl_cy[0]);
     int c0 = 0, cn = 0;
     if (lane < 9) {
       const int gx = gx0 + (lane % 3) - 1, gy = gy0 + (lane / 3) - 1;
       if (gx >= 0 && gx < W.lvl_cx[0] && gy >= 0 && gy < W.lvl_cy[0]) {
         const int c = W.lvl_base[0] + gy * W.lvl_cx[0] + gx;
-        cn = W.cell_cnt[c]; if (cn > W.cell_cap) cn = W.cell_cap;
+        cn = W.cell_cnt[CELL_STRIDE * c]; if (cn > W.cell_cap) cn = W.cell_cap;
         c0 = c * W.cell_cap;
       }
     }
     int pre = cn;
     for (int d = 1; d < 16; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
-    if (lane < 9) { L.s_end[lane] = pre; L.s_c0[lane] = c0; L.s_cn[lane] = cn; }
-    __syncthreads();
-    const int T = L.s_end[8];
+    if (lane < 9) { s_end[lane] = pre; s_c0[lane] = c0; s_cn[lane] = cn; }
+    wave_sync();
+    const int T = s_end[8];
     for (int base = 0; base < T; base += 64) {
       const int t = base + lane;
       bool ok = false;
-      int j = 0;
+      CellItem it; it.e = 0; it.pad = 0; it.r = 0;
       if (t < T) {
         int cell = 0;
-        for (int c = 0; c < 8; ++c) if (t >= L.s_end[c]) cell = c + 1;
-        const int q = L.s_c0[cell] + (t - (L.s_end[cell] - L.s_cn[cell]));
-        const CellItem it = W.cell_item[q];
-        j = it.e;
-        if (j > i) {
+        for (int c = 0; c < 8; ++c) if (t >= s_end[c]) cell = c + 1;
+        it = W.cell_item[s_c0[cell] + (t - (s_end[cell] - s_cn[cell]))];
+        if (it.e > i) {
           const double dx = xi - it.x, dy = yi - it.y, R = ri + it.r, d2 = dx * dx + dy * dy;
           ok = !(d2 > R * R * 1.000001) && (::sqrt(d2) < R);       // :103
         }
       }
       const unsigned long long m = __ballot(ok);
-      if (ok) { const int r = H + __popcll(m & ((1ULL << lane) - 1ULL)); if (r < 64) L.hit[r] = j; }
+      if (ok) { const int r = H + __popcll(m & ((1ULL << lane) - 1ULL)); if (r < 64) { hit[r] = it.e; haux[r] = it.pad; hr[r] = it.r; } }
       H += __popcll(m);
     }
   }
-  __syncthreads();
+  wave_sync();
   if (H > W.pot_cap || H > 64) {
     if (lane == 0) { atomicAdd(&W.counters[C_ERR_POT], 1ULL); atomicMax(&W.counters[C_NEED_POT], (unsigned long long)H); }
     H = 0;
   }
-  const int mine = lane < H ? L.hit[lane] : 0x7fffffff;
+  const int mine = lane < H ? hit[lane] : 0x7fffffff;
   int rank = 0;
-  for (int k = 0; k < H; ++k) rank += (L.hit[k] < mine) ? 1 : 0;
-  if (lane < H) L.sorted[rank] = mine;
-  __syncthreads();
-  const int j = lane < H ? L.sorted[lane] : 0;
-  const int num = lane < H ? W.ext_num[j] : 0;
+  for (int k = 0; k < H; ++k) rank += (hit[k] < mine) ? 1 : 0;
+  if (lane < H) { sj[rank] = mine; saux[rank] = haux[lane]; sr[rank] = hr[lane]; }
+  wave_sync();
+  const int j = lane < H ? sj[lane] : 0;
+  const int aux = lane < H ? saux[lane] : 0;
+  const int num = lane < H ? aux_num(aux) : 0;        // FloeNum of the entry: negative for a ghost
   const int key = iabs(num);
   bool keep = lane < H;
   if (P.PERIODIC) {
-    bool dup = false;
+    bool dup = false;                                // an earlier entry IS the floe this one is an image of
     for (int k = 0; k < H; ++k) { const int nk = __shfl(num, k); if (k < lane && lane < H && nk == key) dup = true; }
-    for (int q = 0; q < ninit; ++q) if (L.init[q] == key) dup = true;          // (:94-99)
+    if (ghost && lane < H && key >= 1) {             // ... or that floe is on the root's list
+      const int k = key - 1;
+      if (k > si && k >= F.nb && si >= F.nb && F.alive[k] && is_present(k, W) && alive_i && !(rx != rx) && present_i) {
+        const double dx = rx - F.Xi[k], dy = ry - F.Yi[k], R = ri + F.rmax[k], d2 = dx * dx + dy * dy;
+        if (!(d2 > R * R * 1.000001) && (::sqrt(d2) < R)) dup = true;
+      }
+    }
     if (keep && dup) {
-      const double lim = szc::mind(2 * P.Lx, 2 * P.Ly), R = ri + F.rmax[W.ext_src[j]];
+      const double lim = szc::mind(2 * P.Lx, 2 * P.Ly), R = ri + sr[lane];
       keep = 2 * R > lim;
     }
   }
@@ -232,12 +265,10 @@ __device__ inline int broad_entry_wave(int i, int ninit, bool keep_init, int N, 
   const int K = __popcll(km);
   const int idx = __popcll(km & ((1ULL << lane) - 1ULL));
   if (keep) W.pot_list[(size_t)i * W.pot_cap + idx] = j + 1;
-  __syncthreads();                                    // (L.init has been read by every lane)
-  if (keep && keep_init) L.init[idx] = j + 1;
   // the pairs of this entry (pair_count), which of its candidates they are, the ring vertices before each
-  const bool rel = keep && i >= F.nb && pair_relevant(i, j, W);
-  const int ni = W.ext_nv[i];
-  const int nvj = rel ? ni + W.ext_nv[j] : 0;
+  const bool rel = keep && pair_relevant(i, j, W);
+  int nvj = 0;
+  if (rel) { const int c = aux_nv(aux); nvj = ni + (c < 1023 ? c : W.ext_nv[j]); }
   if (rel) (void)__hip_atomic_fetch_add(&W.inc_pre[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int inc = nvj;
   for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
@@ -245,35 +276,31 @@ __device__ inline int broad_entry_wave(int i, int ninit, bool keep_init, int N, 
   long long nv = __shfl(inc, 63);
   unsigned long long relm;
   if (W.owned) {
-    if (keep) L.relf[idx] = rel ? 1 : 0;
-    __syncthreads();
-    relm = __ballot(lane < K && L.relf[lane] != 0);
-  } else relm = (i >= F.nb) ? ((K >= 64) ? ~0ULL : ((1ULL << K) - 1ULL)) : 0ULL;
+    if (keep) relf[idx] = rel ? 1 : 0;
+    wave_sync();
+    relm = __ballot(lane < K && relf[lane] != 0);
+  } else relm = (K >= 64) ? ~0ULL : ((1ULL << K) - 1ULL);
   int cnt = __popcll(__ballot(rel));
-  if (lane == 0) {
-    if (has_wall_pair(i, N, F, P, W)) { ++cnt; nv += ni + 4; }
-    W.pot_cnt[i] = K; W.pair_cnt[i] = cnt; W.pair_nv[i] = nv; W.rel_mask[i] = relm;
-    if (cnt) atomicAdd(&W.pair_agg[i >> 6], (unsigned long long)cnt | ((unsigned long long)nv << 24));
-  }
-  return K;
+  if (has_wall_pair(i, N, F, P, W)) { ++cnt; nv += ni + 4; }
+  if (lane == 0) { W.pot_cnt[i] = K; W.pair_cnt[i] = cnt; W.pair_nv[i] = nv; W.rel_mask[i] = relm; }
+  return (unsigned long long)cnt | ((unsigned long long)nv << 24);
 }
-// a wave per real floe: its own list, then those of its ghosts (the x ghost, the y ghost, the y ghost of the x ghost)
-__global__ void __launch_bounds__(64) kf_broad(Floes F, Params P, Work W) {
-  __shared__ BroadLds L;
-  const int i = blockIdx.x;
-  if (i >= F.n) return;
-  const int N = dev_next(W);
-  int K = 0;
-  if (i >= F.nb) K = broad_entry_wave(i, 0, P.PERIODIC != 0, N, L, F, P, W);
-  if (!P.PERIODIC) return;
-  const int gx = W.xg_of[i], gy = W.yg_of[i];
-  if (gx >= 0) {
-    (void)broad_entry_wave(gx, K, false, N, L, F, P, W);
-    const int gxy = W.yg_of[gx];
-    if (gxy >= 0) (void)broad_entry_wave(gxy, K, false, N, L, F, P, W);
+// sixteen waves, sixteen consecutive entries per workgroup; the group's pair totals are one plain store (no atomics: the
+// L2 serves the atomics of a cache line one by one, and 1e4 of them on the few lines of such sums took 12 us)
+__global__ void __launch_bounds__(1024) kf_broad(Floes F, Params P, Work W) {
+  __shared__ BroadWave L[16];
+  __shared__ unsigned long long tot[16];
+  const int w = threadIdx.x >> 6;
+  const unsigned long long mine = broad_entry(16 * blockIdx.x + w, L[w], F, P, W);
+  if ((threadIdx.x & 63) == 0) tot[w] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long sum = 0;
+    for (int q = 0; q < 16; ++q) sum += tot[q];
+    W.pair_agg[blockIdx.x] = sum;
   }
-  if (gy >= 0) (void)broad_entry_wave(gy, K, false, N, L, F, P, W);
 }
+
 
 // ---- kf_pairs ------------------------------------------------------------------------------------------------------
 __device__ inline int nth_set_bit(unsigned long long m, int q) {   // position of the q-th (0-based) set bit of m
@@ -297,7 +324,7 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
   if (T == 0 && t == 0) W.counters[C_SCR_BUMP] = scratch_bump;
   if (T >= ntiles) return;
   unsigned long long before = 0;
-  for (int u = t; u < T; u += 512) before += W.pair_agg[u];
+  for (int u = t; u < 4 * T; u += 512) before += W.pair_agg[u];      // (kf_broad's sums: four groups of 16 entries to a tile)
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
   if (lane == 0) red[t >> 6] = before;
   __syncthreads();
@@ -321,10 +348,12 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
   __syncthreads();
   const int tp = (int)s_base[64];
   const bool walls = W.wall_list != nullptr;
+  long long teamv = 0;                                  // ring vertices of the pairs the team pass will take (its algorithmic bytes: bench.py)
   for (int pl0 = 0; pl0 < tp; pl0 += 512) {
     const int pl = pl0 + t;
     int cls = PC_DONE;
     i64 p = 0;
+    int team_nv = 0;
     if (pl < tp) {
       int lo = 0;                                     // the entry whose range holds pl: the last one with s_base <= pl
 #pragma unroll
@@ -344,14 +373,10 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
       if (p < W.cap_pairs) {
         W.pair_i[p] = i; W.pair_j[p] = j; W.pair_nvoff[p] = nvo;
         cls = pair_classify_ij(p, i, j, nvo, prev_n, P, W);
+        team_nv = j >= 0 ? W.ext_nv[i] + W.ext_nv[j] : 0;
       }
     }
-    {   // ring vertices of the pairs the team pass will take (its algorithmic bytes: bench.py)
-      long long tv = 0;
-      if (cls == PC_LIVE || cls == PC_COLD || cls == PC_WIDE) tv = W.ext_nv[W.pair_i[p]] + W.ext_nv[W.pair_j[p]];
-      for (int d = 32; d > 0; d >>= 1) tv += __shfl_xor(tv, d);
-      if (lane == 0 && tv) atomicAdd(&W.counters[C_TEAMV], (unsigned long long)tv);
-    }
+    if (cls == PC_LIVE || cls == PC_COLD || cls == PC_WIDE) teamv += team_nv;
     // the lists are appended to a wave at a time (k_pair_classify)
     unsigned long long mine = 0, m_own = 0;
 #pragma unroll
@@ -371,6 +396,11 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
     if (cls >= PC_LIVE && cls <= PC_GENERAL)
       (cls == PC_LIVE ? W.live_list : cls == PC_WIDE ? W.wide_list : cls == PC_COLD ? W.cold_list : cls == PC_GENERAL ? (walls ? W.wall_list : W.retry_list) : W.team_list)[base + __popcll(m_own & ((1ULL << lane) - 1ULL))] = (int)p;
   }
+  for (int d = 32; d > 0; d >>= 1) teamv += __shfl_xor(teamv, d);
+  __syncthreads();
+  if (lane == 0) red[t >> 6] = (unsigned long long)teamv;
+  __syncthreads();
+  if (t == 0) { unsigned long long v = 0; for (int q = 0; q < 8; ++q) v += red[q]; if (v) atomicAdd(&W.counters[C_TEAMV], v); }
 }
 
 // ---- kf_rows ---------------------------------------------------------------------------------------------------------
@@ -385,18 +415,20 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
 __global__ void __launch_bounds__(1024) kf_rows(int publish, unsigned long long *host_copy, GoRule rule, Floes F, Params P, Work W) {
   __shared__ unsigned long long red[16];
   __shared__ long long s_off[64];
-  const bool go = publish ? go_by_rule(W.counters, rule) : (W.counters[C_GO] != 0);
+  const unsigned long long prows = publish ? pair_rows_total(W.counters, W.prow_part) : 0ULL;    // (every wave for itself)
+  const bool go = publish ? go_by_rule(W.counters, rule, prows) : (W.counters[C_GO] != 0);
   const int T = blockIdx.x, t = threadIdx.x;
-  if (publish && T == 0 && t < (int)C_COUNT) {
-    host_copy[t] = (t == C_GO) ? (go ? 1ULL : 0ULL) : W.counters[t];
-    if (t == C_GO) W.counters[C_GO] = go ? 1ULL : 0ULL;
+  if (publish && T == 0 && t < (int)C_SLOTS) {
+    const int c = t * C_STRIDE;
+    host_copy[c] = (c == C_GO) ? (go ? 1ULL : 0ULL) : (c == C_PAIRROWS) ? prows : W.counters[c];
+    if (c == C_GO) W.counters[C_GO] = go ? 1ULL : 0ULL;
   }
   if (!go) return;
   const int N = dev_next(W);
   const int ntiles = (N + 63) >> 6;
   if (T >= ntiles) return;
   unsigned long long before = 0;
-  for (int u = t; u < T; u += 1024) before += W.row_agg[u];
+  for (int u = t; u < T; u += 1024) before += W.row_agg[(size_t)AGG_STRIDE * u];
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
   if ((t & 63) == 0) red[t >> 6] = before;
   __syncthreads();
@@ -517,24 +549,4 @@ __global__ void __launch_bounds__(1024) kf_rows(int publish, unsigned long long 
     centre_check(e, x, y, F, P, W);
     if (iabs(kill - (e + 1)) > 0 && kill > 0) atomic_max(&W.tmax[kill - 1], e + 1);     // transfer_collect
   }
-}
-
-// ---- kf_row_fill -----------------------------------------------------------------------------------------------------
-// One wave per tile of 64 entries: ScanRows from the tile counts (k_row_count has added them up), then k_row_fill.
-__global__ void __launch_bounds__(64) kf_row_fill(Floes F, Params P, Work W) {
-  if (!W.counters[C_GO]) return;
-  const int T = blockIdx.x, lane = threadIdx.x;
-  const int N = dev_next(W);
-  const int ntiles = (N + 63) >> 6;
-  if (T >= ntiles) return;
-  unsigned long long before = 0;
-  for (int u = lane; u < T; u += 64) before += W.row_agg[u];
-  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
-  const int i = 64 * T + lane;
-  const long long cnt = i < N ? W.row_cnt[i] : 0;
-  long long inc = cnt;
-  for (int d = 1; d < 64; d <<= 1) { const long long a = __shfl_up(inc, d); if (lane >= d) inc += a; }
-  if (i < N) W.row_off[i] = (i64)before + inc - cnt;
-  if (T == ntiles - 1 && lane == 63) { W.counters[C_NROWS] = before + (unsigned long long)inc; W.row_off[N] = (i64)before + inc; }
-  if (i < N) { row_fill(i, N, F, P, W); transfer_collect(i, F, W); }
 }

@@ -13,7 +13,7 @@ int sz_step_configure(szContext *ctx, StepState *S);   // step.hip: tuning knobs
 namespace {
 
 __global__ void k_counters_init(Floes F, Work W) {
-  int e = threadIdx.x;
+  const int e = threadIdx.x * C_STRIDE;
   if (e < C_COUNT) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
 }
 // sums of the stress history / points inside the Monte-Carlo mask of the floes ids[0..cnt) (all floes when ids == nullptr)
