@@ -402,19 +402,43 @@ __device__ inline unsigned long long pair_rows_total(const unsigned long long *c
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v + counters[C_PAIRROWS];
 }
+// (by a whole wave: lane k looks at counter k -- one round of loads, where `a || b || c ...` over the counters compiles to
+// a chain of scalar loads, each waiting for the one before: 5 us at the head of the back half, measured)
+// (k, v: this lane's counter -- word offset and value; GO_LEAVE is the caller's: it needs C_GO itself)
+__device__ inline bool go_by_values(int k, unsigned long long v, const GoRule &rule, unsigned long long pair_rows) {
+  if (rule.mode == GO_SET) return true;
+  bool bad = false;
+  switch (k) {
+    case C_NEED_MC: case C_ERR_POT: case C_ERR_ARENA: case C_ERR_CLIP: case C_RETRY: case C_BIG: case C_ERR_CELL: bad = v != 0; break;
+    case C_NPAIRS: bad = (long long)v > rule.spec_np; break;
+    case C_NVTOT: bad = (long long)v > rule.spec_nvt; break;
+    case C_TEAM: bad = rule.team_pending && v != 0; break;
+    case C_NEXT: bad = rule.next_cap > 0 && (long long)v > rule.next_cap; break;
+    default: break;
+  }
+  return __ballot(bad) == 0ULL && !(2 * (long long)pair_rows + 1 > rule.rows_cap);
+}
 __device__ inline bool go_by_rule(const unsigned long long *counters, const GoRule &rule, unsigned long long pair_rows) {
   if (rule.mode == GO_SET) return true;
-  if (rule.mode == GO_IF_CLEAN)
-    return !(counters[C_NEED_MC] || counters[C_ERR_POT] || (long long)counters[C_NPAIRS] > rule.spec_np || (long long)counters[C_NVTOT] > rule.spec_nvt ||
-             counters[C_ERR_ARENA] || counters[C_ERR_CLIP] || counters[C_RETRY] || counters[C_BIG] || (rule.team_pending && counters[C_TEAM]) || counters[C_ERR_CELL] ||
-             (rule.next_cap > 0 && (long long)counters[C_NEXT] > rule.next_cap) || 2 * (long long)pair_rows + 1 > rule.rows_cap);
-  return counters[C_GO] != 0;
+  if (rule.mode != GO_IF_CLEAN) return counters[C_GO] != 0;
+  const int k = (int)(threadIdx.x & 63) * C_STRIDE;
+  const unsigned long long v = k < (int)C_COUNT ? counters[k] : 0ULL;
+  bool bad = false;
+  switch (k) {
+    case C_NEED_MC: case C_ERR_POT: case C_ERR_ARENA: case C_ERR_CLIP: case C_RETRY: case C_BIG: case C_ERR_CELL: bad = v != 0; break;
+    case C_NPAIRS: bad = (long long)v > rule.spec_np; break;
+    case C_NVTOT: bad = (long long)v > rule.spec_nvt; break;
+    case C_TEAM: bad = rule.team_pending && v != 0; break;
+    case C_NEXT: bad = rule.next_cap > 0 && (long long)v > rule.next_cap; break;
+    default: break;
+  }
+  return __ballot(bad) == 0ULL && !(2 * (long long)pair_rows + 1 > rule.rows_cap);
 }
 __global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go, const unsigned long long *parts) {
   const unsigned long long prows = pair_rows_total(counters, parts);
+  const unsigned long long go = go_by_rule(counters, rule, prows) ? 1ULL : 0ULL;
   const unsigned e = threadIdx.x * C_STRIDE;
   if (e >= (unsigned)C_COUNT) return;
-  const unsigned long long go = go_by_rule(counters, rule, prows) ? 1ULL : 0ULL;
   const unsigned long long v = (e == C_GO) ? go : (e == C_PAIRROWS) ? prows : counters[e];
   host_copy[e] = v;
   const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
@@ -588,23 +612,6 @@ __global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first
   if (i >= last || !W.counters[C_GO]) return;
   if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
   (void)forcing_block(i, F, P, W, fold, red, &scnt);
-}
-// The fused back half (step_fused.hpp).  kf_integrate: a thread per real floe -- the transfer marks, integrate_pre and,
-// for the floes whose forcing is not due, integrate_post at once (the three parts of calc_trajectory touch one floe
-// only).  On a step that refreshes the forcing every live floe waits for k_forcing and k_integrate_post; on the others
-// the few floes thinner than 0.1 m (calc_trajectory.m:94,121) go on a list that a handful of workgroups stride.
-__global__ void __launch_bounds__(64) kf_integrate(Floes F, Params P, Work W) {   // grid: max(n, cap_ext) threads
-  if (!W.counters[C_GO]) return;
-  const int z = blockIdx.x * blockDim.x + threadIdx.x;
-  if (z < W.cap_ext) transfer_apply(z, F, W);
-  const int i = z + F.nb;
-  if (i < F.n) {
-    integrate_pre(i, F, P, W);
-    const int fl = W.st_flag[i];
-    if ((fl & ST_GO) && !(fl & ST_FORCE)) integrate_post(i, F, P, W);
-    else if ((fl & ST_GO) && !P.doInt) W.force_list[atomicAdd(&W.counters[C_FORCE], 1ULL)] = i;
-  }
-  if (z < F.nb) { F.collision_force[2 * z] = 0; F.collision_force[2 * z + 1] = 0; F.collision_torque[z] = 0; F.OverlapArea[z] = 0; }
 }
 // The floes of force_list (kf_integrate; a step that does not refresh the forcing for everybody): forcing, then
 // integrate_post, a few workgroups striding the list.  (No register cap here, unlike k_forcing: with integrate_post
@@ -905,13 +912,14 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   const int ntiles = (n + 63) / 64, ntiles_ext = (cap + 63) / 64;
   if ((rc = sz_reserve(ctx, S->cell_cnt, nc * 4 * CELL_STRIDE)) || (rc = sz_reserve(ctx, S->cell_item, nc * (size_t)S->cell_cap * sizeof(CellItem))) ||
       (rc = sz_reserve(ctx, S->gh_mask, 16 * (size_t)ntiles)) || (rc = sz_reserve(ctx, S->gh_agg, 8 * (size_t)ntiles)) ||
-      (rc = sz_reserve(ctx, S->pair_agg, 8 * 4 * (size_t)ntiles_ext)) || (rc = sz_reserve(ctx, S->row_agg, 8 * (size_t)AGG_STRIDE * (ntiles_ext + 64))) ||
+      (rc = sz_reserve(ctx, S->pair_agg, 8 * (64 / BROAD_WAVES) * (size_t)ntiles_ext)) || (rc = sz_reserve(ctx, S->row_agg, 8 * (size_t)AGG_STRIDE * (ntiles_ext + 64))) ||
       (rc = sz_reserve(ctx, S->rel_mask, 8 * (size_t)cap)) || (rc = sz_reserve(ctx, S->pot_nvpre, 4 * (size_t)cap * S->pot_cap)) ||
-      (rc = sz_reserve(ctx, S->force_list, 4 * (size_t)n))) return rc;
+      (rc = sz_reserve(ctx, S->force_list, 4 * (size_t)n)) || (rc = sz_reserve(ctx, S->hint, 32 * (size_t)cap))) return rc;
   W.cell_item = (CellItem *)S->cell_item.p; W.cell_cnt = (int *)S->cell_cnt.p; W.cell_cap = S->cell_cap;
   W.gh_mask = (unsigned long long *)S->gh_mask.p; W.gh_agg = (unsigned long long *)S->gh_agg.p;
   W.pair_agg = (unsigned long long *)S->pair_agg.p; W.row_agg = (unsigned long long *)S->row_agg.p;
   W.prow_part = W.row_agg + (size_t)AGG_STRIDE * ntiles_ext;     // (64 more lines of the same buffer)
+  W.hint = (int *)S->hint.p;
   W.rel_mask = (unsigned long long *)S->rel_mask.p; W.pot_nvpre = (int *)S->pot_nvpre.p; W.force_list = (int *)S->force_list.p;
   S->speculating = true; S->fused = true;
   W.reg_rows = 1;
@@ -923,9 +931,10 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   if ((rc = bind_pairs(ctx, S, np, nvt, main_bytes))) return rc;
   hipLaunchKernelGGL(kf_front_a, grid_for(cap, 256), dim3(256), 0, st, (int)nc - 1, ntiles_ext, F, P, W);
   hipLaunchKernelGGL(kf_front_b, dim3((unsigned)ntiles), dim3(1024), 0, st, ntiles, F, P, W);
-  hipLaunchKernelGGL(kf_broad, grid_for(S->next_cap, 16), dim3(1024), 0, st, F, P, W);
+  const unsigned tiles = grid_for(S->next_cap, 64).x;      // tiles of 64 entries the per-entry launches cover
+  hipLaunchKernelGGL(kf_broad, dim3((64 / BROAD_WAVES) * tiles), dim3(64 * BROAD_WAVES), 0, st, F, P, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
-  hipLaunchKernelGGL(kf_pairs, dim3((unsigned)ntiles_ext), dim3(512), 0, st, (S->stepped && !S->no_hint) ? S->last_next : 0, (unsigned long long)main_bytes, F, P, W);
+  hipLaunchKernelGGL(kf_pairs, dim3(tiles), dim3(512), 0, st, (S->hint_valid && !S->no_hint) ? S->last_next : 0, (unsigned long long)main_bytes, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   return SZ_OK;
 }
@@ -1191,7 +1200,7 @@ static int step_back_a(szContext *ctx, StepState *S) {
     const i64 entries = S->back_queued ? S->next_cap : (i64)S->N;
     hipLaunchKernelGGL(kf_rows, grid_for(entries > 0 ? entries : 1, 64), dim3(1024), 0, st, publish, S->c_dev, S->go_rule, F, P, W);
     SZ_HIP(ctx, hipEventRecord(S->ev[4], st));
-    hipLaunchKernelGGL(kf_integrate, grid_for(n > cap ? n : cap, 64), dim3(64), 0, st, F, P, W);
+    hipLaunchKernelGGL(kf_integrate, grid_for(std::max<i64>(16 * (i64)(n - S->nb), cap), 256), dim3(256), 0, st, F, P, W);
     SZ_HIP(ctx, hipGetLastError());
     return SZ_OK;
   }
@@ -1239,6 +1248,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
   ++S->steps_done; if (S->fused) ++S->steps_fused;
+  S->hint_valid = S->fused;      // (kf_rows has left next step's contact hints)
   S->last_team_vertices = (i64)c[C_TEAMV];
   S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS]; S->last_team = (i64)c[C_TEAM];
   S->last_deferred = S->retried - (W.wall_list ? 0 : S->last_walls) + (i64)c[C_BIG];   // pairs of this step that waited for the host besides the floes at the walls
@@ -1411,6 +1421,11 @@ int szStepShardFinish(szContext *ctx, const void *d_recv, int64_t seg_max, int64
   return step_back_b(ctx, S, stats);
 }
 
+#if defined(SZ_FUSED_CLOCKS)
+int szDebugFusedClocks(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_fused_clock), sizeof(unsigned long long) * SZ_FC_KERNELS * SZ_FC_BLOCKS * SZ_FC_SLOTS) == hipSuccess ? 0 : -1;
+}
+#endif
 int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n) {
   if (!ctx || !out || n < 0) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;

@@ -209,11 +209,12 @@ struct Work {
   // ---- the fused launch chain of the steady step (step_fused.hpp): tiles of 64 consecutive floes / entries ----
   int cell_cap;                          // > 0: cell c owns the slots [c * cell_cap, (c + 1) * cell_cap) of cell_item, filled by atomic append (no cell scan); 0: CSR by cell_off
   unsigned long long *gh_mask, *gh_agg;  // [2 * tiles] ballots of the x / y ghost flags of a tile's floes; [tiles] their counts packed x | y << 21 | both << 42
-  unsigned long long *pair_agg;          // [groups of 16 entries] pairs (low 24 bits) and pair vertices (<< 24) of the group's entries (kf_broad: a workgroup each)
+  unsigned long long *pair_agg;          // [groups of 4 entries] pairs (low 24 bits) and pair vertices (<< 24) of the group's entries (kf_broad: a workgroup each)
   unsigned long long *row_agg;           // [AGG_STRIDE * tiles of 64 entries] contact rows of a tile's entries (a 128-byte line each: bumped by atomics)
   unsigned long long *prow_part;         // [AGG_STRIDE * 64] C_PAIRROWS in 64 parts (pair p bumps part p & 63), a line each
   unsigned long long *rel_mask;          // [cap_ext] bit k: candidate k of the entry is a pair this rank evaluates (pair_relevant)
   int *pot_nvpre;                        // [cap_ext * pot_cap] ring vertices of the entry's pairs before candidate k
+  int *hint;                             // [8 * cap_ext] the partners (j + 1, 0: none) of the entry's first eight own pairs in contact in the step before (kf_rows -> kf_pairs)
   int reg_rows;                          // 1: a pair registers its rows with both floes the moment it completes (pair_done) -- no k_incoming / k_row_count
   int *force_list;                       // [n] floes whose forcing is due though the step does not refresh it for all (C_FORCE of them)
 };
@@ -800,12 +801,13 @@ SZ_HD void narrow_convex(i64 p, const int *list, const Floes &F, const Params &P
 //   team_list  the lane-per-pair kernels (walls, rings too long for the block, coordinates out of the fast range)
 // The order inside a list is arbitrary (every pair writes its own words).  Returns the class; the caller appends.
 enum { PC_DONE = 0, PC_LIVE = 1, PC_WIDE = 2, PC_OTHER = 3, PC_COLD = 4, PC_GENERAL = 5 };   // PC_GENERAL: straight to the general sweep (a floe at a wall: the box has horizontal edges, no fast path takes it)
-SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Params &P, Work &W);
+SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Params &P, Work &W, int live_hint = -1);
 SZ_HD int pair_classify(i64 p, int prev_n, const Params &P, Work &W) {
   return pair_classify_ij(p, W.pair_i[p], W.pair_j[p], W.pair_nvoff[p], prev_n, P, W);
 }
-// (the pair's words passed in: the fused chain classifies a pair in the thread that has just written them)
-SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Params &P, Work &W) {
+// (the pair's words passed in: the fused chain classifies a pair in the thread that has just written them; live_hint
+// 0 / 1: was the pair in contact in the step before, looked up by the caller -- -1: look it up in that step's rows)
+SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Params &P, Work &W, int live_hint) {
   const bool boundary = (j == WALL);
   const double *ri = W.ext_rec + (size_t)REC_WORDS * i, *rj = boundary ? ri : W.ext_rec + (size_t)REC_WORDS * j;
   const int n1 = (int)ri[REC_NSTORED], n2 = boundary ? 4 : (int)rj[REC_NSTORED];
@@ -826,6 +828,7 @@ SZ_HD int pair_classify_ij(i64 p, int i, int j, i64 nvoff, int prev_n, const Par
   if (ri[REC_INRANGE] == 0 || rj[REC_INRANGE] == 0) return PC_OTHER;
   if (apart) return PC_DONE;
   if (n1 + n2 - 2 > 16) return PC_WIDE;
+  if (live_hint >= 0) return live_hint ? PC_LIVE : PC_COLD;
   if (i < prev_n && W.rows != nullptr) {
     const i64 r0 = W.row_off[i];
     i64 r1 = W.row_off[i + 1];

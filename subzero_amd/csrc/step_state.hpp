@@ -93,7 +93,8 @@ struct StepState {
   bool fused_on = true;           // SUBZERO_FUSED=0: the scan-based chain always
   bool fused = false;             // this step's front ran fused (its back half then does too)
   int cell_cap = 32;              // slots per grid cell (SUBZERO_CELL_CAP); doubles when a step finds a cell full
-  DevBuf gh_mask, gh_agg, pair_agg, row_agg, rel_mask, pot_nvpre, force_list;
+  DevBuf gh_mask, gh_agg, pair_agg, row_agg, rel_mask, pot_nvpre, force_list, hint;
+  bool hint_valid = false;        // the step before ran fused: W.hint holds its contacts
   long long steps_done = 0, steps_fused = 0, last_team_vertices = 0;   // szStepDiagnostics
   bool no_hint = false, debug_lists = false;   // SUBZERO_NO_HINT, SUBZERO_DEBUG_LISTS (read once)
 };

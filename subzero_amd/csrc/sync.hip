@@ -96,7 +96,7 @@ void destroy_state(StepState *S) {
                     &S->retry_copy, &S->big_list, &S->team_list, &S->wide_list, &S->live_list, &S->cold_list, &S->wall_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
                     &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->pot_list, &S->inc_list,
                     &S->stage_d, &S->stage_i, &S->stage_ids, &S->sp_masks, &S->sp_edges_dev, &S->sp_counts,
-                    &S->gh_mask, &S->gh_agg, &S->pair_agg, &S->row_agg, &S->rel_mask, &S->pot_nvpre, &S->force_list};
+                    &S->gh_mask, &S->gh_agg, &S->pair_agg, &S->row_agg, &S->rel_mask, &S->pot_nvpre, &S->force_list, &S->hint};
   for (DevBuf *b : more) sz_release(*b);
   for (DevBuf &b : S->post) sz_release(b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
