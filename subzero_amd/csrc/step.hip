@@ -21,6 +21,7 @@
 // fallback exists: every failure is an error code.
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include "context.hpp"
 #include "step_core.hpp"
 #include "step_state.hpp"
@@ -434,16 +435,23 @@ __device__ inline bool go_by_rule(const unsigned long long *counters, const GoRu
   }
   return __ballot(bad) == 0ULL && !(2 * (long long)pair_rows + 1 > rule.rows_cap);
 }
-__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go, const unsigned long long *parts) {
+// (seq != 0: the last word of the host's copy -- host_copy[C_COUNT] -- is set to seq once the others are out: the host
+// spins on it instead of sleeping in hipStreamSynchronize, whose wake-up costs some tens of microseconds per step)
+__global__ void k_publish(unsigned long long *counters, unsigned long long *host_copy, long long reset_next, GoRule rule, int reset_only_if_go, const unsigned long long *parts, unsigned long long seq = 0) {
   const unsigned long long prows = pair_rows_total(counters, parts);
   const unsigned long long go = go_by_rule(counters, rule, prows) ? 1ULL : 0ULL;
   const unsigned e = threadIdx.x * C_STRIDE;
-  if (e >= (unsigned)C_COUNT) return;
-  const unsigned long long v = (e == C_GO) ? go : (e == C_PAIRROWS) ? prows : counters[e];
-  host_copy[e] = v;
-  const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
-  if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
-  else if (e == C_GO) counters[e] = go;
+  if (e < (unsigned)C_COUNT) {
+    const unsigned long long v = (e == C_GO) ? go : (e == C_PAIRROWS) ? prows : counters[e];
+    host_copy[e] = v;
+    const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
+    if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
+    else if (e == C_GO) counters[e] = go;
+  }
+  if (seq) {
+    __threadfence_system();                             // (every lane's words are out before the flag)
+    if (threadIdx.x == 0) __hip_atomic_store(&host_copy[C_COUNT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 static_assert(C_SLOTS <= 64, "k_publish is launched with one wave");
 __global__ void k_export_header(char *base, i64 ns, const unsigned long long *rows, i64 status, i64 rows_max) {
@@ -604,14 +612,93 @@ __device__ inline bool forcing_block(int i, const Floes &F, const Params &P, Wor
   if (t == 0) { F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt; }
   return true;
 }
+// The same with the lanes kept busy: only the Monte-Carlo points INSIDE the floe are evaluated (~55 % of a Voronoi cell's
+// 1000), and with point q on thread q mod 256 the other lanes of a wave sat idle through both passes.  The points inside
+// are listed (ballots + a prefix over the workgroup), lane c mod 256 evaluates the c-th of them and leaves its values at
+// the point's index in LDS, and thread t then adds up ITS points t, t + 256, ... from there -- the same values into the
+// same partial in the same order as before (MC_PARTS), so every sum is bit-identical.  n_mc <= 1024.
+struct ForcingLds { double v[3][1024]; double fold[256]; double red[3]; unsigned short lst[1024]; int wcnt[4][4]; int scnt; };
+__device__ inline bool forcing_block_dense(int i, const Floes &F, const Params &P, Work &W, ForcingLds &L) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nmc = F.n_mc;
+  const double *mx = F.mcX + i * F.mc_si, *my = F.mcY + i * F.mc_si;
+  const unsigned char *A = F.mcA + i * F.mc_si;
+  const long long sq = F.mc_sq;
+  ForceCtx c;
+  force_ctx(i, F, P, c);
+  __syncthreads();                                              // (the block of the floe before is done with)
+  bool in[4];
+  unsigned long long bal[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int q = t + 256 * s;
+    in[s] = q < nmc && A[q * sq] != 0;
+    bal[s] = __ballot(in[s]);
+    if (lane == 0) L.wcnt[s][wv] = __popcll(bal[s]);
+  }
+  __syncthreads();
+  int cnt = 0;                                                  // the list in order of (round s, wave, lane); cnt: its length
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w == wv && in[s]) L.lst[cnt + __popcll(bal[s] & ((1ULL << lane) - 1ULL))] = (unsigned short)(t + 256 * s);
+      cnt += L.wcnt[s][w];
+    }
+  }
+  __syncthreads();
+  if (cnt == 0) { // calc_trajectory.m:100-110 would regenerate the points with rand()
+    if (t == 0) { atomicAdd(&W.counters[C_ERR_MC], 1ULL); W.st_flag[i] = 0; }
+    return false;
+  }
+  // pass 1: every point inside the floe is sampled once -- winds for the first mean, ocean velocities and polar angle
+  // kept in registers for the second
+  McPoint kept[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = t + 256 * k;
+    if (cc < cnt) {
+      const int q = L.lst[cc];
+      double uw, vw;
+      point_sample(c, P, mx[q * sq], my[q * sq], true, true, uw, vw, kept[k]);
+      L.v[0][q] = uw; L.v[1][q] = vw;
+    }
+  }
+  __syncthreads();
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) if (in[s]) { a0 += L.v[0][t + 256 * s]; a1 += L.v[1][t + 256 * s]; }
+  const double su = mc_fold_block(a0, L.fold), sv = mc_fold_block(a1, L.fold);
+  if (t == 0) { L.red[0] = su; L.red[1] = sv; }
+  __syncthreads();
+  wind_stress(c, L.red[0], L.red[1], cnt);
+  // pass 2: stresses and torque
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = t + 256 * k;
+    if (cc < cnt) {
+      const int q = L.lst[cc];
+      double Fx, Fy, tq;
+      point_force(c, kept[k], Fx, Fy, tq);
+      L.v[0][q] = Fx; L.v[1][q] = Fy; L.v[2][q] = tq;
+    }
+  }
+  __syncthreads();
+  a0 = 0.0; a1 = 0.0;
+  double a2 = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) if (in[s]) { a0 += L.v[0][t + 256 * s]; a1 += L.v[1][t + 256 * s]; a2 += L.v[2][t + 256 * s]; }
+  const double sFx = mc_fold_block(a0, L.fold), sFy = mc_fold_block(a1, L.fold), sT = mc_fold_block(a2, L.fold);
+  if (t == 0) { F.FxOA[i] = sFx / cnt; F.FyOA[i] = sFy / cnt; F.torqueOA[i] = sT / cnt; }
+  return true;
+}
 __global__ void __launch_bounds__(256) SZ_FORCING_WAVES_ATTR k_forcing(int first, int last, Floes F, Params P, Work W) {
-  __shared__ double fold[256];
-  __shared__ double red[3];
-  __shared__ int scnt;
+  __shared__ ForcingLds L;
   const int i = blockIdx.x + first;
   if (i >= last || !W.counters[C_GO]) return;
   if ((W.st_flag[i] & (ST_GO | ST_FORCE)) != (ST_GO | ST_FORCE)) return; // uniform over the workgroup
-  (void)forcing_block(i, F, P, W, fold, red, &scnt);
+  if (F.n_mc <= 1024) (void)forcing_block_dense(i, F, P, W, L);
+  else (void)forcing_block(i, F, P, W, L.fold, L.red, &L.scnt);
 }
 // The floes of force_list (kf_integrate; a step that does not refresh the forcing for everybody): forcing, then
 // integrate_post, a few workgroups striding the list.  (No register cap here, unlike k_forcing: with integrate_post
@@ -687,6 +774,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   if (const char *v = getenv("SUBZERO_SPECULATE")) S->no_speculation = atoi(v) == 0;
   if (const char *v = getenv("SUBZERO_SPECULATE_BACK")) S->no_back_speculation = atoi(v) == 0;
   if (const char *v = getenv("SUBZERO_BROAD_WAVE")) S->broad_wave = atoi(v) != 0;
+  if (const char *v = getenv("SUBZERO_SPIN_WAIT")) S->spin_wait = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_FUSED")) S->fused_on = atoi(v) != 0;
   if (const char *v = getenv("SUBZERO_CELL_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->cell_cap = l; }
   S->no_hint = getenv("SUBZERO_NO_HINT") != nullptr;
@@ -1229,9 +1317,24 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   if (!S->fused || P.doInt) hipLaunchKernelGGL(k_integrate_post, grid_for(n, 64), dim3(64), 0, st, F, P, W);
   SZ_HIP(ctx, hipGetLastError());
   SZ_HIP(ctx, hipEventRecord(S->ev[5], st));
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, S->back_queued ? 1 : 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));
+  const unsigned long long seq = S->spin_wait ? ++S->publish_seq : 0ULL;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, S->back_queued ? 1 : 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr), seq);
   SZ_HIP(ctx, hipGetLastError());
-  SZ_HIP(ctx, hipStreamSynchronize(st));
+  if (seq) {
+    // the step's last kernel raises a flag in the pinned copy of the counters: spin on it (with a look at the stream now and
+    // then, so that a failed launch cannot leave the host spinning)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long long spins = 0;; ++spins) {
+      if (__atomic_load_n(&c[C_COUNT], __ATOMIC_ACQUIRE) == seq) break;
+      if ((spins & 0xfff) == 0xfff) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) { if (__atomic_load_n(&c[C_COUNT], __ATOMIC_ACQUIRE) == seq) break; SZ_HIP(ctx, hipStreamSynchronize(st)); break; }
+        if (q != hipErrorNotReady) SZ_HIP(ctx, q);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { SZ_HIP(ctx, hipStreamSynchronize(st)); break; }
+      }
+      __builtin_ia32_pause();
+    }
+  } else SZ_HIP(ctx, hipStreamSynchronize(st));
   if (S->back_queued) {
     S->back_queued = false;
     if (!c[C_GO]) return STEP_BACK_NOGO;     // the narrow phase left work for the host: nothing after it has run, the counters are as it left them
@@ -1255,6 +1358,7 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   if (S->debug_lists) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld | walls %lld (%s) deferred besides %lld big %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS], (long long)c[C_WALLS], W.wall_list ? "beside the team pass" : "on the retry list", (long long)S->last_deferred, (long long)c[C_BIG]);
   if (stats) {
     float ms;
+    SZ_HIP(ctx, hipEventSynchronize(S->ev[5]));   // (the flag of k_publish may reach the host before the runtime has seen the event's signal)
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[1])); stats->broad_ms = ms;
     SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[2], S->ev[3])); stats->narrow_ms = ms;

@@ -96,6 +96,8 @@ struct StepState {
   DevBuf gh_mask, gh_agg, pair_agg, row_agg, rel_mask, pot_nvpre, force_list, hint;
   bool hint_valid = false;        // the step before ran fused: W.hint holds its contacts
   long long steps_done = 0, steps_fused = 0, last_team_vertices = 0;   // szStepDiagnostics
+  bool spin_wait = true;          // the host waits for the step's last kernel by spinning on a flag in the pinned counters (SUBZERO_SPIN_WAIT=0: hipStreamSynchronize)
+  unsigned long long publish_seq = 0;
   bool no_hint = false, debug_lists = false;   // SUBZERO_NO_HINT, SUBZERO_DEBUG_LISTS (read once)
 };
 

@@ -119,8 +119,8 @@ int build_state(szContext *ctx, const szFloeState *h, StepState *old, const int3
   *out = S;
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
   { int rc0 = dev_alloc(ctx, S, S->scan_agg, 1024); if (rc0) return rc0; }
-  SZ_HIP(ctx, hipHostMalloc((void **)&S->c, C_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
-  memset(S->c, 0, C_COUNT * sizeof(unsigned long long));
+  SZ_HIP(ctx, hipHostMalloc((void **)&S->c, (C_COUNT + C_STRIDE) * sizeof(unsigned long long), hipHostMallocDefault));   // (+ the flag of k_publish)
+  memset(S->c, 0, (C_COUNT + C_STRIDE) * sizeof(unsigned long long));
   SZ_HIP(ctx, hipHostGetDevicePointer((void **)&S->c_dev, S->c, 0));
   int rc;
   if ((rc = sz_step_configure(ctx, S))) return rc;
