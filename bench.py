@@ -7,14 +7,17 @@ floe field; every 10th step refreshes the ocean/wind forcing, as the reference d
 concentration 1.0, periodic box, dt = 10 s (the configuration the metric's target is quoted on).
 
 One JSON line on stdout (rank 0).  `value` is floe-timesteps/s with all inputs resident in HBM.
-  roofline     : the pair-interaction kernel (k_narrow_team: a team of 16 or 32 lanes per candidate pair, all pairs
-                 whose bounding boxes meet) priced by the ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per ring vertex of
-                 both rings + 2 x 56 B of body scalars + 56 B per contact row, summed over ALL candidate pairs of the
-                 step) over the HIP-event duration of the narrow phase, against the 8 TB/s HBM3E peak.  The kernel is
-                 bound by the vector issue rate of irregular int64/FP64 geometry, not by HBM: the fraction is reported
-                 as computed ("limiter" says so).  `traffic` is the PMC figure of THIS round's profile of the same
-                 command (profiles/r03_pmc_narrow.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes);
-                 null when that file is absent -- a bench run cannot collect PMC counters by itself.
+  roofline     : the pair-interaction kernel (k_narrow_team: a team of 16 or 32 lanes per candidate pair) priced by the
+                 ALGORITHMIC bytes of SURVEY.md 8(d) (16 B per ring vertex of both rings + 2 x 56 B of body scalars +
+                 56 B per contact row) summed over THE PAIRS THAT LAUNCH PROCESSES -- the hot, cold and wide lists the
+                 classification leaves it (szStepStats.team_pairs / team_vertices; every contact row of a steady step
+                 comes from one of them) -- over the HIP-event duration of that launch alone, against the 8 TB/s HBM3E
+                 peak.  The kernel is bound by the vector issue rate of irregular int64/FP64 geometry, not by HBM: the
+                 fraction is reported as computed ("limiter" says so).  `traffic` is the PMC figure of THIS round's
+                 profile of the same command (profiles/r04_pmc_narrow.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+                 separate passes); null when that file is absent -- a bench run cannot collect PMC counters by itself.
+  pair_stage   : the same figure for the whole pair stage -- ALL candidate pairs of the step (the quarter whose boxes
+                 are apart is answered by the classification inside kf_pairs) over kf_pairs + k_narrow_team.
   cpu_baseline : the CPU oracle (C++ restatement of the MATLAB path around the reference's own Clipper)
                  on the host cores, a bounded sample of the same workload.  TEST INFRASTRUCTURE timed as a
                  baseline only; the product path never calls it.
@@ -223,8 +226,8 @@ def main():
     for _ in range(args.warmup):
         P.doInt = int(it % 10 == 0); sim.step(P); it += 1
     ctx.check(ctx.L.szSynchronize(ctx.h), "sync")
-    narrow_ms = pair_bytes = 0.0
-    pairs = rows = 0
+    narrow_ms = pair_bytes = team_bytes = stage_ms = 0.0
+    pairs = rows = team_pairs = 0
     dev_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -234,6 +237,9 @@ def main():
         pairs += st.n_pairs; rows += st.n_rows
         # B_pair = 16 (n_i+1 + n_j+1) + 2*56 + 56 K, summed over the candidate pairs
         pair_bytes += 16.0 * st.pair_vertices + 112.0 * st.n_pairs + 56.0 * st.pair_rows
+        # ... and over the pairs k_narrow_team itself processes (its three lists)
+        team_bytes += 16.0 * st.team_vertices + 112.0 * st.team_pairs + 56.0 * st.pair_rows
+        team_pairs += st.team_pairs; stage_ms += st.pairs_ms + st.narrow_ms
     ctx.check(ctx.L.szSynchronize(ctx.h), "sync")
     el = time.perf_counter() - t0
 
@@ -246,13 +252,14 @@ def main():
     sim.download(capi.SYNC_ALL)
 
     k = args.steps
-    achieved = (pair_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
+    achieved = (team_bytes / k) / (narrow_ms / k * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
+    stage = (pair_bytes / k) / (stage_ms / k * 1e-3) / 1e9 if stage_ms > 0 else 0.0
     traffic = traffic_src = None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_narrow.json")
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_narrow.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            traffic_src = "profiles/r03_pmc_narrow.json"
+            traffic_src = "profiles/r04_pmc_narrow.json"
         except Exception:
             traffic = None
     out = {
@@ -268,12 +275,16 @@ def main():
         "candidate_pairs_per_s": pairs / el,
         "contact_rows_last_step": int(len(inter)), "collisions_last_step": collisions,
         "device_ms_per_step": dev_ms / k,
-        "roofline": {"bound": "hbm", "kernel": "k_narrow_team (pair interaction: clip + contact force of every candidate pair whose boxes meet; "
-                                               "the boxes-apart pairs are answered by k_pair_classify in front of it)",
+        "roofline": {"bound": "hbm", "kernel": "k_narrow_team (pair interaction: clip + contact force of the pairs on its hot / cold / wide lists, "
+                                               "i.e. every candidate pair whose boxes meet)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "limiter": "FP64 / int64 vector issue of irregular geometry (16 lanes per pair, ~5.4e3 vector instructions per wave of four pairs), not HBM",
-                     "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": pair_bytes / k},
+                     "kernel_ms": narrow_ms / k, "algorithmic_bytes_per_launch": team_bytes / k,
+                     "pairs_per_launch": team_pairs / k, "candidate_pairs_per_step": pairs / k},
+        "pair_stage": {"kernels": "kf_pairs (pair records + classification: answers the pairs whose boxes are apart) + k_narrow_team",
+                       "achieved": stage, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stage / HBM_PEAK_GBS,
+                       "kernel_ms": stage_ms / k, "algorithmic_bytes_per_step": pair_bytes / k, "pairs_per_step": pairs / k},
     }
     if not args.no_clip_line:
         out["post_step_calls"] = post_step_line(sim, S, P)

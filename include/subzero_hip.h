@@ -188,6 +188,10 @@ typedef struct szStepStats {
   int64_t pair_vertices; /* sum of ring sizes over the candidate pairs */
   int64_t retried;     /* pairs re-run at a larger scratch tier */
   int64_t pair_rows;   /* contact rows produced by the candidate pairs (before mirroring) */
+  int64_t team_pairs;  /* pairs on the three lists of the pair-interaction kernel (k_narrow_team: hot + cold + wide); the other
+                          candidates were answered by the classification (boxes apart) or handed to the general sweep */
+  int64_t team_vertices; /* stored ring vertices (both rings) summed over those pairs: what that kernel's roofline is priced on */
+  double pairs_ms;     /* HIP-event time between the broad phase and the pair-interaction kernel: pair records + classification */
 } szStepStats;
 
 /* which fields szFloesDownload copies back */
@@ -243,6 +247,14 @@ enum {
   SZ_DIAG_COUNT
 };
 int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n);
+/* Diagnostic (tests/test_team_clip_gpu.py): the clip INSIDE the pair-interaction kernel alone -- the team form of the
+ * intersection of two single-minimum rings (teamclip.hpp; Clipper's Execute(ctIntersection), private/clipper.cpp:1560-1621,
+ * for that case), `lanes` = 16 or 32 lanes of a wave per pair.  Rings as szClipBatch takes them (2^32 fixed point, CSR).
+ * Pair p: status[p] = 0 and its one output ring (out_n[p] vertices, 0 = empty) at outx / outy[16 p ...], or status[p] = 100:
+ * not this form's case (more than 16 vertices, ties, several minima ...) -- the step hands such a pair to the general sweep. */
+int szDebugTeamClipBatch(szContext *ctx, int32_t lanes, int32_t npairs, const int64_t *ax, const int64_t *ay, const int32_t *aoff,
+                         const int64_t *bx, const int64_t *by, const int32_t *boff, int64_t *outx, int64_t *outy,
+                         int32_t *out_n, int32_t *status);
 /* floes (1-based, ascending) for which the last szStep returned SZ_STEP_NEEDS_MC */
 int szMcEmptyDownload(szContext *ctx, int32_t *ids, int64_t cap, int64_t *count);
 int szFloesDownload(szContext *ctx, szFloeState *host, int what);
@@ -336,7 +348,7 @@ int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const double *c2_boun
 int szCornerCandidates(szContext *ctx, const int32_t *ids, int nsub, int Nb, const double *c2_boundary, int32_t *offsets, int32_t *count,
                        double *angles, uint8_t *da, int64_t cap, int32_t *n_ext, double *kernel_ms);
 
-/* ---- corner grinding, the cut itself for the plain case: Physical_Processes/frac_corner.m:1-189 ------------------------
+/* ---- corner grinding, the cut itself for the plain case: Physical_Processes/frac_corner.m:1-188 ------------------------
  * For the floes ids[s] (1-based) and the `grind` flags the caller formed from szCornerCandidates' angles / da and its own
  * draws (corners.m:91; at offsets[s] .. offsets[s + 1], the layout szCornerCandidates returned): the pieces frac_corner.m
  * returns -- the floe with every broken corner replaced by its two cut points (:20-52, :159-185), then one triangle per

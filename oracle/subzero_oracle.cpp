@@ -1328,17 +1328,17 @@ extern "C" void or_polyangles(const double *x, const double *y, int n, double *o
 }
 
 // ---------------------------------------------------------------------------------------------
-// Physical_Processes/frac_corner.m:1-189 for ONE floe, restated for the case in which the reference's polyshape
-// operations have closed forms: every corner to break is convex and its cut (:20-52) stays inside the two adjacent
-// edges, clear of the neighbouring cuts and of every other edge of the outline.  poly1 (:66-93) is then the outline
-// with that corner replaced by the two cut points, poly2 the triangle, subtract(poly, union(...)) (:160-161) the
-// outline with every such corner replaced.  Returns the pieces in the order Floes = [FloeNEW fracturedFloes] (:188),
+// Physical_Processes/frac_corner.m:1-188 for ONE floe, restated for the case in which the reference's polyshape
+// operations have closed forms: every corner to break is convex and its cut (:19-52) stays inside the two adjacent
+// edges, clear of the neighbouring cuts and of every other edge of the outline.  poly1 (:53-80) is then the outline
+// with that corner replaced by the two cut points, poly2 the triangle, subtract(poly, union(...)) (:136-137) the
+// outline with every such corner replaced.  Returns the pieces in the order Floes = [FloeNEW fracturedFloes] (:185),
 // or nothing when the floe is not that case (the product then leaves it to frac_corner.m as well).
 // polyshape conventions assumed, unpinned by anything the reference holds: area / centroid = ring_area / ring_centroid
 // above; outlines clockwise from the first surviving vertex, a triangle from its first cut point.
 // x, y: poly.Vertices (the stored c_alpha without its closing copy, corners.m:63-68); out: 12 doubles per piece
 // [kind, Xi, Yi, area, mass, h, inertia_moment, rmax, alive, ksi_ice, factor of Stress / StressH, ring length], rings
-// closed (c_alpha = c0, :108-109).
+// closed (c_alpha = c0, :96-97 / :149-150).
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct CornerPiece { double rec[12]; Vec cx, cy; };
@@ -1368,15 +1368,15 @@ bool seg_touch(double ax, double ay, double bx, double by, double cx, double cy,
 CornerPiece make_piece(double kind, const Vec &vx, const Vec &vy, double mass, const OrFloes *F, int i, double factor) {
   CornerPiece P;
   double Xi, Yi;
-  ring_centroid(vx.data(), vy.data(), (int)vx.size(), Xi, Yi);        // :106 / :164
-  const double A = ring_area(vx.data(), vy.data(), (int)vx.size());   // :107 / :165
+  ring_centroid(vx.data(), vy.data(), (int)vx.size(), Xi, Yi);        // :92 / :145
+  const double A = ring_area(vx.data(), vy.data(), (int)vx.size());   // :93 / :146
   double r2 = 0;
   for (size_t k = 0; k < vx.size(); ++k) { P.cx.push_back(vx[k] - Xi); P.cy.push_back(vy[k] - Yi); r2 = std::max(r2, (vx[k] - Xi) * (vx[k] - Xi) + (vy[k] - Yi) * (vy[k] - Yi)); }
-  P.cx.push_back(vx[0] - Xi); P.cy.push_back(vy[0] - Yi);             // :110 / :168
-  const double h = mass / (920.0 * A);                                // :109 / :167
+  P.cx.push_back(vx[0] - Xi); P.cy.push_back(vy[0] - Yi);             // :96 / :149
+  const double h = mass / (920.0 * A);                                // :95 / :148
   P.rec[0] = kind; P.rec[1] = F->Xi[i] + Xi; P.rec[2] = F->Yi[i] + Yi; P.rec[3] = A; P.rec[4] = mass; P.rec[5] = h;
-  P.rec[6] = polygon_moments(P.cx, P.cy, h); P.rec[7] = sqrt(r2); P.rec[8] = (A < 1e4) ? 0.0 : 1.0;   // :112,:114,:129-131
-  P.rec[9] = A / F->area[i] * F->ksi_ice[i]; P.rec[10] = factor; P.rec[11] = (double)P.cx.size();   // :135, :121-122
+  P.rec[6] = polygon_moments(P.cx, P.cy, h); P.rec[7] = sqrt(r2); P.rec[8] = (A < 1e4) ? 0.0 : 1.0;   // :98,:100,:113-115 / :151,:153,:166-168
+  P.rec[9] = A / F->area[i] * F->ksi_ice[i]; P.rec[10] = factor; P.rec[11] = (double)P.cx.size();   // :119 / :172, :103-104 / :156-157
   return P;
 }
 std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_t *grind_in) {
@@ -1387,9 +1387,9 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
   if (n < 3) return none;
   Vec x(F->cax + v0, F->cax + v0 + n), y(F->cay + v0, F->cay + v0 + n);
   std::vector<uint8_t> grind(grind_in, grind_in + n);
-  const Vec angles = polyangles(x, y);                                // :9
-  const double Anorm = 180.0 - 360.0 / n;                             // :10
-  {                                                                   // :11-14 unique(angles(grind))
+  const Vec angles = polyangles(x, y);                                // :10
+  const double Anorm = 180.0 - 360.0 / n;                             // :11
+  {                                                                   // :12-15 unique(angles(grind))
     Vec ga;
     for (int k = 0; k < n; ++k) if (grind[k]) ga.push_back(angles[k]);
     Vec u = ga;
@@ -1398,7 +1398,7 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
     if (u.size() < ga.size() && grind[0] && grind[n - 1]) grind[n - 1] = 0;
   }
   double alph = angles[0];
-  for (int k = 1; k < n; ++k) alph = std::min(alph, angles[k]);       // :15
+  for (int k = 1; k < n; ++k) alph = std::min(alph, angles[k]);       // :16
   const double Apoly = ring_area(x.data(), y.data(), n);
   if (!(Apoly > 0)) return none;
   struct Cut { double x1, y1, x2, y2; };
@@ -1407,7 +1407,7 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
   for (int jj = 0; jj < n; ++jj) {
     if (!grind[jj]) continue;
     ++ng;
-    const int p = (jj + n - 1) % n, q = (jj + 1) % n;                 // :23-33
+    const int p = (jj + n - 1) % n, q = (jj + 1) % n;                 // :25-33
     const double X1 = x[p], Y1 = y[p], X2 = x[jj], Y2 = y[jj], X3 = x[q], Y3 = y[q];
     const double d1 = sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2)), d2 = sqrt((X3 - X2) * (X3 - X2) + (Y3 - Y2) * (Y3 - Y2));
     const double d = std::min(d1, d2);                                // :34-35
@@ -1438,7 +1438,7 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
     const double tb = sqrt((cut[q].x1 - x[q]) * (cut[q].x1 - x[q]) + (cut[q].y1 - y[q]) * (cut[q].y1 - y[q]));
     if (!(ta + tb < L)) return none;
   }
-  // :159-185 the floe less its corners
+  // :133-180 the floe less its corners
   Vec nx, ny;
   for (int k = 0; k < n; ++k) {
     if (grind[k]) { nx.push_back(cut[k].x1); ny.push_back(cut[k].y1); nx.push_back(cut[k].x2); ny.push_back(cut[k].y2); }
@@ -1446,11 +1446,11 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
   }
   const double Anew = ring_area(nx.data(), ny.data(), (int)nx.size());
   if (!(Anew > 0)) return none;
-  out.push_back(make_piece(0.0, nx, ny, F->mass[i] * Anew / Apoly, F, i, Anew / Apoly));   // :166, :171-172
-  // :54-136 one triangle per corner, with the Atot of poly1 and poly2 of ITS cut
+  out.push_back(make_piece(0.0, nx, ny, F->mass[i] * Anew / Apoly, F, i, Anew / Apoly));   // :147, :156-157
+  // :53-129 one triangle per corner, with the Atot of poly1 and poly2 of ITS cut
   for (int jj = 0; jj < n; ++jj) {
     if (!grind[jj]) continue;
-    Vec tx = {cut[jj].x1, cut[jj].x2, x[jj]}, ty = {cut[jj].y1, cut[jj].y2, y[jj]};   // Pc2, :55 / :64 / :74
+    Vec tx = {cut[jj].x1, cut[jj].x2, x[jj]}, ty = {cut[jj].y1, cut[jj].y2, y[jj]};   // Pc2, :55 / :64 / :73
     const double At = ring_area(tx.data(), ty.data(), 3);
     if (!(At > 0)) return none;
     Vec px, py;                                                       // Pc1
@@ -1459,13 +1459,13 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
       else { px.push_back(x[k]); py.push_back(y[k]); }
     }
     const double A1 = ring_area(px.data(), py.data(), (int)px.size());
-    double Atot = 0;                                                  // :95-97 a = R1(area(R1) > 10)
+    double Atot = 0;                                                  // :82-84 a = R1(area(R1) > 10)
     if (A1 > 10) Atot += A1;
     if (At > 10) Atot += At;
     if (!(Atot > 0)) return none;
-    const double Mtot = F->mass[i] * Atot / Apoly;                    // :98
+    const double Mtot = F->mass[i] * Atot / Apoly;                    // :85
     if ((tx[1] - tx[0]) * (ty[2] - ty[0]) - (tx[2] - tx[0]) * (ty[1] - ty[0]) > 0) { std::swap(tx[1], tx[2]); std::swap(ty[1], ty[2]); }   // clockwise
-    out.push_back(make_piece(1.0, tx, ty, Mtot * At / Atot, F, i, At / Atot));   // :108, :121-122
+    out.push_back(make_piece(1.0, tx, ty, Mtot * At / Atot, F, i, At / Atot));   // :94, :103-104
   }
   return out;
 }

@@ -72,7 +72,8 @@ class StepStats(ctypes.Structure):
                 ("rows_ms", ctypes.c_double), ("integrate_ms", ctypes.c_double),
                 ("n_ext", ctypes.c_int64), ("n_pairs", ctypes.c_int64), ("n_rows", ctypes.c_int64),
                 ("pair_vertices", ctypes.c_int64), ("retried", ctypes.c_int64),
-                ("pair_rows", ctypes.c_int64)]
+                ("pair_rows", ctypes.c_int64), ("team_pairs", ctypes.c_int64), ("team_vertices", ctypes.c_int64),
+                ("pairs_ms", ctypes.c_double)]
 
 
 SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3
@@ -144,6 +145,7 @@ class ParamPacker:
 EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
+    "szDebugTeamClipBatch",
     "szFloesUpload", "szStep", "szStepDiagnostics", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
     "szEulerianData", "szCornerCandidates", "szCornerCuts", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
@@ -173,6 +175,8 @@ def load():
     L.szClipBatch.argtypes = [_vp, ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p,
                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
+    L.szDebugTeamClipBatch.argtypes = [_vp, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _i32p, _i64p, _i64p, _i32p,
+                                       _i64p, _i64p, _i32p, _i32p]
     L.szClipPathsBatch.argtypes = [_vp, ctypes.c_int, _i64p, _i64p, _i32p, _i32p, _i64p, _i64p, _i32p, _i32p,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    _i64p, _i64p, ctypes.c_int64, _i32p, ctypes.c_int64, _i32p, _i32p]
@@ -257,6 +261,20 @@ class Context:
                 continue
             self.check(rc, "szClipBatch")
             return ox, oy, roff, proff, st[:n]
+
+    def team_clip_batch(self, ax, ay, aoff, bx, by, boff, lanes=16):
+        """The clip inside the pair-interaction kernel alone (szDebugTeamClipBatch; tests): -> the layout of clip_batch;
+        status 100 = not the team form's case."""
+        n = len(aoff) - 1
+        ox = np.zeros(16 * max(n, 1), np.int64); oy = np.zeros(16 * max(n, 1), np.int64)
+        cnt = np.zeros(max(n, 1), np.int32); st = np.zeros(max(n, 1), np.int32)
+        self.check(self.L.szDebugTeamClipBatch(self.h, lanes, n, ax, ay, aoff, bx, by, boff, ox, oy, cnt, st), "szDebugTeamClipBatch")
+        cnt = cnt[:n]; st = st[:n]
+        has = (cnt > 0).astype(np.int32)
+        proff = np.zeros(n + 1, np.int32); proff[1:] = np.cumsum(has)
+        roff = np.zeros(int(proff[-1]) + 1, np.int32); roff[1:] = np.cumsum(cnt[cnt > 0])
+        keep = (np.arange(16)[None, :] < cnt[:, None]).ravel()
+        return ox[:16 * n][keep], oy[:16 * n][keep], roff, proff, st
 
     def clip_paths_batch(self, ax, ay, a_ring_off, a_pair_off, bx, by, b_ring_off, b_pair_off, method, subj_fill=0, clip_fill=0):
         """clip_batch with several contours per operand (ring CSR + pair -> ring range CSR)."""

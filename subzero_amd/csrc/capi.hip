@@ -32,7 +32,7 @@ int szCreate(szContext **out, int device) {
 int szDestroy(szContext *ctx) {
   if (!ctx) return SZ_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)sz_sync_all(ctx);
   sz_step_destroy(ctx);
   DevBuf *bufs[] = {&ctx->ws, &ctx->ovx, &ctx->ovy, &ctx->oroff, &ctx->ov_base, &ctx->or_base,
                     &ctx->nrings, &ctx->status, &ctx->retry_list, &ctx->counters, &ctx->clip_meta, &ctx->clip_lists,

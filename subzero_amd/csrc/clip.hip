@@ -523,12 +523,11 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
     if (stats) memset(stats, 0, sizeof(*stats));
     return SZ_OK;
   }
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute((const void *)k_clip, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_clip_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_clip_sweep_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    once = true;
+  if (!ctx->clip_lds_set) {   // per context, i.e. per device: hipFuncSetAttribute applies to the current device only
+    SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_clip, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_clip_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SZ_HIP(ctx, hipFuncSetAttribute((const void *)k_clip_sweep_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->clip_lds_set = true;
   }
   // Single rings in fixed point (szClipBatch and what the fracture entries build on it): front pass + sweep classes,
   // one pair per wave.  Everything else (several contours, double input, SUBZERO_CLIP_LANES set): k_clip, one sweep

@@ -26,6 +26,7 @@ struct szContext {
   // clip path buffers
   DevBuf ws, ovx, ovy, oroff, ov_base, or_base, nrings, status, retry_list, counters;
   DevBuf clip_meta, clip_lists;      // front pass -> sweep pass (clip.hip)
+  bool clip_lds_set = false;         // the clip kernels' dynamic-LDS limit has been raised on this context's device
   // Three side streams for everything in the library that runs kernels side by side (the sweep passes of the clip batch,
   // the wall pairs of a step): with the context's own stream that makes four, the number of hardware queues a process
   // gets by default (GPU_MAX_HW_QUEUES) -- a fifth stream shares a queue with another and silently runs behind it.
@@ -74,6 +75,13 @@ inline int sz_side_streams(szContext *ctx) {
     SZ_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[k], hipEventDisableTiming));
   }
   return SZ_OK;
+}
+// everything the context has in flight, side streams included (an error return between a fork and its join leaves work
+// on a side stream that the main stream never waited for): before buffers or events are freed
+inline hipError_t sz_sync_all(szContext *ctx) {
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < 3; ++k) if (ctx->side[k]) { const hipError_t e2 = hipStreamSynchronize(ctx->side[k]); if (e == hipSuccess) e = e2; }
+  return e;
 }
 inline void sz_release(DevBuf &b) {
   if (b.p) (void)hipFree(b.p);

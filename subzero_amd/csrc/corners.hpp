@@ -119,16 +119,16 @@ SZ_HD int nearest_vertex(double px, double py, const double *x, const double *y,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// frac_corner.m:1-189 for the PLAIN case: every corner to break off is convex, its two cut points lie
+// frac_corner.m:1-188 for the PLAIN case: every corner to break off is convex, its two cut points lie
 // inside the two adjacent edges without meeting the cut of a neighbouring corner, and the cut neither crosses another
-// edge nor leaves an empty piece.  Then the reference's polyshape operations have closed forms: poly1 of :66-93 is the
+// edge nor leaves an empty piece.  Then the reference's polyshape operations have closed forms: poly1 of :53-80 is the
 // outline with the one corner replaced by its two cut points, poly2 the triangle, and subtract(poly, union(triangles))
-// of :160-161 the outline with every broken corner replaced -- no boolean operation is needed.  Anything else returns 0
+// of :136-137 the outline with every broken corner replaced -- no boolean operation is needed.  Anything else returns 0
 // (nothing written): the caller leaves that floe to frac_corner.m itself.
 // polyshape conventions assumed (the reference holds no output of these functions to pin them):
 // area / centroid = the shoelace forms relative to the first vertex (contact.hpp region_area / region_centroid), outlines
 // listed clockwise from the first surviving stored vertex, a new triangle from its first cut point.
-// Monte-Carlo points of the new floes (:124-126,:178-180) are rand: the caller draws them (the step reports floes whose
+// Monte-Carlo points of the new floes (:108-110,:161-163) are rand: the caller draws them (the step reports floes whose
 // mask is empty: SZ_STEP_NEEDS_MC).
 // ---------------------------------------------------------------------------------------------------------------------
 enum { PIECE_KIND = 0, PIECE_XI, PIECE_YI, PIECE_AREA, PIECE_MASS, PIECE_H, PIECE_INERTIA, PIECE_RMAX, PIECE_ALIVE, PIECE_KSI,
@@ -180,7 +180,7 @@ SZ_HD bool segments_meet(double ax, double ay, double bx, double by, double cx, 
   if (d4 == 0 && on(cx, cy, dx, dy, bx, by)) return true;
   return false;
 }
-// one piece into the output: scalars of frac_corner.m:104-136 / :163-185 and the closed c_alpha ring
+// one piece into the output: scalars of frac_corner.m:91-125 / :144-178 and the closed c_alpha ring
 SZ_HD void put_piece(double kind, const double *px, const double *py, int m, double mass, double floe_area_field, double floe_ksi,
                      double stress_factor, double fx, double fy, double *rec, double *rx, double *ry) {
   double cx, cy;
@@ -195,14 +195,14 @@ SZ_HD void put_piece(double kind, const double *px, const double *py, int m, dou
   rec[PIECE_KSI] = area / floe_area_field * floe_ksi; rec[PIECE_STRESS_FACTOR] = stress_factor; rec[PIECE_NV] = (double)(m + 1);
 }
 
-// x, y[n]: the floe's outline without its closing copy (corners.m:63-68), grind[n] (modified: the quirk of :12-14).
+// x, y[n]: the floe's outline without its closing copy (corners.m:63-68), grind[n] (modified: the quirk of :12-15).
 // tmpx / tmpy: n + 2 * n doubles of scratch.  Output: rec[(1 + ng) * PIECE_WORDS], rings at rx / ry (capacity
 // n + 1 + 5 ng), ring_off[2 + ng].  -> number of pieces (main first, then the triangles in vertex order), 0: not plain.
 template <class Acos>
 SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned char *grind, double mass, double area_field, double ksi,
                             double fx, double fy, double *tmpx, double *tmpy, double *rec, double *rx, double *ry, int *ring_off, Acos acos_fn) {
   if (n < 3) return 0;
-  // :9-15
+  // :10-16
   double alph = 1e300;
   int ng = 0;
   bool equal_angles = false;
@@ -217,7 +217,7 @@ SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned ch
   const double Anorm = 180.0 - 360.0 / n;
   const double poly_area = ring_area_abs(x, y, n);
   if (!(poly_area > 0)) return 0;
-  // cut points of every ground corner (:20-52)
+  // cut points of every ground corner (:19-52)
   double *c1x = tmpx, *c1y = tmpy, *c2x = tmpx + n, *c2y = tmpy + n;
   for (int k = 0; k < n; ++k) {
     if (!grind[k]) continue;
@@ -253,7 +253,7 @@ SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned ch
     const double tb = ::sqrt((c1x[kn] - x[kn]) * (c1x[kn] - x[kn]) + (c1y[kn] - y[kn]) * (c1y[kn] - y[kn]));
     if (!(ta + tb < L)) return 0;
   }
-  // the main piece: every ground corner replaced by its two cut points (:159-185)
+  // the main piece: every ground corner replaced by its two cut points (:133-180)
   double *mx = rx, *my = ry;                       // built in place at the head of the ring output, then re-centred
   int m = 0;
   double *bx = tmpx + 2 * n, *by = tmpy + 2 * n;   // (scratch beyond the cut points: n + ng values)
@@ -267,7 +267,7 @@ SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned ch
   ring_off[0] = 0;
   put_piece(0.0, bx, by, m, mass * new_area / poly_area, area_field, ksi, new_area / poly_area, fx, fy, rec, mx, my);
   at += m + 1; ++np; ring_off[np] = at;
-  // the triangles (:66-136), each with the Atot of ITS single cut
+  // the triangles (:53-129), each with the Atot of ITS single cut
   for (int k = 0; k < n; ++k) {
     if (!grind[k]) continue;
     double tx[3] = {c1x[k], c2x[k], x[k]}, ty[3] = {c1y[k], c2y[k], y[k]};

@@ -119,6 +119,67 @@ __global__ void __launch_bounds__(256) k_pair_classify(i64 count, const unsigned
 }
 }
 
+// ---- szDebugTeamClipBatch: the clip of the team pass ALONE (tests) -------------------------------------------------------
+// One team per pair, 64 / G pairs per wave, rings in 2^32 fixed point as the B1 surface takes them; the closing copy of a
+// ring is dropped as the step's staging does.  status 100 (ST_BAIL): not this form's case (the step hands such a pair on).
+namespace {
+template <int G>
+__global__ void __launch_bounds__(64) k_debug_team_clip(int npairs, const i64 *ax, const i64 *ay, const int *aoff, const i64 *bx, const i64 *by,
+                                                        const int *boff, i64 *outx, i64 *outy, int *out_n, int *status) {
+  __shared__ sztm::ClipScratch scr[64 / G];
+  __shared__ i64 ox[64 / G][sztm::T_CAPV], oy[64 / G][sztm::T_CAPV];
+  const sztm::Team<G> T = sztm::Team<G>::here();
+  const int tw = sztm::Team<G>::index_in_wave();
+  const int p = (int)blockIdx.x * (64 / G) + tw;
+  if (p >= npairs) return;                                  // (team-uniform: the teams of a wave may diverge from each other)
+  int na = aoff[p + 1] - aoff[p], nb = boff[p + 1] - boff[p];
+  const i64 *pax = ax + aoff[p], *pay = ay + aoff[p], *pbx = bx + boff[p], *pby = by + boff[p];
+  if (na > 1 && pax[na - 1] == pax[0] && pay[na - 1] == pay[0]) --na;
+  if (nb > 1 && pbx[nb - 1] == pbx[0] && pby[nb - 1] == pby[0]) --nb;
+  int st = szx::ST_BAIL, n = 0;
+  if (na <= (int)sztm::T_NV && nb <= (int)sztm::T_NV && na >= 1 && nb >= 1) {
+    sztm::ClipScratch *S = &scr[tw];
+    for (int i = T.lane; i < na; i += G) { S->fx[0][i] = pax[i]; S->fy[0][i] = pay[i]; }
+    for (int i = T.lane; i < nb; i += G) { S->fx[1][i] = pbx[i]; S->fy[1][i] = pby[i]; }
+    T.sync(TEAM_SITE);
+    st = sztm::team_clip(T, S, na, nb, ox[tw], oy[tw], &n);
+    T.sync(TEAM_SITE);
+    if (st == szv::ST_OK) for (int i = T.lane; i < n; i += G) { outx[(size_t)p * sztm::T_CAPV + i] = ox[tw][i]; outy[(size_t)p * sztm::T_CAPV + i] = oy[tw][i]; }
+  }
+  if (T.lane == 0) { status[p] = st; out_n[p] = st == szv::ST_OK ? n : 0; }
+}
+}
+extern "C" int szDebugTeamClipBatch(szContext *ctx, int lanes, int npairs, const int64_t *ax, const int64_t *ay, const int32_t *aoff,
+                                    const int64_t *bx, const int64_t *by, const int32_t *boff, int64_t *outx, int64_t *outy,
+                                    int32_t *out_n, int32_t *status) {
+  if (!ctx || npairs < 0 || (lanes != 16 && lanes != 32) || !ax || !ay || !aoff || !bx || !by || !boff || !outx || !outy || !out_n || !status) return SZ_ERR_BAD_ARG;
+  if (npairs == 0) return SZ_OK;
+  for (int p = 0; p < npairs; ++p) if (aoff[p + 1] < aoff[p] || boff[p + 1] < boff[p]) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szDebugTeamClipBatch: offsets of pair %d descend", p);
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t na = (size_t)aoff[npairs], nb = (size_t)boff[npairs], no = (size_t)npairs * sztm::T_CAPV;
+  DevBuf d[11];
+  const size_t bytes[11] = {8 * na, 8 * na, 4 * ((size_t)npairs + 1), 8 * nb, 8 * nb, 4 * ((size_t)npairs + 1), 8 * no, 8 * no, 4 * (size_t)npairs, 4 * (size_t)npairs, 0};
+  const void *src[6] = {ax, ay, aoff, bx, by, boff};
+  int rc = SZ_OK;
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 10 && !rc; ++k) rc = sz_reserve(ctx, d[k], bytes[k] + 8);
+  for (int k = 0; k < 6 && !rc && e == hipSuccess; ++k) e = hipMemcpyAsync(d[k].p, src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
+  if (!rc && e == hipSuccess) {
+    const unsigned grid = (unsigned)((npairs + 64 / lanes - 1) / (64 / lanes));
+    if (lanes == 16) hipLaunchKernelGGL(k_debug_team_clip<16>, dim3(grid), dim3(64), 0, ctx->stream, npairs, (const i64 *)d[0].p, (const i64 *)d[1].p, (const int *)d[2].p, (const i64 *)d[3].p, (const i64 *)d[4].p, (const int *)d[5].p, (i64 *)d[6].p, (i64 *)d[7].p, (int *)d[8].p, (int *)d[9].p);
+    else hipLaunchKernelGGL(k_debug_team_clip<32>, dim3(grid), dim3(64), 0, ctx->stream, npairs, (const i64 *)d[0].p, (const i64 *)d[1].p, (const int *)d[2].p, (const i64 *)d[3].p, (const i64 *)d[4].p, (const int *)d[5].p, (i64 *)d[6].p, (i64 *)d[7].p, (int *)d[8].p, (int *)d[9].p);
+    e = hipGetLastError();
+  }
+  void *dst[4] = {outx, outy, out_n, status};
+  for (int k = 0; k < 4 && !rc && e == hipSuccess; ++k) e = hipMemcpyAsync(dst[k], d[6 + k].p, bytes[6 + k], hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = e2;
+  for (int k = 0; k < 10; ++k) sz_release(d[k]);
+  if (rc) return rc;
+  if (e != hipSuccess) return sz_fail(ctx, SZ_ERR_HIP, "szDebugTeamClipBatch: %s", hipGetErrorString(e));
+  return SZ_OK;
+}
+
 void sz_launch_pair_classify(hipStream_t st, i64 count, const unsigned long long *dev_count, int prev_n, const Params &P, const Work &W) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_pair_classify, grid_for(count, 256), dim3(256), 0, st, count, dev_count, prev_n, P, W);

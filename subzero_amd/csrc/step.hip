@@ -1367,6 +1367,8 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
     stats->n_ext = S->N; stats->n_pairs = np; stats->n_rows = S->nr; stats->pair_vertices = S->nvt;
     stats->retried = S->retried + (W.wall_list ? S->last_walls : 0);   // (pairs through the general sweep: deferred ones and the floes at the walls)
     stats->pair_rows = S->pair_rows_local;
+    stats->team_pairs = S->last_hot + S->last_cold + S->last_wide; stats->team_vertices = S->last_team_vertices;
+    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[1], S->ev[2])); stats->pairs_ms = ms;
   }
   return SZ_OK;
 }

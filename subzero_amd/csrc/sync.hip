@@ -332,7 +332,7 @@ int szFloesUpload(szContext *ctx, const szFloeState *h) {
   int rc = check_image(ctx, h, "szFloesUpload");
   if (rc) return rc;
   SZ_HIP(ctx, hipSetDevice(ctx->device));
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SZ_HIP(ctx, sz_sync_all(ctx));
   sz_step_destroy(ctx);
   StepState *S = nullptr;
   rc = build_state(ctx, h, nullptr, nullptr, &S);
@@ -351,7 +351,7 @@ int szFloesResync(szContext *ctx, const szFloeState *h, const int32_t *src) {
   for (int k = 0; k < h->n; ++k)
     if (src[k] < 0 || src[k] > old->n) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFloesResync: src[%d] = %d is not a floe of the resident array", k, src[k]);
   SZ_HIP(ctx, hipSetDevice(ctx->device));
-  SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SZ_HIP(ctx, sz_sync_all(ctx));
   StepState *S = nullptr;
   rc = build_state(ctx, h, old, src, &S);
   if (rc) { destroy_state(S); return rc; }   // the resident array is still the old one

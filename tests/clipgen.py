@@ -511,6 +511,12 @@ def run_gpu(ctx, ps, method, fill_s=0, fill_c=0):
     return ClipResult(ox, oy, roff, proff, st)
 
 
+def run_team_gpu(ctx, ps, G=16):
+    """run_team on the device: the clip of the pair-interaction kernel alone, G lanes of a wave per pair."""
+    ax, ay, aoff, bx, by, boff = ps.arrays()
+    return ClipResult(*ctx.team_clip_batch(ax, ay, aoff, bx, by, boff, G))
+
+
 def rings_of(res, p):
     return res.rings(p)
 

@@ -244,7 +244,7 @@ def polyangles(x, y):
 
 
 def frac_corner(S, ids, offsets, grind):
-    """frac_corner.m:1-189 restated (oracle) for the plain case, for the floes ids (1-based) with the grind flags laid
+    """frac_corner.m:1-188 restated (oracle) for the plain case, for the floes ids (1-based) with the grind flags laid
     out at `offsets` -> (npieces per floe, piece_off, pieces [P x 12], rings: list of 2 x m closed c_alpha)."""
     L = lib()
     ip = ctypes.POINTER(ctypes.c_int32)

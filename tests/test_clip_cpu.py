@@ -192,3 +192,20 @@ def test_sweep_inside_a_byte_budget(budget):
             assert g.compare(base, h, len(ps)) == []
             total += len(ps); done += h.budget[0]
     assert done > 0.2 * total          # (the small classes hold the short rings; the large ones nearly everything)
+
+
+@pytest.mark.parametrize("lanes", [16, 32])
+def test_team_form_of_the_clip_matches_the_reference(lanes):
+    """teamclip.hpp (the clip inside the pair-interaction kernel: one scanline per lane, its lanes as fibers here) against
+    the reference's Clipper build: every pair identical or handed on (100; 104 = wants the 32-lane team), and the hand-on
+    rates those of the corpora (tests/test_team_clip_gpu.py runs the same on the device)."""
+    ref = g.ref_lib()
+    for gen, n, least in ((g.convex_pairs, 4000, 0.6), (g.neighbour_pairs, 4000, 0.5), (g.monotone_pairs, 3000, 0.3), (g.hull_pairs, 3000, 0.02)):
+        ps = gen(n, seed=99 + lanes)
+        t = g.run_team(ps, lanes)
+        assert lanes == 16 or not (t.status == 104).any()
+        t.status[t.status == 104] = 100
+        base = g.run_ref(ps, 1) if ref is not None else g.run_host(ps, 1)
+        bad, done = g.compare_where_done(base, t, len(ps))
+        assert bad == [], bad[:5]
+        assert done >= least * len(ps), (gen.__name__, done)
