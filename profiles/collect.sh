@@ -16,8 +16,8 @@ echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_write -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-clip-line > /dev/null 2> $out/${tag}_write.err
 echo "write pass done"
 python3 profiles/make_summaries.py $tag $out/${tag}_stats $out/${tag}_fetch $out/${tag}_write
-python3 profiles/timed_region.py $out/${tag}_stats 100 $out/${tag}_kernel_stats_timed_region.csv > /dev/null
 cp profiles/${tag}_* $out/ 2>/dev/null || true
+python3 profiles/timed_region.py $out/${tag}_stats 100 $out/${tag}_kernel_stats_timed_region.csv > /dev/null
 # keep the merged-back output small: the raw traces are not needed once summarised
 rm -rf $out/${tag}_fetch $out/${tag}_write
 find $out/${tag}_stats -name "*kernel_trace.csv" -size +40M -delete

@@ -4,7 +4,7 @@ usage: python profiles/kernel_meta.py [pattern ...]   (substring filters on the 
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-so = os.path.join(ROOT, "subzero_amd", "csrc", "libsubzero_hip.so")
+so = os.environ.get('SUBZERO_HIP_LIB') or os.path.join(ROOT, 'subzero_amd', 'csrc', 'libsubzero_hip.so')
 pats = sys.argv[1:]
 with tempfile.TemporaryDirectory() as d:
     # every object of the library carries its own bundle: list the fat binary sections through the bundler

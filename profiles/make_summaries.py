@@ -48,24 +48,7 @@ def main():
     tag, stats, fetch, write = sys.argv[1:5]
     here = os.path.dirname(os.path.abspath(__file__))
     shutil.copy(glob.glob(os.path.join(stats, "*", "*kernel_stats.csv"))[0], os.path.join(here, tag + "_kernel_stats.csv"))
-    # the same statistics over the TIMED region of that command alone (the last 100 of the 120 steps): rocprofv3's own
-    # summary averages the warm-up launches in too (one of the first team passes takes 12 ms while the runtime sets up
-    # the kernel's scratch), bench.py's roofline object does not
-    Ds = durations(stats)
-    steps = len(Ds[HOT]); timed = steps - 20 if steps > 20 else steps
-    with open(os.path.join(here, tag + "_kernel_stats_timed_region.csv"), "w") as out:
-        out.write('"Name","CallsPerStep","AverageNs","MinNs","MaxNs","NsPerStep"\n')
-        rows = []
-        for k, v in Ds.items():
-            if len(v) < steps or len(v) % steps:      # per-step kernels only (not the clip batch / post-step entries)
-                continue
-            per = len(v) // steps
-            w = v[-timed * per:]
-            rows.append((k, per, sum(w) / len(w), min(w), max(w), sum(w) / timed))
-        rows.sort(key=lambda r: -r[5])
-        for r in rows:
-            out.write('"%s",%d,%.1f,%.0f,%.0f,%.1f\n' % r)
-        out.write('"(sum over the kernels of a step)",,,,,%.1f\n' % sum(r[5] for r in rows))
+    # (the statistics over the TIMED region alone, with the idle time between the kernels: profiles/timed_region.py)
     F, Wr, D = counters(fetch, "FETCH_SIZE"), counters(write, "WRITE_SIZE"), durations(fetch)
     rows = []
     for k in F:

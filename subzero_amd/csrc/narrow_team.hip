@@ -26,7 +26,7 @@ extern "C" int szDebugTeamPhases(unsigned long long *out, int nwaves) {
 
 namespace {
 #ifndef SZ_TEAM_WAVES
-#define SZ_TEAM_WAVES 3   // waves per SIMD the kernel is built for: 168 registers (at 128, for 4 waves, it spills 76 of them and is 8 % slower)
+#define SZ_TEAM_WAVES 4   // waves per SIMD the kernel is built for: 128 registers (round 4: team-uniform values kept in the block across the clips)
 #endif
 // One launch for the three lists of pair_classify (counts on the device); a wave takes four pairs of 16 lanes (or two
 // of 32) at a time.  The grid is laid out from what the lists held in the step before -- any size is correct, the
@@ -38,6 +38,11 @@ namespace {
 //                                      (measured), short-lived ones one by one leave the chip a third empty
 __global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team(int wide_blocks, int hot_blocks, int cold_blocks, int ratio, Floes F, Params P, Work W) {
   __shared__ sztm::TeamBlock blocks[4];
+#if defined(SZ_TEAM_LDS_PAD)
+  // tuning builds only (make team_variant): idle LDS that caps the waves per SIMD below what the registers allow
+  __shared__ volatile int lds_pad[SZ_TEAM_LDS_PAD / 4];
+  if (wide_blocks < 0) lds_pad[threadIdx.x] = hot_blocks;
+#endif
 #if defined(SZ_TEAM_PHASES)
   if (threadIdx.x == 0) { for (int k = 0; k < SZ_TP_SLOTS; ++k) sz_tp_acc[k] = 0; sz_tp_cur = 0; sz_tp_base = 0; sz_tp_last = wall_clock64(); sz_tp_acc[48] = sz_tp_last; }
 #endif
@@ -46,20 +51,26 @@ __global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team(int wide_bloc
     const sztm::Team<32> T = sztm::Team<32>::here();
     const int tw = sztm::Team<32>::index_in_wave();
     const i64 n = (i64)W.counters[C_WIDE];
-    for (i64 t = (i64)b * 2 + tw; t < n; t += (i64)wide_blocks * 2) narrow_team((i64)W.wide_list[t], T, &blocks[tw], F, P, W, false, true);
+    for (i64 t = (i64)b * 2 + tw; t < n; t += (i64)wide_blocks * 2) {
+      sztm::Team<32> Tp = T; int twp = tw;
+      sztm::opaque(Tp.lane); sztm::opaque(twp);               // (team.hpp opaque: nothing of the lane hoisted out of this loop)
+      narrow_team((i64)W.wide_list[t], Tp, &blocks[twp], F, P, W, false, true);
+    }
   } else {
     const sztm::Team<16> T = sztm::Team<16>::here();
     const int tw = sztm::Team<16>::index_in_wave();
     // hot and cold workgroups take turns in the order of dispatch (`ratio` hot ones, then a cold one): both kinds run
     // for tens of microseconds, and a kind left for the end would leave the chip part empty for its whole duration
     const int k = b - wide_blocks, g = k / (ratio + 1), r = k % (ratio + 1);
-    if (r < ratio) {
-      const int h = g * ratio + r;
-      const i64 n = (i64)W.counters[C_LIVE];
-      if (h < hot_blocks) for (i64 t = (i64)h * 4 + tw; t < n; t += (i64)hot_blocks * 4) narrow_team((i64)W.live_list[t], T, &blocks[tw], F, P, W, false, true);
-    } else if (g < cold_blocks) {
-      const i64 n = (i64)W.counters[C_COLD];
-      for (i64 t = (i64)g * 4 + tw; t < n; t += (i64)cold_blocks * 4) narrow_team((i64)W.cold_list[t], T, &blocks[tw], F, P, W, true, true);
+    // (one instance of the model for both kinds: `cold` only says whether the no-row certificate is tried first)
+    const bool hot = r < ratio;
+    const int blk = hot ? g * ratio + r : g, nblk = hot ? hot_blocks : cold_blocks;
+    const int *list = hot ? W.live_list : W.cold_list;
+    const i64 n = (i64)W.counters[hot ? C_LIVE : C_COLD];
+    if (blk < nblk) for (i64 t = (i64)blk * 4 + tw; t < n; t += (i64)nblk * 4) {
+      sztm::Team<16> Tp = T; int twp = tw;
+      sztm::opaque(Tp.lane); sztm::opaque(twp);
+      narrow_team((i64)list[t], Tp, &blocks[twp], F, P, W, !hot, true);
     }
   }
 #if defined(SZ_TEAM_PHASES)

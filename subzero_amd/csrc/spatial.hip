@@ -63,8 +63,8 @@ int szSpatialInit(szContext *ctx, int rank, int world, const double *edges, doub
   for (int r = 0; r < world; ++r) if (!(edges[r] < edges[r + 1])) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szSpatialInit: strip edges must ascend");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   const double reach = 2 * S->rmax_max_all;
-  if (!(halo > 0)) halo = 2 * reach;
-  if (halo < 2 * reach) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szSpatialInit: the halo must be at least 2 x (2 max rmax) = %g m wide", 2 * reach);
+  if (!(halo > 0)) halo = reach;
+  if (halo < reach) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szSpatialInit: the halo must be at least the reach of a pair, 2 max rmax = %g m, wide", reach);
   if (world > 1)
     for (int r = 0; r < world; ++r)
       if (edges[r + 1] - edges[r] < halo)

@@ -862,7 +862,6 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   SZTM_PHASE(0);
   const int i = W.pair_i[p], j = W.pair_j[p];
   const bool boundary = (j == WALL);
-  const i64 nvoff = W.pair_nvoff[p];
   // lane l: word l of the records, vertex l of the rings
   {
     const int l = T.lane & 15, half = T.lane >> 4;               // (32-lane teams: the upper half loads the partner's)
@@ -878,17 +877,20 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   }
   T.sync(TEAM_SITE);
   const int n1 = (int)B->u.rec[0][REC_NSTORED], n2 = boundary ? 4 : (int)B->u.rec[1][REC_NSTORED];
-  const i64 bytes = scratch_bytes_for((i64)n1 + n2, 1);
-  const i64 off = (i64)SCR_PER_V * (nvoff + 2 * p) + (i64)SCR_PER_PAIR * p;
   // (prepared: pair_classify has written the pair's words -- slice, no rows, status OK -- and checked the arena)
-  if (T.lane == 0 && !prepared) {
-    W.pair_scr[p] = off; W.pair_mult[p] = 1;
-    W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
-    W.pair_rowoff[p] = off / 8;
-  }
-  if (!prepared && !(off + bytes <= W.scratch_bytes)) {
-    if (T.lane == 0) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); }
-    return;
+  if (!prepared) {
+    const i64 nvoff = W.pair_nvoff[p];
+    const i64 bytes = scratch_bytes_for((i64)n1 + n2, 1);
+    const i64 off = (i64)SCR_PER_V * (nvoff + 2 * p) + (i64)SCR_PER_PAIR * p;
+    if (T.lane == 0) {
+      W.pair_scr[p] = off; W.pair_mult[p] = 1;
+      W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
+      W.pair_rowoff[p] = off / 8;
+    }
+    if (!(off + bytes <= W.scratch_bytes)) {
+      if (T.lane == 0) { W.pair_status[p] = szv::ST_WORKSPACE; atomic_add(&W.counters[C_ERR_ARENA], 1ULL); }
+      return;
+    }
   }
   const szc::Box bx1 = {B->u.rec[0][REC_BX0], B->u.rec[0][REC_BX1], B->u.rec[0][REC_BY0], B->u.rec[0][REC_BY1]};
   const szc::Box bx2 = {B->u.rec[1][REC_BX0], B->u.rec[1][REC_BX1], B->u.rec[1][REC_BY0], B->u.rec[1][REC_BY1]};
@@ -899,18 +901,22 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   sg.cold = cold;
   // the bodies (contact.hpp Body) stay in the block: words REC_X .. REC_AREA of the records, in that order
   static_assert((int)REC_X == (int)sztm::BODY_X && (int)REC_AREA == (int)sztm::BODY_AREA && (int)REC_KSI == (int)sztm::BODY_KSI, "record and body word order");
+  static_assert((int)sztm::BODY_WORDS == (int)sztm::BODY_AREA + 2, "the spare word of a body holds the entry's index");
   if (T.lane < (int)sztm::BODY_WORDS) {
     const int w = T.lane;
     // (a pair with the domain box never gets as far as its second body here: it is answered from the floe's bounding
-    // box or handed to the general sweep)
-    B->body[0][w] = B->u.rec[0][w]; B->body[1][w] = B->u.rec[1][w];
+    // box or handed to the general sweep.  The spare word: the entries i, j -- whatever every lane of the team holds
+    // alike costs each of them a register for the whole model, so the tail below reads them back from the block)
+    const bool spare = w == (int)sztm::BODY_WORDS - 1;
+    B->body[0][w] = spare ? (double)i : B->u.rec[0][w]; B->body[1][w] = spare ? (double)j : B->u.rec[1][w];
   }
   T.sync(TEAM_SITE);
   szc::PairOut out;
-  double row[5] = {0, 0, 0, 0, 0};
+  double row[5];                         // (written when out.nrows == 1)
   sztm::BoundaryBox bb = {P.bnd_xmax, P.bnd_xmin, P.bnd_ymax, P.bnd_ymin, P.bnd_area, P.bnd_rect != 0};
   const int st = sztm::pair_contact_team(T, B, sg, bx1, bx2, boundary, bb, P.PERIODIC != 0, P.Modulus, P.dt, P.mu, P.nu, row, out);
   if (T.lane != 0) return;
+  const int i2 = (int)B->body[0][sztm::BODY_WORDS - 1], j2 = (int)B->body[1][sztm::BODY_WORDS - 1];
   if (!prepared || st != szv::ST_OK) W.pair_status[p] = st;
   if (st == szc::ST_DEFER_BIG) { const unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL); W.big_list[k] = (int)p; return; }
   if (st == szc::ST_DEFER || st == sztm::ST_DEFER_WIDE || st == szv::ST_WORKSPACE || st == szv::ST_OUT_CAPACITY) {
@@ -925,10 +931,11 @@ SZ_TEAM void narrow_team(i64 p, const sztm::Team<G> &T, sztm::TeamBlock *B, cons
   if (sabs != 0) flag |= 4;                                       // :135 / :157
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
   if (flag & 4) {
-    double *rows = (double *)(W.scratch + off);
+    const i64 off2 = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;   // (`off` again, from the pair's own word)
+    double *rows = (double *)(W.scratch + off2);
     rows[0] = row[0]; rows[1] = row[1]; rows[2] = row[2]; rows[3] = row[3]; rows[4] = row[4];
     W.pair_nrows[p] = out.nrows;
-    pair_done(p, i, j, out.nrows, W);
+    pair_done(p, i2, j2, out.nrows, W);
   }
   if (flag) W.pair_flag[p] = flag;
 }

@@ -127,6 +127,18 @@ struct Team {
   }
 };
 
+// `v` as a value the compiler cannot see through.  Inside a loop over pairs (or over the two clips of a pair) everything
+// that depends only on the lane number -- ring and vertex of the lane, its LDS addresses, masks -- is loop-invariant: the
+// compiler hoists it out of the loop and holds it in registers across the whole body (40 of them, measured), which costs
+// the kernel a wave per SIMD.  A lane number laundered at the top of the body keeps those values where they are used.
+SZ_TEAM void opaque(int &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+
 // call sites: the line number tells the host runtime where a lane stands
 #define TEAM_SITE (__LINE__ * 256)
 

@@ -31,7 +31,12 @@ struct TeamBlock {
   double mx[2][T_NV], my[2][T_NV];           // both rings in metres (c_alpha + position)
   union Coord { i64 f; double m; };
   Coord qx[2][T_CAPV], qy[2][T_CAPV];        // the overlap regions of clip 1 / clip 2: fixed point out of the clip, metres afterwards
-  double px[T_CAPP], py[T_CAPP];             // InterX crossings: sorted, unique
+  // InterX crossings (sorted, unique) -- and, while no crossings are held, the pair's team-uniform values that must
+  // survive a clip: a value every lane holds alike costs a vector register in each of them, and the clip needs the
+  // registers (the kernel is built for four waves per SIMD: 128 registers).  keep[0..3]: the first floe's box until the
+  // merge flags (:54-60), before InterX; keep[0..8]: area, centroid, direction, dl, contact point, stiffness across the
+  // second clip, after the crossings' last use.
+  union { struct { double px[T_CAPP], py[T_CAPP]; }; double keep[2 * T_CAPP]; };
   double body[2][BODY_WORDS];                // what floe_interactions.m reads of floe1 / floe2 (contact.hpp Body)
   union {
     double rec[2][16];                       // the two entries' records as loaded (step_core.hpp narrow_team), until the first clip
@@ -349,9 +354,10 @@ struct BoundaryBox { double xmax, xmin, ymax, ymin, area; bool rect; };
 // everything the rings hold, formed once per floe and step -- step_core.hpp cell_count); row: the contact row
 // [Fx, Fy, Px, Py, overlap] when out.nrows == 1.  Every lane returns the same status, `out` and row.
 template <int G>
-SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, const szc::Box &b1, const szc::Box &b2, bool boundary,
+SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, const szc::Box &b1_in, const szc::Box &b2, bool boundary,
                               const BoundaryBox &bb, bool periodic, double Modulus, double dt, double mu, double nu, double *row, szc::PairOut &out) {
   SZTM_PHASE(1);
+  const szc::Box &b1 = b1_in;          // (valid up to the first clip; after it the box is read back from B->keep)
   out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   if (boundary) {   // only floes at the walls need the clip against the box (general sweep: the box has horizontal edges)
     // (contact.hpp well_inside_box: the floe's box more than 1e-6 m inside an axis-aligned rectangular domain box;
@@ -375,17 +381,24 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, 
     if (!(amin < 0.55 * mind(B->body[0][BODY_AREA], B->body[1][BODY_AREA]))) amin = 0;
     if (certainly_no_rows(T, B, n1, n2, cmax, amin)) { szc::no_contact(out); return szv::ST_OK; }
   }
+  if (T.lane == 0) { B->keep[0] = b1.x0; B->keep[1] = b1.x1; B->keep[2] = b1.y0; B->keep[3] = b1.y1; }
   T.sync(TEAM_SITE);
   SZTM_PHASE(2);
-  // ---- the first clip (:29), the model up to the force direction, the second clip (:140-155): one instance of the
-  // clip in the code, passed through twice (the kernel must stay within the instruction cache) ----
+  // ---- the first clip (:29), the model up to the force direction, the second clip (:140-155) ----
   int nr = 0, nt = 0, tslot = 0;
-  double Ar = 0, cx = 0, cy = 0, fdx = 0, fdy = 0, dl = 0, pcx = 0, pcy = 0, Force_factor = 0;
-  const double Gm = Modulus / (2 * (1 + nu));
+  double sx = 0, sy = 0;                 // the shift of the second clip (the force direction; dead once its rings are staged)
+  // (SZ_TEAM_ONE_CLIP: one instance of the clip in the code, passed through twice -- smaller code, but what the clip
+  // holds then stays live around the loop: 24 registers more than the kernel's 128)
+#if defined(SZ_TEAM_ONE_CLIP)
 #pragma nounroll
+#else
+#pragma unroll
+#endif
   for (int pass = 0; pass < 2; ++pass) {
   int nout = 0;
-  const int st = clip_staged(T, B, n1, n2, pass == 1, fdx, fdy, pass, &nout);
+  Team<G> Tc = T;
+  opaque(Tc.lane);
+  const int st = clip_staged(Tc, B, n1, n2, pass == 1, sx, sy, pass, &nout);
   if (st == ST_WIDE) return ST_DEFER_WIDE;
   if (st == szx::ST_BAIL) return szc::ST_DEFER;
   if (st != szv::ST_OK) return st;
@@ -395,6 +408,7 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, 
   const RegionM R = {B->qx[0], B->qy[0], nr};
   SZTM_PHASE(3);
   // ---- pair_finish ----
+  double Ar = 0, cx = 0, cy = 0, fdx = 0, fdy = 0, dl = 0, pcx = 0, pcy = 0, Force_factor = 0;
   const double area1 = B->body[0][BODY_AREA], area2 = B->body[1][BODY_AREA];
   double h1 = B->body[0][BODY_H], h2 = B->body[1][BODY_H];                                // :10-21
   double r1 = ::sqrt(area1), r2 = ::sqrt(area2);
@@ -409,8 +423,9 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, 
   SZTM_PHASE(4);
   {                                                                                       // :54-60
     const double bxmax = bb.xmax, bxmin = bb.xmin, bymax = bb.ymax, bymin = bb.ymin, barea = bb.area;
-    // (the box of the staged ring: the closing copy left out is a copy of vertex 0)
-    const bool inside = (b1.x1 < bxmax && b1.x0 > bxmin && b1.y1 < bymax && b1.y0 > bymin);
+    // (the box of the staged ring: the closing copy left out is a copy of vertex 0; kept in the block across the clip)
+    const double b1x0 = B->keep[0], b1x1 = B->keep[1], b1y0 = B->keep[2], b1y1 = B->keep[3];
+    const bool inside = (b1x1 < bxmax && b1x0 > bxmin && b1y1 < bymax && b1y0 > bymin);
     if (inside || area2 < 0.95 * barea || periodic) {
       double sumAr = 0;
       if (nreg) sumAr += Ar;
@@ -489,8 +504,21 @@ SZ_TEAM int pair_contact_team(const Team<G> &T, TeamBlock *B, const Staged &sg, 
   }
   SZTM_PHASE(6);
   // :140-155 shift ring 1 by the unit direction and clip again (not shifted: the first clip again, same rings, same result)
-  if (dl < 0.1) { fdx = 0; fdy = 0; nt = nr; tslot = 0; break; }
+  const bool again = !(dl < 0.1);
+  if (!again) { fdx = 0; fdy = 0; }
+  // (the crossings have had their last use: their room keeps what the rest of the model needs across the second clip)
+  T.sync(TEAM_SITE);
+  if (T.lane == 0) {
+    B->keep[0] = Ar; B->keep[1] = cx; B->keep[2] = cy; B->keep[3] = fdx; B->keep[4] = fdy; B->keep[5] = dl;
+    B->keep[6] = pcx; B->keep[7] = pcy; B->keep[8] = Force_factor;
   }
+  sx = fdx; sy = fdy;
+  if (!again) { nt = nr; tslot = 0; break; }
+  }
+  T.sync(TEAM_SITE);
+  const double Ar = B->keep[0], cx = B->keep[1], cy = B->keep[2], dl = B->keep[5], pcx = B->keep[6], pcy = B->keep[7], Force_factor = B->keep[8];
+  double fdx = B->keep[3], fdy = B->keep[4];
+  const double Gm = Modulus / (2 * (1 + nu));
   const RegionM R = {B->qx[0], B->qy[0], nr};
   SZTM_PHASE(7);
   if (nt > 0) {                                                                            // :156-165 (one region at most)

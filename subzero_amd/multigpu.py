@@ -204,7 +204,7 @@ def strip_edges(floes, world, Lx, halo=None, axis=0):
     (default 2 x reach = 4 max rmax) wide.  Every rank computes the same edges from the same uploaded array."""
     rmax = float(np.max(floes.rmax))
     bin_ = 2 * rmax
-    halo = 4 * rmax if halo is None else halo
+    halo = 2 * rmax if halo is None else halo
     c = floes.Yi if axis else floes.Xi
     x = np.sort(c[np.isfinite(floes.Xi) & np.isfinite(floes.Yi) & (floes.alive > 0)])
     edges = [-float(Lx)]

@@ -487,8 +487,8 @@ int host_spatial_init(HFloes *hf, int rank, int world, const double *edges, doub
   const int n = hf->n;
   double rm = 0;
   for (int i = 0; i < n; ++i) rm = szc::maxd(rm, hf->rmax[i]);
-  if (!(halo > 0)) halo = 4 * rm;          // 2 x reach, reach = 2 max rmax
-  if (halo < 4 * rm) return -2;
+  if (!(halo > 0)) halo = 2 * rm;          // reach = 2 max rmax
+  if (halo < 2 * rm) return -2;
   if (world > 1) for (int r = 0; r < world; ++r) if (edges[r + 1] - edges[r] < halo) return -2;
   g_sp_rank = rank; g_sp_world = world; g_sp_halo = halo;
   g_sp_edges.assign(edges, edges + world + 1);
