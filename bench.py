@@ -120,19 +120,22 @@ def clip_kernel_line(ctx, with_cpu, n_pairs=20000, cpu_pairs=3000):
 
 
 def post_step_line(sim, S, P, reps=3):
-    """Call-level milliseconds (wall clock around the C-ABI call: kernels, transfers, host work) of the post-step entries
-    of SURVEY.md 8(f) on the resident field, next to the cadence the reference driver calls them at."""
+    """Call-level milliseconds (wall clock around the C-ABI call: kernels, transfers, host work inside the library; the
+    Python wrapper's own time beside it) of the post-step entries of SURVEY.md 8(f) on the resident field, next to the
+    cadence the reference driver calls them at."""
     from subzero_amd import capi, corners
     rng = np.random.default_rng(7)
     keep = corners.keep_mask(rng.uniform(size=S.n), S.OverlapArea, S.area, 0)
     ids = (np.nonzero(~keep)[0] + 1).astype(np.int32)                     # Subzero.m:341-348: ~70 % of the floes
 
     def timed(fn):
+        """(ms of the C-ABI call itself, ms of the Python wrapper around it -- array allocation, result views --, result)"""
         fn()
+        c = 0.0
         t0 = time.perf_counter()
         for _ in range(reps):
-            out = fn()
-        return (time.perf_counter() - t0) / reps * 1e3, out
+            out = fn(); c += sim.last_call_ms
+        return (c / reps, (time.perf_counter() - t0) / reps * 1e3), out
     ms_c, (off, cnt, ang, da, n0, k_c) = timed(lambda: sim.corner_candidates(ids, 0, P.c2_boundary))
     grind, frac = corners.grind_flags(off, cnt, ang, da, rng.uniform(size=corners.draws_needed(cnt)))
     sel = np.nonzero(frac)[0]
@@ -145,11 +148,11 @@ def post_step_line(sim, S, P, reps=3):
     ms_e, (eul, k_e) = timed(lambda: sim.eulerian_data(40, 40, 0, P.c2_boundary, True))
     fids = ids[:max(1, len(ids) // 20)]
     ms_d, _ = timed(lambda: sim.fracture_deform(fids))
-    return {"corner_candidates": {"call_ms": ms_c, "kernel_ms": k_c, "floes": int(len(ids)), "cadence": "every 10th step, ~70 % of the floes (Subzero.m:339-352)"},
-            "corner_cuts": {"call_ms": ms_k, "kernel_ms": k_k, "floes": int(len(sel)), "cut_on_device": int((npieces > 0).sum()), "pieces": int(len(pieces)),
+    return {"corner_candidates": {"call_ms": ms_c[0], "python_wrapper_ms": ms_c[1], "kernel_ms": k_c, "floes": int(len(ids)), "cadence": "every 10th step, ~70 % of the floes (Subzero.m:339-352)"},
+            "corner_cuts": {"call_ms": ms_k[0], "python_wrapper_ms": ms_k[1], "kernel_ms": k_k, "floes": int(len(sel)), "cut_on_device": int((npieces > 0).sum()), "pieces": int(len(pieces)),
                             "cadence": "with corner_candidates, the floes with more than one corner to break (corners.m:94-98)"},
-            "eulerian_data": {"call_ms": ms_e, "kernel_ms": k_e, "grid": "40 x 40", "cadence": "every 150th step, or every step with AVERAGE (Subzero.m:304-314)"},
-            "fracture_deform": {"call_ms": ms_d, "floes": int(len(fids)), "cadence": "every 75th step, the floes picked by fracture.m:51-55 (Subzero.m:220)"}}
+            "eulerian_data": {"call_ms": ms_e[0], "python_wrapper_ms": ms_e[1], "kernel_ms": k_e, "grid": "40 x 40", "cadence": "every 150th step, or every step with AVERAGE (Subzero.m:304-314)"},
+            "fracture_deform": {"call_ms": ms_d[0], "python_wrapper_ms": ms_d[1], "floes": int(len(fids)), "cadence": "every 75th step, the floes picked by fracture.m:51-55 (Subzero.m:220)"}}
 
 
 def other_fields_line(ctx):

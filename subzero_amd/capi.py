@@ -2,6 +2,7 @@
 missing (there is no CPU fallback by design)."""
 import ctypes
 import os
+import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -410,8 +411,10 @@ class FloeInteractions:
         out = np.zeros((18, Nx, Ny))        # [field][ii][jj]: column-major Ny x Nx per field
         ms = ctypes.c_double()
         self.ctx.L.szEulerianData.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp]
-        self.ctx.check(self.ctx.L.szEulerianData(self.ctx.h, Nx, Ny, Nb, cb.ctypes.data_as(_dp), int(periodic),
-                                                 out.ctypes.data_as(_dp), ctypes.byref(ms)), "szEulerianData")
+        t0 = time.perf_counter()
+        rc = self.ctx.L.szEulerianData(self.ctx.h, Nx, Ny, Nb, cb.ctypes.data_as(_dp), int(periodic), out.ctypes.data_as(_dp), ctypes.byref(ms))
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3
+        self.ctx.check(rc, "szEulerianData")
         return {k: out[q].T.copy() for q, k in enumerate(self.EULERIAN_FIELDS)}, ms.value
 
     def corner_candidates(self, ids, Nb, c2_boundary):
@@ -420,7 +423,8 @@ class FloeInteractions:
         ids = np.ascontiguousarray(ids, np.int32)
         nsub = len(ids)
         vo = self.floes.vert_off
-        total = int(sum(int(vo[i]) - int(vo[i - 1]) for i in ids if 1 <= i <= self.floes.n))
+        ok = ids[(ids >= 1) & (ids <= self.floes.n)].astype(np.int64)
+        total = int((vo[ok].astype(np.int64) - vo[ok - 1]).sum())
         offsets = np.zeros(nsub + 1, np.int32); count = np.zeros(max(nsub, 1), np.int32)
         ang = np.zeros(total + 1); da = np.zeros(total + 1, np.uint8)
         n_ext = ctypes.c_int32(); ms = ctypes.c_double()
@@ -428,10 +432,12 @@ class FloeInteractions:
         u8 = ctypes.POINTER(ctypes.c_uint8)
         self.ctx.L.szCornerCandidates.argtypes = [_vp, _ip, ctypes.c_int, ctypes.c_int, _dp, _ip, _ip, _dp, u8, ctypes.c_int64,
                                                   _ip, _dp]
-        self.ctx.check(self.ctx.L.szCornerCandidates(self.ctx.h, ids.ctypes.data_as(_ip), nsub, int(Nb), cb.ctypes.data_as(_dp),
-                                                     offsets.ctypes.data_as(_ip), count.ctypes.data_as(_ip), ang.ctypes.data_as(_dp),
-                                                     da.ctypes.data_as(u8), total, ctypes.byref(n_ext), ctypes.byref(ms)),
-                       "szCornerCandidates")
+        t0 = time.perf_counter()
+        rc = self.ctx.L.szCornerCandidates(self.ctx.h, ids.ctypes.data_as(_ip), nsub, int(Nb), cb.ctypes.data_as(_dp),
+                                           offsets.ctypes.data_as(_ip), count.ctypes.data_as(_ip), ang.ctypes.data_as(_dp),
+                                           da.ctypes.data_as(u8), total, ctypes.byref(n_ext), ctypes.byref(ms))
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3       # wall clock of the C-ABI call itself (bench.py)
+        self.ctx.check(rc, "szCornerCandidates")
         return offsets, count[:nsub], ang[:total], da[:total], n_ext.value, ms.value
 
     def corner_cuts(self, ids, offsets, grind):
@@ -448,9 +454,12 @@ class FloeInteractions:
         u8 = ctypes.POINTER(ctypes.c_uint8)
         L = self.ctx.L
         L.szCornerCuts.argtypes = [_vp, _ip, ctypes.c_int, _ip, u8, _ip, _ip, _dp, ctypes.c_int64, _ip, _dp, _dp, ctypes.c_int64, _dp]
-        self.ctx.check(L.szCornerCuts(self.ctx.h, ids.ctypes.data_as(_ip), nsel, offsets.ctypes.data_as(_ip), grind.ctypes.data_as(u8),
-                                      npieces.ctypes.data_as(_ip), poff.ctypes.data_as(_ip), pieces.ctypes.data_as(_dp), cap_p,
-                                      roff.ctypes.data_as(_ip), rx.ctypes.data_as(_dp), ry.ctypes.data_as(_dp), cap_r, ctypes.byref(ms)), "szCornerCuts")
+        t0 = time.perf_counter()
+        rc = L.szCornerCuts(self.ctx.h, ids.ctypes.data_as(_ip), nsel, offsets.ctypes.data_as(_ip), grind.ctypes.data_as(u8),
+                            npieces.ctypes.data_as(_ip), poff.ctypes.data_as(_ip), pieces.ctypes.data_as(_dp), cap_p,
+                            roff.ctypes.data_as(_ip), rx.ctypes.data_as(_dp), ry.ctypes.data_as(_dp), cap_r, ctypes.byref(ms))
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3
+        self.ctx.check(rc, "szCornerCuts")
         P = int(poff[nsel])
         rings = [np.stack([rx[roff[q]:roff[q + 1]], ry[roff[q]:roff[q + 1]]]) for q in range(P)]
         return npieces[:nsel], poff, pieces[:P], rings, ms.value
@@ -465,9 +474,12 @@ class FloeInteractions:
         cap = 4 * int(self.floes.vert_off[-1]) + 64 * nsel + 64
         cx = np.zeros(cap); cy = np.zeros(cap)
         self.ctx.L.szFractureDeform.argtypes = [_vp, _ip, ctypes.c_int, _ip, _dp, _dp, _dp, _ip, _dp, _dp, ctypes.c_int64]
-        self.ctx.check(self.ctx.L.szFractureDeform(self.ctx.h, ids.ctypes.data_as(_ip), nsel, changed.ctypes.data_as(_ip), X.ctypes.data_as(_dp),
-                                                   Y.ctypes.data_as(_dp), A.ctypes.data_as(_dp), roff.ctypes.data_as(_ip), cx.ctypes.data_as(_dp),
-                                                   cy.ctypes.data_as(_dp), cap), "szFractureDeform")
+        t0 = time.perf_counter()
+        rc = self.ctx.L.szFractureDeform(self.ctx.h, ids.ctypes.data_as(_ip), nsel, changed.ctypes.data_as(_ip), X.ctypes.data_as(_dp),
+                                         Y.ctypes.data_as(_dp), A.ctypes.data_as(_dp), roff.ctypes.data_as(_ip), cx.ctypes.data_as(_dp),
+                                         cy.ctypes.data_as(_dp), cap)
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3
+        self.ctx.check(rc, "szFractureDeform")
         rings = [np.stack([cx[roff[s]:roff[s + 1]], cy[roff[s]:roff[s + 1]]]) for s in range(nsel)]
         return changed[:nsel], X[:nsel], Y[:nsel], A[:nsel], rings
 

@@ -39,6 +39,9 @@ int szDestroy(szContext *ctx) {
                     &ctx->in_ax, &ctx->in_ay, &ctx->in_aoff, &ctx->in_bx, &ctx->in_by, &ctx->in_boff,
                     &ctx->in_fax, &ctx->in_fay, &ctx->in_fbx, &ctx->in_fby};
   for (DevBuf *b : bufs) sz_release(*b);
+  sz_release(ctx->d_in); sz_release(ctx->d_out);
+  if (ctx->h_in.p) (void)hipHostFree(ctx->h_in.p);
+  if (ctx->h_out.p) (void)hipHostFree(ctx->h_out.p);
   for (int k = 0; k < 3; ++k) {
     if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
     if (ctx->side_join[k]) (void)hipEventDestroy(ctx->side_join[k]);

@@ -14,6 +14,18 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// pinned host memory (hipHostMalloc), grow-only: what an entry's small arrays travel through, packed into ONE transfer
+// each way (a hipMemcpyAsync from or to pageable memory is staged by the runtime and costs tens of microseconds each)
+struct HostStage {
+  char *p = nullptr;
+  size_t cap = 0;
+};
+// layout of several arrays in one buffer, 16-byte aligned
+struct Packer {
+  size_t at = 0;
+  size_t add(size_t bytes) { const size_t o = at; at = (at + bytes + 15) & ~(size_t)15; return o; }
+};
+
 struct szContext {
   int device = 0;
   hipStream_t stream = nullptr;      // the stream everything runs on: own_stream, or the caller's (szSetStream)
@@ -26,6 +38,8 @@ struct szContext {
   // clip path buffers
   DevBuf ws, ovx, ovy, oroff, ov_base, or_base, nrings, status, retry_list, counters;
   DevBuf clip_meta, clip_lists;      // front pass -> sweep pass (clip.hip)
+  HostStage h_in, h_out;             // staging of the post-step entries (corners.hip ...)
+  DevBuf d_in, d_out;
   bool clip_lds_set = false;         // the clip kernels' dynamic-LDS limit has been raised on this context's device
   // Three side streams for everything in the library that runs kernels side by side (the sweep passes of the clip batch,
   // the wall pairs of a step): with the context's own stream that makes four, the number of hardware queues a process
@@ -65,6 +79,14 @@ inline int sz_reserve(szContext *ctx, DevBuf &b, size_t bytes) {
   size_t want = bytes + bytes / 4 + 256;
   SZ_HIP(ctx, hipMalloc(&b.p, want));
   b.cap = want;
+  return SZ_OK;
+}
+inline int sz_stage_reserve(szContext *ctx, HostStage &h, size_t bytes) {
+  if (bytes <= h.cap && h.p) return SZ_OK;
+  if (h.p) { SZ_HIP(ctx, hipHostFree(h.p)); h.p = nullptr; h.cap = 0; }
+  const size_t want = bytes + bytes / 4 + 4096;
+  SZ_HIP(ctx, hipHostMalloc((void **)&h.p, want, hipHostMallocDefault));
+  h.cap = want;
   return SZ_OK;
 }
 inline int sz_side_streams(szContext *ctx) {

@@ -36,8 +36,18 @@ namespace {
 //   the next cold_blocks               cold_list (most stop at the no-row certificate, ~9 us a wave) -- several waves'
 //                                      worth per workgroup: the dispatcher starts ~110 workgroups per microsecond
 //                                      (measured), short-lived ones one by one leave the chip a third empty
-__global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team(int wide_blocks, int hot_blocks, int cold_blocks, int ratio, Floes F, Params P, Work W) {
+#ifndef SZ_TEAM_WPB
+#define SZ_TEAM_WPB 1     // waves per workgroup (each wave on its own: no barrier between them)
+#endif
+__global__ void __launch_bounds__(64 * SZ_TEAM_WPB, SZ_TEAM_WAVES) k_narrow_team(int wide_blocks, int hot_blocks, int cold_blocks, int ratio, Floes F, Params P, Work W) {
+#if SZ_TEAM_WPB == 1
   __shared__ sztm::TeamBlock blocks[4];
+  const int wave = 0;
+#else
+  __shared__ sztm::TeamBlock blocks_all[4 * SZ_TEAM_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a scalar: the same in every lane of the wave)
+  sztm::TeamBlock *blocks = blocks_all + 4 * wave;
+#endif
 #if defined(SZ_TEAM_LDS_PAD)
   // tuning builds only (make team_variant): idle LDS that caps the waves per SIMD below what the registers allow
   __shared__ volatile int lds_pad[SZ_TEAM_LDS_PAD / 4];
@@ -46,7 +56,7 @@ __global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team(int wide_bloc
 #if defined(SZ_TEAM_PHASES)
   if (threadIdx.x == 0) { for (int k = 0; k < SZ_TP_SLOTS; ++k) sz_tp_acc[k] = 0; sz_tp_cur = 0; sz_tp_base = 0; sz_tp_last = wall_clock64(); sz_tp_acc[48] = sz_tp_last; }
 #endif
-  const int b = (int)blockIdx.x;
+  const int b = (int)blockIdx.x * SZ_TEAM_WPB + wave;   // the wave's place in the order of dispatch
   if (b < wide_blocks) {
     const sztm::Team<32> T = sztm::Team<32>::here();
     const int tw = sztm::Team<32>::index_in_wave();
@@ -209,7 +219,7 @@ void sz_launch_narrow_team(hipStream_t st, i64 count, i64 hot, i64 cold, i64 wid
   i64 ratio = (hb + cb / 2) / cb;                       // hot workgroups per cold one in the order of dispatch
   if (ratio < 1) ratio = 1;
   const i64 groups = std::max((hb + ratio - 1) / ratio, cb);
-  hipLaunchKernelGGL(k_narrow_team, dim3((unsigned)(wb + groups * (ratio + 1))), dim3(64), 0, st, (int)wb, (int)hb, (int)cb, (int)ratio, F, P, W);
+  hipLaunchKernelGGL(k_narrow_team, dim3((unsigned)((wb + groups * (ratio + 1) + SZ_TEAM_WPB - 1) / SZ_TEAM_WPB)), dim3(64 * SZ_TEAM_WPB), 0, st, (int)wb, (int)hb, (int)cb, (int)ratio, F, P, W);
 }
 // ... over a range of the pair list, unclassified, 32 lanes per pair (the sharded step: a segment of the pair list)
 void sz_launch_narrow_team_range(hipStream_t st, i64 first, i64 count, const Floes &F, const Params &P, const Work &W) {
