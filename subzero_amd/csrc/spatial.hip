@@ -102,7 +102,7 @@ int64_t szSpatialMessageBytes(szContext *ctx, int64_t cap_rec, int64_t cap_dbl, 
 static SpatialGeom geom_of(const StepState *S, int periodic) {
   SpatialGeom g;
   g.rank = S->sp_rank; g.world = S->sp_world; g.periodic = periodic;
-  g.lo = S->sp_edges[S->sp_rank]; g.hi = S->sp_edges[S->sp_rank + 1]; g.halo = S->sp_halo;
+  g.lo = S->sp_edges[S->sp_rank]; g.hi = S->sp_edges[S->sp_rank + 1]; g.halo = S->sp_halo; g.rmax_max = S->rmax_max_all;
   g.has_left = S->sp_world > 1 && (periodic || S->sp_rank > 0);
   g.has_right = S->sp_world > 1 && (periodic || S->sp_rank < S->sp_world - 1);
   g.axis = S->sp_axis;

@@ -10,11 +10,14 @@
 // and Monte-Carlo points exist once: in the owner's rows; they travel only when a floe changes strip.
 //
 // One exchange per step, before the pair phase, with the left and the right neighbour (the strips form a ring when the
-// domain is periodic): the floes within `halo` = 2 x reach (reach = 2 max rmax = the largest rmax_i + rmax_j) of the
-// shared edge -- 26 scalars + ring, 208 + 16 nv bytes each -- and the few floes whose centroid crossed the edge, with
-// their whole state.  2 x reach, because a rank must evaluate the candidate list of every lower-indexed partner of its
-// floes, and such a partner (within reach of the strip) has its own candidates within reach of itself.  With the halo
-// in place each rank runs the unchanged pipeline on what it knows: ghosts (the reference's rule, from the rings it has),
+// domain is periodic): the floes that can be a partner of a floe beyond the shared edge -- floe i within rmax_i + max rmax
+// of it (the candidate test of floe_interactions_all.m:101-103 is |c_i - c_j| < rmax_i + rmax_j, and c_j lies beyond the
+// edge) -- 26 scalars + ring, 208 + 16 nv bytes each -- and the few floes whose centroid crossed the edge, with their
+// whole state.  (Rounds 2-3 sent everything within 4 max rmax: "a rank must evaluate the candidate list of every
+// lower-indexed partner of its floes".  It need not evaluate that list WHOLE: of a halo floe k's pairs only those with
+// an owned floe are relevant (pair_relevant), and whether (k, i) is a candidate depends on k, i and the images of i
+// alone -- the `mems` rule of :101-113 compares FloeNums, and entries of other floes never carry i's number.  So k's
+// other partners may be absent.)  With the halo in place each rank runs the unchanged pipeline on what it knows: ghosts (the reference's rule, from the rings it has),
 // grid, candidate lists, the pairs that involve a floe it owns (a pair between two ranks' floes is evaluated by both:
 // same inputs, same arithmetic, same rows -- nothing is sent back), contact rows, and calc_trajectory for its own floes.
 // Results for owned floes are bit-identical to the single-GPU step (tests/test_spatial_*.py).
@@ -29,7 +32,8 @@ enum { SP_OK = 0, SP_OVERFLOW = 1 };
 struct SpatialGeom {
   int rank, world, periodic;
   double lo, hi;        // my strip [lo, hi)
-  double halo;          // width of the halo region along x
+  double halo;          // width of the halo region along the strip axis for a floe of the largest rmax (>= 2 max rmax)
+  double rmax_max;      // the largest rmax of the field: a floe of radius r is halo material within halo - (rmax_max - r) of an edge
   int has_left, has_right;
   int axis;             // 0: strips along x (edges are x values), 1: along y
 };
@@ -109,6 +113,9 @@ SZ_HD void sp_classify(int i, const Floes &F, const Work &W, const SpatialGeom &
   const double x = g.axis ? F.Yi[i] : F.Xi[i];       // (the coordinate the strips are cut along)
   if (!F.alive[i] || x != x || F.Xi[i] != F.Xi[i]) return;   // dead or sacked floes stay where they are, nobody needs them
   const int s = sp_strip_of(x, edges, g.world);
+  // how near an edge this floe is halo material: a neighbour's floe j can be its partner only within rmax_i + rmax_j <=
+  // rmax_i + rmax_max of it (floe_interactions_all.m:101-103), and j's centroid lies beyond the edge
+  const double need = g.halo - (g.rmax_max - F.rmax[i]);
   const int lrank = (g.rank + g.world - 1) % g.world, rrank = (g.rank + 1) % g.world;
   if (s != g.rank && g.world > 1) {
     const bool to_right = (s == rrank) && g.has_right && !(s == lrank && g.has_left && x < g.lo);
@@ -117,13 +124,13 @@ SZ_HD void sp_classify(int i, const Floes &F, const Work &W, const SpatialGeom &
       if (!sp_put(i, true, F, W, to_right ? right : left)) return;   // (no room: it stays mine, the caller is told)
       owned[i] = 0;
       // (and it may be needed as halo on the other side as well)
-      if (to_right && g.has_left && x - g.lo < g.halo) sp_put(i, false, F, W, left);
-      if (to_left && g.has_right && g.hi - x < g.halo) sp_put(i, false, F, W, right);
+      if (to_right && g.has_left && x - g.lo < need) sp_put(i, false, F, W, left);
+      if (to_left && g.has_right && g.hi - x < need) sp_put(i, false, F, W, right);
       return;
     }
   }
-  if (g.has_left && x - g.lo < g.halo) sp_put(i, false, F, W, left);
-  if (g.has_right && g.hi - x < g.halo) sp_put(i, false, F, W, right);
+  if (g.has_left && x - g.lo < need) sp_put(i, false, F, W, left);
+  if (g.has_right && g.hi - x < need) sp_put(i, false, F, W, right);
 }
 
 // record k of a received message into the arrays (the bulk rows of migrants are copied by sp_take_bulk)

@@ -149,6 +149,9 @@ __global__ void __launch_bounds__(1024) kf_front_b(int ntiles, Floes F, Params P
   const int N = F.n;
   const int f = 64 * w + (t >> 4), l = t & 15;
   const bool have = f < N;
+  // (sharded step: a tile none of whose floes this rank holds has no ghosts, no records and no grid items to write; the
+  // last tile stays for the totals)
+  if (W.present && !__syncthreads_or(have && W.present[f] != 0) && w != ntiles - 1) return;
   const double ox = have ? F.Xi[f] : 0, oy = have ? F.Yi[f] : 0;
   const int v0 = have ? F.vert_off[f] : 0, nvf = have ? F.vert_off[f + 1] - v0 : 0;
   const int alive = have ? F.alive[f] : 0;
@@ -234,6 +237,9 @@ __device__ inline unsigned long long broad_entry(int i, BroadWave &L, const Floe
   const int lane = threadIdx.x & 63;
   if (i < F.nb || i >= W.cap_ext) return 0ULL;
   const bool ghost = i >= F.n;
+  // (spatially sharded step: a floe this rank does not hold this step has no list -- ext_clear has left its counts at 0 --
+  // and its wave leaves at once: on a rank of eight, seven waves in eight)
+  if (!ghost && W.present && !W.present[i]) return 0ULL;
   // (an entry beyond this step's list reads stale words of the arrays and leaves)
   const int N = dev_next(W);
   const int si = ghost ? W.ext_src[i] : i;
@@ -386,6 +392,9 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
   long long cnt = 0, nv = 0;
   const int e0 = 64 * T + t;
   if (t < 64 && e0 < W.cap_ext) { cnt = W.pair_cnt[e0]; nv = W.pair_nv[e0]; pair_room(e0, W); }
+  // (a tile whose entries have no pairs -- the floes of other ranks in a sharded step, the slack of the grid -- has nothing
+  // to place: pair_base is read for entries with pairs only; the last tile stays for the totals)
+  if (!__syncthreads_or(cnt != 0) && T != (int)gridDim.x - 1) return;
   unsigned long long before = 0;
   for (int u = t; u < (64 / BROAD_WAVES) * T; u += 512) before += W.pair_agg[u];      // (kf_broad's sums, a workgroup of BROAD_WAVES entries each)
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
@@ -680,6 +689,9 @@ __global__ void __launch_bounds__(256) kf_integrate(Floes F, Params P, Work W) {
   if (t < F.nb) { F.collision_force[2 * t] = 0; F.collision_force[2 * t + 1] = 0; F.collision_torque[t] = 0; F.OverlapArea[t] = 0; }
   const int i = F.nb + (t >> 4), l = t & 15;
   if (i >= F.n) return;
+  // (sharded step: another rank integrates this floe -- asked before the round of loads below, so that the waves of
+  // floes that are not this rank's cost one byte each)
+  if (W.owned && !W.owned[i]) { if (l == 0) W.st_flag[i] = 0; return; }
   // ---- first round of loads: the floe's scalars, its ghosts, its row range, its ring range
   const int gxe = P.PERIODIC ? W.xg_of[i] : -1, gye = P.PERIODIC ? W.yg_of[i] : -1;
   const i64 r0 = W.row_off[i], r1 = W.row_off[i + 1];

@@ -201,7 +201,8 @@ def strip_axis(Lx, Ly):
 def strip_edges(floes, world, Lx, halo=None, axis=0):
     """Edges of `world` strips over [-Lx, Lx] along `axis` (Lx = the half-extent of the box along it): floe-count
     quantiles of the centroids, moved onto multiples of the broad-phase bin (2 max rmax) and kept at least `halo`
-    (default 2 x reach = 4 max rmax) wide.  Every rank computes the same edges from the same uploaded array."""
+    (default: the reach of a pair, 2 max rmax -- what a floe of the largest rmax needs; a floe of radius r travels within
+    r + max rmax of an edge, spatial_core.hpp) wide.  Every rank computes the same edges from the same uploaded array."""
     rmax = float(np.max(floes.rmax))
     bin_ = 2 * rmax
     halo = 2 * rmax if halo is None else halo
@@ -289,6 +290,11 @@ class GpuSpatialBackend:
         """(records, doubles, migrants, status) of a received message header (a 64-byte device tensor)."""
         h = t.view(self.torch.int64).cpu().numpy()
         return int(h[0]), int(h[1]), int(h[2]), int(h[3])
+
+    def headers(self, ts):
+        """header() of several received messages with ONE read-back (one host wait per step for both neighbours' messages)."""
+        h = self.torch.stack([t.view(self.torch.int64) for t in ts]).cpu().numpy()
+        return [(int(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in h]
 
     def bulk_row(self):
         S = self.sim.floes
@@ -417,7 +423,10 @@ class SpatialInteractions:
                         ops.append(dist.P2POp(dist.irecv, t, e[1], self.group, tag=e[5]))
             self._round(ops)
             self.rounds += 1
-            hdr = {e[0]: be.header(v[e[4]][0])[:3] for e in edges}
+            if hasattr(be, "headers"):
+                hdr = {e[0]: h[:3] for e, h in zip(edges, be.headers([v[e[4]][0] for e in edges]))}
+            else:
+                hdr = {e[0]: be.header(v[e[4]][0])[:3] for e in edges}
             # second round: everything on the first step; afterwards, per edge, the two arrays of records in full when
             # they outgrew what was agreed, and the rows of the floes that changed strip when there are any
             def rest(cnt, plan):
@@ -476,7 +485,8 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
         P.doInt = int(it % 10 == 0)
         st = sim.step(P); it += 1
         narrow_ms += st.narrow_ms; pairs += st.n_pairs
-        pair_bytes += 16.0 * st.pair_vertices + 112.0 * st.n_pairs + 56.0 * st.pair_rows
+        # SURVEY.md 8(d) B_pair over the pairs the team kernel processes (its three lists), as bench.py prices it at N = 1
+        pair_bytes += 16.0 * st.team_vertices + 112.0 * st.team_pairs + 56.0 * st.pair_rows
     torch.cuda.synchronize(); dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -512,16 +522,29 @@ def bench_main(args, rank, local_rank, world):
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     k = args.steps
-    # weak: same seeds on every rank -> identical arrays; box 2e5 * world x 2e5 m
-    S, P = bench_mod.build_workload(args.floes * world, Lx=1e5 * world, Ly=1e5)
+    # weak: the one-GPU field repeated `world` times along x (same seeds on every rank -> identical arrays; box 2e5 * world x
+    # 2e5 m), floes numbered copy by copy.  SUBZERO_WEAK_RANDOM=1: one Voronoi field of world x as many seeds instead --
+    # floe numbers then carry no position, every 64-floe tile of the arrays holds a few floes of every rank, and the
+    # per-floe kernels of a rank cost what they cost on the whole field
+    if os.environ.get("SUBZERO_WEAK_RANDOM") == "1":
+        S, P = bench_mod.build_workload(args.floes * world, Lx=1e5 * world, Ly=1e5)
+    else:
+        from . import synth
+        S0, _ = bench_mod.build_workload(args.floes)
+        _, P = bench_mod.build_workload(64, Lx=1e5 * world, Ly=1e5)      # (the parameters of the long box: boundary, ocean grid)
+        S = synth.tile_field(S0, world, 1e5)
+        P.Modulus = synth.reference_modulus(S)
     el, st = _spatial_run(S, P, rank, local_rank, world, k, args.warmup, torch, dist)
     strong = None
     try:
         S1, P1 = bench_mod.build_workload(args.floes)
         el1, st1 = _spatial_run(S1, P1, rank, local_rank, world, k, args.warmup, torch, dist)
-        strong = {"value": S1.n * k / el1, "unit": "floe-timesteps/s", "floes": int(S1.n), "ms_per_step": el1 / k * 1e3,
-                  "timesteps_per_s": k / el1, "present_floes_max": st1["present_floes_max"], "halo_m": st1["halo_m"],
-                  "bytes_sent_per_rank_step_max": st1["bytes_sent_per_rank_step_max"]}
+        strong = {"workload": "BASELINE.json configs[3]: the ONE-GPU field (pack%d, +-1e5 m box) cut into %d strips -- fixed total work" % (S1.n, world),
+                  "value": S1.n * k / el1, "unit": "floe-timesteps/s", "scaling": "strong", "floes": int(S1.n), "ms_per_step": el1 / k * 1e3,
+                  "timesteps_per_s": k / el1, "owned_floes_rank0": st1["owned_floes_rank0"], "present_floes_max": st1["present_floes_max"],
+                  "halo_m": st1["halo_m"], "strip_edges_m": st1["strip_edges_m"],
+                  "bytes_sent_per_rank_step_max": st1["bytes_sent_per_rank_step_max"],
+                  "contact_pairs_per_s": st1["collisions_last_step"] * k / el1}
     except ValueError as e:        # strips narrower than the halo: this field cannot be cut that finely
         strong = {"value": None, "note": str(e)}
     if rank == 0:
@@ -531,9 +554,11 @@ def bench_main(args, rank, local_rank, world):
             "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": el / k * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64+int64", "data": "synthetic",
-            "config": {"workload": "pack%d: %d Voronoi floes (%d per GPU), concentration 1.0, periodic +-%.3g x +-1e5 m box, "
-                                   "dt=10 s, collisions + ocean drag (forcing refreshed every 10th step)"
-                                   % (S.n, S.n, args.floes, 1e5 * world),
+            "config": {"workload": "`value` is the WEAK-scaling figure: pack%d, %d Voronoi floes (%d per GPU: the one-GPU field repeated along x, numbered copy by copy), "
+                                   "concentration 1.0, periodic +-%.3g x +-1e5 m box, dt=10 s, collisions + ocean drag (forcing refreshed every "
+                                   "10th step); the STRONG-scaling figure of BASELINE.json configs[3] (the 1e4-floe field itself cut into %d "
+                                   "strips) is the `strong_scaling` object of this line"
+                                   % (S.n, S.n, args.floes, 1e5 * world, world),
                        "floes": int(S.n), "floes_per_gpu": int(args.floes),
                        "parallelism": "%d GPUs: floes owned by x-strips, one RCCL send/recv of halo floes with each neighbour per step "
                                       "(ring), border pairs evaluated on both sides" % world},
@@ -543,7 +568,7 @@ def bench_main(args, rank, local_rank, world):
             "candidate_pairs_evaluated_per_s": st["pairs_evaluated"] / el,
             "spatial": {k2: st[k2] for k2 in ("owned_floes_rank0", "present_floes_max", "bytes_sent_per_rank_step_max", "halo_m")},
             "strong_scaling": strong,
-            "roofline": {"bound": "hbm", "kernel": "k_narrow_team (rank 0's pairs)",
+            "roofline": {"bound": "hbm", "kernel": "k_narrow_team (rank 0's launch: the pairs on its hot / cold / wide lists)",
                          "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None,
                          "limiter": "FP64 / int64 vector issue of irregular geometry (16 lanes per pair), not HBM",

@@ -201,6 +201,27 @@ def voronoi_field(n_floes, concentration=1.0, Lx=1e5, Ly=1e5, seed=1, vel_seed=2
     return S
 
 
+def tile_field(S0, copies, Lx):
+    """`copies` images of the field S0 (box half-width Lx) side by side along x, numbered copy by copy: floe i of copy c
+    is floe c * S0.n + i at x + (2 c - (copies - 1)) Lx.  The weak-scaling workload of the multi-GPU bench: every GPU's
+    share is the one-GPU field, and -- like any field whose floes are numbered strip by strip -- the floes a rank holds
+    are a run of consecutive numbers."""
+    n0, nv0 = S0.n, int(S0.vert_off[-1])
+    vo = np.concatenate([S0.vert_off[:-1].astype(np.int64) + c * nv0 for c in range(copies)] + [np.array([copies * nv0])]).astype(np.int32)
+    S = FloeState(copies * n0, vo, S0.nb, S0.n_stress, S0.n_mc)
+    for k in FloeState.ARRAYS:
+        if k in ("vert_off", "kill", "transfer"):
+            continue
+        src = getattr(S0, k)
+        rows = nv0 if k in ("c0x", "c0y", "cax", "cay") else n0
+        dst = getattr(S, k)
+        for c in range(copies):
+            dst[c * rows:(c + 1) * rows] = src
+    for c in range(copies):
+        S.Xi[c * n0:(c + 1) * n0] += (2 * c - (copies - 1)) * Lx
+    return S
+
+
 def config(name, n_stress=N_STRESS, n_mc=N_MC):
     """The BASELINE.json configurations as (FloeState, StepParams), SURVEY.md section 8(d)."""
     if name == "plumbing10":      # configs[0]: ~10 floes, full pack, dt = 10 s, non-periodic (out-of-box Subzero.m)

@@ -57,7 +57,7 @@ static bool g_sp_active = false;
 static std::vector<unsigned char> g_sp_masks;     // present[n] then owned[n]
 static std::vector<double> g_sp_edges;
 static int g_sp_rank = 0, g_sp_world = 1, g_sp_axis = 0;
-static double g_sp_halo = 0;
+static double g_sp_halo = 0, g_sp_rmax_max = 0;
 static int g_narrow_mode = 3;   // (the GPU default: team pass first)
 static long long g_big_pairs = 0;
 extern "C" long long host_big_pairs(void) { return g_big_pairs; }
@@ -490,7 +490,7 @@ int host_spatial_init(HFloes *hf, int rank, int world, const double *edges, doub
   if (!(halo > 0)) halo = 2 * rm;          // reach = 2 max rmax
   if (halo < 2 * rm) return -2;
   if (world > 1) for (int r = 0; r < world; ++r) if (edges[r + 1] - edges[r] < halo) return -2;
-  g_sp_rank = rank; g_sp_world = world; g_sp_halo = halo;
+  g_sp_rank = rank; g_sp_world = world; g_sp_halo = halo; g_sp_rmax_max = rm;
   g_sp_edges.assign(edges, edges + world + 1);
   g_sp_masks.assign(2 * (size_t)n, 0);
   for (int i = 0; i < n; ++i) {
@@ -510,7 +510,7 @@ int64_t host_spatial_message_bytes(HFloes *hf, int64_t cap_rec, int64_t cap_dbl,
 static SpatialGeom host_geom(int periodic) {
   SpatialGeom g;
   g.rank = g_sp_rank; g.world = g_sp_world; g.periodic = periodic;
-  g.lo = g_sp_edges[g_sp_rank]; g.hi = g_sp_edges[g_sp_rank + 1]; g.halo = g_sp_halo;
+  g.lo = g_sp_edges[g_sp_rank]; g.hi = g_sp_edges[g_sp_rank + 1]; g.halo = g_sp_halo; g.rmax_max = g_sp_rmax_max;
   g.has_left = g_sp_world > 1 && (periodic || g_sp_rank > 0);
   g.has_right = g_sp_world > 1 && (periodic || g_sp_rank < g_sp_world - 1);
   g.axis = g_sp_axis;

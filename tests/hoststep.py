@@ -18,7 +18,7 @@ def lib():
     path = os.path.join(ROOT, "tests", "hostsim", "libstep_host.so")
     src = os.path.join(ROOT, "tests", "hostsim", "step_host.cpp")
     hdrs = [os.path.join(ROOT, "subzero_amd", "csrc", h) for h in ("step_core.hpp", "contact.hpp", "vatti.hpp", "convex.hpp", "trim.hpp", "detmath.hpp",
-                                                                 "team.hpp", "teamclip.hpp", "teamcontact.hpp")]
+                                                                 "team.hpp", "teamclip.hpp", "teamcontact.hpp", "spatial_core.hpp")]
     hdrs.append(os.path.join(ROOT, "tests", "hostsim", "team_host.hpp"))
     if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off",

@@ -137,7 +137,8 @@ def _worker(rank, world, port, scene, steps, drift, q):
         from subzero_amd import multigpu
         dist.init_process_group("gloo", rank=rank, world_size=world)
         kw = dict(scene[2]); tiny = kw.pop("tiny_migrant_room", False); axis = kw.pop("strip_axis", 0)
-        S, P = getattr(scenes, scene[0])(*scene[1], **kw)
+        made = getattr(scenes, scene[0])(*scene[1], **kw)
+        S, P = made[0], made[1]
         P.set_reference_ocean()
         (S.Vi if axis else S.Ui)[:] += drift           # a common drift: floes cross strip edges (and the periodic edge)
         ref = S.copy()
@@ -216,6 +217,19 @@ def test_spatial_step_equals_single_process(world, periodic):
         # strip (their 5 KB rows of history and points here -- 49 KB in a model run -- travel separately) or a message
         # outgrows the size agreed from the step before
         assert r[10] == 8 and r[10] + 1 <= r[9] <= 2 * r[10], (r[9], r[10])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_floes_of_unlike_size_and_a_ghost_across_the_strip_ring(world):
+    """The halo is per floe -- floe i travels when it lies within rmax_i + max rmax of a strip edge (round 4; 4 max rmax for
+    every floe before) -- so a field of unlike sizes is where a floe too few would show: one floe four times the median
+    among small ones, sitting on the periodic x edge (its ghost is a partner of the FIRST strip's floes while the last
+    strip owns it), everything drifting across the edges.  Owned floes bit-identical to the single-process step."""
+    res = run(world, ("big_among_small", (2500,), {"ratio": 4.0, "periodic": True, "centre": (9.2e4, 1.0e4), "sides": 24, "n_stress": 6, "n_mc": 80}), 6, 30.0)
+    assert res[0][7] > 100
+    total = sum(r[5] for r in res)
+    for r in res:
+        assert r[4] < total
 
 
 def test_strips_along_y_equal_single_process():
