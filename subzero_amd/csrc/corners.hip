@@ -113,6 +113,9 @@ __global__ void k_corner_cuts(Floes F, const int *ids, int nsel, const int *voff
   int n = F.vert_off[i + 1] - v0;
   const double *x = F.cax + v0, *y = F.cay + v0;
   if (n > 1 && x[0] == x[n - 1] && y[0] == y[n - 1]) --n;                      // corners.m:66-68
+  // (the caller's slot may be one short of the stored length -- a ring stored closed; an UNCLOSED ring in such a slot would
+  // read the next floe's first flag as its last corner: not cut here)
+  if (n > voff[s + 1] - voff[s]) { npieces[s] = 0; return; }
   unsigned char *g = grind_tmp + voff[s];
   for (int k = 0; k < n; ++k) g[k] = grind_in[voff[s] + k];
   npieces[s] = szk::frac_corner_plain(x, y, n, g, F.mass[i], F.area[i], F.ksi_ice[i], F.Xi[i], F.Yi[i], tmpx + slot_tmp[s], tmpy + slot_tmp[s],

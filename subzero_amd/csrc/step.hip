@@ -424,16 +424,7 @@ __device__ inline bool go_by_rule(const unsigned long long *counters, const GoRu
   if (rule.mode != GO_IF_CLEAN) return counters[C_GO] != 0;
   const int k = (int)(threadIdx.x & 63) * C_STRIDE;
   const unsigned long long v = k < (int)C_COUNT ? counters[k] : 0ULL;
-  bool bad = false;
-  switch (k) {
-    case C_NEED_MC: case C_ERR_POT: case C_ERR_ARENA: case C_ERR_CLIP: case C_RETRY: case C_BIG: case C_ERR_CELL: bad = v != 0; break;
-    case C_NPAIRS: bad = (long long)v > rule.spec_np; break;
-    case C_NVTOT: bad = (long long)v > rule.spec_nvt; break;
-    case C_TEAM: bad = rule.team_pending && v != 0; break;
-    case C_NEXT: bad = rule.next_cap > 0 && (long long)v > rule.next_cap; break;
-    default: break;
-  }
-  return __ballot(bad) == 0ULL && !(2 * (long long)pair_rows + 1 > rule.rows_cap);
+  return go_by_values(k, v, rule, pair_rows);      // (one statement of the rule: ADVICE r3)
 }
 // (seq != 0: the last word of the host's copy -- host_copy[C_COUNT] -- is set to seq once the others are out: the host
 // spins on it instead of sleeping in hipStreamSynchronize, whose wake-up costs some tens of microseconds per step)
