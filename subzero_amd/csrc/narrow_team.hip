@@ -32,10 +32,9 @@ namespace {
 // of 32) at a time.  The grid is laid out from what the lists held in the step before -- any size is correct, the
 // waves stride over their list:
 //   blocks [0, wide_blocks)            wide_list, 32 lanes per pair         (few, and the longest: first)
-//   the next hot_blocks                live_list (in contact last step: the whole model, ~45 us a wave) -- a wave each
-//   the next cold_blocks               cold_list (most stop at the no-row certificate, ~9 us a wave) -- several waves'
-//                                      worth per workgroup: the dispatcher starts ~110 workgroups per microsecond
-//                                      (measured), short-lived ones one by one leave the chip a third empty
+//   then, in the order sz_launch_narrow_team picks (cold first by default: measured there),
+//   hot_blocks                         live_list (in contact last step: the whole model, ~45 us a wave) -- a wave each
+//   cold_blocks                        cold_list (most stop at the no-row certificate, ~9 us a wave)
 #ifndef SZ_TEAM_WPB
 #define SZ_TEAM_WPB 1     // waves per workgroup (each wave on its own: no barrier between them)
 #endif
@@ -71,10 +70,21 @@ __global__ void __launch_bounds__(64 * SZ_TEAM_WPB, SZ_TEAM_WAVES) k_narrow_team
     const int tw = sztm::Team<16>::index_in_wave();
     // hot and cold workgroups take turns in the order of dispatch (`ratio` hot ones, then a cold one): both kinds run
     // for tens of microseconds, and a kind left for the end would leave the chip part empty for its whole duration
-    const int k = b - wide_blocks, g = k / (ratio + 1), r = k % (ratio + 1);
     // (one instance of the model for both kinds: `cold` only says whether the no-row certificate is tried first)
-    const bool hot = r < ratio;
-    const int blk = hot ? g * ratio + r : g, nblk = hot ? hot_blocks : cold_blocks;
+    const int k = b - wide_blocks;
+    bool hot; int blk;
+    if (ratio > 0) {
+      // `ratio` hot workgroups, then a cold one, until the hot list is covered; the rest of the cold ones behind
+      const int n1 = (hot_blocks + ratio - 1) / ratio, p1 = n1 * (ratio + 1);
+      if (k < p1) { const int g = k / (ratio + 1), r = k % (ratio + 1); hot = r < ratio; blk = hot ? g * ratio + r : g; }
+      else { hot = false; blk = n1 + (k - p1); }
+    }
+    else if (ratio == 0) { hot = k < hot_blocks; blk = hot ? k : k - hot_blocks; }       // every hot workgroup first
+    else {                                                                               // -ratio cold workgroups first, then every hot one, then the other cold ones
+      const int c1 = -ratio < cold_blocks ? -ratio : cold_blocks;
+      hot = k >= c1 && k < c1 + hot_blocks; blk = hot ? k - c1 : (k < c1 ? k : k - hot_blocks);
+    }
+    const int nblk = hot ? hot_blocks : cold_blocks;
     const int *list = hot ? W.live_list : W.cold_list;
     const i64 n = (i64)W.counters[hot ? C_LIVE : C_COLD];
     if (blk < nblk) for (i64 t = (i64)blk * 4 + tw; t < n; t += (i64)nblk * 4) {
@@ -97,7 +107,11 @@ __global__ void __launch_bounds__(64, SZ_TEAM_WAVES) k_narrow_team_range(i64 fir
   const int tw = sztm::Team<G>::index_in_wave();
   if (list) {
     const i64 n = (i64)*list_count;
-    for (i64 t = (i64)blockIdx.x * (64 / G) + tw; t < n; t += (i64)gridDim.x * (64 / G)) narrow_team((i64)list[t], T, &blocks[tw], F, P, W);
+    for (i64 t = (i64)blockIdx.x * (64 / G) + tw; t < n; t += (i64)gridDim.x * (64 / G)) {
+      sztm::Team<G> Tp = T; int twp = tw;
+      sztm::opaque(Tp.lane); sztm::opaque(twp);               // (team.hpp opaque: nothing of the lane hoisted out of this loop)
+      narrow_team((i64)list[t], Tp, &blocks[twp], F, P, W);
+    }
   } else {
     const i64 t = (i64)blockIdx.x * (64 / G) + tw;
     if (t < count) narrow_team(first + t, T, &blocks[tw], F, P, W);
@@ -218,8 +232,24 @@ void sz_launch_narrow_team(hipStream_t st, i64 count, i64 hot, i64 cold, i64 wid
   if (wb > 512) wb = 512;
   i64 ratio = (hb + cb / 2) / cb;                       // hot workgroups per cold one in the order of dispatch
   if (ratio < 1) ratio = 1;
-  const i64 groups = std::max((hb + ratio - 1) / ratio, cb);
-  hipLaunchKernelGGL(k_narrow_team, dim3((unsigned)((wb + groups * (ratio + 1) + SZ_TEAM_WPB - 1) / SZ_TEAM_WPB)), dim3(64 * SZ_TEAM_WPB), 0, st, (int)wb, (int)hb, (int)cb, (int)ratio, F, P, W);
+  // Order of dispatch (SUBZERO_TEAM_ORDER: 0 interleaved, 1 hot first, 2 cold first -- the default since round 4).  With
+  // four waves per SIMD the chip holds 4096 waves.  Measured at 1e4 floes (profiles/team_order.sh; timelines by
+  // profiles/team_phases.py): hot first 0.103 ms -- the 3.4 k hot waves fill the chip for 38 us during which nothing else
+  // starts, then the cold ones, whose long items (a pair newly in contact runs the whole model) make a 40 us tail; `ratio`
+  // hot per cold, any ratio, 0.102-0.106; cold first 0.095: the cold waves are through in ~10 us each, the hot ones start
+  // as they leave and keep the chip full until 50 us; the share of the cold workgroups put first, 15 % ... 100 %: 0.103 ...
+  // 0.095, monotone.
+  static int order = -1;
+  if (order < 0) { const char *v = getenv("SUBZERO_TEAM_ORDER"); order = v ? atoi(v) : 2; if (order < 0 || order > 2) order = 2; }
+  static int fixed_ratio = -1;                          // SUBZERO_TEAM_RATIO: hot workgroups per cold one (0: chosen here)
+  if (fixed_ratio < 0) { const char *v = getenv("SUBZERO_TEAM_RATIO"); fixed_ratio = v ? atoi(v) : 0; if (fixed_ratio < 0 || fixed_ratio > 64) fixed_ratio = 0; }
+  if (fixed_ratio) ratio = fixed_ratio;
+  const i64 n1 = (hb + ratio - 1) / ratio;
+  i64 blocks = wb + n1 * (ratio + 1) + std::max<i64>(0, cb - n1);
+  static double split = -1;                             // SUBZERO_TEAM_SPLIT: share of the cold workgroups dispatched before the hot ones (order 2)
+  if (split < 0) { const char *v = getenv("SUBZERO_TEAM_SPLIT"); split = v ? atof(v) : 1.0; if (!(split >= 0 && split <= 1)) split = 1.0; }
+  if (order) { ratio = order == 1 ? 0 : -std::max<i64>(1, (i64)(split * (double)cb)); blocks = wb + hb + cb; }
+  hipLaunchKernelGGL(k_narrow_team, dim3((unsigned)((blocks + SZ_TEAM_WPB - 1) / SZ_TEAM_WPB)), dim3(64 * SZ_TEAM_WPB), 0, st, (int)wb, (int)hb, (int)cb, (int)ratio, F, P, W);
 }
 // ... over a range of the pair list, unclassified, 32 lanes per pair (the sharded step: a segment of the pair list)
 void sz_launch_narrow_team_range(hipStream_t st, i64 first, i64 count, const Floes &F, const Params &P, const Work &W) {

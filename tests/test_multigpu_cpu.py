@@ -185,3 +185,26 @@ def test_sharded_step_equals_single_process_gloo_world2(scene):
     for (n0, lo0, hi0), (n1, lo1, hi1) in zip(res[0][2], res[1][2]):
         assert n0 == n1 and lo0 == 0 and hi0 == lo1 and hi1 == n1
     assert res[0][3] > 0
+
+
+def test_tile_field_numbers_the_copies_one_after_the_other():
+    """synth.tile_field (the weak-scaling field of bench.py --gpus N): copy c of the one-GPU field is floes
+    [c n0, (c + 1) n0), shifted by (2 c - (copies - 1)) Lx; everything else of a floe is its original's."""
+    from subzero_amd import synth
+    S0 = synth.voronoi_field(300, 1.0, seed=5, n_stress=4, n_mc=50)
+    S = synth.tile_field(S0, 3, 1e5)
+    n0, nv0 = S0.n, int(S0.vert_off[-1])
+    assert S.n == 3 * n0 and int(S.vert_off[-1]) == 3 * nv0
+    for c in range(3):
+        sl = slice(c * n0, (c + 1) * n0)
+        assert np.array_equal(S.Xi[sl], S0.Xi + (2 * c - 2) * 1e5) and np.array_equal(S.Yi[sl], S0.Yi)
+        assert np.array_equal(S.rmax[sl], S0.rmax) and np.array_equal(S.Ui[sl], S0.Ui) and np.array_equal(S.mcA[sl], S0.mcA)
+        assert np.array_equal(S.vert_off[c * n0:(c + 1) * n0 + 1] - c * nv0, S0.vert_off)
+        assert np.array_equal(S.c0x[c * nv0:(c + 1) * nv0], S0.c0x)
+    # strips over the long box: a rank's floes are a run of consecutive numbers but for the few at the copies' seams
+    from subzero_amd import multigpu
+    edges, halo = multigpu.strip_edges(S, 3, 3e5)
+    own = np.digitize(S.Xi, edges[1:-1])
+    for r in range(3):
+        ids = np.nonzero(own == r)[0]
+        assert len(ids) > 0.8 * n0 and (np.diff(ids) == 1).mean() > 0.9
