@@ -180,8 +180,12 @@ typedef struct szStepParams {
 } szStepParams;
 
 typedef struct szStepStats {
-  double step_ms;      /* HIP-event time of the whole step on the context's stream */
-  double broad_ms, narrow_ms, rows_ms, integrate_ms;
+  /* HIP-event stage times.  As szStep returns them they are those of step `times_step` -- normally THE STEP BEFORE this
+   * one: the runtime sees an event's signal some microseconds after the step's own completion reaches the host, and
+   * waiting for it would cost every step that much; the events are read one step late, while the host waits for the next
+   * step anyway.  szStepTimes waits for the events of the last step and returns its times. */
+  double step_ms;      /* the whole step on the context's stream */
+  double broad_ms, narrow_ms, rows_ms, integrate_ms;   /* narrow_ms: the pair-interaction kernel (k_narrow_team) alone */
   int64_t n_ext;       /* real + ghost floes */
   int64_t n_pairs;     /* candidate pairs incl. floe-vs-wall candidates */
   int64_t n_rows;      /* contact rows over the extended list */
@@ -192,6 +196,7 @@ typedef struct szStepStats {
                           candidates were answered by the classification (boxes apart) or handed to the general sweep */
   int64_t team_vertices; /* stored ring vertices (both rings) summed over those pairs: what that kernel's roofline is priced on */
   double pairs_ms;     /* HIP-event time between the broad phase and the pair-interaction kernel: pair records + classification */
+  int64_t times_step;  /* the step (0-based count of completed steps of this array) the *_ms fields belong to; -1: none yet */
 } szStepStats;
 
 /* which fields szFloesDownload copies back */
@@ -247,6 +252,8 @@ enum {
   SZ_DIAG_COUNT
 };
 int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n);
+/* The *_ms fields and times_step of `stats` for the LAST completed step (waits for its events; the other fields are left). */
+int szStepTimes(szContext *ctx, szStepStats *stats);
 /* Diagnostic (tests/test_team_clip_gpu.py): the clip INSIDE the pair-interaction kernel alone -- the team form of the
  * intersection of two single-minimum rings (teamclip.hpp; Clipper's Execute(ctIntersection), private/clipper.cpp:1560-1621,
  * for that case), `lanes` = 16 or 32 lanes of a wave per pair.  Rings as szClipBatch takes them (2^32 fixed point, CSR).

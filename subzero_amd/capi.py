@@ -74,7 +74,7 @@ class StepStats(ctypes.Structure):
                 ("n_ext", ctypes.c_int64), ("n_pairs", ctypes.c_int64), ("n_rows", ctypes.c_int64),
                 ("pair_vertices", ctypes.c_int64), ("retried", ctypes.c_int64),
                 ("pair_rows", ctypes.c_int64), ("team_pairs", ctypes.c_int64), ("team_vertices", ctypes.c_int64),
-                ("pairs_ms", ctypes.c_double)]
+                ("pairs_ms", ctypes.c_double), ("times_step", ctypes.c_int64)]
 
 
 SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3
@@ -147,7 +147,7 @@ EXPORTS = [
     "szAbiVersion", "szCreate", "szDestroy", "szLastError",
     "szClipBatch", "szClipPathsBatch", "szPolyclipBatch", "szClipBatchDevice", "szOrientation",
     "szDebugTeamClipBatch",
-    "szFloesUpload", "szStep", "szStepDiagnostics", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
+    "szFloesUpload", "szStep", "szStepDiagnostics", "szStepTimes", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
     "szEulerianData", "szCornerCandidates", "szCornerCuts", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
@@ -189,6 +189,7 @@ def load():
     L.szOrientation.argtypes = [_i64p, _i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.szFloesUpload.argtypes = [_vp, ctypes.POINTER(FloeStateC)]
     L.szStep.argtypes = [_vp, ctypes.POINTER(StepParamsC), ctypes.POINTER(StepStats)]
+    L.szStepTimes.argtypes = [_vp, ctypes.POINTER(StepStats)]
     L.szStepDiagnostics.argtypes = [_vp, _i64p, ctypes.c_int32]
     L.szFloesDownload.argtypes = [_vp, ctypes.POINTER(FloeStateC), ctypes.c_int]
     L.szInteractionsDownload.argtypes = [_vp, _ip, _dp, ctypes.c_int64]
@@ -359,6 +360,12 @@ class FloeInteractions:
         if rc == SZ_STEP_NEEDS_MC:
             raise NeedsMc(self.mc_empty())
         self.ctx.check(rc, "szStep")
+        return st
+
+    def step_times(self):
+        """Stage times of the LAST step (szStepTimes waits for its events; `step` returns those of the step before)."""
+        st = StepStats()
+        self.ctx.check(self.ctx.L.szStepTimes(self.ctx.h, ctypes.byref(st)), "szStepTimes")
         return st
 
     DIAG = ("steps", "steps_fused", "spec_misses", "back_misses", "list_hot", "list_cold", "list_wide", "list_handed_on",

@@ -22,6 +22,10 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#if defined(SZ_HOST_CLOCKS)
+// diagnostic build (make diag_host): where the HOST's time of a step goes (one context per process in that build)
+static struct { std::chrono::steady_clock::time_point entry, ret; bool have = false; int n = 0; double first = 0, queue = 0, wait = 0, tail = 0, between = 0; } g_hc;
+#endif
 #include "context.hpp"
 #include "step_core.hpp"
 #include "step_state.hpp"
@@ -1009,6 +1013,9 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   i64 main_bytes = 0;
   if ((rc = bind_pairs(ctx, S, np, nvt, main_bytes))) return rc;
   hipLaunchKernelGGL(kf_front_a, grid_for(cap, 256), dim3(256), 0, st, (int)nc - 1, ntiles_ext, F, P, W);
+#if defined(SZ_HOST_CLOCKS)
+  g_hc.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_hc.entry).count();
+#endif
   hipLaunchKernelGGL(kf_front_b, dim3((unsigned)ntiles), dim3(1024), 0, st, ntiles, F, P, W);
   const unsigned tiles = grid_for(S->next_cap, 64).x;      // tiles of 64 entries the per-entry launches cover
   hipLaunchKernelGGL(kf_broad, dim3((64 / BROAD_WAVES) * tiles), dim3(64 * BROAD_WAVES), 0, st, F, P, W);
@@ -1300,6 +1307,17 @@ static int step_back_a(szContext *ctx, StepState *S) {
   return SZ_OK;
 }
 
+// step / broad / pairs / narrow / rows / integrate milliseconds from a set of events whose last one has completed
+static void stage_times(hipEvent_t *ev, float *out) {
+  const int a[6] = {0, 0, 1, 2, 3, 4}, b[6] = {5, 1, 2, 3, 4, 5};
+  for (int k = 0; k < 6; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[a[k]], ev[b[k]]) != hipSuccess) ms = 0; out[k] = ms; }
+}
+// at the start of a step: the events of the step before become the set that is read late
+static void begin_step_events(StepState *S) {
+  for (int k = 0; k < 6; ++k) std::swap(S->ev[k], S->ev_prev[k]);
+  S->prev_pending = S->ev_recorded; S->ev_recorded = false;
+  if (S->prev_pending) S->prev_step = S->steps_done - 1;
+}
 static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   hipStream_t st = ctx->stream;
   Floes &F = S->F; Work &W = S->W; Params &P = S->P;
@@ -1311,6 +1329,11 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   const unsigned long long seq = S->spin_wait ? ++S->publish_seq : 0ULL;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, W.counters, S->c_dev, (long long)n, GoRule{GO_LEAVE, 0, 0, 0, 0, 0}, S->back_queued ? 1 : 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr), seq);
   SZ_HIP(ctx, hipGetLastError());
+#if defined(SZ_HOST_CLOCKS)
+  const auto hc_q = std::chrono::steady_clock::now();
+  g_hc.queue += std::chrono::duration<double, std::micro>(hc_q - g_hc.entry).count();
+#endif
+  if (S->prev_pending) { stage_times(S->ev_prev, S->prev_ms); S->prev_pending = false; }   // (the step before: complete long ago, nothing waits)
   if (seq) {
     // the step's last kernel raises a flag in the pinned copy of the counters: spin on it (with a look at the stream now and
     // then, so that a failed launch cannot leave the host spinning)
@@ -1326,6 +1349,10 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
       __builtin_ia32_pause();
     }
   } else SZ_HIP(ctx, hipStreamSynchronize(st));
+#if defined(SZ_HOST_CLOCKS)
+  const auto hc_w = std::chrono::steady_clock::now();
+  g_hc.wait += std::chrono::duration<double, std::micro>(hc_w - hc_q).count();
+#endif
   if (S->back_queued) {
     S->back_queued = false;
     if (!c[C_GO]) return STEP_BACK_NOGO;     // the narrow phase left work for the host: nothing after it has run, the counters are as it left them
@@ -1347,20 +1374,26 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS]; S->last_team = (i64)c[C_TEAM];
   S->last_deferred = S->retried - (W.wall_list ? 0 : S->last_walls) + (i64)c[C_BIG];   // pairs of this step that waited for the host besides the floes at the walls
   if (S->debug_lists) fprintf(stderr, "lists: pairs %lld hot %lld cold %lld wide %lld other %lld pair_rows %lld | walls %lld (%s) deferred besides %lld big %lld\n", (long long)np, (long long)c[C_LIVE], (long long)c[C_COLD], (long long)c[C_WIDE], (long long)c[C_TEAM], (long long)c[C_PAIRROWS], (long long)c[C_WALLS], W.wall_list ? "beside the team pass" : "on the retry list", (long long)S->last_deferred, (long long)c[C_BIG]);
+  S->ev_recorded = true;
   if (stats) {
-    float ms;
-    SZ_HIP(ctx, hipEventSynchronize(S->ev[5]));   // (the flag of k_publish may reach the host before the runtime has seen the event's signal)
-    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[5])); stats->step_ms = ms;
-    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[0], S->ev[1])); stats->broad_ms = ms;
-    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[2], S->ev[3])); stats->narrow_ms = ms;
-    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[3], S->ev[4])); stats->rows_ms = ms;
-    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[4], S->ev[5])); stats->integrate_ms = ms;
+    // (the stage times of the step BEFORE: this step's events are read while the host waits for the next one -- or by
+    // szStepTimes, which waits for them)
+    stats->step_ms = S->prev_ms[0]; stats->broad_ms = S->prev_ms[1]; stats->pairs_ms = S->prev_ms[2]; stats->narrow_ms = S->prev_ms[3];
+    stats->rows_ms = S->prev_ms[4]; stats->integrate_ms = S->prev_ms[5]; stats->times_step = S->prev_step;
     stats->n_ext = S->N; stats->n_pairs = np; stats->n_rows = S->nr; stats->pair_vertices = S->nvt;
     stats->retried = S->retried + (W.wall_list ? S->last_walls : 0);   // (pairs through the general sweep: deferred ones and the floes at the walls)
     stats->pair_rows = S->pair_rows_local;
     stats->team_pairs = S->last_hot + S->last_cold + S->last_wide; stats->team_vertices = S->last_team_vertices;
-    SZ_HIP(ctx, hipEventElapsedTime(&ms, S->ev[1], S->ev[2])); stats->pairs_ms = ms;
   }
+#if defined(SZ_HOST_CLOCKS)
+  g_hc.ret = std::chrono::steady_clock::now(); g_hc.have = true;
+  g_hc.tail += std::chrono::duration<double, std::micro>(g_hc.ret - hc_w).count();
+  if (++g_hc.n == 200) {
+    fprintf(stderr, "host clocks per step (us): entry -> first launch %.1f, entry -> everything queued %.1f, waiting for the step %.1f, flag -> return %.1f, between two calls (the caller) %.1f\n",
+            g_hc.first / g_hc.n, g_hc.queue / g_hc.n, g_hc.wait / g_hc.n, g_hc.tail / g_hc.n, g_hc.between / g_hc.n);
+    g_hc.n = 0; g_hc.first = g_hc.queue = g_hc.wait = g_hc.tail = g_hc.between = 0;
+  }
+#endif
   return SZ_OK;
 }
 
@@ -1386,6 +1419,11 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStep: no floes uploaded");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
+  begin_step_events(S);
+#if defined(SZ_HOST_CLOCKS)
+  g_hc.entry = std::chrono::steady_clock::now();
+  if (g_hc.have) g_hc.between += std::chrono::duration<double, std::micro>(g_hc.entry - g_hc.ret).count();
+#endif
   int rc;
   // Steady state: the front stages and the narrow phase are queued back to back, sized by the last step's counts plus
   // a margin, and validated at the one read-back after the narrow phase (one host round trip fewer per step).
@@ -1433,6 +1471,7 @@ int szStepShardBegin(szContext *ctx, const szStepParams *hp, int rank, int world
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepShardBegin: no floes uploaded");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
+  begin_step_events(S);
   memset(info, 0, sizeof(*info));
   info->seg_rows = -1;
   int rc;
@@ -1523,6 +1562,18 @@ int szDebugFusedClocks(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(sz_fused_clock), sizeof(unsigned long long) * SZ_FC_KERNELS * SZ_FC_BLOCKS * SZ_FC_SLOTS) == hipSuccess ? 0 : -1;
 }
 #endif
+int szStepTimes(szContext *ctx, szStepStats *stats) {
+  if (!ctx || !stats) return SZ_ERR_BAD_ARG;
+  StepState *S = ctx->step;
+  if (!S || !S->ev_recorded) return sz_fail(ctx, SZ_ERR_STATE, "szStepTimes: no completed step");
+  SZ_HIP(ctx, hipSetDevice(ctx->device));
+  SZ_HIP(ctx, hipEventSynchronize(S->ev[5]));   // (the runtime sees the event's signal a little after the step's own flag reached the host)
+  float ms[6];
+  stage_times(S->ev, ms);
+  stats->step_ms = ms[0]; stats->broad_ms = ms[1]; stats->pairs_ms = ms[2]; stats->narrow_ms = ms[3]; stats->rows_ms = ms[4]; stats->integrate_ms = ms[5];
+  stats->times_step = S->steps_done - 1;
+  return SZ_OK;
+}
 int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n) {
   if (!ctx || !out || n < 0) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include "context.hpp"
 #include "step_core.hpp"
 
@@ -79,6 +80,13 @@ struct StepState {
   bool back_spec_ok = false, no_back_speculation = false;   // ... when the previous step deferred no pair (SUBZERO_SPECULATE_BACK=0: never)
   bool counters_clean = false;    // the last step ended by resetting the device counters (k_publish with reset)
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // The stage times of a step (szStepStats) are read from its events one step LATE: the runtime sees an event's signal some
+  // microseconds after the step's own completion flag reaches the host, and waiting for it cost every step 8 us (measured).
+  // Two sets of events take turns; the set of the step before is read while the host waits for the current step anyway.
+  hipEvent_t ev_prev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_recorded = false, prev_pending = false;
+  float prev_ms[6] = {0, 0, 0, 0, 0, 0};      // step, broad, pairs, narrow, rows, integrate of step `prev_step`
+  long long prev_step = -1;
   // the floes at the walls are swept on a stream of their own beside the team pass (step.hip step_narrow_first)
   hipEvent_t wall_fork = nullptr, wall_join = nullptr;
   long long last_team = 0;        // pairs the team pass handed on to the lane-per-pair fast pass in the step before

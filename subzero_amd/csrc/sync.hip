@@ -100,6 +100,7 @@ void destroy_state(StepState *S) {
   for (DevBuf *b : more) sz_release(*b);
   for (DevBuf &b : S->post) sz_release(b);
   for (hipEvent_t &e : S->ev) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t &e : S->ev_prev) if (e) (void)hipEventDestroy(e);
   if (S->wall_fork) (void)hipEventDestroy(S->wall_fork);
   if (S->wall_join) (void)hipEventDestroy(S->wall_join);
   if (S->c) (void)hipHostFree(S->c);
@@ -118,6 +119,7 @@ int build_state(szContext *ctx, const szFloeState *h, StepState *old, const int3
   StepState *S = new StepState();
   *out = S;
   for (hipEvent_t &e : S->ev) SZ_HIP(ctx, hipEventCreate(&e));
+  for (hipEvent_t &e : S->ev_prev) SZ_HIP(ctx, hipEventCreate(&e));
   { int rc0 = dev_alloc(ctx, S, S->scan_agg, 1024); if (rc0) return rc0; }
   SZ_HIP(ctx, hipHostMalloc((void **)&S->c, (C_COUNT + C_STRIDE) * sizeof(unsigned long long), hipHostMallocDefault));   // (+ the flag of k_publish)
   memset(S->c, 0, (C_COUNT + C_STRIDE) * sizeof(unsigned long long));

@@ -484,7 +484,7 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
     for _ in range(steps):
         P.doInt = int(it % 10 == 0)
         st = sim.step(P); it += 1
-        narrow_ms += st.narrow_ms; pairs += st.n_pairs
+        narrow_ms += st.narrow_ms; pairs += st.n_pairs          # (stage times: those of the step before, szStepStats -- one step's lag in a steady run)
         # SURVEY.md 8(d) B_pair over the pairs the team kernel processes (its three lists), as bench.py prices it at N = 1
         pair_bytes += 16.0 * st.team_vertices + 112.0 * st.team_pairs + 56.0 * st.pair_rows
     torch.cuda.synchronize(); dist.barrier()

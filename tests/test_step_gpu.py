@@ -245,3 +245,19 @@ def test_wall_pairs_beside_the_team_pass(ctx, monkeypatch, early):
     S, P = scenes.pack(2500, periodic=False, seed=17, vel_seed=18, sigma=0.2, n_stress=4, n_mc=120)
     A, G, exact = lockstep(ctx, S, P, 8)
     assert exact
+
+
+def test_stage_times_lag_one_step_and_szStepTimes_is_exact(ctx):
+    """szStepStats: the HIP-event stage times a step returns are those of the step before (read while the host waits
+    anyway); szStepTimes waits for the last step's events."""
+    S, P = scenes.pack(300, periodic=True)
+    sim = capi.FloeInteractions(ctx, S)
+    seen = []
+    for it in range(4):
+        P.doInt = int(it == 0)
+        st = sim.step(P)
+        seen.append((int(st.times_step), st.step_ms, st.narrow_ms))
+    assert [s[0] for s in seen] == [-1, 0, 1, 2] and seen[0][1] == 0
+    assert all(s[1] > 0 for s in seen[1:])
+    last = sim.step_times()
+    assert int(last.times_step) == 3 and last.step_ms > 0 and last.step_ms >= last.narrow_ms >= 0
