@@ -145,12 +145,17 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   auto cleanup = [&]() { (void)d_ext; (void)d_ent; (void)d_grid; (void)d_out; (void)d_flag; };
   if ((rc = sz_reserve(ctx, d_ext, (size_t)n * 16 + 16))) return rc;
   hipLaunchKernelGGL(k_eul_extent, grid_for(n, 256), dim3(256), 0, st, S->F, (double *)d_ext.p);
-  std::vector<double> ext((size_t)2 * n), x((size_t)n), y((size_t)n);
-  std::vector<int> alive((size_t)n);
-  hipError_t he = hipMemcpyAsync(ext.data(), d_ext.p, ext.size() * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(x.data(), S->F.Xi, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(y.data(), S->F.Yi, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(alive.data(), S->F.alive, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+  // (read back into the context's pinned staging buffer: a copy to pageable memory is staged by the runtime, tens of
+  // microseconds each)
+  Packer back;
+  const size_t b_ext = back.add((size_t)2 * n * 8), b_x = back.add((size_t)n * 8), b_y = back.add((size_t)n * 8), b_al = back.add((size_t)n * 4);
+  if ((rc = sz_stage_reserve(ctx, ctx->h_out, back.at))) return rc;
+  const double *ext = (const double *)(ctx->h_out.p + b_ext), *x = (const double *)(ctx->h_out.p + b_x), *y = (const double *)(ctx->h_out.p + b_y);
+  const int *alive = (const int *)(ctx->h_out.p + b_al);
+  hipError_t he = hipMemcpyAsync(ctx->h_out.p + b_ext, d_ext.p, (size_t)2 * n * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p + b_x, S->F.Xi, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p + b_y, S->F.Yi, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p + b_al, S->F.alive, (size_t)n * 4, hipMemcpyDeviceToHost, st);
   if (he == hipSuccess) he = hipStreamSynchronize(st);
   if (he != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szEulerianData: %s", hipGetErrorString(he)); }
   double Lx = c2b[0], Ly = c2b[1], xmin = c2b[0], ymin = c2b[1];
@@ -319,8 +324,14 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   }
   if ((rc = sz_reserve(ctx, d_ent, (size_t)(M + 1) * sizeof(EulEnt))) || (rc = sz_reserve(ctx, d_grid, grid.size() * 8)) ||
       (rc = sz_reserve(ctx, d_out, EUL_FIELDS * cells * 8)) || (rc = sz_reserve(ctx, d_flag, 16))) { cleanup(); cleanup2(); return rc; }
-  he = hipMemcpyAsync(d_ent.p, E.data(), (size_t)M * sizeof(EulEnt), hipMemcpyHostToDevice, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(d_grid.p, grid.data(), grid.size() * 8, hipMemcpyHostToDevice, st);
+  // (entities, grid lines and the result through the pinned staging buffer, as the read-back above)
+  Packer up;
+  const size_t u_ent = up.add((size_t)(M + 1) * sizeof(EulEnt)), u_grid = up.add(grid.size() * 8), u_out = up.add(EUL_FIELDS * cells * 8);
+  if ((rc = sz_stage_reserve(ctx, ctx->h_in, up.at))) { cleanup(); cleanup2(); return rc; }
+  if (M) memcpy(ctx->h_in.p + u_ent, E.data(), (size_t)M * sizeof(EulEnt));
+  memcpy(ctx->h_in.p + u_grid, grid.data(), grid.size() * 8);
+  he = hipMemcpyAsync(d_ent.p, ctx->h_in.p + u_ent, (size_t)M * sizeof(EulEnt), hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_grid.p, ctx->h_in.p + u_grid, grid.size() * 8, hipMemcpyHostToDevice, st);
   if (he == hipSuccess) he = hipMemsetAsync(d_out.p, 0, EUL_FIELDS * cells * 8, st);
   if (he == hipSuccess) he = hipMemsetAsync(d_flag.p, 0, 16, st);
   if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
@@ -350,8 +361,9 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
     if (he == hipSuccess) he = hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st);
     if (he == hipSuccess) he = hipStreamSynchronize(st);
   }
-  if (he == hipSuccess) he = hipMemcpyAsync(out, d_out.p, EUL_FIELDS * cells * 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_in.p + u_out, d_out.p, EUL_FIELDS * cells * 8, hipMemcpyDeviceToHost, st);
   if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he == hipSuccess) memcpy(out, ctx->h_in.p + u_out, EUL_FIELDS * cells * 8);
   float ms = 0;
   if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   cleanup(); cleanup2();
