@@ -166,11 +166,12 @@ def other_fields_line(ctx):
     def run(name, S, P, warm, steps):
         sim = capi.FloeInteractions(ctx, S)
         it = 0
+        P.queue_ahead = 1                  # (as the headline loop: every step is followed by another with the same parameters)
         for _ in range(warm):
-            P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+            P.doInt = int(it % 10 == 0); P.next_doInt = int((it + 1) % 10 == 0); sim.step(P); it += 1
         t = time.perf_counter(); general = 0
         for _ in range(steps):
-            P.doInt = int(it % 10 == 0); st = sim.step(P); it += 1; general += st.retried
+            P.doInt = int(it % 10 == 0); P.next_doInt = int((it + 1) % 10 == 0); st = sim.step(P); it += 1; general += st.retried
         el = time.perf_counter() - t
         out[name] = {"floes": int(S.n), "candidate_pairs": int(st.n_pairs), "ms_per_step": el / steps * 1e3,
                      "floe_timesteps_per_s": S.n * steps / el, "pairs_through_the_general_sweep_per_step": general / steps}
@@ -226,15 +227,19 @@ def main():
     ctx = capi.Context(local_rank)
     sim = capi.FloeInteractions(ctx, S)
     it = 0
+    # szStepParams.flags: every step of this loop is followed by another with the same parameters, and says so
+    # (SZ_STEP_QUEUE_AHEAD, the next doInt announced): the first kernels of the next step wait on the device while the host
+    # returns here and calls again (include/subzero_hip.h)
+    P.queue_ahead = 1
     for _ in range(args.warmup):
-        P.doInt = int(it % 10 == 0); sim.step(P); it += 1
+        P.doInt = int(it % 10 == 0); P.next_doInt = int((it + 1) % 10 == 0); sim.step(P); it += 1
     ctx.check(ctx.L.szSynchronize(ctx.h), "sync")
     narrow_ms = pair_bytes = team_bytes = stage_ms = 0.0
     pairs = rows = team_pairs = 0
     dev_ms = 0.0
     t0 = time.perf_counter()
     for q in range(args.steps):
-        P.doInt = int(it % 10 == 0)
+        P.doInt = int(it % 10 == 0); P.next_doInt = int((it + 1) % 10 == 0)
         st = sim.step(P); it += 1
         # (the stage times a step returns are those of the step before -- include/subzero_hip.h szStepStats: the first call's
         # belong to the last warm-up step and are left out, the last timed step's are fetched after the loop)
@@ -250,6 +255,8 @@ def main():
     el = time.perf_counter() - t0
     st = sim.step_times()
     narrow_ms += st.narrow_ms; dev_ms += st.step_ms; stage_ms += st.pairs_ms + st.narrow_ms
+    P.queue_ahead = 0; P.next_doInt = 0
+    queued_ahead = sim.diagnostics()["steps_ahead"]
 
     off, inter = sim.interactions()
     collisions = capi.collision_count(inter)
@@ -283,6 +290,7 @@ def main():
         "candidate_pairs_per_s": pairs / el,
         "contact_rows_last_step": int(len(inter)), "collisions_last_step": collisions,
         "device_ms_per_step": dev_ms / k,
+        "steps_with_front_kernels_queued_ahead": int(queued_ahead),
         "roofline": {"bound": "hbm", "kernel": "k_narrow_team (pair interaction: clip + contact force of the pairs on its hot / cold / wide lists, "
                                                "i.e. every candidate pair whose boxes meet)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

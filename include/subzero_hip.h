@@ -169,7 +169,8 @@ typedef struct szFloeState {
 typedef struct szStepParams {
   double dt, HFo, Modulus;
   double mu, nu;            /* floe_interactions.m:20-21 (0.2, 0.3 as shipped) */
-  int32_t doInt, COLLISION, PERIODIC, reserved;
+  int32_t doInt, COLLISION, PERIODIC;
+  int32_t flags;       /* SZ_STEP_* below; 0: none */
   double c2_boundary[10];   /* 2x5 column-major: x0,y0,x1,y1,... */
   double fb_h, fb_area, fb_Xi, fb_Yi, fb_Ui, fb_Vi, fb_ksi_ice; /* floebound (Subzero.m:67-69) */
   int32_t nxo, nyo;
@@ -178,6 +179,13 @@ typedef struct szStepParams {
   const double *Uwind, *Vwind; /* winds.u, winds.v, same shape */
   double fCoriolis, turn_angle;
 } szStepParams;
+
+/* szStepParams.flags.  SZ_STEP_QUEUE_AHEAD: the caller will call szStep again with the same parameters -- but for doInt, which
+ * it announces by SZ_STEP_NEXT_DOINT -- before it changes the floes (szFloesUpdate) or asks for the ghost list
+ * (szGhostsDownload): the library then queues the first kernels of that next step behind this one's, and the device does
+ * not idle while the host returns to its caller and comes back.  A promise not kept costs nothing but the benefit (the
+ * next step finds its parameters changed and launches those kernels afresh; szGhostsDownload reports SZ_ERR_STATE). */
+enum { SZ_STEP_QUEUE_AHEAD = 1, SZ_STEP_NEXT_DOINT = 2 };
 
 typedef struct szStepStats {
   /* HIP-event stage times.  As szStep returns them they are those of step `times_step` -- normally THE STEP BEFORE this
@@ -249,6 +257,7 @@ enum {
   SZ_DIAG_LIST_WALLS,       /* last step: floes against the domain box (general sweep) */
   SZ_DIAG_TEAM_VERTICES,    /* last step: stored ring vertices (both rings) summed over the pairs of the three lists */
   SZ_DIAG_CELL_CAP, SZ_DIAG_POT_CAP,   /* slots per grid cell / candidates per floe the lists hold now */
+  SZ_DIAG_STEPS_AHEAD,      /* steps that used front kernels queued ahead by the step before (SZ_STEP_QUEUE_AHEAD) */
   SZ_DIAG_COUNT
 };
 int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n);

@@ -58,7 +58,7 @@ class StepParamsC(ctypes.Structure):
     _fields_ = [("dt", ctypes.c_double), ("HFo", ctypes.c_double), ("Modulus", ctypes.c_double),
                 ("mu", ctypes.c_double), ("nu", ctypes.c_double),
                 ("doInt", ctypes.c_int32), ("COLLISION", ctypes.c_int32), ("PERIODIC", ctypes.c_int32),
-                ("reserved", ctypes.c_int32),
+                ("flags", ctypes.c_int32),
                 ("c2_boundary", ctypes.c_double * 10),
                 ("fb_h", ctypes.c_double), ("fb_area", ctypes.c_double), ("fb_Xi", ctypes.c_double),
                 ("fb_Yi", ctypes.c_double), ("fb_Ui", ctypes.c_double), ("fb_Vi", ctypes.c_double),
@@ -78,6 +78,7 @@ class StepStats(ctypes.Structure):
 
 
 SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3
+STEP_QUEUE_AHEAD, STEP_NEXT_DOINT = 1, 2     # szStepParams.flags
 F_STATE, F_RING, F_STRESSH, F_MC, F_ALL = 1, 2, 4, 8, 15
 SZ_STEP_NEEDS_MC = 2
 
@@ -108,7 +109,7 @@ def pack_params(P, repack_grids=True):
     for k in ["dt", "HFo", "Modulus", "mu", "nu", "doInt", "COLLISION", "PERIODIC", "fb_h", "fb_area", "fb_Xi",
               "fb_Yi", "fb_Ui", "fb_Vi", "fb_ksi_ice", "fCoriolis", "turn_angle"]:
         setattr(c, k, getattr(P, k))
-    c.reserved = 0
+    c.flags = 0
     cb = np.asarray(P.c2_boundary, np.float64)
     for k in range(5):
         c.c2_boundary[2 * k] = cb[0, k]; c.c2_boundary[2 * k + 1] = cb[1, k]
@@ -135,10 +136,13 @@ class ParamPacker:
 
     def pack(self, P):
         key = tuple(getattr(P, k) for k in self._SCALARS) + (np.asarray(P.c2_boundary, np.float64).tobytes(),)
+        # queue_ahead / next_doInt (optional attributes of P): szStepParams.flags, SZ_STEP_QUEUE_AHEAD | SZ_STEP_NEXT_DOINT
+        flags = (STEP_QUEUE_AHEAD if getattr(P, "queue_ahead", 0) else 0) | (STEP_NEXT_DOINT if getattr(P, "next_doInt", 0) else 0)
         if self._cp is not None and not P.doInt and key == self._key:
-            self._cp.doInt = 0
+            self._cp.doInt = 0; self._cp.flags = flags
             return self._cp
         self._cp, self._key = pack_params(P, repack_grids=self._cp is None), key
+        self._cp.flags = flags
         return self._cp
 
 
@@ -369,7 +373,7 @@ class FloeInteractions:
         return st
 
     DIAG = ("steps", "steps_fused", "spec_misses", "back_misses", "list_hot", "list_cold", "list_wide", "list_handed_on",
-            "list_walls", "team_vertices", "cell_cap", "pot_cap")
+            "list_walls", "team_vertices", "cell_cap", "pot_cap", "steps_ahead")
 
     def diagnostics(self):
         """How the steps of this array have run (szStepDiagnostics): a dict over DIAG."""

@@ -440,7 +440,8 @@ __global__ void k_publish(unsigned long long *counters, unsigned long long *host
     const unsigned long long v = (e == C_GO) ? go : (e == C_PAIRROWS) ? prows : counters[e];
     host_copy[e] = v;
     const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
-    if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
+    if (e == C_AHEAD) counters[e] = go;                 // (the step's last publish: did it run to its end? -- kf_front_a / b queued ahead)
+    else if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
     else if (e == C_GO) counters[e] = go;
   }
   if (seq) {
@@ -813,7 +814,7 @@ static int step_params(szContext *ctx, StepState *S, const szStepParams *hp) {
   }
   Params &P = S->P;
   P.dt = hp->dt; P.HFo = hp->HFo; P.Modulus = hp->Modulus; P.mu = hp->mu; P.nu = hp->nu;
-  P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;
+  P.doInt = hp->doInt; P.COLLISION = hp->COLLISION; P.PERIODIC = hp->PERIODIC; P.reserved = 0;   // (hp->flags: StepState::step_flags)
   memcpy(P.c2_boundary, hp->c2_boundary, sizeof(P.c2_boundary));
   P.fb_h = hp->fb_h; P.fb_area = hp->fb_area; P.fb_Xi = hp->fb_Xi; P.fb_Yi = hp->fb_Yi; P.fb_Ui = hp->fb_Ui;
   P.fb_Vi = hp->fb_Vi; P.fb_ksi_ice = hp->fb_ksi_ice;
@@ -975,6 +976,12 @@ static bool fused_eligible(StepState *S, const szStepParams *hp) {
   if (tmp.n_levels != 1) return false;
   return (size_t)tmp.lvl_base[1] * (size_t)S->cell_cap * sizeof(CellItem) <= ((size_t)512 << 20);
 }
+// what kf_front_a / kf_front_b read of the parameters (ghost rule, grid, the Monte-Carlo pre-check)
+static bool front_params_same(const Params &a, const Params &b) {
+  if (!(a.dt == b.dt && a.HFo == b.HFo && a.doInt == b.doInt && a.COLLISION == b.COLLISION && a.PERIODIC == b.PERIODIC && a.Lx == b.Lx && a.Ly == b.Ly)) return false;
+  for (int k = 0; k < 10; ++k) if (!(a.c2_boundary[k] == b.c2_boundary[k])) return false;
+  return true;
+}
 // The front stages and the pair records of a speculative step as four launches (step_fused.hpp); capacities from the step
 // before, no read-back.
 static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp) {
@@ -986,9 +993,8 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   Work &W = S->W;
   const int n = S->n, cap = W.cap_ext;
   W.g_rows = nullptr;
-  SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
   S->mc_empty.clear();
-  if (!S->counters_clean) hipLaunchKernelGGL(k_counters_clear, dim3(1), dim3(64), 0, st, F, W);
+  const bool was_clean = S->counters_clean;
   S->counters_clean = false;
   grid_levels(S->rmax_max, S->rmax_p90, P.Lx, P.Ly, W);
   const size_t nc = (size_t)W.lvl_base[W.n_levels] + 1;
@@ -1012,11 +1018,22 @@ static int step_front_fused(szContext *ctx, StepState *S, const szStepParams *hp
   S->classified = true;
   i64 main_bytes = 0;
   if ((rc = bind_pairs(ctx, S, np, nvt, main_bytes))) return rc;
-  hipLaunchKernelGGL(kf_front_a, grid_for(cap, 256), dim3(256), 0, st, (int)nc - 1, ntiles_ext, F, P, W);
+  // the first two kernels: queued ahead behind the step before (step_back_b) -- used if nothing they read has changed
+  // since -- or launched now
+  const StepState::FrontSig sig = {W.cell_item, W.cell_cnt, W.gh_mask, W.gh_agg, W.row_agg, W.prow_part, W.cell_cap, cap, (int)nc, ntiles, ntiles_ext, 0};
+  S->front_sig = sig;
+  const bool ahead = S->ahead_pending && was_clean && front_params_same(S->ahead_P, P) && memcmp(&S->ahead_sig, &sig, sizeof(sig)) == 0;
+  S->ahead_pending = false;
+  if (ahead) ++S->steps_ahead;
+  else {
+    SZ_HIP(ctx, hipEventRecord(S->ev[0], st));
+    if (!was_clean) hipLaunchKernelGGL(k_counters_clear, dim3(1), dim3(64), 0, st, F, W);
+    hipLaunchKernelGGL(kf_front_a, grid_for(cap, 256), dim3(256), 0, st, (int)nc - 1, ntiles_ext, 0, F, P, W);
+  }
 #if defined(SZ_HOST_CLOCKS)
   g_hc.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_hc.entry).count();
 #endif
-  hipLaunchKernelGGL(kf_front_b, dim3((unsigned)ntiles), dim3(1024), 0, st, ntiles, F, P, W);
+  if (!ahead) hipLaunchKernelGGL(kf_front_b, dim3((unsigned)ntiles), dim3(1024), 0, st, ntiles, 0, F, P, W);
   const unsigned tiles = grid_for(S->next_cap, 64).x;      // tiles of 64 entries the per-entry launches cover
   hipLaunchKernelGGL(kf_broad, dim3((64 / BROAD_WAVES) * tiles), dim3(64 * BROAD_WAVES), 0, st, F, P, W);
   SZ_HIP(ctx, hipEventRecord(S->ev[1], st));
@@ -1334,6 +1351,20 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   g_hc.queue += std::chrono::duration<double, std::micro>(hc_q - g_hc.entry).count();
 #endif
   if (S->prev_pending) { stage_times(S->ev_prev, S->prev_ms); S->prev_pending = false; }   // (the step before: complete long ago, nothing waits)
+  // queue-ahead: the next step's first two kernels behind this step's last one (they run only if this step ran to its
+  // end: C_AHEAD, written by the publish above).  Not for a sharded step (the halo arrives between two steps).
+  bool queued_ahead = false;
+  if ((S->step_flags & SZ_STEP_QUEUE_AHEAD) && S->fused && !W.present && S->front_sig.cell_item) {
+    Params Pn = P;
+    Pn.doInt = (S->step_flags & SZ_STEP_NEXT_DOINT) ? 1 : 0;
+    const StepState::FrontSig &g = S->front_sig;
+    SZ_HIP(ctx, hipEventRecord(S->ev_prev[0], st));      // (that set's times have just been read: it is the next step's now)
+    hipLaunchKernelGGL(kf_front_a, grid_for(g.cap_ext, 256), dim3(256), 0, st, g.nc - 1, g.ntiles_ext, 1, F, Pn, W);
+    hipLaunchKernelGGL(kf_front_b, dim3((unsigned)g.ntiles), dim3(1024), 0, st, g.ntiles, 1, F, Pn, W);
+    SZ_HIP(ctx, hipGetLastError());
+    S->ahead_P = Pn; S->ahead_sig = g;
+    queued_ahead = true;
+  }
   if (seq) {
     // the step's last kernel raises a flag in the pinned copy of the counters: spin on it (with a look at the stream now and
     // then, so that a failed launch cannot leave the host spinning)
@@ -1369,6 +1400,8 @@ static int step_back_b(szContext *ctx, StepState *S, szStepStats *stats) {
   const i64 np = S->np;
   S->last_npairs = np; S->last_next = S->N; S->stepped = true;
   ++S->steps_done; if (S->fused) ++S->steps_fused;
+  S->ahead_valid = queued_ahead;     // (the step ran to its end: what was queued ahead runs too)
+  S->ghosts_overwritten = queued_ahead;
   S->hint_valid = S->fused;      // (kf_rows has left next step's contact hints)
   S->last_team_vertices = (i64)c[C_TEAMV];
   S->last_hot = (i64)c[C_LIVE]; S->last_cold = (i64)c[C_COLD]; S->last_wide = (i64)c[C_WIDE]; S->last_walls = (i64)c[C_WALLS]; S->last_team = (i64)c[C_TEAM];
@@ -1420,6 +1453,8 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStep: no floes uploaded");
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   begin_step_events(S);
+  S->step_flags = hp->flags;
+  S->ahead_pending = S->ahead_valid; S->ahead_valid = false;     // (what was queued ahead serves this call or none)
 #if defined(SZ_HOST_CLOCKS)
   g_hc.entry = std::chrono::steady_clock::now();
   if (g_hc.have) g_hc.between += std::chrono::duration<double, std::micro>(g_hc.entry - g_hc.ret).count();
@@ -1579,7 +1614,7 @@ int szStepDiagnostics(szContext *ctx, int64_t *out, int32_t n) {
   StepState *S = ctx->step;
   if (!S) return sz_fail(ctx, SZ_ERR_STATE, "szStepDiagnostics: no floes uploaded");
   const int64_t v[SZ_DIAG_COUNT] = {S->steps_done, S->steps_fused, S->spec_misses, S->back_misses, S->last_hot, S->last_cold, S->last_wide,
-                                    S->last_team, S->last_walls, S->last_team_vertices, S->cell_cap, S->pot_cap};
+                                    S->last_team, S->last_walls, S->last_team_vertices, S->cell_cap, S->pot_cap, S->steps_ahead};
   for (int k = 0; k < n && k < (int)SZ_DIAG_COUNT; ++k) out[k] = v[k];
   return SZ_OK;
 }

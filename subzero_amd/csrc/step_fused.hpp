@@ -40,13 +40,16 @@ __device__ unsigned long long sz_fused_clock[SZ_FC_KERNELS * SZ_FC_BLOCKS * SZ_F
 #endif
 enum { CELL_STRIDE = 8 };   // ints between the fill counts of two grid cells (four cells to a 128-byte line: the appends are atomics)
 // ---- kf_front_a ----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kf_front_a(int ncells, int ntiles_ext, Floes F, Params P, Work W) {
+// (ahead: queued behind the step BEFORE the one it belongs to, szStepParams.flags -- it runs only if that step ran to its
+// end: a step that left work for the host still needs the arrays this kernel clears)
+__global__ void __launch_bounds__(256) kf_front_a(int ncells, int ntiles_ext, int ahead, Floes F, Params P, Work W) {
   FCLK(5, 0);
+  if (ahead && !W.counters[C_AHEAD]) return;
   const int e = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
   for (int c = e; c < ncells; c += stride) W.cell_cnt[CELL_STRIDE * c] = 0;
   for (int t = e; t < ntiles_ext; t += stride) W.row_agg[(size_t)AGG_STRIDE * t] = 0;
   if (e < 64) W.prow_part[(size_t)AGG_STRIDE * e] = 0;
-  if (e < W.cap_ext) { ext_clear(e, W); marks_clear(e, F); }
+  if (e < W.cap_ext) ext_clear(e, W);           // (the kill / transfer marks of the step before: kf_pairs -- the caller may still read them)
   FCLK(5, 1);
   int fx = 0, fy = 0;
   if (e < F.n) {
@@ -142,9 +145,10 @@ __device__ inline void ext_record_lanes(int e, int n, int v0, double ox, double 
 // One workgroup per tile of 64 floes, 16 lanes per floe.  Ghost slots as ScanGhosts places them: x ghost of k at N + px,
 // y ghost of k at N + GX + py, y ghost of k's x ghost at N + GX + GYreal + pxy, the p's = exclusive counts over the
 // floes before k.  Two rounds of loads: what the lane's floe and tile own at known addresses, then the ring.
-__global__ void __launch_bounds__(1024) kf_front_b(int ntiles, Floes F, Params P, Work W) {
+__global__ void __launch_bounds__(1024) kf_front_b(int ntiles, int ahead, Floes F, Params P, Work W) {
   __shared__ unsigned long long red[2][16];
   FCLK(4, 0);
+  if (ahead && !W.counters[C_AHEAD]) return;
   const int w = blockIdx.x, t = threadIdx.x;
   const int N = F.n;
   const int f = 64 * w + (t >> 4), l = t & 15;
@@ -388,6 +392,7 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
   FCLK(1, 0);
   const int T = blockIdx.x, t = threadIdx.x, lane = t & 63;
   if (T == 0 && t == 0) W.counters[C_SCR_BUMP] = scratch_bump;
+  for (int e = T * 512 + t; e < W.cap_ext; e += (int)gridDim.x * 512) marks_clear(e, F);    // :123 (the back half of the step sets them)
   // first round: the sums of the groups before this tile, and (first wave) the counts of its entries
   long long cnt = 0, nv = 0;
   const int e0 = 64 * T + t;

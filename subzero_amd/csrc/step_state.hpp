@@ -87,6 +87,18 @@ struct StepState {
   bool ev_recorded = false, prev_pending = false;
   float prev_ms[6] = {0, 0, 0, 0, 0, 0};      // step, broad, pairs, narrow, rows, integrate of step `prev_step`
   long long prev_step = -1;
+  // Queue-ahead (szStepParams.flags & SZ_STEP_QUEUE_AHEAD): the first two kernels of the NEXT step (kf_front_a / kf_front_b:
+  // they read the floe array and a handful of parameters, nothing of the pair buffers) are queued behind this step's last
+  // kernel before the host waits for it, so that the device has work while the host returns to its caller and comes back
+  // (24 us between two steps otherwise).  They run only if this step ran to its end (C_AHEAD); the next szStep uses them
+  // if nothing they read has changed -- parameters, grid, buffers -- and launches them afresh otherwise.
+  struct FrontSig { const void *cell_item, *cell_cnt, *gh_mask, *gh_agg, *row_agg, *prow_part; int cell_cap, cap_ext, nc, ntiles, ntiles_ext, pad; };
+  bool ahead_valid = false, ahead_pending = false;
+  bool ghosts_overwritten = false; // the last step queued the next one's front kernels: they have rebuilt the ghost list (szGhostsDownload refuses)
+  FrontSig ahead_sig = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0}, front_sig = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+  Params ahead_P;
+  int step_flags = 0;              // szStepParams.flags of the step under way
+  long long steps_ahead = 0;       // szStepDiagnostics: steps whose front kernels had been queued ahead and were used
   // the floes at the walls are swept on a stream of their own beside the team pass (step.hip step_narrow_first)
   hipEvent_t wall_fork = nullptr, wall_join = nullptr;
   long long last_team = 0;        // pairs the team pass handed on to the lane-per-pair fast pass in the step before

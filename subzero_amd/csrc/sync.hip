@@ -370,6 +370,7 @@ int szFloesUpdate(szContext *ctx, const szFloeState *h, const int32_t *ids, int3
   if (!valid_ids(S, ids, nids)) return sz_fail(ctx, SZ_ERR_BAD_ARG, "szFloesUpdate: floe number out of range");
   if (nids == 0) return SZ_OK;
   SZ_HIP(ctx, hipSetDevice(ctx->device));
+  S->ahead_valid = false;      // (what the step before queued ahead for the next one has read the floes as they were)
   return move_fields(ctx, S, const_cast<szFloeState *>(h), ids, nids, what, true);
 }
 
@@ -453,6 +454,8 @@ int szGhostsDownload(szContext *ctx, int32_t *src, int32_t *parent, double *Xi, 
   if (!ctx || !nghost) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
   if (!S || !S->stepped) return sz_fail(ctx, SZ_ERR_STATE, "szGhostsDownload: no step taken");
+  if (S->ghosts_overwritten)
+    return sz_fail(ctx, SZ_ERR_STATE, "szGhostsDownload: the last step was asked to queue the next one ahead (SZ_STEP_QUEUE_AHEAD): the ghost list it made has been overwritten");
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int n = S->n;
   const i64 g = (i64)S->last_next - n;

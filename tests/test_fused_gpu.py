@@ -103,3 +103,51 @@ def test_full_size_field(ctx, ctx2, monkeypatch):
     P = synth.StepParams(dt=10.0, Lx=1e5, Ly=1e5, periodic=True)
     P.Modulus = synth.reference_modulus(S)
     run(ctx, ctx2, S, P, 8, monkeypatch)
+
+
+def test_queue_ahead_changes_nothing_but_the_wait(ctx, ctx2):
+    """SZ_STEP_QUEUE_AHEAD: the first kernels of the next step queued behind this one's.  Two copies of a field, one stepped
+    plainly, one with the promise kept (next doInt announced), broken (announced wrongly; a floe updated between two
+    steps) and on steps that refresh the forcing: the same pairs, rows, state and marks after every step; the ghost list
+    is refused after a step that queued ahead (also when an update has voided what was queued: the list is overwritten
+    all the same) and served after one that did not."""
+    S, P = scenes.pack(900, periodic=True)
+    P.set_reference_ocean()
+    A = S.copy(); B = S.copy()
+    plain = capi.FloeInteractions(ctx, A)
+    ahead = capi.FloeInteractions(ctx2, B)
+    import copy
+    Pa = copy.copy(P)
+    steps = 30
+    refused = 0
+    for it in range(steps):
+        P.doInt = Pa.doInt = int(it % 5 == 0)
+        nxt = int((it + 1) % 5 == 0)
+        Pa.queue_ahead = 0 if it in (11, steps - 1) else 1
+        Pa.next_doInt = (1 - nxt) if it in (6, 9) else nxt          # (steps 6 and 9 announce the wrong doInt)
+        plain.step(P); ahead.step(Pa)
+        if it == 14:                                                # the caller changes a floe between two steps: what was queued ahead is void
+            for sim, T in ((plain, A), (ahead, B)):
+                sim.download(capi.SYNC_ALL)
+                T.Ui[3] += 0.05; T.Vi[7] -= 0.02
+                sim.update(np.array([4, 8], np.int32), capi.F_STATE)
+        pa, na = plain.pairs(); pb, nb = ahead.pairs()
+        assert na == nb and np.array_equal(pa, pb), "step %d: candidate pairs differ" % it
+        oa, ra = plain.interactions(); ob, rb = ahead.interactions()
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb), "step %d: contact rows differ" % it
+        plain.download(capi.SYNC_ALL); ahead.download(capi.SYNC_ALL)
+        bad = hoststep.compare_states(A, B, exact=True)
+        assert bad == [], "step %d: %s" % (it, bad)
+        assert np.array_equal(A.kill, B.kill) and np.array_equal(A.transfer, B.transfer), "step %d: kill / transfer differ" % it
+        try:
+            got = ahead.ghosts()
+        except capi.SubzeroError:                       # the step queued the next one ahead: its ghost list is gone
+            assert Pa.queue_ahead, it
+            refused += 1
+        else:
+            for x, y in zip(plain.ghosts(), got):
+                assert np.array_equal(x, y)
+    assert refused >= steps - 8, refused
+    d = ahead.diagnostics()
+    assert d["steps_ahead"] >= steps - 8, d           # (not after the first steps, the two wrong announcements, the update, the step that did not ask)
+    assert plain.diagnostics()["steps_ahead"] == 0
