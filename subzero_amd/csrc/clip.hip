@@ -94,12 +94,12 @@ __device__ __attribute__((noinline, flatten)) int clip_in_slice(void *slice, con
   __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
   return szv::clip_rings_t<szv::WideLds>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
 }
-// (for the sweep pass, where all 64 lanes of the wave run the sweep alike: vatti.hpp WideLdsWave)
+// (for the sweep pass, where all 64 lanes of the wave run the sweep alike: vatti.hpp WideLdsWaveMirror)
 __device__ __attribute__((noinline, flatten)) int clip_in_slice_wave(void *slice, const szv::Caps &caps, const RingI64 &ra, int na,
                                                             const RingI64 &rb, int nb, int method, int fill_s, int fill_c,
                                                             SlotSink &sink) {
   __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
-  return szv::clip_rings_t<szv::WideLdsWave>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
+  return szv::clip_rings_t<szv::WideLdsWaveMirror>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
 }
 // (the same inlined into its caller: k_clip_sweep_small, a kernel compiled for four waves per SIMD -- a function of its
 // own is compiled for all 256 registers whatever its caller asks for)
@@ -107,7 +107,7 @@ __device__ __attribute__((always_inline)) int clip_in_slice_inlined(void *slice,
                                                                     const RingI64 &rb, int nb, int method, int fill_s, int fill_c,
                                                                     SlotSink &sink) {
   __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)slice));
-  return szv::clip_rings_t<szv::WideLdsWave>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
+  return szv::clip_rings_t<szv::WideLdsWaveMirror>(slice, caps, ra, na, rb, nb, method, fill_s, fill_c, sink);
 }
 
 #if defined(SZ_CLIP_CLOCKS)
@@ -301,11 +301,8 @@ __global__ void __launch_bounds__(64) k_clip_front(ClipArgs a) {
         apart = wave_heights_distinct(sy, ea, sy + na, eb);
       }
     } else if (evenodd && na + nb >= 24) {
-      if (lane == 0) {
-        ta = szt::trim_ring(sx, sy, na, q);
-        tb = szt::trim_ring(sx + na, sy + na, nb, q);
-      }
-      ta = __shfl(ta, 0); tb = __shfl(tb, 0);
+      ta = szt::trim_ring_wave(sx, sy, na, q);       // (by the wave; rings of more than 128 vertices: every lane the serial scan alike)
+      tb = szt::trim_ring_wave(sx + na, sy + na, nb, q);
       __syncthreads();
       if (ta != na || tb != nb) {
         // (an untouched ring may still carry its closing duplicate: not a tie -- trim_pair)

@@ -8,24 +8,24 @@
 // Diagnostic build only (make EXTRA=-DSZ_PHASE_PROFILE): wall-clock time of the parts of the contact model per
 // pair of the general kernels, summed and for the slowest pair; read with szDebugPhases.  Not in the product build.
 #include <hip/hip_runtime.h>
-struct SzPhaseState { unsigned long long last, t[20]; int cur, trim[4], ntrim; };
-__device__ unsigned long long sz_phase_acc[20];
-__device__ unsigned long long sz_phase_worst[28];
+struct SzPhaseState { unsigned long long last, t[24]; int cur, trim[4], ntrim; };
+__device__ unsigned long long sz_phase_acc[24];
+__device__ unsigned long long sz_phase_worst[32];
 __device__ SzPhaseState sz_phase_state[1 << 17];
 static __host__ __device__ inline void sz_phase_mark(int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
   SzPhaseState &s = sz_phase_state[(blockIdx.x * blockDim.x + threadIdx.x) & 0x1ffff];
   const unsigned long long now = wall_clock64();
-  if (k == 8) { for (int i = 0; i < 20; ++i) s.t[i] = 0; s.ntrim = 0; }
-  else s.t[s.cur < 20 ? s.cur : 9] += now - s.last;
+  if (k == 8) { for (int i = 0; i < 24; ++i) s.t[i] = 0; s.ntrim = 0; }
+  else s.t[s.cur < 24 ? s.cur : 9] += now - s.last;
   s.last = now; s.cur = k;
   if (k == 0) {
     unsigned long long tot = 0;
-    for (int i = 1; i < 20; ++i) { tot += s.t[i]; atomicAdd(&sz_phase_acc[i], s.t[i]); }
+    for (int i = 1; i < 24; ++i) { tot += s.t[i]; atomicAdd(&sz_phase_acc[i], s.t[i]); }
     if (atomicMax(&sz_phase_worst[0], tot) < tot) {
-      for (int i = 1; i < 20; ++i) sz_phase_worst[i] = s.t[i];
-      for (int i = 0; i < 4; ++i) sz_phase_worst[20 + i] = i < s.ntrim ? (unsigned long long)s.trim[i] : 0ull;
-      sz_phase_worst[24] = (unsigned long long)s.ntrim;
+      for (int i = 1; i < 24; ++i) sz_phase_worst[i] = s.t[i];
+      for (int i = 0; i < 4; ++i) sz_phase_worst[24 + i] = i < s.ntrim ? (unsigned long long)s.trim[i] : 0ull;
+      sz_phase_worst[28] = (unsigned long long)s.ntrim;
     }
   }
 #endif
@@ -42,11 +42,11 @@ static __host__ __device__ inline void sz_trim_mark(int before, int after) {
 #endif
 #include "step_core.hpp"
 #if defined(SZ_PHASE_PROFILE)
-extern "C" int szDebugPhases(unsigned long long *out26, int reset) {
-  unsigned long long z[28] = {0};
-  if (hipMemcpyFromSymbol(out26, HIP_SYMBOL(sz_phase_acc), sizeof(unsigned long long) * 20) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out26 + 20, HIP_SYMBOL(sz_phase_worst), sizeof(unsigned long long) * 28) != hipSuccess) return -1;
-  if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_acc), z, 160); (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_worst), z, 224); }
+extern "C" int szDebugPhases(unsigned long long *out56, int reset) {
+  unsigned long long z[32] = {0};
+  if (hipMemcpyFromSymbol(out56, HIP_SYMBOL(sz_phase_acc), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out56 + 24, HIP_SYMBOL(sz_phase_worst), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_acc), z, 192); (void)hipMemcpyToSymbol(HIP_SYMBOL(sz_phase_worst), z, 256); }
   return 0;
 }
 #endif

@@ -172,6 +172,68 @@ __device__ inline bool wave_heights_distinct(const i64 *y1, int n1, const i64 *y
   }
   return __ballot(same) == 0ULL;
 }
+// trim_ring by a whole wave, for rings of up to 128 vertices (two per lane): the side codes by the lanes, four ballots
+// per chunk; the serial scan of trim_ring then goes from RUN to run on those masks (a run from s ends at the last e
+// for which the codes of s..e still have a side in common -- the greedy narrowing of `side` there stops at exactly
+// that e -- so its length is the longest stretch of ones from bit s among the masks of the sides s lies beyond; a
+// stretch of vertices inside the box is kept whole), and the kept vertices are moved by the lanes that hold them.
+// Every lane returns the same; x / y must be in LDS (or otherwise coherent inside a wave).
+__device__ inline int ones_from(unsigned long long lo, unsigned long long hi, int s) {   // ones in a row from bit s of hi:lo
+  unsigned long long a, b;
+  if (s == 0) { a = lo; b = hi; }
+  else if (s < 64) { a = (lo >> s) | (hi << (64 - s)); b = hi >> s; }
+  else { a = hi >> (s - 64); b = 0; }
+  if (~a) return __builtin_ctzll(~a);
+  return 64 + (~b ? __builtin_ctzll(~b) : 64);
+}
+__device__ inline int trim_ring_wave(i64 *x, i64 *y, int n, const Box &q) {
+  int m = n;
+  if (m > 1 && x[m - 1] == x[0] && y[m - 1] == y[0]) --m;
+  if (m < MIN_RING) return n;
+  if (m > 128) return trim_ring(x, y, n, q);
+  const int lane = (int)(threadIdx.x & 63);
+  i64 vx0 = 0, vy0 = 0, vx1 = 0, vy1 = 0;
+  int c0 = 0, c1 = 0;
+  if (lane < m) { vx0 = x[lane]; vy0 = y[lane]; c0 = beyond(vx0, vy0, q); }
+  if (lane + 64 < m) { vx1 = x[lane + 64]; vy1 = y[lane + 64]; c1 = beyond(vx1, vy1, q); }
+  unsigned long long lo[4], hi[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { lo[b] = __ballot((c0 >> b) & 1); hi[b] = __ballot((c1 >> b) & 1); }
+  const unsigned long long any_lo = lo[0] | lo[1] | lo[2] | lo[3], any_hi = hi[0] | hi[1] | hi[2] | hi[3];
+  if ((any_lo | any_hi) == 0ULL) return n;                  // every vertex inside the box: nothing to cut
+  unsigned long long keep_lo = ~0ULL, keep_hi = ~0ULL;      // (bits beyond m - 1 are never looked at)
+  int s = 0;
+  while (s < m) {
+    // a stretch of vertices inside the box (code 0): kept, each a run of its own
+    const int inside = ones_from(~any_lo, ~any_hi, s);
+    s += inside;
+    if (s >= m) break;
+    int len = 1;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const int l = ones_from(lo[b], hi[b], s); len = l > len ? l : len; }
+    int e = s + len - 1;
+    if (e > m - 1) e = m - 1;
+    if (e - s >= 4) {
+      Pt a, b, c, d;
+      a.x = x[s]; a.y = y[s]; b.x = x[s + 1]; b.y = y[s + 1];
+      c.x = x[e - 1]; c.y = y[e - 1]; d.x = x[e]; d.y = y[e];
+      if (!szv::collinear3(a, b, c) && !szv::collinear3(b, c, d))
+        for (int k = s + 2; k <= e - 2; ++k) { if (k < 64) keep_lo &= ~(1ULL << k); else keep_hi &= ~(1ULL << (k - 64)); }
+    }
+    s = e + 1;
+  }
+  const unsigned long long in_lo = m >= 64 ? ~0ULL : ((1ULL << m) - 1ULL);
+  const unsigned long long in_hi = m >= 128 ? ~0ULL : (m > 64 ? ((1ULL << (m - 64)) - 1ULL) : 0ULL);
+  keep_lo &= in_lo; keep_hi &= in_hi;
+  const int w = __popcll(keep_lo) + __popcll(keep_hi);
+  if (w == m) return n;
+  __builtin_amdgcn_wave_barrier();                          // (every read of the scan above before the first write below)
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+  if ((keep_lo >> lane) & 1ULL) { const int at = __popcll(keep_lo & below); x[at] = vx0; y[at] = vy0; }
+  if ((keep_hi >> lane) & 1ULL) { const int at = __popcll(keep_lo) + __popcll(keep_hi & below); x[at] = vx1; y[at] = vy1; }
+  __builtin_amdgcn_wave_barrier();
+  return w;
+}
 // trim_pair by a whole wave (every lane returns the same)
 __device__ inline bool trim_pair_wave(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *by, int &nb) {
   if (na < 1 || nb < 1 || (na < MIN_RING && nb < MIN_RING)) return true;
@@ -179,7 +241,7 @@ __device__ inline bool trim_pair_wave(i64 *ax, i64 *ay, int &na, i64 *bx, i64 *b
   wave_box(ax, ay, na, A); wave_box(bx, by, nb, B);
   common_box(A, B, q);
   if (box_empty(q)) return true;
-  const int ta = trim_ring(ax, ay, na, q), tb = trim_ring(bx, by, nb, q);
+  const int ta = trim_ring_wave(ax, ay, na, q), tb = trim_ring_wave(bx, by, nb, q);
   if (ta == na && tb == nb) return true;
   __builtin_amdgcn_wave_barrier();
   const int ea = (ta == na && na > 1 && ax[na - 1] == ax[0] && ay[na - 1] == ay[0]) ? na - 1 : ta;

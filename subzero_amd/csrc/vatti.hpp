@@ -73,6 +73,7 @@ enum { KIND_SUBJECT = 0, KIND_CLIP = 1 };
 template <class Ix, class Wn>
 struct Records {
   static const bool kWave = false;   // (see WideLdsWave)
+  static const bool kMirror = false; // (see WideLdsWaveMirror)
   struct Edge {
     Pt bot, cur, top;
     double slope; // dx/dy, SZV_HORIZONTAL for dy == 0
@@ -116,6 +117,11 @@ struct WideLds : Records<int, int> {};
 // ... and for a sweep that ALL 64 lanes of a wave run alike (clip.hip k_clip_sweep): the one walk over the active edges
 // per beam (build_crossings) then spreads over the lanes -- lane k takes the k-th edge
 struct WideLdsWave : Records<int, int> { static const bool kWave = true; };
+// ... with the active-edge list mirrored in the lanes (SweepT::am): the clip batch's sweep pass, whose long outlines hold
+// many active edges.  The step's wave-per-pair kernel sweeps rings trimmed to a few dozen vertices with a handful of
+// active edges, where the mirror's upkeep costs what the short walks did and its registers more (measured: 2500 evolved
+// outlines 0.94 -> 0.99 ms/step with it, the clip batch 4.3 -> 3.8 ms)
+struct WideLdsWaveMirror : Records<int, int> { static const bool kWave = true; static const bool kMirror = true; };
 
 // ---- numeric kernels ----------------------------------------------------------------------
 
@@ -374,6 +380,16 @@ struct SweepT {
   // list is then unchanged in between); note[0] their number, note[1..4] the first four
   bool beam_in_order;
   SZ_HD int *end_note() const { return (int *)X; }
+  // WideLdsWave: every ring so far went in by add_ring_wave (AddPath's plain case: all its vertices are edges, none
+  // horizontal) / the pending scanlines were laid out at once from the vertices' heights (prebuild_beams)
+  bool all_plain, beams_prebuilt;
+  // WideLdsWave: the active-edge list again, dense and in list order, an edge per lane -- lane k holds the k-th active
+  // edge in `am` (NIL beyond the `an` edges of the list; an < 0: no mirror -- more than 64 active edges, or not a wave).
+  // The linked list in the records stays what the sweep's serial parts walk; the mirror is kept in step by the four
+  // functions that change the list (ael_insert / ael_remove / ael_swap / ael_advance), and what asks "the k-th edge" or
+  // "where in the list" -- the lane-per-edge walk of build_crossings, the place of a new edge, the winding counts of a
+  // new bound -- reads it instead of following the links one dependent load after the other.
+  int am, an;
 
   SZ_HD void bind(void *buf, int nv) { bind_caps(buf, caps_for(nv)); }
   SZ_HD void bind_caps(void *buf, const Caps &c) {
@@ -393,6 +409,8 @@ struct SweepT {
     err = ST_OK;
     reverse_out = 0;
     y_now = 0; beam_in_order = false;
+    all_plain = Rec::kWave; beams_prebuilt = false;
+    am = NIL; an = -1;
   }
   SZ_HD void fail(int code) { if (err == ST_OK) err = code; }
 
@@ -460,6 +478,7 @@ struct SweepT {
   // pending heights for a long outline, and walking down to it is a chain of dependent loads -- the reference keeps a
   // binary heap and drops duplicates when it pops, clipper.cpp:1332-1349; the heights come out the same)
   SZ_HD void push_beam(i64 y) {
+    if (beams_prebuilt) return;             // (every height the sweep will push is there already)
     int k = nB;
     if (k > 0 && !(B[k - 1] < y)) {
       int lo = 0;
@@ -475,6 +494,37 @@ struct SweepT {
     B[k] = y;
     ++nB;
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The pending scanlines at once, by the wave (WideLdsWave, every ring plain): the heights the sweep pushes one by one --
+  // a local minimum's when run() starts, an edge's top when the edge becomes active (clipper.cpp:1332-1349 InsertScanbeam
+  // from :1229-1243, :2036-2060, :2975-2997) -- are, over a whole sweep, the heights of all the vertices: every edge of
+  // a ring becomes active (its bound starts at a local minimum and each edge hands on to the next at its top), a
+  // height is pushed before the sweep reaches it, and the sweep pops the largest pending one whenever it was pushed.  So
+  // the array is filled here with every vertex's height at its rank, and push_beam has nothing left to do -- when no
+  // two vertices share a height (then the rank is the place; otherwise the heights are pushed as before).
+  __device__ void prebuild_beams() {
+    const int lane = (int)(threadIdx.x & 63), n = nE;
+    if (n > cap.beams || n < 1) return;
+    bool dup = false;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < n) {
+        const i64 yi = E[i].cur.y;                        // (cur: still the vertex add_ring_wave put there)
+        int less = 0;
+        for (int j = 0; j < n; ++j) {
+          const i64 yj = E[j].cur.y;
+          less += (int)(yj < yi);
+          dup |= (yj == yi) && j < i;
+        }
+        if (less < n) B[less] = yi;
+      }
+    }
+    if (__ballot(dup) != 0ULL) return;
+    nB = n;
+    beams_prebuilt = true;
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
   SZ_HD bool pop_beam(i64 &y) {
     if (nB == 0) return false;
     y = B[--nB];
@@ -554,6 +604,78 @@ struct SweepT {
     return !(p.x > hi || p.y > hi || -p.x > hi || -p.y > hi);
   }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  // add_ring by the 64 lanes of a wave that all run the sweep alike (WideLdsWave), for the ring AddPath leaves as it is:
+  // no repeated vertex, no collinear triple (clipper.cpp:1100-1114 removes nothing) and no horizontal edge (none of
+  // the special cases of clipper.cpp:960-1043, 1146-1221).  Then every edge's record is a function of four consecutive
+  // vertices: lane i writes edge i -- orientation and slope (:1118-1131), the link to the next edge of its bound
+  // (ProcessBound's walk to the local maximum without horizontals: the bound goes on while the next edge ascends the
+  // same way), WindDelta of the two bottom edges of a local minimum (:1189-1198) -- and the local minima are listed
+  // in ring order from the first vertex, the order the serial walk below finds them in (it starts at `first`, takes
+  // a minimum, continues past the top of its forward bound: ascending vertex numbers).  Returns 1 / 0 = add_ring's
+  // true / false, -1: not this case, nothing written or counted (the serial code below does the ring).
+  template <class Ring>
+  __device__ int add_ring_wave(const Ring &ring, int hi, int kind, int base) {
+    const int lane = (int)(threadIdx.x & 63);
+    bool plain = true;
+    for (int i0 = 0; i0 <= hi; i0 += 64) {               // first round: is it the plain case?
+      const int i = i0 + lane;
+      bool bad = false;
+      if (i <= hi) {
+        const Pt pp = ring(i == 0 ? hi : i - 1), p = ring(i), pn = ring(i == hi ? 0 : i + 1);
+        bad = !in_range(p) || p.y == pn.y || collinear3(pp, p, pn);     // (the serial loop reports a vertex out of range)
+      }
+      if (__ballot(bad) != 0ULL) plain = false;
+    }
+    if (!plain) return -1;
+    int nmin = 0;                                        // local minima before this chunk of 64 vertices
+    for (int i0 = 0; i0 <= hi; i0 += 64) {
+      const int i = i0 + lane;
+      bool is_min = false;
+      LocMin lm;
+      lm.y = 0; lm.left = lm.right = NIL;
+      if (i <= hi) {
+        const int ip = i == 0 ? hi : i - 1, in = i == hi ? 0 : i + 1, inn = in == hi ? 0 : in + 1;
+        const Pt pp = ring(ip), p = ring(i), pn = ring(in), pnn = ring(inn);
+        // edge k "ascends forward" when its bottom is vertex k (y grows downwards)
+        const bool asc_prev = pp.y > p.y, asc = p.y > pn.y, asc_next = pn.y > pnn.y;
+        Edge &e = E[base + i];
+        e.cur = p;
+        if (asc) { e.bot = p; e.top = pn; } else { e.top = p; e.bot = pn; }
+        set_slope(e);
+        e.nxt = base + in;
+        e.prv = base + ip;
+        e.up = asc ? (asc_next ? base + in : NIL) : (!asc_prev ? base + ip : NIL);
+        e.anext = e.aprev = e.snext = e.sprev = NIL;
+        e.wind = e.wind2 = 0;
+        e.ring = NIL;
+        e.kind = (signed char)kind;
+        e.side = SIDE_NONE;
+        // a local minimum at vertex k: edge k ascends forward from it, edge k - 1 backward; WindDelta +1 / -1
+        is_min = asc && !asc_prev;
+        e.wdelta = is_min ? (signed char)1 : ((asc_next && !asc) ? (signed char)-1 : (signed char)0);
+        e.pad = 0;
+        if (is_min) {
+          // (the slope of edge i - 1 as its own lane computes it: bottom at vertex i, top at vertex i - 1)
+          const double slope_prev = (double)(pp.x - p.x) / (double)(pp.y - p.y);
+          lm.y = p.y;
+          if (e.slope < slope_prev) { lm.left = base + ip; lm.right = base + i; }
+          else { lm.left = base + i; lm.right = base + ip; }
+        }
+      }
+      const unsigned long long mm = __ballot(is_min);
+      const int total = nmin + __popcll(mm);
+      if (nM + total > cap.minima) { fail(ST_WORKSPACE); return 0; }
+      if (is_min) M[nM + nmin + __popcll(mm & ((1ULL << lane) - 1ULL))] = lm;
+      nmin = total;
+    }
+    nE += hi + 1;
+    nM += nmin;
+    __builtin_amdgcn_wave_barrier();
+    return 1;
+  }
+#endif
+
   // Adds one closed ring.  Returns false when the ring is degenerate (as AddPath does).
   template <class Ring>
   SZ_HD bool add_ring(const Ring &ring, int n, int kind) {
@@ -563,6 +685,10 @@ struct SweepT {
     if (hi < 2) return false;
     if (nE + hi + 1 > cap.edges) { fail(ST_WORKSPACE); return false; }
     const int base = nE;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kWave) { const int r = add_ring_wave(ring, hi, kind, base); if (r >= 0) return r != 0; }
+#endif
+    all_plain = false;
     for (int i = 0; i <= hi; ++i) {
       Edge &e = E[base + i];
       Pt p = ring(i);
@@ -650,7 +776,38 @@ struct SweepT {
     }
     return E[e2].cur.x < E[e1].cur.x;
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  __device__ int ael_index(int e) const {                      // the place of e in the mirror, -1: not there
+    const unsigned long long m = __ballot(am == e);
+    return m ? (int)__builtin_ctzll(m) : -1;
+  }
+  // ael_insert by the wave: every lane asks goes_before of its own edge, the first one (behind `from`) that answers yes is
+  // the place -- what the walk below finds (it stops in front of the first edge the new one goes before)
+  __device__ bool ael_insert_wave(int e, int from) {
+    if (an >= 64) { an = -1; return false; }
+    int start = 0;
+    if (from != NIL) { const int f = ael_index(from); if (f < 0) { an = -1; return false; } start = f + 1; }
+    const int lane = (int)(threadIdx.x & 63);
+    bool gb = false;
+    if (am != NIL) gb = goes_before(am, e);
+    unsigned long long m = __ballot(gb);
+    if (start > 0) m &= ~((1ULL << start) - 1ULL);
+    const int pos = m ? (int)__builtin_ctzll(m) : an;
+    const int p = pos > 0 ? __shfl(am, pos - 1) : NIL;
+    const int n = pos < an ? __shfl(am, pos) : NIL;
+    E[e].aprev = p; E[e].anext = n;
+    if (p != NIL) E[p].anext = e; else ael = e;
+    if (n != NIL) E[n].aprev = e;
+    const int up1 = __shfl_up(am, 1);
+    if (lane > pos) am = up1; else if (lane == pos) am = e;
+    ++an;
+    return true;
+  }
+#endif
   SZ_HD void ael_insert(int e, int from) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kMirror && an >= 0 && ael_insert_wave(e, from)) return;
+#endif
     if (ael == NIL) {
       E[e].aprev = E[e].anext = NIL;
       ael = e;
@@ -674,9 +831,24 @@ struct SweepT {
     if (p != NIL) E[p].anext = n; else ael = n;
     if (n != NIL) E[n].aprev = p;
     E[e].anext = E[e].aprev = NIL;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kMirror && an >= 0) {
+      const int idx = ael_index(e);
+      if (idx < 0) an = -1;
+      else {
+        const int lane = (int)(threadIdx.x & 63);
+        const int dn = __shfl_down(am, 1);
+        if (lane >= idx) am = (lane >= an - 1) ? NIL : dn;
+        --an;
+      }
+    }
+#endif
   }
   SZ_HD void ael_swap(int a, int b) {
     if (E[a].anext == E[a].aprev || E[b].anext == E[b].aprev) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kMirror && an >= 0) { if (am == a) am = b; else if (am == b) am = a; }
+#endif
     if (E[a].anext == b) {
       int n = E[b].anext;
       if (n != NIL) E[n].aprev = a;
@@ -707,6 +879,9 @@ struct SweepT {
   SZ_HD int ael_advance(int e) {
     int u = E[e].up;
     if (u == NIL) { fail(ST_CLIP_ERROR); return e; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kMirror && an >= 0 && am == e) am = u;
+#endif
     E[u].ring = E[e].ring;
     int p = E[e].aprev, n = E[e].anext;
     if (p != NIL) E[p].anext = u; else ael = u;
@@ -784,7 +959,36 @@ struct SweepT {
   SZ_HD int fill_of(int e) const { return E[e].kind == KIND_SUBJECT ? fill_s : fill_c; }
   SZ_HD int alt_fill_of(int e) const { return E[e].kind == KIND_SUBJECT ? fill_c : fill_s; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  // set_winding for even-odd fill on both sides, by the wave: the nearest edge of the same kind below ei in the list
+  // and the number of edges between the two are a ballot each over the mirror (clipper.cpp:1660-1737: the two walks
+  // below)
+  __device__ bool set_winding_wave(int ei) {
+    const int pos = ael_index(ei);
+    if (pos < 0) { an = -1; return false; }
+    Edge &g = E[ei];
+    int kd = -1, wd = 0;
+    if (am != NIL) { kd = E[am].kind; wd = E[am].wdelta; }
+    const unsigned long long below = pos > 0 ? ((1ULL << pos) - 1ULL) : 0ULL;
+    const unsigned long long m_nz = __ballot(wd != 0) & below;
+    const unsigned long long m_same = __ballot(kd == (int)g.kind && wd != 0) & below;
+    int start = 0;
+    g.wind = g.wdelta;
+    if (m_same == 0ULL) g.wind2 = 0;
+    else {
+      const int j = 63 - (int)__builtin_clzll(m_same);
+      g.wind2 = E[__shfl(am, j)].wind2;
+      start = j + 1;
+    }
+    const int cnt = (int)__popcll(start > 0 ? (m_nz & ~((1ULL << start) - 1ULL)) : m_nz);
+    if (cnt > 0) g.wind2 = (cnt & 1) ? (g.wind2 == 0 ? 1 : 0) : (g.wind2 == 0 ? 0 : 1);
+    return true;
+  }
+#endif
   SZ_HD void set_winding(int ei) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kMirror && an >= 0 && fill_s == FILL_EVENODD && fill_c == FILL_EVENODD && set_winding_wave(ei)) return;
+#endif
     Edge &g = E[ei];
     int e = g.aprev;
     while (e != NIL && (E[e].kind != g.kind || E[e].wdelta == 0)) e = E[e].aprev;
@@ -1344,7 +1548,8 @@ struct SweepT {
       // list, x at the top of the beam, whether it ends there; neighbours compare by shuffle
       const int lane = (int)(threadIdx.x & 63);
       int mine = NIL, n = 0;
-      for (int q = ael; q != NIL && n <= 64; q = E[q].anext, ++n) if (n == lane) mine = q;
+      if (Rec::kMirror && an >= 0) { mine = am; n = an; }
+      else for (int q = ael; q != NIL && n <= 64; q = E[q].anext, ++n) if (n == lane) mine = q;
       if (n <= 64) {
         i64 x = 0;
         bool ends = false;
@@ -1822,6 +2027,9 @@ struct SweepT {
     SZV_PHASE(13);
     gnu_sort(M, nM, LocMinLess<LocMin>());
     nB = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Rec::kWave && all_plain) prebuild_beams();
+#endif
     for (int i = 0; i < nM; ++i) {
       push_beam(M[i].y);
       Edge &l = E[M[i].left];
@@ -1833,6 +2041,12 @@ struct SweepT {
     sel = NIL;
     cur_lm = 0;
     nR = nP = nJ = nG = nX = 0;
+    am = NIL;
+#if defined(__HIP_DEVICE_COMPILE__)
+    an = Rec::kMirror ? 0 : -1;
+#else
+    an = -1;
+#endif
 
     bool ok = true;
     i64 bot_y, top_y = 0;
