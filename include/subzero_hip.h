@@ -43,6 +43,9 @@ enum {
   SZ_STEP_NEEDS_MC = 2   /* szStep, not an error: floes whose ocean/wind forcing is due have an empty Monte-Carlo mask
                             (calc_trajectory.m:100-110 draws new points with rand); NOTHING of the floe array was
                             changed; fetch them with szMcEmptyDownload, regenerate on the host, szFloesUpdate, step again */
+  , SZ_STEP_VETOED = 3   /* szStep after szSpatialUnpackQueued, not an error: a neighbour's message did not fit what was agreed
+                            to travel, so its records were not taken; NOTHING of the floe array was changed; exchange the rest
+                            (szSpatialHeaders tells what), szSpatialUnpackKnown, step again */
 };
 
 /* per-clip status, one per pair (what the mex would have done for that call) */
@@ -441,6 +444,39 @@ int szSpatialUnpackKnown(szContext *ctx, const void *d_from_left, const void *d_
                          int64_t cap_doubles, int64_t cap_migrants, const int64_t *left_counts, const int64_t *right_counts,
                          szSpatialInfo *info);
 int szSpatialOwned(szContext *ctx, uint8_t *owned);   /* owned[i] = 1: this rank integrates floe i (n bytes) */
+
+/* The same exchange with ONE host round trip per step, the step's own.  Both ends of an edge agree beforehand, from what the
+ * edge carried the step before (+ a margin), how much of a message travels: plan = {records, doubles, migrants} -- room
+ * for the rows (stress history, Monte-Carlo points: 49 KB in a model run) of a couple of floes changing strip included, so
+ * that the odd floe that crosses an edge needs no second round.
+ *
+ *   szSpatialPackQueued   (periodic, d_left, d_right, caps, plan_left, plan_right)
+ *                                                                queued on the context's stream; nothing is read back
+ *   [caller: header + the planned leading part of the two record arrays, each way, one grouped round]
+ *   szSpatialUnpackQueued (d_from_left, d_from_right, caps, plan_left, plan_right)
+ *                                                                queued: the DEVICE reads each header; a message within its
+ *                                                                plan is taken; one that outgrew it (more records, doubles
+ *                                                                or floes changing strip than agreed, or an overflow on the
+ *                                                                sender's side) is left alone and vetoes the step
+ *   szStep                                                       SZ_OK, or SZ_STEP_VETOED with nothing changed
+ *   szSpatialHeaders      (headers[32], &vetoed)                 after that szStep, no device work: the four headers (my
+ *                                                                message to the left / right, the message from the left /
+ *                                                                right; 8 int64 each: records, doubles, migrants, status,
+ *                                                                then what the edge needs) -- both ends of an edge see the
+ *                                                                same numbers and so agree on whether a second round is due
+ *   second round only (a message beyond its plan, floes changing strip):
+ *   szSpatialPackFinish   (d_left, d_right, caps, &info)         the rows of the floes that changed strip into the messages
+ *                                                                (info as szSpatialPack's; on overflow the ownership is given
+ *                                                                back: szSpatialPack again with more room)
+ *   [caller: the rest of each message], szSpatialUnpackKnown, and szStep again if the first one was vetoed.
+ * In steady state (no floe crossing an edge this step) the host touches the device once per step instead of three times. */
+int szSpatialPackQueued(szContext *ctx, int periodic, void *d_left, void *d_right, int64_t cap_records, int64_t cap_doubles,
+                        int64_t cap_migrants, const int64_t *plan_left, const int64_t *plan_right);
+int szSpatialPackFinish(szContext *ctx, void *d_left, void *d_right, int64_t cap_records, int64_t cap_doubles, int64_t cap_migrants,
+                        szSpatialInfo *info);
+int szSpatialUnpackQueued(szContext *ctx, const void *d_from_left, const void *d_from_right, int64_t cap_records,
+                          int64_t cap_doubles, int64_t cap_migrants, const int64_t *plan_left, const int64_t *plan_right);
+int szSpatialHeaders(szContext *ctx, int64_t *headers32, int32_t *vetoed);
 
 /* clipper(P, delta, type [, info]) offset mode (mexclipper.cpp:146-203): ClipperOffset with AddPaths(P, jt,
  * etClosedPolygon), Execute(solution, delta).  x / y / ring_off: the nrings contours of P (int64, as the mex reads

@@ -13,7 +13,89 @@ import numpy as np
 import torch
 import bench
 from subzero_amd import multigpu
-from test_spatial_gpu import Rank, deliver
+from test_spatial_gpu import Rank, deliver, deliver_planned, plan_of
+from subzero_amd import capi
+
+
+def run_queued(S, P, world, steps, warm=8):
+    """The same with the queued exchange (szSpatialPackQueued / UnpackQueued: one host round trip per step, the step's own):
+    per rank, the host time from the queued unpack to the step's return, and -- apart, because the emulation has to wait
+    for the pack before it can copy the messages, which a rank of a real job does not -- the pack."""
+    Lx = float(P.c2_boundary[0].max())
+    edges, halo = multigpu.strip_edges(S, world, Lx)
+    ranks = [Rank(S, r, world, edges, halo) for r in range(world)]
+    periodic = bool(P.PERIODIC)
+    has = lambda R, side: world > 1 and (periodic or (R.rank > 0 if side == "left" else R.rank < world - 1))
+    sides = (("left", "send_left", -1, "from_right"), ("right", "send_right", +1, "from_left"))
+    last = {}
+    t_pack = np.zeros(world); t_rest = np.zeros(world); vetoed = 0; dev = np.zeros(world)
+    for it in range(warm + steps):
+        P.doInt = int(it % 10 == 0)
+        if it == 0:
+            infos = []
+            for Rk in ranks:
+                with Rk.be.stream_scope(): infos.append(Rk.be.pack(P.PERIODIC, Rk.buf["send_left"], Rk.buf["send_right"], Rk.caps))
+            torch.cuda.synchronize()
+            for Rk, sent in zip(ranks, infos):
+                for side, skey, d, dkey in sides:
+                    if has(Rk, side):
+                        deliver(Rk, skey, ranks[(Rk.rank + d) % world], dkey)
+                        last[(Rk.rank, side)] = tuple(int(getattr(sent, side + "_" + f)) for f in ("records", "doubles", "migrants"))
+            torch.cuda.synchronize()
+            for Rk in ranks:
+                with Rk.be.stream_scope():
+                    Rk.be.unpack(Rk.buf["from_left"] if has(Rk, "left") else None, Rk.buf["from_right"] if has(Rk, "right") else None, Rk.caps)
+                    Rk.be.step(P)
+            continue
+        for k, Rk in enumerate(ranks):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with Rk.be.stream_scope():
+                Rk.be.pack_queued(P.PERIODIC, Rk.buf["send_left"], Rk.buf["send_right"], Rk.caps,
+                                  plan_of(last[(Rk.rank, "left")]) if has(Rk, "left") else None, plan_of(last[(Rk.rank, "right")]) if has(Rk, "right") else None)
+            torch.cuda.synchronize()
+            if it >= warm: t_pack[k] += time.perf_counter() - t0
+        for Rk in ranks:
+            for side, skey, d, dkey in sides:
+                if has(Rk, side): deliver_planned(Rk, skey, ranks[(Rk.rank + d) % world], dkey, plan_of(last[(Rk.rank, side)]))
+        torch.cuda.synchronize()
+        veto = {}
+        for k, Rk in enumerate(ranks):
+            pl = plan_of(last[((Rk.rank - 1) % world, "right")]) if has(Rk, "left") else None
+            pr = plan_of(last[((Rk.rank + 1) % world, "left")]) if has(Rk, "right") else None
+            t0 = time.perf_counter()
+            with Rk.be.stream_scope():
+                Rk.be.unpack_queued(Rk.buf["from_left"] if pl else None, Rk.buf["from_right"] if pr else None, Rk.caps, pl, pr)
+                try:
+                    st = Rk.be.step(P); veto[k] = False
+                    if it >= warm: dev[k] += st.step_ms
+                except capi.StepVetoed:
+                    veto[k] = True
+                Rk.out_h, Rk.in_h, _ = Rk.be.headers_host()
+            if it >= warm: t_rest[k] += time.perf_counter() - t0
+        for Rk in ranks:           # second round where a message is beyond its plan
+            if any(has(Rk, side) and (Rk.out_h[side][0] > plan_of(last[(Rk.rank, side)])[0] or Rk.out_h[side][1] > plan_of(last[(Rk.rank, side)])[1]
+                                      or Rk.out_h[side][2] > plan_of(last[(Rk.rank, side)])[2]) for side in ("left", "right")):
+                with Rk.be.stream_scope(): Rk.be.pack_finish(Rk.buf["send_left"], Rk.buf["send_right"], Rk.caps)
+                torch.cuda.synchronize()
+                for side, skey, d, dkey in sides:
+                    if has(Rk, side): deliver(Rk, skey, ranks[(Rk.rank + d) % world], dkey)
+        torch.cuda.synchronize()
+        for k, Rk in enumerate(ranks):
+            if veto[k]:
+                vetoed += int(it >= warm)
+                counts = {s_: Rk.in_h[s_][:3] for s_ in ("left", "right") if has(Rk, s_)}
+                t0 = time.perf_counter()
+                with Rk.be.stream_scope():
+                    Rk.be.unpack(Rk.buf["from_left"] if has(Rk, "left") else None, Rk.buf["from_right"] if has(Rk, "right") else None, Rk.caps, counts=counts, want_info=False)
+                    Rk.be.step(P)
+                if it >= warm: t_rest[k] += time.perf_counter() - t0
+            for side in ("left", "right"):
+                if has(Rk, side): last[(Rk.rank, side)] = Rk.out_h[side][:3]
+    for Rk in ranks: Rk.be.close()
+    return {"world": world, "floes": int(S.n), "exchange": "queued", "unpack_plus_step_ms_per_rank": [round(float(v), 4) for v in t_rest / steps * 1e3],
+            "slowest_rank_unpack_plus_step_ms": float(t_rest.max() / steps * 1e3),
+            "pack_queued_ms (with a wait for the device that only the emulation needs)": float(t_pack.max() / steps * 1e3),
+            "rank_steps_vetoed_and_repeated": int(vetoed), "rank_steps": int(world * steps)}
 
 
 def run(S, P, world, steps, warm=8):
@@ -70,6 +152,13 @@ if __name__ == "__main__":
         S, P = bench.build_workload(10000)
         out["strong_x%d" % w] = run(S, P, w, steps)
         print(json.dumps(out["strong_x%d" % w]), flush=True)
+    for w in sorted({2, world}):
+        S, P = bench.build_workload(10000)
+        out["strong_x%d_queued" % w] = run_queued(S, P, w, steps)
+        print(json.dumps(out["strong_x%d_queued" % w]), flush=True)
     S, P = bench.build_workload(10000 * 2, Lx=2e5)
     out["weak_x2"] = run(S, P, 2, steps)
+    S, P = bench.build_workload(10000 * 2, Lx=2e5)
+    out["weak_x2_queued"] = run_queued(S, P, 2, steps)
+    print(json.dumps(out["weak_x2_queued"]), flush=True)
     print(json.dumps(out))

@@ -81,6 +81,12 @@ SYNC_DYNAMIC, SYNC_STRESSH, SYNC_ALL = 1, 2, 3
 STEP_QUEUE_AHEAD, STEP_NEXT_DOINT = 1, 2     # szStepParams.flags
 F_STATE, F_RING, F_STRESSH, F_MC, F_ALL = 1, 2, 4, 8, 15
 SZ_STEP_NEEDS_MC = 2
+SZ_STEP_VETOED = 3
+
+
+class StepVetoed(SubzeroError):
+    """szStep returned SZ_STEP_VETOED (spatial partition, queued exchange): nothing was changed; the caller exchanges the
+    rest of the messages and steps again (multigpu.SpatialInteractions does)."""
 
 
 class NeedsMc(SubzeroError):
@@ -363,6 +369,8 @@ class FloeInteractions:
         rc = self.ctx.L.szStep(self.ctx.h, ctypes.byref(cp), ctypes.byref(st))
         if rc == SZ_STEP_NEEDS_MC:
             raise NeedsMc(self.mc_empty())
+        if rc == SZ_STEP_VETOED:
+            raise StepVetoed("szStep: vetoed by a queued unpack (a neighbour's message outgrew its plan); nothing was changed")
         self.ctx.check(rc, "szStep")
         return st
 

@@ -41,7 +41,7 @@ __device__ inline int dev_next(const Work &W) { return (int)W.counters[C_NEXT]; 
 
 __global__ void k_counters_clear(Floes F, Work W) {
   const int e = threadIdx.x * C_STRIDE;
-  if (e < C_COUNT && e != C_SCR_BUMP) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
+  if (e < C_COUNT && e != C_SCR_BUMP && e != C_VETO) W.counters[e] = (e == C_NEXT) ? (unsigned long long)F.n : 0ULL;
 }
 __global__ void k_ext_clear(Floes F, Params P, Work W) {   // (and the cells of the broad-phase grid: one launch fewer)
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,7 +414,7 @@ __device__ inline bool go_by_values(int k, unsigned long long v, const GoRule &r
   if (rule.mode == GO_SET) return true;
   bool bad = false;
   switch (k) {
-    case C_NEED_MC: case C_ERR_POT: case C_ERR_ARENA: case C_ERR_CLIP: case C_RETRY: case C_BIG: case C_ERR_CELL: bad = v != 0; break;
+    case C_NEED_MC: case C_ERR_POT: case C_ERR_ARENA: case C_ERR_CLIP: case C_RETRY: case C_BIG: case C_ERR_CELL: case C_VETO: bad = v != 0; break;
     case C_NPAIRS: bad = (long long)v > rule.spec_np; break;
     case C_NVTOT: bad = (long long)v > rule.spec_nvt; break;
     case C_TEAM: bad = rule.team_pending && v != 0; break;
@@ -441,7 +441,7 @@ __global__ void k_publish(unsigned long long *counters, unsigned long long *host
     host_copy[e] = v;
     const bool reset = reset_next >= 0 && (!reset_only_if_go || go);
     if (e == C_AHEAD) counters[e] = go;                 // (the step's last publish: did it run to its end? -- kf_front_a / b queued ahead)
-    else if (reset) { if (e != C_SCR_BUMP) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
+    else if (reset) { if (e != C_SCR_BUMP && e != C_VETO) counters[e] = (e == C_NEXT) ? (unsigned long long)reset_next : 0ULL; }
     else if (e == C_GO) counters[e] = go;
   }
   if (seq) {
@@ -1447,6 +1447,15 @@ static int step_back(szContext *ctx, StepState *S, szStepStats *stats) {
   return step_back_b(ctx, S, stats);
 }
 
+// (a vetoed step has run its front half and narrow phase at most: the floe array is as it was, the next szStep starts over)
+static int step_vetoed(szContext *ctx, StepState *S) {
+  S->counters_clean = false;
+  S->back_queued = false; S->publish_with_incoming = false;
+  ++S->steps_vetoed;
+  sz_fail(ctx, SZ_STEP_VETOED, "szStep: a neighbour's message did not fit what was agreed to travel (szSpatialUnpackQueued); nothing was changed");
+  return SZ_STEP_VETOED;
+}
+
 int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   if (!ctx || !hp) return SZ_ERR_BAD_ARG;
   StepState *S = ctx->step;
@@ -1460,9 +1469,20 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
   if (g_hc.have) g_hc.between += std::chrono::duration<double, std::micro>(g_hc.entry - g_hc.ret).count();
 #endif
   int rc;
+  const bool speculative = S->spec_np > 0 && !S->no_speculation && S->convex_fast && !S->fast_path;
+  // Spatial partition, queued exchange: the neighbours' messages were unpacked without a look at their headers
+  // (szSpatialUnpackQueued).  A message that outgrew what was agreed to travel has raised C_VETO on the device: the
+  // queued back half then does not run (GoRule) and this call reports SZ_STEP_VETOED with nothing changed.  A step
+  // that would read the counters back half-way anyway (not in steady state) asks before it starts.
+  const bool veto_armed = S->sp_unpack_queued;
+  S->sp_unpack_queued = false;
+  if (veto_armed && !(speculative && S->back_spec_ok)) {
+    SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (S->sp_hdr && S->sp_hdr[4 * SP_HDR_WORDS]) return step_vetoed(ctx, S);
+  }
   // Steady state: the front stages and the narrow phase are queued back to back, sized by the last step's counts plus
   // a margin, and validated at the one read-back after the narrow phase (one host round trip fewer per step).
-  if (S->spec_np > 0 && !S->no_speculation && S->convex_fast && !S->fast_path) {
+  if (speculative) {
     if ((rc = fused_eligible(S, hp) ? step_front_fused(ctx, S, hp) : step_front(ctx, S, hp, true))) return rc;
     const bool queue_back = S->back_spec_ok;
     if ((rc = step_narrow_first(ctx, S, 0, S->spec_np, queue_back))) return rc;
@@ -1476,6 +1496,7 @@ int szStep(szContext *ctx, const szStepParams *hp, szStepStats *stats) {
         if (!rc) spec_caps(S);
         return rc;
       }
+      if (veto_armed && S->c[C_VETO]) return step_vetoed(ctx, S);
       ++S->back_misses;
       hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, S->W.counters, S->c_dev, -1LL, GoRule{GO_SET, 0, 0, 0, 0, 0}, 0, (const unsigned long long *)(S->fused ? S->W.prow_part : nullptr));   // from here on the host decides
       SZ_HIP(ctx, hipGetLastError());

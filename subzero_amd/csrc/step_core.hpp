@@ -135,7 +135,8 @@ enum {
   C_TEAMV = 26 * C_STRIDE,   // ring vertices (stored lengths, both rings) of the pairs on the team pass's three lists: what that kernel's roofline is priced on
   C_FORCE = 27 * C_STRIDE,   // fused back half: floes on force_list (forcing due on a step that does not refresh it for everybody: h < 0.1)
   C_AHEAD = 28 * C_STRIDE,   // the step's last publish: 1 when the step ran to its end -- the front kernels queued ahead for the NEXT step (szStepParams.flags) run only then
-  C_SLOTS = 29, C_COUNT = C_SLOTS * C_STRIDE
+  C_VETO = 29 * C_STRIDE,    // spatial partition, queued exchange (szSpatialUnpackQueued): a neighbour's message did not fit what was agreed to travel -- the step must not run its back half (GoRule); kept by k_counters_clear, cleared by the pack of the next step
+  C_SLOTS = 30, C_COUNT = C_SLOTS * C_STRIDE
 };
 
 // one floe in the uniform grid: position, bounding radius and index side by side, so that a candidate test

@@ -10,6 +10,7 @@
 using namespace szs;
 
 // what the back half of the step -- contact rows, calc_trajectory -- is to do (step.hip k_publish)
+enum { SP_HDR_WORDS = 8 };   // (= SP_HDR of spatial_core.hpp: int64s of a message header)
 struct GoRule { int mode; long long spec_np, spec_nvt, rows_cap; int team_pending; long long next_cap; };   // next_cap > 0: entries of the extended list the queued back half covers   // team_pending: pairs on team_list have not had their pass   // mode 0: leave C_GO, 1: go, 2: go if the narrow phase is complete and fits
 enum { GO_LEAVE = 0, GO_SET = 1, GO_IF_CLEAN = 2 };
 
@@ -42,11 +43,15 @@ struct StepState {
   double rmax_max = 0, rmax_p90 = 0; // over the floes that can be candidates (i >= Nb)
   double rmax_max_all = 0;           // over all floes (the reach of the spatially sharded step)
   // spatially sharded step (spatial.hip)
+  int sp_pack_periodic = 0;        // (szSpatialPackQueued's argument, for szSpatialPackFinish)
+  bool sp_unpack_queued = false;   // szSpatialUnpackQueued since the last szStep: that step honours C_VETO
+  long long steps_vetoed = 0;
   int sp_rank = 0, sp_world = 1, sp_axis = 0;   // (axis the strips are cut along: 0 x, 1 y; szSpatialSetAxis)
   double sp_halo = 0;
   std::vector<double> sp_edges;
   DevBuf sp_masks, sp_edges_dev, sp_counts;   // present[n] then owned[n]; strip edges; two counters
-  long long *sp_hdr = nullptr;                // pinned: the headers of the two messages a Pack produced
+  // pinned, 5 x SP_HDR_WORDS: the headers of the two messages a Pack produced, of the two a queued Unpack took in, the veto
+  long long *sp_hdr = nullptr;
   Params P;                       // parameters of the step in flight
   unsigned long long *c = nullptr; // host copy of the device counters (pinned; k_publish writes it)
   unsigned long long *c_dev = nullptr; // the same buffer as the device sees it

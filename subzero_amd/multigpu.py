@@ -286,6 +286,42 @@ class GpuSpatialBackend:
     def step(self, P):
         return self.sim.step(P)
 
+    # -- the exchange with one host round trip per step (include/subzero_hip.h szSpatialPackQueued ...) --
+    def pack_queued(self, periodic, left, right, caps, plan_left=None, plan_right=None):
+        L = self.ctx.L
+        L.szSpatialPackQueued.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        arr = lambda c: (ctypes.c_int64 * 3)(*c) if c is not None else None
+        self.ctx.check(L.szSpatialPackQueued(self.ctx.h, int(periodic), ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr()),
+                                             caps[0], caps[1], caps[2], arr(plan_left), arr(plan_right)), "szSpatialPackQueued")
+
+    def pack_finish(self, left, right, caps):
+        L = self.ctx.L
+        L.szSpatialPackFinish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(SpatialInfo)]
+        info = SpatialInfo()
+        self.ctx.check(L.szSpatialPackFinish(self.ctx.h, ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr()), caps[0], caps[1], caps[2],
+                                             ctypes.byref(info)), "szSpatialPackFinish")
+        return info
+
+    def unpack_queued(self, from_left, from_right, caps, plan_left, plan_right):
+        L = self.ctx.L
+        L.szSpatialUnpackQueued.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        arr = lambda c: (ctypes.c_int64 * 3)(*c) if c is not None else None
+        self.ctx.check(L.szSpatialUnpackQueued(self.ctx.h, p(from_left), p(from_right), caps[0], caps[1], caps[2], arr(plan_left), arr(plan_right)),
+                       "szSpatialUnpackQueued")
+
+    def headers_host(self):
+        """After the step that followed pack_queued / unpack_queued: ({"left": hdr, "right": hdr} of my messages, the same of
+        the received ones, vetoed); hdr = (records, doubles, migrants, status)."""
+        L = self.ctx.L
+        L.szSpatialHeaders.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]
+        h = (ctypes.c_int64 * 32)(); v = ctypes.c_int32(0)
+        self.ctx.check(L.szSpatialHeaders(self.ctx.h, h, ctypes.byref(v)), "szSpatialHeaders")
+        q = lambda k: (int(h[8 * k]), int(h[8 * k + 1]), int(h[8 * k + 2]), int(h[8 * k + 3]))
+        return {"left": q(0), "right": q(1)}, {"left": q(2), "right": q(3)}, bool(v.value)
+
     def header(self, t):
         """(records, doubles, migrants, status) of a received message header (a 64-byte device tensor)."""
         h = t.view(self.torch.int64).cpu().numpy()
@@ -326,6 +362,9 @@ class SpatialInteractions:
         self.bytes_sent = 0
         self.regrown = 0
         self.rounds = 0                      # grouped send / recv rounds so far (one per step in steady state)
+        self.second_rounds = 0               # steps of the queued exchange that needed a second round
+        # the exchange with one host round trip per step, when the backend has it (SUBZERO_SPATIAL_QUEUED=0: never)
+        self.queued = hasattr(backend, "pack_queued") and os.environ.get("SUBZERO_SPATIAL_QUEUED", "1") != "0"
         self.last_out, self.last_in = {}, {}   # per edge: (records, doubles, migrants) of the last message sent / received
         self.last = None
 
@@ -349,6 +388,144 @@ class SpatialInteractions:
         return (c[0] + c[0] // 4 + 16, c[1] + c[1] // 4 + 1024, 0)
 
     def step(self, P):
+        """One step of the partitioned job.  With a backend that has the queued entry points (the GPU one) and an agreed
+        size for every edge -- from the second step on -- the host touches the device ONCE per step (`_step_queued`);
+        otherwise, and while the caller wants the counts of owned / present floes, `_step_classic`."""
+        if self.world > 1 and self.queued and not self.count_present and self._edges_planned(P):
+            return self._step_queued(P)
+        return self._step_classic(P)
+
+    @staticmethod
+    def _plan_queued(c):
+        """_plan for the queued exchange: room for the rows of a couple of floes changing strip travels with the first round
+        (49 KB each in a model run: microseconds over xGMI), so that the odd floe crossing an edge -- at sea-ice drift speeds
+        a step in five or ten sees one -- does not veto the receiver's step."""
+        return (c[0] + c[0] // 4 + 16, c[1] + c[1] // 4 + 1024, max(2, c[2] + 1))
+
+    def _my_edges(self, P):
+        left, right = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        hl = bool(P.PERIODIC) or self.rank > 0
+        hr = bool(P.PERIODIC) or self.rank < self.world - 1
+        # (edge, peer, key of my send buffer, tag of what I send, key of my receive buffer, tag of what I receive): see _step_classic
+        return [e for e in (("left", left, "send_left", 1, "from_left", 2), ("right", right, "send_right", 2, "from_right", 1))
+                if (hl if e[0] == "left" else hr)]
+
+    def _edges_planned(self, P):
+        return all(e[0] in self.last_out and e[0] in self.last_in for e in self._my_edges(P))
+
+    def _step_queued(self, P):
+        """pack -> exchange -> unpack -> step with nothing read back in between (include/subzero_hip.h szSpatialPackQueued):
+        the same first round as `_step_classic`'s steady state -- header + the agreed leading part of the two record arrays,
+        each way -- but the DEVICE reads the received headers: a message within its plan is taken, one beyond it (or with
+        a floe that changed strip, whose rows travel separately) vetoes the step, which then changes nothing.  After the
+        step's own read-back the host reads the four headers from pinned memory; both ends of an edge see the same numbers
+        and so agree on whether a second round is due -- the sender packs the rows of its migrants and sends the rest, the
+        vetoed receiver unpacks and steps again.  Steady state: one host round trip per step instead of three."""
+        from . import capi
+        be, dist = self.be, self.dist
+        with be.stream_scope():
+            bulk_row = be.bulk_row()
+            edges = self._my_edges(P)
+            plan_out = {e[0]: self._plan_queued(self.last_out[e[0]]) for e in edges}
+            plan_in = {e[0]: self._plan_queued(self.last_in[e[0]]) for e in edges}
+            for pl in list(plan_out.values()) + list(plan_in.values()):
+                self.caps = tuple(max(a, b) for a, b in zip(self.caps, pl))
+            caps = self.caps
+            nbytes = be.message_bytes(caps)
+            bufs = {k: be.buffer(k, nbytes) for k in ("send_left", "send_right", "from_left", "from_right")}
+            be.pack_queued(P.PERIODIC, bufs["send_left"], bufs["send_right"], caps, plan_out.get("left"), plan_out.get("right"))
+            v = {k: self._views(b, caps, bulk_row) for k, b in bufs.items()}
+            recv_order = list(reversed(edges))
+
+            def parts(key, cnt):
+                _, rec, dbl, bulk = v[key]
+                out = []
+                if cnt[0]: out.append(rec[:4 * cnt[0]])
+                if cnt[1]: out.append(dbl[:8 * cnt[1]])
+                if cnt[2]: out.append(bulk[:cnt[2] * bulk_row])
+                return out
+
+            ops = []
+            for e in edges:
+                ops.append(dist.P2POp(dist.isend, v[e[2]][0], e[1], self.group, tag=e[3])); self.bytes_sent += 64
+                for t in parts(e[2], plan_out[e[0]]):
+                    ops.append(dist.P2POp(dist.isend, t, e[1], self.group, tag=e[3])); self.bytes_sent += t.numel()
+            for e in recv_order:
+                ops.append(dist.P2POp(dist.irecv, v[e[4]][0], e[1], self.group, tag=e[5]))
+                for t in parts(e[4], plan_in[e[0]]):
+                    ops.append(dist.P2POp(dist.irecv, t, e[1], self.group, tag=e[5]))
+            self._round(ops)
+            self.rounds += 1
+            names = [e[0] for e in edges]
+            be.unpack_queued(bufs["from_left"] if "left" in names else None, bufs["from_right"] if "right" in names else None, caps,
+                             plan_in.get("left"), plan_in.get("right"))
+            vetoed, pending, st = False, None, None
+            try:
+                st = be.step(P)
+            except capi.StepVetoed:
+                vetoed = True
+            except capi.NeedsMc as exc:           # (the step changed nothing and is rank-local from here on: retry_local)
+                pending = exc
+            out_h, in_h, _ = be.headers_host()
+            if any(out_h[k][3] != 0 or in_h[k][3] != 0 for k in names):
+                # more floes changed strip across one edge in one step than a message has room for (max(64, n / 16)): the
+                # queued exchange has no repair for that (the classic one packs again into larger buffers before it sends)
+                be.pack_finish(bufs["send_left"], bufs["send_right"], caps)       # (gives the ownership back)
+                raise capi.SubzeroError("spatial exchange: a message overflowed its capacities in the queued exchange "
+                                        "(SUBZERO_SPATIAL_QUEUED=0 selects the classic exchange, which grows them)")
+            out_cnt = {k: out_h[k][:3] for k in names}
+            hdr = {k: in_h[k][:3] for k in names}
+
+            def rest(cnt, plan):
+                big = cnt[0] > plan[0] or cnt[1] > plan[1]
+                return (cnt[0] if big else 0, cnt[1] if big else 0, cnt[2] if cnt[2] > plan[2] else 0)
+            rest_out = {k: rest(out_cnt[k], plan_out[k]) for k in names}
+            rest_in = {k: rest(hdr[k], plan_in[k]) for k in names}
+            second = any(any(c) for c in rest_out.values()) or any(any(c) for c in rest_in.values())
+            rcaps = caps
+            if vetoed and not any(any(c) for c in rest_in.values()):
+                raise capi.SubzeroError("spatial exchange: the step was vetoed but no received message is beyond its plan")
+            if second:
+                self.second_rounds += 1
+                if any(any(c) for c in rest_out.values()) and any(c[2] for c in out_cnt.values()):
+                    be.pack_finish(bufs["send_left"], bufs["send_right"], caps)   # the rows of my floes that changed strip (all of them, again)
+                rcaps = tuple(max([caps[q]] + [hdr[k][q] for k in names]) for q in range(3))
+                if rcaps != caps:                                 # a neighbour's message is larger than my buffers
+                    rbytes = be.message_bytes(rcaps)
+                    for e in edges:
+                        k = e[4]
+                        old = [t.clone() for t in v[k]]
+                        bufs[k] = be.buffer(k, rbytes)
+                        v[k] = self._views(bufs[k], rcaps, bulk_row)
+                        for a, b in zip(v[k], old):
+                            m = min(a.numel(), b.numel())
+                            a[:m].copy_(b[:m])
+                    self.regrown += 1
+                ops = []
+                for e in edges:
+                    for t in parts(e[2], rest_out[e[0]]):
+                        ops.append(dist.P2POp(dist.isend, t, e[1], self.group, tag=e[3])); self.bytes_sent += t.numel()
+                for e in recv_order:
+                    for t in parts(e[4], rest_in[e[0]]):
+                        ops.append(dist.P2POp(dist.irecv, t, e[1], self.group, tag=e[5]))
+                self._round(ops)
+                self.rounds += 1
+                if rcaps != caps:
+                    # (my send buffers keep their layout for this step; from the next one every buffer has the larger one)
+                    self.caps = tuple(max(a, b) for a, b in zip(self.caps, rcaps))
+            for k in names:
+                self.last_out[k] = out_cnt[k]; self.last_in[k] = hdr[k]
+            self.exchanges += 1
+            self.last = None
+            if vetoed:
+                be.unpack(bufs["from_left"] if "left" in names else None, bufs["from_right"] if "right" in names else None, rcaps,
+                          counts=hdr, want_info=False)
+                st = be.step(P)
+            if pending is not None:
+                raise pending
+            return st
+
+    def _step_classic(self, P):
         """pack -> exchange -> unpack -> step.  In steady state the exchange is ONE grouped round of send / recv per step:
         each message travels as header + the leading part of its three arrays, sized from what the same edge carried
         last step plus a margin (both ends know that number); the header says how much of it is used.  Only the

@@ -82,6 +82,7 @@ class HostSpatialBackend:
         return self._info(raw)
 
     def unpack(self, from_left, from_right, caps, counts=None, want_info=True):
+        self._q_veto = False          # (the caller has looked at the headers: whatever a queued unpack vetoed is settled)
         raw = (ctypes.c_int64 * 14)()
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         assert self.L.host_spatial_unpack(ctypes.byref(self.cf), p(from_left), p(from_right), caps[0], caps[1], caps[2], raw) == 0
@@ -93,10 +94,49 @@ class HostSpatialBackend:
         h = t.view(self.torch.int64).numpy()
         return int(h[0]), int(h[1]), int(h[2]), int(h[3])
 
+    # -- the queued exchange (include/subzero_hip.h szSpatialPackQueued ...) with the device's part played here: a message
+    # within its plan is taken, one beyond it is left alone and vetoes the step.  (The host build packs the rows of the
+    # migrants with the message: pack_finish has nothing left to do.)  What this exercises under a real process group is
+    # multigpu.SpatialInteractions._step_queued: who sends and receives what, and that both ends of an edge agree.
+    def pack_queued(self, periodic, left, right, caps, plan_left=None, plan_right=None):
+        self._q_sent = self.pack(periodic, left, right, caps)
+        self._q_veto = bool(self._q_sent.overflow)
+
+    def pack_finish(self, left, right, caps):
+        return self._q_sent
+
+    def unpack_queued(self, from_left, from_right, caps, plan_left, plan_right):
+        self._q_in = {"left": (0, 0, 0, 0), "right": (0, 0, 0, 0)}
+        take = {"left": None, "right": None}
+        for name, t, plan in (("left", from_left, plan_left), ("right", from_right, plan_right)):
+            if t is None:
+                continue
+            h = self.header(t[:64])
+            self._q_in[name] = h
+            if h[3] == 0 and h[0] <= plan[0] and h[1] <= plan[1] and h[2] <= plan[2]:
+                take[name] = t
+            else:
+                self._q_veto = True
+        veto = self._q_veto
+        if take["left"] is not None or take["right"] is not None:
+            self.unpack(take["left"], take["right"], caps)
+        self._q_veto = veto
+
+    def headers_host(self):
+        i = self._q_sent
+        st = 1 if i.overflow else 0
+        out = {"left": (int(i.left_records), int(i.left_doubles), int(i.left_migrants), st),
+               "right": (int(i.right_records), int(i.right_doubles), int(i.right_migrants), st)}
+        return out, dict(self._q_in), False
+
     def bulk_row(self):
         return ((self.S.n_stress * 32 + self.S.n_mc * 17 + 7) // 8) * 8
 
     def step(self, P):
+        if getattr(self, "_q_veto", False):
+            from subzero_amd import capi
+            self._q_veto = False
+            raise capi.StepVetoed("vetoed")
         self.result = self.hs.step(self.S, P)
         self.ghosts = self.hs.last_ghosts()
         return self.result
@@ -136,7 +176,7 @@ def _worker(rank, world, port, scene, steps, drift, q):
         import scenes
         from subzero_amd import multigpu
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        kw = dict(scene[2]); tiny = kw.pop("tiny_migrant_room", False); axis = kw.pop("strip_axis", 0)
+        kw = dict(scene[2]); tiny = kw.pop("tiny_migrant_room", False); axis = kw.pop("strip_axis", 0); queued = kw.pop("queued", False)
         made = getattr(scenes, scene[0])(*scene[1], **kw)
         S, P = made[0], made[1]
         P.set_reference_ocean()
@@ -178,13 +218,16 @@ def _worker(rank, world, port, scene, steps, drift, q):
             for i in ids:
                 assert named_rows(be.result, be.ghosts, S.n, i) == named_rows(r1, g1, S.n, i), "step %d: contact rows of floe %d" % (it, i + 1)
                 assert ref.kill[i] == S.kill[i], (it, i)
-            most_present = max(most_present, int(sim.last[1].n_present))
+            if sim.last is not None:
+                most_present = max(most_present, int(sim.last[1].n_present))
+            if queued:
+                sim.count_present = False            # (from the second step on: the exchange with one host round trip per step)
         moved = int((own != owned0).sum())
         dist.destroy_process_group()
-        q.put((rank, "ok", moved, be.migrants_in, most_present, int(own.sum()), sim.bytes_sent // max(sim.exchanges, 1), len(r1.inter), sim.regrown, sim.rounds, sim.exchanges))
+        q.put((rank, "ok", moved, be.migrants_in, most_present, int(own.sum()), sim.bytes_sent // max(sim.exchanges, 1), len(r1.inter), sim.regrown, sim.rounds, sim.exchanges, sim.second_rounds))
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0, 0, 0, 0, 0, 0, 0, 0))
+        q.put((rank, "fail: %s\n%s" % (e, traceback.format_exc()), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
 
 
 def run(world, scene, steps, drift):
@@ -254,3 +297,23 @@ def test_one_round_per_step_when_no_floe_changes_strip():
     for r in res:
         assert r[10] == 6 and r[9] == 7, (r[9], r[10])
     assert sum(r[3] for r in res) == 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_queued_exchange_equals_single_process(world):
+    """The exchange with one host round trip per step (SpatialInteractions._step_queued; the device's part -- take a message
+    within its plan, veto the step otherwise -- played by the host backend): floes drift across the strip edges, so some
+    steps are vetoed on the receiving rank and settled by a second round; owned floes bit-identical to the single-process
+    step after every step, ownership a partition, nobody left waiting."""
+    n = 2700 if world == 3 else 1800
+    res = run(world, ("pack", (n,), {"periodic": True, "n_stress": 6, "n_mc": 80, "queued": True}), 10, 45.0)
+    assert sum(r[3] for r in res) > 0, "no floe changed strip"
+    assert sum(r[11] for r in res) > 0, "no step of the queued exchange needed its second round"
+    for r in res:
+        assert r[10] == 10 and r[9] < 2 * r[10] + 1, (r[9], r[10])
+
+
+def test_queued_exchange_is_one_round_per_step_at_rest():
+    res = run(2, ("pack", (1800,), {"periodic": True, "n_stress": 6, "n_mc": 80, "queued": True}), 6, 0.0)
+    for r in res:
+        assert r[10] == 6 and r[9] == 7 and r[11] == 0, (r[9], r[10], r[11])

@@ -104,6 +104,146 @@ def test_emulated_ranks_match_the_oracle(world, periodic):
         R.be.close()
 
 
+def plan_of(c):
+    return multigpu.SpatialInteractions._plan_queued(c)
+
+
+def deliver_planned(src, skey, dst, dkey, plan):
+    """First round of the queued exchange: the header and the agreed leading part of the two record arrays."""
+    hs, rs, ds, bs = src.views(skey); hd, rd, dd, bd = dst.views(dkey)
+    row = src.be.bulk_row()
+    hd.copy_(hs); rd[:4 * plan[0]].copy_(rs[:4 * plan[0]]); dd[:8 * plan[1]].copy_(ds[:8 * plan[1]]); bd[:plan[2] * row].copy_(bs[:plan[2] * row])
+
+
+@pytest.mark.parametrize("world,periodic", [(2, True), (3, True), (2, False)])
+def test_queued_exchange_on_emulated_ranks(world, periodic):
+    """szSpatialPackQueued / UnpackQueued / szStep / szSpatialHeaders / PackFinish through the C ABI, ranks emulated on one
+    card: nothing is read back between pack and step; the device takes a message within its plan and vetoes the step
+    otherwise (a floe changed strip, a message outgrew its plan); a vetoed step changes nothing and is repeated after the
+    second round.  Owned floes against the oracle after every step, ownership a partition."""
+    import torch
+    n = 2700 if world == 3 else 1800
+    S, P = scenes.pack(n, periodic=periodic, n_stress=6, n_mc=80)
+    P.set_reference_ocean()
+    S.Ui += 45.0 if periodic else 12.0
+    A = S.copy()
+    edges, halo = multigpu.strip_edges(S, world, float(P.c2_boundary[0].max()))
+    ranks = [Rank(S, r, world, edges, halo) for r in range(world)]
+    last = {}                                # (sender rank, side) -> (records, doubles, migrants) of the message before
+    vetoed_steps = clean_steps = moved = 0
+    sides = (("left", "send_left", -1, "from_right"), ("right", "send_right", +1, "from_left"))
+    for it in range(10):
+        P.doInt = int(it % 4 == 0)
+        ra = oracle.step(A, P, threads=16)
+        has = lambda R, side: periodic or (R.rank > 0 if side == "left" else R.rank < world - 1)
+        if it == 0:                          # the first step: the classic exchange (nothing is agreed yet)
+            infos = []
+            for R in ranks:
+                with R.be.stream_scope():
+                    infos.append(R.be.pack(P.PERIODIC, R.buf["send_left"], R.buf["send_right"], R.caps))
+            torch.cuda.synchronize()
+            for R, sent in zip(ranks, infos):
+                for side, skey, d, dkey in sides:
+                    if has(R, side):
+                        deliver(R, skey, ranks[(R.rank + d) % world], dkey)
+                        last[(R.rank, side)] = (int(getattr(sent, side + "_records")), int(getattr(sent, side + "_doubles")), int(getattr(sent, side + "_migrants")))
+            torch.cuda.synchronize()
+            for R in ranks:
+                with R.be.stream_scope():
+                    R.be.unpack(R.buf["from_left"] if has(R, "left") else None, R.buf["from_right"] if has(R, "right") else None, R.caps)
+                    R.be.step(P)
+        else:
+            for R in ranks:
+                with R.be.stream_scope():
+                    R.be.pack_queued(P.PERIODIC, R.buf["send_left"], R.buf["send_right"], R.caps,
+                                     plan_of(last[(R.rank, "left")]) if has(R, "left") else None, plan_of(last[(R.rank, "right")]) if has(R, "right") else None)
+            torch.cuda.synchronize()         # (stands for the stream order of RCCL's send behind the pack)
+            for R in ranks:
+                for side, skey, d, dkey in sides:
+                    if has(R, side):
+                        deliver_planned(R, skey, ranks[(R.rank + d) % world], dkey, plan_of(last[(R.rank, side)]))
+            torch.cuda.synchronize()
+            veto = {}
+            for R in ranks:
+                # what arrives from my left is my left neighbour's message to ITS right, and the other way round
+                pl = plan_of(last[((R.rank - 1) % world, "right")]) if has(R, "left") else None
+                pr = plan_of(last[((R.rank + 1) % world, "left")]) if has(R, "right") else None
+                with R.be.stream_scope():
+                    R.be.unpack_queued(R.buf["from_left"] if pl else None, R.buf["from_right"] if pr else None, R.caps, pl, pr)
+                    before = R.be.sim.download(capi.SYNC_ALL).copy() if it == 3 else None
+                    try:
+                        R.be.step(P); veto[R.rank] = False
+                    except capi.StepVetoed:
+                        veto[R.rank] = True
+                        if before is not None:       # a vetoed step has changed nothing
+                            assert hoststep.compare_states(before, R.be.sim.download(capi.SYNC_ALL), exact=True) == []
+                    out_h, in_h, v = R.be.headers_host()
+                    assert v == veto[R.rank]
+                    R.out_h, R.in_h = out_h, in_h
+            # both ends of an edge have seen the same header
+            for R in ranks:
+                for side, skey, d, dkey in sides:
+                    if has(R, side):
+                        assert ranks[(R.rank + d) % world].in_h["right" if side == "left" else "left"] == R.out_h[side]
+            # second round: the sender whose message is beyond its plan (or carries floes that changed strip) finishes its
+            # pack and sends everything; the vetoed receiver unpacks with the counts it has read, and steps again
+            for R in ranks:
+                beyond = False
+                for side, skey, d, dkey in sides:
+                    if has(R, side):
+                        c, pn = R.out_h[side], plan_of(last[(R.rank, side)])
+                        assert c[3] == 0
+                        if c[0] > pn[0] or c[1] > pn[1] or c[2] > pn[2]:
+                            beyond = True
+                if beyond:
+                    with R.be.stream_scope():
+                        R.be.pack_finish(R.buf["send_left"], R.buf["send_right"], R.caps)
+                    torch.cuda.synchronize()
+                    for side, skey, d, dkey in sides:
+                        if has(R, side):
+                            _, m = deliver(R, skey, ranks[(R.rank + d) % world], dkey); moved += m
+            torch.cuda.synchronize()
+            for R in ranks:
+                expect = any(has(R, s) and (R.in_h[s][0] > plan_of(last[((R.rank + (-1 if s == "left" else 1)) % world, "right" if s == "left" else "left")])[0]
+                                            or R.in_h[s][1] > plan_of(last[((R.rank + (-1 if s == "left" else 1)) % world, "right" if s == "left" else "left")])[1]
+                                            or R.in_h[s][2] > plan_of(last[((R.rank + (-1 if s == "left" else 1)) % world, "right" if s == "left" else "left")])[2]) for s in ("left", "right"))
+                assert veto[R.rank] == expect, (it, R.rank)
+                if veto[R.rank]:
+                    vetoed_steps += 1
+                    counts = {s: R.in_h[s][:3] for s in ("left", "right") if has(R, s)}
+                    with R.be.stream_scope():
+                        R.be.unpack(R.buf["from_left"] if has(R, "left") else None, R.buf["from_right"] if has(R, "right") else None, R.caps, counts=counts, want_info=False)
+                        R.be.step(P)
+                else:
+                    clean_steps += 1
+            for R in ranks:
+                for side in ("left", "right"):
+                    if has(R, side):
+                        last[(R.rank, side)] = R.out_h[side][:3]
+        own = np.zeros(S.n, int)
+        for R in ranks:
+            G = R.be.sim.download(capi.SYNC_ALL)
+            off, rows = R.be.sim.interactions()
+            mine = R.be.owned()
+            own += mine
+            ids = np.nonzero(mine)[0]
+            for f in hoststep.STATE_FIELDS:
+                if f in ("kill", "transfer", "cax", "cay"):
+                    continue
+                a, b = np.asarray(getattr(A, f))[ids], np.asarray(getattr(G, f))[ids]
+                assert ((a == b) | (np.isnan(a.astype(float)) & np.isnan(b.astype(float)))).all(), "step %d rank %d: %s" % (it, R.rank, f)
+            assert (np.abs(A.Stress[ids] - G.Stress[ids]) <= hoststep.stress_bound(A)[ids]).all()
+            assert np.array_equal(A.StressH[ids], G.StressH[ids]), "step %d rank %d: the stress history of a floe that changed strip" % (it, R.rank)
+            for i in ids[::7]:
+                a = ra.inter[ra.inter_off[i]:ra.inter_off[i + 1]]; b = rows[off[i]:off[i + 1]]
+                assert a.shape == b.shape and np.array_equal(a[:, 1:], b[:, 1:]), (it, R.rank, i)
+        assert (own == 1).all(), "step %d: ownership is not a partition" % it
+    assert vetoed_steps > 0 and clean_steps > 0 and moved > 0, (vetoed_steps, clean_steps, moved)
+    print("queued exchange x%d: %d rank-steps taken in one go, %d vetoed and repeated after a second round, %d floes changed strip" % (world, clean_steps, vetoed_steps, moved))
+    for R in ranks:
+        R.be.close()
+
+
 def test_orchestration_with_a_one_rank_rccl_group():
     import os
     import torch
