@@ -160,6 +160,7 @@ EXPORTS = [
     "szFloesUpload", "szStep", "szStepDiagnostics", "szStepTimes", "szFloesDownload", "szInteractionsDownload", "szPairsDownload",
     "szFloesUpdate", "szFloesFetch", "szFloesResync", "szMcEmptyDownload", "szGhostsDownload",
     "szEulerianData", "szCornerCandidates", "szCornerCuts", "szFractureDeform", "szPotentialInteractions", "szOffsetPaths", "szSpatialInit", "szSpatialSetAxis", "szSpatialMessageBytes", "szSpatialPack", "szSpatialUnpack", "szSpatialUnpackKnown", "szSpatialOwned",
+    "szSpatialPackQueued", "szSpatialPackFinish", "szSpatialUnpackQueued", "szSpatialHeaders",
     "szShardSegmentBytes", "szStepShardBegin", "szStepShardExport", "szStepShardFinish",
     "szShardForcingBytes", "szStepShardForcing", "szStepShardEnd",
     "szDeviceAlloc", "szDeviceFree", "szCopyToDevice", "szCopyToHost", "szSynchronize", "szSetStream",
