@@ -96,9 +96,15 @@ __global__ void __launch_bounds__(64) k_narrow_wave(i64 count, const int *list, 
 // quarter of a millisecond came on top of the step.  The waves stride over the list: any grid size is correct.
 __global__ void __launch_bounds__(64) k_narrow_walls(int lds_per_wave, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (threadIdx.x != 0) return;
+  // (all 64 lanes on the pair, as k_narrow_wave: the conversion to fixed point, InterX and the ring set-up of the sweep
+  // spread over them -- SUBZERO_WALLS_LANE0: lane 0 alone, as until round 4)
   const i64 n = (i64)W.counters[C_WALLS];
-  for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_lds(t, W.wall_list, 1, F, P, W, (void *)smem, lds_per_wave);
+  if (lds_per_wave < 0) {
+    if (threadIdx.x != 0) return;
+    for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_lds(t, W.wall_list, 1, F, P, W, (void *)smem, -lds_per_wave);
+    return;
+  }
+  for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_wave(t, W.wall_list, F, P, W, (void *)smem, lds_per_wave);
 }
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).

@@ -1078,7 +1078,8 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
         i64 room = ((i64)160 * 1024 / per_cu) & ~(i64)1023;
         if (room > S->retry_lds_max) room = S->retry_lds_max;
         if (room < S->retry_lds) room = S->retry_lds;
-        szl_k_narrow_walls(dim3((unsigned)wg), (size_t)room, st, (int)room, F, P, W);
+        static const bool walls_lane0 = getenv("SUBZERO_WALLS_LANE0") != nullptr;     // (a tuning comparison)
+        szl_k_narrow_walls(dim3((unsigned)wg), (size_t)room, st, walls_lane0 ? -(int)room : (int)room, F, P, W);
         SZ_HIP(ctx, hipGetLastError());
         SZ_HIP(ctx, hipEventRecord(S->ev[2], ts));
       }
