@@ -263,6 +263,19 @@ __device__ bool pair_slots(const ClipArgs &a, int p, int a0, int na, int b0, int
   return !(s.woff + s.wbytes > a.ws_cap || s.voff + s.cv > a.ov_cap || s.roff + s.cr + 1 > a.or_cap || s.nv > 0x3FFFFFFF);
 }
 
+// does the ring (open, n vertices, no two of a height) hold three consecutive vertices that are not on one line?  (by the wave)
+__device__ inline bool wave_ring_proper(const i64 *x, const i64 *y, int n) {
+  if (n < 3) return false;
+  bool ok = false;
+  for (int i = (int)(threadIdx.x & 63); i < n; i += 64) {
+    const int p = i == 0 ? n - 1 : i - 1, q = i + 1 == n ? 0 : i + 1;
+    szv::Pt a, b, c;
+    a.x = x[p]; a.y = y[p]; b.x = x[i]; b.y = y[i]; c.x = x[q]; c.y = y[q];
+    ok |= !szv::collinear3(a, b, c);
+  }
+  return __ballot(ok) != 0ULL;
+}
+
 // Front pass, one pair per wave: staging, boxes, the pairs that are apart (finished here), trimming; every other pair is
 // appended to the list of the smallest slice class that holds the records of its (trimmed) rings.
 __global__ void __launch_bounds__(64) k_clip_front(ClipArgs a) {
@@ -298,7 +311,10 @@ __global__ void __launch_bounds__(64) k_clip_front(ClipArgs a) {
       if (szt::box_in_range(A) && szt::box_in_range(B)) {
         const int ea = (na > 1 && sx[na - 1] == sx[0] && sy[na - 1] == sy[0]) ? na - 1 : na;
         const int eb = (nb > 1 && sx[na + nb - 1] == sx[na] && sy[na + nb - 1] == sy[na]) ? nb - 1 : nb;
-        apart = wave_heights_distinct(sy, ea, sy + na, eb);
+        // (... and at least one ring that AddPath keeps: with both rings degenerate -- two distinct points and a closing
+        // copy, or every vertex on one line -- Execute has no local minimum and fails, clipper.cpp:1560-1570 -> "Clipper
+        // Error."; a ring with distinct heights and a consecutive triple that is not collinear keeps three vertices)
+        apart = wave_heights_distinct(sy, ea, sy + na, eb) && (wave_ring_proper(sx, sy, ea) || wave_ring_proper(sx + na, sy + na, eb));
       }
     } else if (evenodd && na + nb >= 24) {
       ta = szt::trim_ring_wave(sx, sy, na, q);       // (by the wave; rings of more than 128 vertices: every lane the serial scan alike)

@@ -113,7 +113,8 @@ SZ_HD bool box_empty(const Box &q) { return q.xmin > q.xmax || q.ymin > q.ymax; 
 // error (clipper.cpp:883-896), which `in_range` of both boxes rules out, and its "Clipper Error." for a ring that is
 // degenerate on its own (a lone lattice polygon with coincident vertices and edges can fail DoMaxima or the crossing
 // order, clipper.cpp:2841,3005): clip.hip answers without a sweep only when no two vertices of the pair share a
-// height, the condition under which this file trims at all.
+// height, the condition under which this file trims at all -- and when at least one of the rings is a ring AddPath keeps
+// (three consecutive vertices not on one line): with BOTH rings degenerate Execute finds no local minimum and fails.
 SZ_HD bool box_in_range(const Box &b) {
   const i64 hi = 0x3FFFFFFFFFFFFFFFLL;
   return !(b.xmax > hi || b.ymax > hi || -b.xmin > hi || -b.ymin > hi);

@@ -70,6 +70,23 @@ def test_empty_and_degenerate(ctx):
         assert g.compare(h, r, len(ps)) == []
     r = g.run_gpu(ctx, ps, 1)
     assert r.status.tolist() == [0, 1, 0, 0, 0]
+    # Both rings degenerate, their boxes APART and no two vertices of a height (found by tests/campaign_clip_gpu.py, round 4:
+    # the front pass answered "apart, empty" where the reference has no local minimum and fails): two distinct points and a
+    # closing copy; every vertex on one line; and, for contrast, one degenerate ring beside a proper one (empty, no error).
+    seg_a = np.array([[1, 6], [1, 5], [1, 6]], np.int64) << 32
+    seg_b = np.array([[2, 0], [0, 1], [2, 0]], np.int64) << 32
+    line_a = np.array([[10, 10], [12, 12], [11, 11], [14, 14]], np.int64) << 32
+    line_b = np.array([[0, 0], [3, 1], [6, 2]], np.int64) << 32
+    tri = np.array([[20, 0], [23, 1], [21, 4]], np.int64) << 32
+    d = g.PairSet()
+    d.add(seg_a, seg_b, fixed=True); d.add(line_a, line_b, fixed=True); d.add(seg_a, tri, fixed=True); d.add(tri, line_b, fixed=True)
+    ref = g.ref_lib()
+    for m in range(4):
+        r, h = g.run_gpu(ctx, d, m), g.run_host(d, m)
+        assert g.compare(h, r, len(d)) == []
+        if ref is not None:
+            assert g.compare(g.run_ref(d, m), r, len(d)) == []
+    assert g.run_gpu(ctx, d, 1).status.tolist() == [1, 1, 0, 0]
     # zero pairs
     e = g.PairSet()
     ox, oy, roff, proff, st = ctx.clip_batch(*e.arrays(), 1)
