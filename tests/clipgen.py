@@ -478,12 +478,13 @@ def compare(r1, r2, n):
     return bad
 
 
-GOLDEN_SETS = ["shapes", "convex", "lattice", "rect", "clipper_test_m"]
+GOLDEN_SETS = ["shapes", "convex", "lattice", "rect", "clipper_test_m", "clipper_demo"]
+GOLDEN_FILES = {"clipper_demo": "clipper_demo_golden.npz"}     # (the input of Clipper's own console demo, as the reference ships it)
 
 
 def load_golden(name):
-    """(PairSet-like arrays, {method: ClipResult}) from tests/golden/clip_golden.npz."""
-    d = np.load(os.path.join(ROOT, "tests", "golden", "clip_golden.npz"))
+    """(PairSet-like arrays, {method: ClipResult}) from tests/golden/clip_golden.npz (clipper_demo_golden.npz)."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", GOLDEN_FILES.get(name, "clip_golden.npz")))
     inp = tuple(np.ascontiguousarray(d["%s/%s" % (name, k)]) for k in ("ax", "ay", "aoff", "bx", "by", "boff"))
     res = {}
     for m in range(4):
