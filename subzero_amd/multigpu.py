@@ -656,6 +656,7 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
         if sim.last: present = max(present, int(sim.last[1].n_present))
     sim.count_present = False        # (the counts of owned / present floes cost a host round trip per step: warm-up only)
     dist.barrier(); torch.cuda.synchronize()
+    rounds0, second0 = sim.rounds, sim.second_rounds
     t0 = time.perf_counter()
     narrow_ms = 0.0; pairs = 0; pair_bytes = 0.0
     for _ in range(steps):
@@ -672,13 +673,18 @@ def _spatial_run(S, P, rank, local_rank, world, steps, warmup, torch, dist):
     mine = be.owned()
     keep = np.repeat(mine, np.diff(off))
     cnt = torch.tensor([capi.collision_count(rows[keep]), float(pairs), float(mine.sum()), float(present),
-                        float(sim.bytes_sent / max(sim.exchanges, 1))], dtype=torch.float64, device=be.device)
+                        float(sim.bytes_sent / max(sim.exchanges, 1)), float(sim.rounds - rounds0), float(sim.second_rounds - second0)],
+                       dtype=torch.float64, device=be.device)
     tot = cnt.clone(); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     mx = cnt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     stats = {"collisions_last_step": float(tot[0]), "pairs_evaluated": float(tot[1]), "owned_floes_rank0": int(cnt[2]),
              "present_floes_max": int(mx[3]), "bytes_sent_per_rank_step_max": float(mx[4]),
              "narrow_ms": narrow_ms / max(steps, 1), "pair_bytes": pair_bytes / max(steps, 1), "halo_m": halo,
-             "strip_axis": "y" if axis else "x", "strip_edges_m": [float(e) for e in edges]}
+             "strip_axis": "y" if axis else "x", "strip_edges_m": [float(e) for e in edges],
+             # the exchange: "queued" = one host round trip per step (szSpatialPackQueued ...); message rounds per step of the
+             # busiest rank (1.0: every step in one round), and the rank-steps of the timed region that needed a second round
+             "exchange": "queued" if (sim.queued and world > 1) else "classic",
+             "message_rounds_per_step_max": float(mx[5]) / max(steps, 1), "second_rounds_all_ranks": int(tot[6])}
     be.close()
     return float(el.item()), stats
 
@@ -743,7 +749,8 @@ def bench_main(args, rank, local_rank, world):
             "contact_pairs_per_s": st["collisions_last_step"] * k / el,
             "contact_pairs_basis": "collisions of the last timed step (owned floes, summed over ranks) x steps / time",
             "candidate_pairs_evaluated_per_s": st["pairs_evaluated"] / el,
-            "spatial": {k2: st[k2] for k2 in ("owned_floes_rank0", "present_floes_max", "bytes_sent_per_rank_step_max", "halo_m")},
+            "spatial": {k2: st[k2] for k2 in ("owned_floes_rank0", "present_floes_max", "bytes_sent_per_rank_step_max", "halo_m", "exchange",
+                                              "message_rounds_per_step_max", "second_rounds_all_ranks")},
             "strong_scaling": strong,
             "roofline": {"bound": "hbm", "kernel": "k_narrow_team (rank 0's launch: the pairs on its hot / cold / wide lists)",
                          "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
