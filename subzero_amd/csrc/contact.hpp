@@ -227,6 +227,11 @@ struct PairScratch {
   double *rows; int cap_rows;     // output: 5 doubles per contact row [Fx, Fy, Px, Py, overlap]
   int wave;                       // 1: all 64 lanes of the wave run this pair alike and the fixed-point rings are in LDS --
                                   // the conversion and the trimming then spread over the lanes (step_core.hpp narrow_t)
+  // The overlap regions of a pair shared out over several waves (step_core.hpp narrow_t, k_narrow_wave): task `task_slot`
+  // of `task_n` runs the pair like any other up to the loop over the regions, and there takes the region whose contact
+  // row is number task_slot (the last task: that one and every later one) -- the second and third clip of a region
+  // depend on the first clip alone, not on the regions before it.  task_n = 1: every region (the plain case).
+  int task_slot, task_n;
 };
 
 struct PairOut {
@@ -808,6 +813,15 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
     const int nr = S.r1off[k + 1] - S.r1off[k];
     double Ar = region_area(RX, RY, nr);
     if (Ar < Amin) continue;                                                           // :83
+    if (S.task_n > 1) {       // (another wave's region: its row is counted, not made)
+      const int r = out.nrows;
+      const bool mine = r == S.task_slot || (S.task_slot == S.task_n - 1 && r >= S.task_n - 1);
+      if (!mine) {
+        if (out.nrows >= S.cap_rows) return szv::ST_OUT_CAPACITY;
+        ++out.nrows;
+        continue;
+      }
+    }
     double cx, cy;
     region_centroid(RX, RY, nr, cx, cy);                                               // :96-97
     // :98-100 nearest region vertex of each crossing; keep those closer than 1 m
@@ -838,6 +852,40 @@ SZ_HD int pair_finish(const Ring &ring1, const Body &f1, const Ring &ring2, cons
       SZC_PHASE(5);
       int non = 0;
       double sfx = 0, sfy = 0, sb = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (S.wave) {
+        // (a wave on the pair: an edge of the region per lane for what costs -- the inside test against the region, the
+        // distance to ring 1, O(nr) and O(n1) each -- then the three sums edge by edge in the order of the loop below,
+        // by every lane alike from the lanes' values: the same additions in the same order)
+        const int lane = (int)(threadIdx.x & 63);
+        for (int e0 = 0; e0 < nr; e0 += 64) {
+          const int e = e0 + lane;
+          double b = 0, nx = 0, ny = 0;
+          bool close = false;
+          if (e < nr) {
+            const int e1 = (e + 1 == nr) ? 0 : e + 1;
+            const double xa = from_fixed(RX[e]), ya = from_fixed(RY[e]), xb = from_fixed(RX[e1]), yb = from_fixed(RY[e1]);
+            const double xgh = xb - xa, ygh = yb - ya;
+            const double xm = (xb + xa) / 2, ym = (yb + ya) / 2;
+            b = ::sqrt(xgh * xgh + ygh * ygh);
+            nx = -ygh / b; ny = xgh / b;
+            const double xt = xm + nx / 100, yt = ym + ny / 100;
+            if (!in_region(xt, yt, RX, RY, nr)) { nx = -nx; ny = -ny; }
+            close = closer_than_1e8(xm, ym, c1);
+          }
+          const unsigned long long mc = __ballot(close);
+          const int cnt = nr - e0 < 64 ? nr - e0 : 64;
+          for (int k = 0; k < cnt; ++k) {
+            if (!((mc >> k) & 1ULL)) continue;
+            const double bk = __shfl(b, k), nxk = __shfl(nx, k), nyk = __shfl(ny, k);
+            ++non;
+            sfx += (-Force_factor * bk) * nxk;
+            sfy += (-Force_factor * bk) * nyk;
+            sb += bk;
+          }
+        }
+      } else
+#endif
       for (int e = 0; e < nr; ++e) {
         int e1 = (e + 1 == nr) ? 0 : e + 1;
         double xa = from_fixed(RX[e]), ya = from_fixed(RY[e]), xb = from_fixed(RX[e1]), yb = from_fixed(RY[e1]);

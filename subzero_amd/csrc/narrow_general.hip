@@ -85,10 +85,14 @@ __global__ void __launch_bounds__(64) k_narrow_lds(i64 count, const int *list, i
 // k_narrow_lds with one pair per wave and ALL 64 lanes on it (step_core.hpp narrow_t, WAVE): the lanes run the pair's
 // serial parts alike and share the loops over vertices in front of every clip -- the conversion to fixed point and the
 // trimming, a quarter of a long pair's time when one lane does them.  Deferred lists at the 1x tier.
-__global__ void __launch_bounds__(64) k_narrow_wave(i64 count, const int *list, int lds_per_wave, Floes F, Params P, Work W) {
+// (`tasks` waves per pair, the first of each pair in front: workgroup b is task b / count of pair b % count -- a pair whose
+// overlap regions are shared out uses up to `tasks` of them, the others leave at once: step_core.hpp narrow_t)
+__global__ void __launch_bounds__(64) k_narrow_wave(i64 count, const int *list, int lds_per_wave, int tasks, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const i64 t = blockIdx.x;
-  if (t < count) narrow_wave(t, list, F, P, W, (void *)smem, lds_per_wave);
+  const i64 b = blockIdx.x;
+  const i64 t = b % count;
+  const int slot = (int)(b / count);
+  if (slot < tasks) narrow_wave(t, list, F, P, W, (void *)smem, lds_per_wave, slot, tasks);
 }
 // The floes at the walls (k_pair_classify's list of their own): the general sweep of each against the domain box, one
 // pair per wave with the sweep workspace in LDS, launched beside the team pass on a stream of its own -- the box has
@@ -175,8 +179,8 @@ void szl_k_narrow(dim3 grid, size_t lds, hipStream_t st, i64 first, i64 count, c
 void szl_k_narrow_lds(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int mult, int lanes, int lds_per_lane, const Floes &F, const Params &P, const Work &W) {
   hipLaunchKernelGGL(k_narrow_lds, grid, dim3(64), lds, st, count, list, mult, lanes, lds_per_lane, F, P, W);
 }
-void szl_k_narrow_wave(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int lds_per_wave, const Floes &F, const Params &P, const Work &W) {
-  hipLaunchKernelGGL(k_narrow_wave, grid, dim3(64), lds, st, count, list, lds_per_wave, F, P, W);
+void szl_k_narrow_wave(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int lds_per_wave, int tasks, const Floes &F, const Params &P, const Work &W) {
+  hipLaunchKernelGGL(k_narrow_wave, grid, dim3(64), lds, st, count, list, lds_per_wave, tasks, F, P, W);
 }
 void szl_k_narrow_walls(dim3 grid, size_t lds, hipStream_t st, int lds_per_wave, const Floes &F, const Params &P, const Work &W) {
   hipLaunchKernelGGL(k_narrow_walls, grid, dim3(64), lds, st, lds_per_wave, F, P, W);

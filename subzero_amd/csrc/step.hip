@@ -776,6 +776,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   S->no_hint = getenv("SUBZERO_NO_HINT") != nullptr;
   S->debug_lists = getenv("SUBZERO_DEBUG_LISTS") != nullptr;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
+  if (const char *v = getenv("SUBZERO_WAVE_TASKS")) { int l = atoi(v); if (l >= 1 && l <= 4) S->wave_tasks = l; }
   if (const char *v = getenv("SUBZERO_BIG_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->big_lanes = l; }
   { const int rcg = sz_narrow_general_configure(ctx, S->narrow_lds != 0); if (rcg) return rcg; }
   (void)hipFuncSetAttribute((const void *)k_broad_filter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -847,7 +848,7 @@ static int bind_pairs(szContext *ctx, StepState *S, i64 np, i64 nvt, i64 &main_b
         (rc = sz_reserve(ctx, S->wall_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->big_list, npa * 4)) || (rc = sz_reserve(ctx, S->team_list, npa * 4)) || (rc = sz_reserve(ctx, S->wide_list, npa * 4)) || (rc = sz_reserve(ctx, S->live_list, npa * 4)) || (rc = sz_reserve(ctx, S->cold_list, npa * 4)) ||
         (rc = sz_reserve(ctx, S->pair_rowoff, npa * 8)) || (rc = sz_reserve(ctx, S->touch_list, npa * 4)) ||
-        (rc = sz_reserve(ctx, S->pair_nreg, npa * 4))) return rc;
+        (rc = sz_reserve(ctx, S->pair_nreg, npa * 4)) || (rc = sz_reserve(ctx, S->pair_task, npa * 16))) return rc;
     main_bytes = (i64)SCR_PER_V * (nvt + 2 * np) + (i64)SCR_PER_PAIR * np;
     const i64 reserve = main_bytes / 2 + (8 << 20);
     if ((rc = sz_reserve(ctx, S->scratch, (size_t)(main_bytes + reserve)))) return rc;
@@ -861,7 +862,7 @@ static int bind_pairs(szContext *ctx, StepState *S, i64 np, i64 nvt, i64 &main_b
     W.wall_list = (S->walls_early && S->classified && S->retry_lds > 0 && S->stepped && S->last_walls > 0 && S->last_deferred == 0) ? (int *)S->wall_list.p : nullptr;
     W.big_list = (int *)S->big_list.p; W.team_list = (int *)S->team_list.p; W.wide_list = (int *)S->wide_list.p; W.live_list = (int *)S->live_list.p; W.cold_list = (int *)S->cold_list.p;
     W.pair_rowoff = (i64 *)S->pair_rowoff.p;
-    W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p;
+    W.touch_list = (int *)S->touch_list.p; W.pair_nreg = (int *)S->pair_nreg.p; W.pair_task = (int *)S->pair_task.p;
     W.scratch = (char *)S->scratch.p; W.scratch_bytes = (i64)S->scratch.cap;
     return SZ_OK;
   }
@@ -1240,7 +1241,12 @@ static int step_narrow_rest(szContext *ctx, StepState *S) {
     }
     static const bool wave_off = getenv("SUBZERO_WAVE_GENERAL") != nullptr && atoi(getenv("SUBZERO_WAVE_GENERAL")) == 0;
     if (retry_lds > 0 && RL == 1 && mult == 1 && !wave_off)
-      szl_k_narrow_wave(dim3((unsigned)nl), (size_t)retry_lds, st, nl, (const int *)S->retry_copy.p, retry_lds, F, P, W);
+    {
+      // (`wave_tasks` waves per pair: those a pair has no use for leave at once -- narrow_t; only the fused chain's
+      // classification knows how many rows a pair had: elsewhere every pair is one task)
+      const int tasks = S->fused ? S->wave_tasks : 1;
+      szl_k_narrow_wave(dim3((unsigned)(nl * tasks)), (size_t)retry_lds, st, nl, (const int *)S->retry_copy.p, retry_lds, tasks, F, P, W);
+    }
     else if (retry_lds > 0)
       szl_k_narrow_lds(grid_for(nl, RL), (size_t)retry_lds * RL, st, nl, (const int *)S->retry_copy.p, mult, RL, retry_lds, F, P, W);
     else

@@ -178,6 +178,7 @@ struct Work {
   int *cold_list;               // ... not in contact in the step before (C_COLD of them)
   int *touch_list;              // pairs whose first clip found overlap regions (two-stage fast path)
   int *pair_nreg;               // regions of the first clip
+  int *pair_task;               // [4 * cap_pairs] the overlap regions of a general pair shared out over waves (narrow_t, k_narrow_wave): contact rows of the pair in the step before (kf_pairs, from the hint), tasks done, their merged status, spare
   // mirrored rows
   int *inc_cnt, *inc_list;      // [cap_ext], [cap_ext * pot_cap] pair ids
   // contact rows, CSR over the extended list
@@ -634,6 +635,7 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
   S.cap_rows = S.cap_r;
   S.rows = (double *)p; p += up16(40 * (size_t)S.cap_rows);
   S.wave = 0;
+  S.task_slot = 0; S.task_n = 1;
   return p <= end;
 }
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
@@ -658,9 +660,14 @@ SZ_HD void pair_done(i64 p, int i, int j, int nrows, Work &W) {
 // (WAVE: all 64 lanes of the wave are here with the same arguments -- k_narrow_wave, mult 1 -- and run the pair alike:
 // same reads, same plain stores; one lane speaks for the wave where a counter or a list is touched, and the loops that
 // split over vertices -- staging, conversion to fixed point, trimming -- spread over the lanes)
+// (slot / tasks: k_narrow_wave launches `tasks` waves per deferred pair; a pair that had h >= 2 contact rows in the step
+// before -- as many overlap regions, each with a second clip of its own, the long part of such a pair -- is run by
+// min(h, tasks) of them, each taking the regions PairScratch::task_slot names, every one in a scratch slice of its own
+// but with its rows written to the pair's; the task that finishes last puts the pair's result together.  The other
+// waves of a pair leave at once.)
 template <bool CONVEX_ONLY, class Blk, bool LDS_WS = false, bool WAVE = false>
 SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Params &P, Work &W,
-                    void *fast_ws, int fast_ws_bytes, Blk *fast_blk) {
+                    void *fast_ws, int fast_ws_bytes, Blk *fast_blk, int slot = 0, int tasks = 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const bool speaker = !WAVE || (threadIdx.x & 63) == 0;
   const int lane0 = WAVE ? (int)(threadIdx.x & 63) : 0, lanes = WAVE ? 64 : 1;
@@ -669,6 +676,12 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   const int lane0 = 0, lanes = 1;
 #endif
   i64 p = list ? (i64)list[t] : t;
+  int ntasks = 1;
+  if (WAVE && tasks > 1 && W.pair_task) {
+    const int h = W.pair_task[4 * p];
+    ntasks = h < 1 ? 1 : (h > tasks ? tasks : h);
+  }
+  if (slot >= ntasks) return;
   const int i = W.pair_i[p], j = W.pair_j[p];
   const int si = W.ext_src[i];
   const int v1 = F.vert_off[si], n1 = F.vert_off[si + 1] - v1;
@@ -699,15 +712,33 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   i64 off, bytes = scratch_bytes_for((i64)n1 + n2, mult);
   if (!list || mult == 1) off = (i64)SCR_PER_V * (W.pair_nvoff[p] + 2 * p) + (i64)SCR_PER_PAIR * p;  // (a deferred pair redone at 1x keeps its slice)
   else off = (i64)atomic_add(&W.counters[C_SCR_BUMP], (unsigned long long)bytes);
-  W.pair_scr[p] = off; W.pair_mult[p] = mult;
-  W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
-  szc::PairScratch S;
-  if (off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, n1, n2, mult, S)) {
-    W.pair_status[p] = szv::ST_WORKSPACE;
-    if (speaker) atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
-    return;
+  const i64 off0 = off;                      // the pair's own slice: where its rows go, whichever task makes them
+  bool arena_ok = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (WAVE && slot > 0) {                    // a task beyond the first works in a slice of its own, from behind the closed-form part
+    unsigned long long o = 0;
+    if (speaker) o = atomic_add(&W.counters[C_SCR_BUMP], (unsigned long long)bytes);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(o & 0xffffffffULL)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(o >> 32));
+    off = (i64)(((unsigned long long)hi << 32) | lo);
   }
-  W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);   // where row_fill / export_pair find the rows
+#endif
+  szc::PairScratch S;
+  if (ntasks == 1) {
+    W.pair_scr[p] = off; W.pair_mult[p] = mult;
+    W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
+    if (off + bytes > W.scratch_bytes || !carve(W.scratch + off, bytes, n1, n2, mult, S)) {
+      W.pair_status[p] = szv::ST_WORKSPACE;
+      if (speaker) atomic_add(&W.counters[C_ERR_ARENA], 1ULL);
+      return;
+    }
+    W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);   // where row_fill / export_pair find the rows
+  } else {
+    // (the pair's words are written once, by the task that finishes last: below)
+    szc::PairScratch S0;
+    arena_ok = off + bytes <= W.scratch_bytes && carve(W.scratch + off, bytes, n1, n2, mult, S) &&
+               off0 + bytes <= W.scratch_bytes && carve(W.scratch + off0, bytes, n1, n2, mult, S0);
+    if (arena_ok) { S.rows = S0.rows; S.task_slot = slot; S.task_n = ntasks; }
+  }
   // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
   const bool ws_fits_fast = fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes;
   if (ws_fits_fast && !LDS_WS) S.ws = fast_ws;
@@ -741,9 +772,11 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
     }
   }
   szc::PairOut out;
+  out.nrows = 0; out.sentinel = 0; out.has_sentinel = 0;
   int st;
   SZC_PHASE(8);
-  if (CONVEX_ONLY)
+  if (!arena_ok) st = szv::ST_WORKSPACE;
+  else if (CONVEX_ONLY)
     st = szc::pair_contact_fast(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                                 P.mu, P.nu, S, out, fast_blk);
   else if (WAVE)
@@ -753,6 +786,30 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
     st = szc::pair_contact(ring1, b1, ring2, b2, boundary, P.c2_boundary, P.PERIODIC != 0, P.Modulus, P.dt,
                            P.mu, P.nu, S, out, (LDS_WS && fast_ws) ? fast_ws : nullptr, lds_ws_bytes);
   SZC_PHASE(0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (WAVE && ntasks > 1) {
+    // The tasks of a pair meet here: each leaves its status (the one of the lowest task wins: the serial loop over the
+    // regions would have met that failure first) and counts itself done behind a fence -- its rows are out; the one that
+    // counts last speaks for the pair from here on, with every task's rows in the pair's slice.
+    int *task = W.pair_task + 4 * p;
+    int last = 0;
+    if (speaker) {
+      // (a task without room for a slice of its own reports ST_WORKSPACE: the pair is then redone whole at the next tier,
+      // which reports an arena that is really full)
+      if (st != szv::ST_OK) (void)atomicMax(&task[2], ((15 - slot) << 8) | (st & 0xff));
+      __threadfence();
+      last = atomicAdd(&task[1], 1) == ntasks - 1 ? 1 : 0;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    __threadfence();
+    const int merged = __hip_atomic_load(&task[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st = merged ? (merged & 0xff) : (int)szv::ST_OK;
+    W.pair_scr[p] = off0; W.pair_mult[p] = mult;
+    W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
+    W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);
+  }
+#endif
   W.pair_status[p] = st;
   if (st == szc::ST_DEFER_BIG) {
     if (speaker) { unsigned long long k = atomic_add(&W.counters[C_BIG], 1ULL); W.big_list[k] = (int)p; }
@@ -765,6 +822,15 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
   if (st != szv::ST_OK) { if (speaker) atomic_add(&W.counters[C_ERR_CLIP], 1ULL); return; }
   int flag = 0;
   double sabs = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (WAVE && ntasks > 1) {     // (rows of other waves: read past this CU's cache)
+    for (int r = 0; r < out.nrows; ++r) {
+      const double a = __hip_atomic_load(&S.rows[5 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double b = __hip_atomic_load(&S.rows[5 * r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sabs += absd(a) + absd(b);
+    }
+  } else
+#endif
   for (int r = 0; r < out.nrows; ++r) sabs += absd(S.rows[5 * r]) + absd(S.rows[5 * r + 1]);
   if (sabs != 0) flag |= 4;                                       // :135 / :157
   else if (out.has_sentinel && szc::is_inf(out.sentinel)) flag |= (out.sentinel > 0) ? 1 : 2;
@@ -782,8 +848,8 @@ SZ_HD void narrow_lds(i64 t, const int *list, int mult, const Floes &F, const Pa
   narrow_t<false, szx::FastBlock, true>(t, list, mult, F, P, W, lds_ws, lds_stride, nullptr);
 }
 // ... by a whole wave per pair (k_narrow_wave; list at the 1x tier only: no allocation from the bump counter)
-SZ_HD void narrow_wave(i64 t, const int *list, const Floes &F, const Params &P, Work &W, void *lds_ws, int lds_bytes) {
-  narrow_t<false, szx::FastBlock, true, true>(t, list, 1, F, P, W, lds_ws, lds_bytes, nullptr);
+SZ_HD void narrow_wave(i64 t, const int *list, const Floes &F, const Params &P, Work &W, void *lds_ws, int lds_bytes, int slot = 0, int tasks = 1) {
+  narrow_t<false, szx::FastBlock, true, true>(t, list, 1, F, P, W, lds_ws, lds_bytes, nullptr, slot, tasks);
 }
 // the single-minimum fast path only (convex.hpp); pairs it does not cover go to the retry list for narrow()
 template <class Blk>

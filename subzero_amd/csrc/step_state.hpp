@@ -34,7 +34,7 @@ struct StepState {
   DevBuf pair_i, pair_j, pair_nvoff, pair_scr, pair_mult, pair_nrows, pair_status, pair_flag, retry_list, retry_copy, big_list, team_list, wide_list, live_list, cold_list, wall_list;
   DevBuf scratch, rows;
   DevBuf cell_cnt, cell_off, cell_fill, cell_item;
-  DevBuf pair_rowoff, x_off, touch_list, pair_nreg, filter_spill;
+  DevBuf pair_rowoff, x_off, touch_list, pair_nreg, pair_task, filter_spill;
   DevBuf post[64];                // device buffers of the post-step entries (corners.hip, eulerian.hip, fracture.hip): grow-only, kept between calls
   std::vector<long long> hdr;     // segment headers of all ranks (szStepShardFinish)
   long long *scan_agg = nullptr;  // up to 4 x 256 workgroup aggregates of the scan in flight (launch_scan)
@@ -67,6 +67,7 @@ struct StepState {
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
   int broad_wave = 1;   // the wave-per-floe broad phase for real floes (SUBZERO_BROAD_WAVE=0: thread-per-floe kernels only)
+  int wave_tasks = 3;             // waves per deferred pair in the wave-per-pair general pass (SUBZERO_WAVE_TASKS, 1-4): a pair with several overlap regions is shared out over up to that many (step_core.hpp narrow_t)
   int big_lanes = 0;              // pairs per wave of the second fast pass (32-vertex blocks, SUBZERO_BIG_LANES; 0: no such pass: its pairs take
                                   // the general kernel -- the default until the round-1 fault of that kernel is settled)
   int retry_lanes = 0;            // pairs per wave when the general kernel redoes what the fast pass deferred; 0: as few as keep

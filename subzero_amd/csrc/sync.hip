@@ -94,7 +94,7 @@ void destroy_state(StepState *S) {
   DevBuf *more[] = {&S->oXo, &S->oYo, &S->oU, &S->oV, &S->oWu, &S->oWv, &S->pair_i, &S->pair_j, &S->pair_nvoff,
                     &S->pair_scr, &S->pair_mult, &S->pair_nrows, &S->pair_status, &S->pair_flag, &S->retry_list,
                     &S->retry_copy, &S->big_list, &S->team_list, &S->wide_list, &S->live_list, &S->cold_list, &S->wall_list, &S->scratch, &S->rows, &S->cell_cnt, &S->cell_off, &S->cell_fill, &S->cell_item,
-                    &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->filter_spill, &S->pot_list, &S->inc_list,
+                    &S->pair_rowoff, &S->x_off, &S->touch_list, &S->pair_nreg, &S->pair_task, &S->filter_spill, &S->pot_list, &S->inc_list,
                     &S->stage_d, &S->stage_i, &S->stage_ids, &S->sp_masks, &S->sp_edges_dev, &S->sp_counts,
                     &S->gh_mask, &S->gh_agg, &S->pair_agg, &S->row_agg, &S->rel_mask, &S->pot_nvpre, &S->force_list, &S->hint};
   for (DevBuf *b : more) sz_release(*b);
