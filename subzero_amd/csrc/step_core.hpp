@@ -638,6 +638,13 @@ SZ_HD bool carve(char *base, i64 bytes, int n1, int n2, int mult, szc::PairScrat
   S.task_slot = 0; S.task_n = 1;
   return p <= end;
 }
+// where carve() puts the contact rows of a slice (for a task that works in another slice: narrow_t)
+SZ_HD double *slice_rows(char *base, int n1, int n2, int mult) {
+  const int cap_nv = mult * (n1 + n2 + 2);
+  char *p = base + up16((size_t)szv::WS_PER_VERTEX * cap_nv + szv::WS_PER_CLIP);
+  const SmallLayout L = small_layout(n1, n2, 2 * cap_nv + 8, cap_nv / 2 + 4, cap_nv + 8);
+  return (double *)(p + L.end);
+}
 SZ_HD i64 scratch_bytes_for(i64 nv, int mult) { return (i64)SCR_PER_V * mult * (nv + 2) + SCR_PER_PAIR; }
 
 // The pair p = (i, j) has completed with nrows > 0 contact rows -- by the lane that stores the pair's result, whichever
@@ -734,10 +741,8 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
     W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);   // where row_fill / export_pair find the rows
   } else {
     // (the pair's words are written once, by the task that finishes last: below)
-    szc::PairScratch S0;
-    arena_ok = off + bytes <= W.scratch_bytes && carve(W.scratch + off, bytes, n1, n2, mult, S) &&
-               off0 + bytes <= W.scratch_bytes && carve(W.scratch + off0, bytes, n1, n2, mult, S0);
-    if (arena_ok) { S.rows = S0.rows; S.task_slot = slot; S.task_n = ntasks; }
+    arena_ok = off + bytes <= W.scratch_bytes && off0 + bytes <= W.scratch_bytes && carve(W.scratch + off, bytes, n1, n2, mult, S);
+    if (arena_ok) { S.rows = slice_rows(W.scratch + off0, n1, n2, mult); S.task_slot = slot; S.task_n = ntasks; }
   }
   // the sweep workspace may live in faster memory (LDS) when the caller provides a large enough block
   const bool ws_fits_fast = fast_ws && (i64)szv::WS_PER_VERTEX * S.cap_nv + szv::WS_PER_CLIP <= fast_ws_bytes;
