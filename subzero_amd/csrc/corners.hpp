@@ -227,22 +227,34 @@ SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned ch
     const double d1 = ::sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2)), d2 = ::sqrt((X3 - X2) * (X3 - X2) + (Y3 - Y2) * (Y3 - Y2));
     const double d = mind(d1, d2);
     double x1, y1, x2, y2;
-    if (absd(X1 - X2) < 120 && absd(Y1 - Y2) < 120) return 0;                 // (the cut would take the whole edge: not plain)
+    // :36-37 / :43-44 a short edge (under 120 m in x and in y) goes whole: the cut ends AT the neighbouring vertex.  Taken
+    // here (round 4) when that vertex itself stays (its own cut would overlap this one: union / subtract of the
+    // reference, :136-137, not this closed form) and the outline has a vertex to spare.
+    const bool s1 = absd(X1 - X2) < 120 && absd(Y1 - Y2) < 120, s2 = absd(X3 - X2) < 120 && absd(Y3 - Y2) < 120;
+    if ((s1 || s2) && n < 5) return 0;
+    if ((s1 && grind[kp]) || (s2 && grind[kn])) return 0;
+    if (s1) { x1 = X1; y1 = Y1; }
     else if (absd(d * alph / Anorm / 5) < 120) { x1 = X2 + 120 / d1 * (X1 - X2); y1 = Y2 + 120 / d1 * (Y1 - Y2); }
     else { x1 = X2 + d / d1 * alph / Anorm * (X1 - X2) / 5; y1 = Y2 + d / d1 * alph / Anorm * (Y1 - Y2) / 5; }
-    if (absd(X3 - X2) < 120 && absd(Y3 - Y2) < 120) return 0;
+    if (s2) { x2 = X3; y2 = Y3; }
     else if (absd(d * alph / Anorm / 5) < 120) { x2 = X2 + 120 / d2 * (X3 - X2); y2 = Y2 + 120 / d2 * (Y3 - Y2); }
     else { x2 = X2 + d / d2 * alph / Anorm * (X3 - X2) / 5; y2 = Y2 + d / d2 * alph / Anorm * (Y3 - Y2) / 5; }
-    if (absd(x1 - x2) < 0.1) x1 = x1 + 1;                                       // :50-52
+    if (absd(x1 - x2) < 0.1) { if (s1 || s2) return 0; x1 = x1 + 1; }          // :50-52 (with a cut at a vertex: not this form)
     c1x[k] = x1; c1y[k] = y1; c2x[k] = x2; c2y[k] = y2;
-    // the cut must stay inside its two edges and meet no other edge of the outline
+    // the cut must stay inside its two edges (or end at their far vertex: a short edge) and meet no other edge of the outline
     const double t1 = ::sqrt((x1 - X2) * (x1 - X2) + (y1 - Y2) * (y1 - Y2)), t2 = ::sqrt((x2 - X2) * (x2 - X2) + (y2 - Y2) * (y2 - Y2));
-    if (!(t1 > 0 && t1 < d1 && t2 > 0 && t2 < d2)) return 0;
+    if (!(t1 > 0 && (s1 || t1 < d1) && t2 > 0 && (s2 || t2 < d2))) return 0;
+    const int kpp = (kp == 0) ? n - 1 : kp - 1, knn = (kn + 1 == n) ? 0 : kn + 1;
     for (int e = 0; e < n; ++e) {
       const int e1 = (e + 1 == n) ? 0 : e + 1;
       if (e == kp || e == k) continue;                                          // the two edges at the corner
+      if (s1 && e == kpp) continue;                                             // (ends where the cut starts: below)
+      if (s2 && e == kn) continue;                                              // (starts where the cut ends)
       if (segments_meet(x1, y1, x2, y2, x[e], y[e], x[e1], y[e1])) return 0;
     }
+    // a cut from a vertex must leave the outline's edge there at an angle (in line with it, polyshape drops the vertex)
+    if (s1 && (x[kp] - x[kpp]) * (y2 - y[kpp]) - (y[kp] - y[kpp]) * (x2 - x[kpp]) == 0) return 0;
+    if (s2 && (x[kn] - x1) * (y[knn] - y1) - (y[kn] - y1) * (x[knn] - x1) == 0) return 0;
   }
   // neighbouring corners: their cuts on the shared edge must not meet
   for (int k = 0; k < n; ++k) {
@@ -258,9 +270,15 @@ SZ_HD int frac_corner_plain(const double *x, const double *y, int n, unsigned ch
   int m = 0;
   double *bx = tmpx + 2 * n, *by = tmpy + 2 * n;   // (scratch beyond the cut points: n + ng values)
   for (int k = 0; k < n; ++k) {
-    if (grind[k]) { bx[m] = c1x[k]; by[m] = c1y[k]; ++m; bx[m] = c2x[k]; by[m] = c2y[k]; ++m; }
+    if (grind[k]) {
+      // (a cut point that IS the neighbouring vertex -- a short edge -- is in the outline already)
+      const int kp = (k == 0) ? n - 1 : k - 1, kn = (k + 1 == n) ? 0 : k + 1;
+      if (!(c1x[k] == x[kp] && c1y[k] == y[kp])) { bx[m] = c1x[k]; by[m] = c1y[k]; ++m; }
+      if (!(c2x[k] == x[kn] && c2y[k] == y[kn])) { bx[m] = c2x[k]; by[m] = c2y[k]; ++m; }
+    }
     else { bx[m] = x[k]; by[m] = y[k]; ++m; }
   }
+  if (m < 3) return 0;
   const double new_area = ring_area_abs(bx, by, m);
   if (!(new_area > 0)) return 0;
   int np = 0, at = 0;
