@@ -1333,7 +1333,8 @@ extern "C" void or_polyangles(const double *x, const double *y, int n, double *o
 // edges, clear of the neighbouring cuts and of every other edge of the outline.  poly1 (:53-80) is then the outline
 // with that corner replaced by the two cut points, poly2 the triangle, subtract(poly, union(...)) (:136-137) the
 // outline with every such corner replaced.  Returns the pieces in the order Floes = [FloeNEW fracturedFloes] (:185),
-// or nothing when the floe is not that case (the product then leaves it to frac_corner.m as well).
+// or nothing when the floe is not that case (the product then leaves it to frac_corner.m as well).  Round 4: a short edge
+// taken whole (:36-37, :43-44 -- the cut ends at the neighbouring vertex) is that case too when the vertex stays.
 // polyshape conventions assumed, unpinned by anything the reference holds: area / centroid = ring_area / ring_centroid
 // above; outlines clockwise from the first surviving vertex, a triangle from its first cut point.
 // x, y: poly.Vertices (the stored c_alpha without its closing copy, corners.m:63-68); out: 12 doubles per piece
@@ -1412,22 +1413,35 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
     const double d1 = sqrt((X1 - X2) * (X1 - X2) + (Y1 - Y2) * (Y1 - Y2)), d2 = sqrt((X3 - X2) * (X3 - X2) + (Y3 - Y2) * (Y3 - Y2));
     const double d = std::min(d1, d2);                                // :34-35
     Cut c;
-    if (fabs(X1 - X2) < 120 && fabs(Y1 - Y2) < 120) return none;      // :36 the whole edge goes: not the plain case
+    // :36-37 / :43-44 an edge shorter than 120 m in x and in y goes whole: the cut ends AT the neighbouring vertex.  The
+    // closed form covers it when that vertex stays (were it ground too, the two triangles would overlap: the union /
+    // subtract of :136-137) and the outline keeps at least four vertices.
+    const bool s1 = fabs(X1 - X2) < 120 && fabs(Y1 - Y2) < 120, s2 = fabs(X3 - X2) < 120 && fabs(Y3 - Y2) < 120;
+    if ((s1 || s2) && n < 5) return none;
+    if ((s1 && grind[p]) || (s2 && grind[q])) return none;
+    if (s1) { c.x1 = X1; c.y1 = Y1; }                                 // :36-37
     else if (fabs(d * alph / Anorm / 5) < 120) { c.x1 = X2 + 120 / d1 * (X1 - X2); c.y1 = Y2 + 120 / d1 * (Y1 - Y2); }   // :38-39
     else { c.x1 = X2 + d / d1 * alph / Anorm * (X1 - X2) / 5; c.y1 = Y2 + d / d1 * alph / Anorm * (Y1 - Y2) / 5; }     // :41
-    if (fabs(X3 - X2) < 120 && fabs(Y3 - Y2) < 120) return none;      // :43
+    if (s2) { c.x2 = X3; c.y2 = Y3; }                                 // :43-44
     else if (fabs(d * alph / Anorm / 5) < 120) { c.x2 = X2 + 120 / d2 * (X3 - X2); c.y2 = Y2 + 120 / d2 * (Y3 - Y2); }   // :45-46
     else { c.x2 = X2 + d / d2 * alph / Anorm * (X3 - X2) / 5; c.y2 = Y2 + d / d2 * alph / Anorm * (Y3 - Y2) / 5; }     // :48
-    if (fabs(c.x1 - c.x2) < 0.1) c.x1 = c.x1 + 1;                     // :50-52
+    if (fabs(c.x1 - c.x2) < 0.1) { if (s1 || s2) return none; c.x1 = c.x1 + 1; }   // :50-52 (with a cut at a vertex: not this form)
     cut[jj] = c;
-    // the plain case: a convex corner, cut points strictly inside the two edges, the cut clear of every other edge
+    // the closed form: a convex corner, cut points inside the two edges (or at their far vertex: a short edge), the cut
+    // clear of every other edge
     if (angles[jj] >= 180) return none;
     const double t1 = sqrt((c.x1 - X2) * (c.x1 - X2) + (c.y1 - Y2) * (c.y1 - Y2)), t2 = sqrt((c.x2 - X2) * (c.x2 - X2) + (c.y2 - Y2) * (c.y2 - Y2));
-    if (!(t1 > 0 && t1 < d1 && t2 > 0 && t2 < d2)) return none;
+    if (!(t1 > 0 && (s1 || t1 < d1) && t2 > 0 && (s2 || t2 < d2))) return none;
+    const int pp = (p + n - 1) % n, qq = (q + 1) % n;
     for (int e = 0; e < n; ++e) {
       if (e == p || e == jj) continue;
+      if (s1 && e == pp) continue;                                    // (ends where the cut starts: below)
+      if (s2 && e == q) continue;                                     // (starts where the cut ends)
       if (seg_touch(c.x1, c.y1, c.x2, c.y2, x[e], y[e], x[(e + 1) % n], y[(e + 1) % n])) return none;
     }
+    // a cut from a vertex must leave the outline's edge there at an angle (in line with it, polyshape drops the vertex)
+    if (s1 && (x[p] - x[pp]) * (c.y2 - y[pp]) - (y[p] - y[pp]) * (c.x2 - x[pp]) == 0) return none;
+    if (s2 && (x[q] - c.x1) * (y[qq] - c.y1) - (y[q] - c.y1) * (x[qq] - c.x1) == 0) return none;
   }
   if (ng == 0) return none;
   for (int k = 0; k < n; ++k) {                                       // neighbouring cuts on one edge must not meet
@@ -1441,9 +1455,15 @@ std::vector<CornerPiece> frac_corner_plain(const OrFloes *F, int i, const uint8_
   // :133-180 the floe less its corners
   Vec nx, ny;
   for (int k = 0; k < n; ++k) {
-    if (grind[k]) { nx.push_back(cut[k].x1); ny.push_back(cut[k].y1); nx.push_back(cut[k].x2); ny.push_back(cut[k].y2); }
+    if (grind[k]) {
+      // (a cut point that IS the neighbouring vertex -- a short edge -- is in the outline already)
+      const int kp = (k + n - 1) % n, kn = (k + 1) % n;
+      if (!(cut[k].x1 == x[kp] && cut[k].y1 == y[kp])) { nx.push_back(cut[k].x1); ny.push_back(cut[k].y1); }
+      if (!(cut[k].x2 == x[kn] && cut[k].y2 == y[kn])) { nx.push_back(cut[k].x2); ny.push_back(cut[k].y2); }
+    }
     else { nx.push_back(x[k]); ny.push_back(y[k]); }
   }
+  if (nx.size() < 3) return none;
   const double Anew = ring_area(nx.data(), ny.data(), (int)nx.size());
   if (!(Anew > 0)) return none;
   out.push_back(make_piece(0.0, nx, ny, F->mass[i] * Anew / Apoly, F, i, Anew / Apoly));   // :147, :156-157

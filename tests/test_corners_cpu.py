@@ -172,6 +172,40 @@ def test_frac_corner_known_answer_on_a_square():
     assert npieces[0] == 0 and len(pieces) == 0
 
 
+def test_frac_corner_short_edge_goes_whole():
+    """frac_corner.m:43-44: an edge shorter than 120 m in x and in y is taken whole -- the cut ends AT the neighbouring
+    vertex.  A convex pentagon with one 100 m edge (C -> D), corner C broken: the cut starts 120 m up the long edge from C
+    (d = 100 m: the 120 m rule of :45-46) and ends at D; a triangle of 4800 m^2 comes off (dead: under 1e4 m^2, :113-115), the
+    floe keeps its five vertices (C replaced by the one new cut point) and the rest of its area; with D broken as well the
+    two triangles would overlap -- union / subtract of the reference, not this closed form -- and nothing is returned."""
+    import scenes
+    S, P = scenes.pack(6, periodic=False)
+    ring = np.array([[-5000, 5000], [5000, 5000], [5000, -5000], [4920, -5060], [-5000, -5060], [-5000, 5000.0]])
+    x, y = ring[:-1, 0], ring[:-1, 1]
+    area = 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+    T = S.copy()
+    T.n = 1
+    T.vert_off = np.array([0, 6], np.int32)
+    T.cax = ring[:, 0].copy(); T.cay = ring[:, 1].copy(); T.c0x = ring[:, 0].copy(); T.c0y = ring[:, 1].copy()
+    for k in ("Xi", "Yi", "mass", "area", "ksi_ice", "alive", "h"):
+        setattr(T, k, np.asarray(getattr(S, k))[:1].copy())
+    T.Xi[:] = 0.0; T.Yi[:] = 0.0; T.area[:] = area; T.mass[:] = 920.0 * area * 0.5; T.ksi_ice[:] = 2e-6
+    npieces, poff, pieces, rings = oracle.frac_corner(T, [1], [0, 5], np.array([0, 0, 1, 0, 0], np.uint8))
+    assert npieces[0] == 2
+    main, tri = pieces
+    assert abs(tri[3] - 4800.0) < 1e-6 and abs(main[3] - (area - 4800.0)) < 1e-3      # areas: nothing lost
+    assert abs(main[4] + tri[4] - T.mass[0]) < 1e-3 * T.mass[0] * 1e-9 + 1e-3             # nor mass
+    assert tri[8] == 0 and main[8] == 1                                                # the sliver is dead (:113-115)
+    assert main[11] == 6 and tri[11] == 4                                              # five vertices + closing copy; triangle
+    mx, my = rings[0][0] + (main[1] - T.Xi[0]), rings[0][1] + (main[2] - T.Yi[0])      # the main outline, back in floe coordinates
+    got = sorted(zip(np.round(mx[:-1], 6).tolist(), np.round(my[:-1], 6).tolist()))
+    want = sorted([(-5000.0, 5000.0), (5000.0, 5000.0), (5000.0, -4880.0), (4920.0, -5060.0), (-5000.0, -5060.0)])
+    assert got == want                                                                 # C replaced by the cut point on the long edge; D kept
+    # both ends of the short edge broken: not this closed form
+    npieces, poff, pieces, rings = oracle.frac_corner(T, [1], [0, 5], np.array([0, 0, 1, 1, 0], np.uint8))
+    assert npieces[0] == 0
+
+
 def test_generated_outlines_have_no_collinear_vertices():
     """polyshape's default KeepCollinearPoints = false would drop a collinear vertex and shift the indices of `angles` and
     `grind` (corners.m:63-71): the restatement takes poly.Vertices to be the stored outline, which is only right when no
