@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64) k_narrow_wave(i64 count, const int *list, 
 // pair per wave with the sweep workspace in LDS, launched beside the team pass on a stream of its own -- the box has
 // horizontal edges, so no fast path takes these pairs, and queued behind the team pass (as deferred pairs are) their
 // quarter of a millisecond came on top of the step.  The waves stride over the list: any grid size is correct.
-__global__ void __launch_bounds__(64) k_narrow_walls(int lds_per_wave, Floes F, Params P, Work W) {
+__global__ void __launch_bounds__(64) k_narrow_walls(int lds_per_wave, int tasks, Floes F, Params P, Work W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // (all 64 lanes on the pair, as k_narrow_wave: the conversion to fixed point, InterX and the ring set-up of the sweep
   // spread over them -- SUBZERO_WALLS_LANE0: lane 0 alone, as until round 4)
@@ -108,7 +108,9 @@ __global__ void __launch_bounds__(64) k_narrow_walls(int lds_per_wave, Floes F, 
     for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_lds(t, W.wall_list, 1, F, P, W, (void *)smem, -lds_per_wave);
     return;
   }
-  for (i64 t = blockIdx.x; t < n; t += gridDim.x) narrow_wave(t, W.wall_list, F, P, W, (void *)smem, lds_per_wave);
+  // (`tasks` waves per pair as in k_narrow_wave: a floe in a corner of the box, or lying along a wall with several pieces
+  // outside, has as many overlap regions)
+  for (i64 b = blockIdx.x; b < n * tasks; b += gridDim.x) narrow_wave(b % n, W.wall_list, F, P, W, (void *)smem, lds_per_wave, (int)(b / n), tasks);
 }
 // First pass of the default path: every pair through the single-minimum fast path of convex.hpp, whose whole
 // state is one FastBlock of LDS per lane (stride 8 x odd bytes: neighbouring lanes hit different banks).
@@ -182,8 +184,8 @@ void szl_k_narrow_lds(dim3 grid, size_t lds, hipStream_t st, i64 count, const in
 void szl_k_narrow_wave(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int lds_per_wave, int tasks, const Floes &F, const Params &P, const Work &W) {
   hipLaunchKernelGGL(k_narrow_wave, grid, dim3(64), lds, st, count, list, lds_per_wave, tasks, F, P, W);
 }
-void szl_k_narrow_walls(dim3 grid, size_t lds, hipStream_t st, int lds_per_wave, const Floes &F, const Params &P, const Work &W) {
-  hipLaunchKernelGGL(k_narrow_walls, grid, dim3(64), lds, st, lds_per_wave, F, P, W);
+void szl_k_narrow_walls(dim3 grid, size_t lds, hipStream_t st, int lds_per_wave, int tasks, const Floes &F, const Params &P, const Work &W) {
+  hipLaunchKernelGGL(k_narrow_walls, grid, dim3(64), lds, st, lds_per_wave, tasks, F, P, W);
 }
 void szl_k_narrow_convex(dim3 grid, size_t lds, hipStream_t st, i64 first, i64 count, const unsigned long long *dev_count, int lanes, const Floes &F, const Params &P, const Work &W, const int *order) {
   hipLaunchKernelGGL(k_narrow_convex, grid, dim3(64), lds, st, first, count, dev_count, lanes, F, P, W, order);

@@ -13,7 +13,7 @@ int sz_narrow_general_configure(szContext *ctx, bool narrow_in_lds);
 void szl_k_narrow(dim3 grid, size_t lds, hipStream_t st, i64 first, i64 count, const int *list, int mult, int lanes, int lds_per_lane, const Floes &F, const Params &P, const Work &W);
 void szl_k_narrow_lds(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int mult, int lanes, int lds_per_lane, const Floes &F, const Params &P, const Work &W);
 void szl_k_narrow_wave(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int lds_per_wave, int tasks, const Floes &F, const Params &P, const Work &W);
-void szl_k_narrow_walls(dim3 grid, size_t lds, hipStream_t st, int lds_per_wave, const Floes &F, const Params &P, const Work &W);
+void szl_k_narrow_walls(dim3 grid, size_t lds, hipStream_t st, int lds_per_wave, int tasks, const Floes &F, const Params &P, const Work &W);
 void szl_k_narrow_convex(dim3 grid, size_t lds, hipStream_t st, i64 first, i64 count, const unsigned long long *dev_count, int lanes, const Floes &F, const Params &P, const Work &W, const int *order);
 void szl_k_narrow_convex_big(dim3 grid, size_t lds, hipStream_t st, i64 count, const int *list, int lanes, const Floes &F, const Params &P, const Work &W);
 void szl_k_narrow_a(dim3 grid, size_t lds, hipStream_t st, i64 first, i64 count, int lanes, const Floes &F, const Params &P, const Work &W);

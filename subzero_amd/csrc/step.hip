@@ -776,6 +776,7 @@ int sz_step_configure(szContext *ctx, StepState *S) {
   S->no_hint = getenv("SUBZERO_NO_HINT") != nullptr;
   S->debug_lists = getenv("SUBZERO_DEBUG_LISTS") != nullptr;
   if (const char *v = getenv("SUBZERO_POT_CAP")) { int l = atoi(v); if (l >= 1 && l <= 4096) S->pot_cap = l; }
+  S->wall_tasks = getenv("SUBZERO_WALL_TASKS") != nullptr && atoi(getenv("SUBZERO_WALL_TASKS")) != 0;
   if (const char *v = getenv("SUBZERO_WAVE_TASKS")) { int l = atoi(v); if (l >= 1 && l <= 4) S->wave_tasks = l; }
   if (const char *v = getenv("SUBZERO_BIG_LANES")) { int l = atoi(v); if (l >= 0 && l <= 64) S->big_lanes = l; }
   { const int rcg = sz_narrow_general_configure(ctx, S->narrow_lds != 0); if (rcg) return rcg; }
@@ -1080,7 +1081,7 @@ static int step_narrow_first(szContext *ctx, StepState *S, i64 lo, i64 hi, bool 
         if (room > S->retry_lds_max) room = S->retry_lds_max;
         if (room < S->retry_lds) room = S->retry_lds;
         static const bool walls_lane0 = getenv("SUBZERO_WALLS_LANE0") != nullptr;     // (a tuning comparison)
-        szl_k_narrow_walls(dim3((unsigned)wg), (size_t)room, st, walls_lane0 ? -(int)room : (int)room, F, P, W);
+        szl_k_narrow_walls(dim3((unsigned)wg), (size_t)room, st, walls_lane0 ? -(int)room : (int)room, (S->fused && !walls_lane0 && S->wall_tasks) ? S->wave_tasks : 1, F, P, W);
         SZ_HIP(ctx, hipGetLastError());
         SZ_HIP(ctx, hipEventRecord(S->ev[2], ts));
       }

@@ -810,6 +810,10 @@ SZ_HD void narrow_t(i64 t, const int *list, int mult, const Floes &F, const Para
     __threadfence();
     const int merged = __hip_atomic_load(&task[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     st = merged ? (merged & 0xff) : (int)szv::ST_OK;
+    // (the words as kf_pairs left them: a pair that failed at this tier may be run by tasks again in the same step -- the
+    // floes at the walls are swept beside the team pass and, when one of them outgrows its slice, once more with the
+    // deferred pairs; found by tests/campaign_gpu.py: a second run that starts from a full counter never ends)
+    if (speaker) { task[1] = 0; task[2] = 0; }
     W.pair_scr[p] = off0; W.pair_mult[p] = mult;
     W.pair_nrows[p] = 0; W.pair_flag[p] = 0;
     W.pair_rowoff[p] = (i64)(S.rows - (const double *)W.scratch);

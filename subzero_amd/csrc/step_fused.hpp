@@ -38,7 +38,7 @@ __device__ unsigned long long sz_fused_clock[SZ_FC_KERNELS * SZ_FC_BLOCKS * SZ_F
 #else
 #define FCLK(kern, slot) do { } while (0)
 #endif
-enum { HINT_ROWS_SHIFT = 28, HINT_PARTNER_MASK = (1 << 28) - 1 };   // W.hint: partner entry + 1 in the low bits (entries < 2^23), the pair's contact rows (up to 7) above
+enum { HINT_ROWS_SHIFT = 28, HINT_PARTNER_MASK = (1 << 28) - 1 };   // W.hint: partner entry + 1 in the low bits (entries < 2^23; all ones: the wall), the pair's contact rows (up to 7) above
 enum { CELL_STRIDE = 8 };   // ints between the fill counts of two grid cells (four cells to a 128-byte line: the appends are atomics)
 // ---- kf_front_a ----------------------------------------------------------------------------------------------------
 // (ahead: queued behind the step BEFORE the one it belongs to, szStepParams.flags -- it runs only if that step ran to its
@@ -450,9 +450,9 @@ __global__ void __launch_bounds__(512) kf_pairs(int prev_n, unsigned long long s
         // was the pair in contact in the step before? (kf_rows left the partners of i's own pairs in contact; a hint: a
         // wrong one costs time, never a result)
         int live = 0, rows_before = 0;      // (the hint's top bits: the pair's contact rows in that step, HINT_ROWS_SHIFT)
-        if (i < prev_n && j >= 0) {
+        if (i < prev_n && (j >= 0 || wall)) {
           const int4 h0 = *(const int4 *)(W.hint + 8 * (size_t)i), h1 = *(const int4 *)(W.hint + 8 * (size_t)i + 4);
-          const int want = j + 1;
+          const int want = wall ? (int)HINT_PARTNER_MASK : j + 1;       // (the wall: a partner code of its own)
           const int hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
           for (int q8 = 0; q8 < 8; ++q8) if ((hv[q8] & HINT_PARTNER_MASK) == want) { live = 1; rows_before = (hv[q8] >> HINT_ROWS_SHIFT) & 7; }
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(1024) kf_rows(int publish, unsigned long long 
     // pass shares the regions out over waves, and it asks the hint how many there were)
     if (items <= 16) {
       const unsigned mh = (unsigned)((__ballot(own && nr > 0) >> gsh) & 0xffffULL);
-      if (own && nr > 0) { const int rk = __popc(mh & ((1u << l) - 1u)); if (rk < 8) W.hint[8 * (size_t)e + rk] = (j + 1) | ((nr > 7 ? 7 : nr) << HINT_ROWS_SHIFT); }
+      if (own && nr > 0) { const int rk = __popc(mh & ((1u << l) - 1u)); if (rk < 8) W.hint[8 * (size_t)e + rk] = (j == WALL ? (int)HINT_PARTNER_MASK : j + 1) | ((nr > 7 ? 7 : nr) << HINT_ROWS_SHIFT); }
       if (l < 8 && l >= __popc(mh)) W.hint[8 * (size_t)e + l] = 0;
     } else if (l < 8) W.hint[8 * (size_t)e + l] = 0;
     return;
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(1024) kf_rows(int publish, unsigned long long 
   // next step's hint: the partners of the own pairs in contact (kf_pairs sorts the team pass's pairs by it)
   {
     const unsigned mh = (unsigned)((__ballot(own && nr > 0) >> gsh) & 0xffffULL);
-    if (own && nr > 0) { const int rk = __popc(mh & ((1u << l) - 1u)); if (rk < 8) W.hint[8 * (size_t)e + rk] = (j + 1) | ((nr > 7 ? 7 : nr) << HINT_ROWS_SHIFT); }
+    if (own && nr > 0) { const int rk = __popc(mh & ((1u << l) - 1u)); if (rk < 8) W.hint[8 * (size_t)e + rk] = (j == WALL ? (int)HINT_PARTNER_MASK : j + 1) | ((nr > 7 ? 7 : nr) << HINT_ROWS_SHIFT); }
     if (l < 8 && l >= __popc(mh)) W.hint[8 * (size_t)e + l] = 0;
   }
   // kill / transfer marks of the own pairs, the last one in list order that sets each (:138-145)

@@ -67,6 +67,7 @@ struct StepState {
   int convex_fast = 1;            // first pass with the single-minimum fast path only (convex.hpp); SUBZERO_CONVEX_FAST=0: general sweep for all
   int convex_lanes = 0;           // pairs per wave of that pass (SUBZERO_CONVEX_LANES; 0: chosen per launch)
   int broad_wave = 1;   // the wave-per-floe broad phase for real floes (SUBZERO_BROAD_WAVE=0: thread-per-floe kernels only)
+  bool wall_tasks = false;        // the same for the floes at the walls (SUBZERO_WALL_TASKS=1; measured: 0.424 -> 0.414 ms/step between walls, left off)
   int wave_tasks = 3;             // waves per deferred pair in the wave-per-pair general pass (SUBZERO_WAVE_TASKS, 1-4): a pair with several overlap regions is shared out over up to that many (step_core.hpp narrow_t)
   int big_lanes = 0;              // pairs per wave of the second fast pass (32-vertex blocks, SUBZERO_BIG_LANES; 0: no such pass: its pairs take
                                   // the general kernel -- the default until the round-1 fault of that kernel is settled)
