@@ -42,6 +42,7 @@ int szDestroy(szContext *ctx) {
   sz_release(ctx->d_in); sz_release(ctx->d_out);
   if (ctx->h_in.p) (void)hipHostFree(ctx->h_in.p);
   if (ctx->h_out.p) (void)hipHostFree(ctx->h_out.p);
+  if (ctx->h_cnt.p) (void)hipHostFree(ctx->h_cnt.p);
   for (int k = 0; k < 3; ++k) {
     if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
     if (ctx->side_join[k]) (void)hipEventDestroy(ctx->side_join[k]);

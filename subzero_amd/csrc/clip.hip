@@ -469,9 +469,13 @@ int szb::prepare(szContext *ctx, int npairs, i64 total, ClipArgs &a) {
   a.retry = (int *)ctx->retry_list.p; a.retry_cap = npairs;
   a.counters = (unsigned long long *)ctx->counters.p;
   // bump pointers of the retry region start behind the closed-form region
-  unsigned long long init[16] = {0, (unsigned long long)ws_main, (unsigned long long)ov_main,
-                                 (unsigned long long)or_main, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  SZ_HIP(ctx, hipMemcpy(ctx->counters.p, init, sizeof(init), hipMemcpyHostToDevice));
+  // (through pinned words, in stream order: a blocking copy from the stack is staged by the runtime -- the counters'
+  // slots: 0 this start, 1 the front pass's read-back, 2 the read-back of a pass; a caller's two batches are a wait apart)
+  { const int rs = sz_stage_reserve(ctx, ctx->h_cnt, 3 * 16 * 8); if (rs) return rs; }
+  unsigned long long *init = (unsigned long long *)ctx->h_cnt.p;
+  for (int k = 0; k < 16; ++k) init[k] = 0;
+  init[1] = (unsigned long long)ws_main; init[2] = (unsigned long long)ov_main; init[3] = (unsigned long long)or_main;
+  SZ_HIP(ctx, hipMemcpyAsync(ctx->counters.p, init, 16 * 8, hipMemcpyHostToDevice, ctx->stream));
   return SZ_OK;
 }
 
@@ -501,8 +505,8 @@ static int clip_main_in_classes(szContext *ctx, ClipArgs &a) {
   a.lds_per_lane = class_bytes[1];
   hipLaunchKernelGGL(k_clip_front, dim3(a.npairs), dim3(64), (size_t)class_bytes[1], ctx->stream, a);
   SZ_HIP(ctx, hipGetLastError());
-  unsigned long long c[16];
-  SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  const unsigned long long *c = (const unsigned long long *)ctx->h_cnt.p + 16;
+  SZ_HIP(ctx, hipMemcpyAsync((void *)c, a.counters, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SZ_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
   // Six launches on four streams (context.hpp: no more than the hardware queues), the longest sweeps first:
@@ -559,8 +563,8 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
     SZ_HIP(ctx, hipGetLastError());
   }
   SZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  unsigned long long c[8];
-  SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long *c = (unsigned long long *)ctx->h_cnt.p + 32;
+  SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
   SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   SZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -589,7 +593,7 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
     b.lds_per_lane = 0;
     clip_launch(ctx, nlist, b);
     SZ_HIP(ctx, hipGetLastError());
-    SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    SZ_HIP(ctx, hipMemcpyAsync(c, a.counters, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
     SZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   sz_release(list2);
@@ -619,6 +623,25 @@ int upload(szContext *ctx, DevBuf &b, const T *src, size_t n) {
   return SZ_OK;
 }
 
+// A small batch (a pair or two per call is how polyclip.m calls the reference's mex): the six input arrays through the
+// pinned staging buffer into ONE device block with one copy, instead of six copies the runtime stages one by one.
+static int upload_packed(szContext *ctx, const void *const src[6], const size_t bytes[6], const char *dev[6], bool &done) {
+  done = false;
+  size_t tot = 0;
+  for (int k = 0; k < 6; ++k) tot += bytes[k];
+  if (tot > ((size_t)1 << 20)) return SZ_OK;
+  Packer pk;
+  size_t off[6];
+  for (int k = 0; k < 6; ++k) off[k] = pk.add(bytes[k] + 16);
+  int rc;
+  if ((rc = sz_stage_reserve(ctx, ctx->h_in, pk.at)) || (rc = sz_reserve(ctx, ctx->d_in, pk.at))) return rc;
+  for (int k = 0; k < 6; ++k) if (bytes[k]) memcpy(ctx->h_in.p + off[k], src[k], bytes[k]);
+  SZ_HIP(ctx, hipMemcpyAsync(ctx->d_in.p, ctx->h_in.p, pk.at, hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < 6; ++k) dev[k] = (const char *)ctx->d_in.p + off[k];
+  done = true;
+  return SZ_OK;
+}
+
 inline void from_fixed(i64 v, int64_t &o) { o = v; }
 inline void from_fixed(i64 v, double &o) { o = (double)v / 4294967296.0; } // polyclip.m:67
 
@@ -626,32 +649,44 @@ inline void from_fixed(i64 v, double &o) { o = (double)v / 4294967296.0; } // po
 template <class T>
 int gather(szContext *ctx, const ClipArgs &a, T *outx, T *outy, int64_t out_cap, int32_t *ring_off,
            int64_t ring_cap, int32_t *pair_ring_off, int32_t *status) {
-  int n = a.npairs;
-  std::vector<i64> vb(n), rb(n);
-  std::vector<int> nr(n), st(n);
-  SZ_HIP(ctx, hipMemcpy(vb.data(), a.ov_base, (size_t)n * 8, hipMemcpyDeviceToHost));
-  SZ_HIP(ctx, hipMemcpy(rb.data(), a.or_base, (size_t)n * 8, hipMemcpyDeviceToHost));
-  SZ_HIP(ctx, hipMemcpy(nr.data(), a.nrings, (size_t)n * 4, hipMemcpyDeviceToHost));
-  SZ_HIP(ctx, hipMemcpy(st.data(), a.status, (size_t)n * 4, hipMemcpyDeviceToHost));
-  unsigned long long c[8];
-  SZ_HIP(ctx, hipMemcpy(c, a.counters, sizeof(c), hipMemcpyDeviceToHost));
+  const int n = a.npairs;
+  // run() has left the counters of its last pass in the context's pinned words (slot 2): how much of the output arrays
+  // is in use is known without asking again.  Everything comes back in ONE block of async copies and one wait -- into
+  // the pinned staging buffer unless the batch is a large one (there were eight blocking copies to pageable vectors:
+  // most of a call with a pair or two, which is how polyclip.m calls the reference's mex)
+  const unsigned long long *c = (const unsigned long long *)ctx->h_cnt.p + 32;
   size_t used_v = (size_t)c[2], used_r = (size_t)c[3];
   if (used_v > (size_t)a.ov_cap) used_v = (size_t)a.ov_cap;
   if (used_r > (size_t)a.or_cap) used_r = (size_t)a.or_cap;
-  std::vector<i64> hx(used_v), hy(used_v);
-  std::vector<int> hr(used_r);
-  if (used_v) {
-    SZ_HIP(ctx, hipMemcpy(hx.data(), a.ovx, used_v * 8, hipMemcpyDeviceToHost));
-    SZ_HIP(ctx, hipMemcpy(hy.data(), a.ovy, used_v * 8, hipMemcpyDeviceToHost));
+  Packer pk;
+  const size_t o_vb = pk.add((size_t)n * 8), o_rb = pk.add((size_t)n * 8), o_nr = pk.add((size_t)n * 4), o_st = pk.add((size_t)n * 4),
+               o_hx = pk.add(used_v * 8), o_hy = pk.add(used_v * 8), o_hr = pk.add(used_r * 4);
+  std::vector<char> pageable;
+  char *base;
+  if (pk.at <= ((size_t)32 << 20)) { const int rs = sz_stage_reserve(ctx, ctx->h_out, pk.at + 16); if (rs) return rs; base = ctx->h_out.p; }
+  else { pageable.resize(pk.at + 16); base = pageable.data(); }
+  hipStream_t stq = ctx->stream;
+  if (n) {
+    SZ_HIP(ctx, hipMemcpyAsync(base + o_vb, a.ov_base, (size_t)n * 8, hipMemcpyDeviceToHost, stq));
+    SZ_HIP(ctx, hipMemcpyAsync(base + o_rb, a.or_base, (size_t)n * 8, hipMemcpyDeviceToHost, stq));
+    SZ_HIP(ctx, hipMemcpyAsync(base + o_nr, a.nrings, (size_t)n * 4, hipMemcpyDeviceToHost, stq));
+    SZ_HIP(ctx, hipMemcpyAsync(base + o_st, a.status, (size_t)n * 4, hipMemcpyDeviceToHost, stq));
   }
-  if (used_r) SZ_HIP(ctx, hipMemcpy(hr.data(), a.oroff, used_r * 4, hipMemcpyDeviceToHost));
+  if (used_v) {
+    SZ_HIP(ctx, hipMemcpyAsync(base + o_hx, a.ovx, used_v * 8, hipMemcpyDeviceToHost, stq));
+    SZ_HIP(ctx, hipMemcpyAsync(base + o_hy, a.ovy, used_v * 8, hipMemcpyDeviceToHost, stq));
+  }
+  if (used_r) SZ_HIP(ctx, hipMemcpyAsync(base + o_hr, a.oroff, used_r * 4, hipMemcpyDeviceToHost, stq));
+  SZ_HIP(ctx, hipStreamSynchronize(stq));
+  const i64 *vb = (const i64 *)(base + o_vb), *rb = (const i64 *)(base + o_rb), *hx = (const i64 *)(base + o_hx), *hy = (const i64 *)(base + o_hy);
+  const int *nr = (const int *)(base + o_nr), *st = (const int *)(base + o_st), *hr = (const int *)(base + o_hr);
   int64_t nv = 0, nrt = 0;
   pair_ring_off[0] = 0;
   ring_off[0] = 0;
   for (int p = 0; p < n; ++p) {
     status[p] = st[p];
     if (st[p] == SZ_CLIP_OK) {
-      const int *ro = hr.data() + rb[p];
+      const int *ro = hr + rb[p];
       for (int r = 0; r < nr[p]; ++r) {
         int v0 = ro[r], v1 = ro[r + 1];
         if (nrt + 1 > ring_cap || nv + (v1 - v0) > out_cap)
@@ -695,17 +730,26 @@ int szClipBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_t *ay
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   i64 ta = aoff[npairs], tb = boff[npairs];
   int rc;
-  if ((rc = upload(ctx, ctx->in_ax, ax, (size_t)ta))) return rc;
-  if ((rc = upload(ctx, ctx->in_ay, ay, (size_t)ta))) return rc;
-  if ((rc = upload(ctx, ctx->in_aoff, aoff, (size_t)npairs + 1))) return rc;
-  if ((rc = upload(ctx, ctx->in_bx, bx, (size_t)tb))) return rc;
-  if ((rc = upload(ctx, ctx->in_by, by, (size_t)tb))) return rc;
-  if ((rc = upload(ctx, ctx->in_boff, boff, (size_t)npairs + 1))) return rc;
+  const void *const src[6] = {ax, ay, aoff, bx, by, boff};
+  const size_t bytes[6] = {(size_t)ta * 8, (size_t)ta * 8, ((size_t)npairs + 1) * 4, (size_t)tb * 8, (size_t)tb * 8, ((size_t)npairs + 1) * 4};
+  const char *dev[6];
+  bool packed = false;
+  if ((rc = upload_packed(ctx, src, bytes, dev, packed))) return rc;
+  if (!packed) {
+    if ((rc = upload(ctx, ctx->in_ax, ax, (size_t)ta))) return rc;
+    if ((rc = upload(ctx, ctx->in_ay, ay, (size_t)ta))) return rc;
+    if ((rc = upload(ctx, ctx->in_aoff, aoff, (size_t)npairs + 1))) return rc;
+    if ((rc = upload(ctx, ctx->in_bx, bx, (size_t)tb))) return rc;
+    if ((rc = upload(ctx, ctx->in_by, by, (size_t)tb))) return rc;
+    if ((rc = upload(ctx, ctx->in_boff, boff, (size_t)npairs + 1))) return rc;
+    dev[0] = (const char *)ctx->in_ax.p; dev[1] = (const char *)ctx->in_ay.p; dev[2] = (const char *)ctx->in_aoff.p;
+    dev[3] = (const char *)ctx->in_bx.p; dev[4] = (const char *)ctx->in_by.p; dev[5] = (const char *)ctx->in_boff.p;
+  }
   ClipArgs a;
   memset(&a, 0, sizeof(a));
   if ((rc = prepare(ctx, npairs, ta + tb, a))) return rc;
-  a.ax = (const i64 *)ctx->in_ax.p; a.ay = (const i64 *)ctx->in_ay.p; a.aoff = (const int *)ctx->in_aoff.p;
-  a.bx = (const i64 *)ctx->in_bx.p; a.by = (const i64 *)ctx->in_by.p; a.boff = (const int *)ctx->in_boff.p;
+  a.ax = (const i64 *)dev[0]; a.ay = (const i64 *)dev[1]; a.aoff = (const int *)dev[2];
+  a.bx = (const i64 *)dev[3]; a.by = (const i64 *)dev[4]; a.boff = (const int *)dev[5];
   a.method = method; a.fill_s = subj_fill; a.fill_c = clip_fill;
   if ((rc = run(ctx, a, nullptr))) return rc;
   return gather<int64_t>(ctx, a, outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);
@@ -812,18 +856,27 @@ int szPolyclipBatch(szContext *ctx, int npairs, const double *ax, const double *
   SZ_HIP(ctx, hipSetDevice(ctx->device));
   i64 ta = aoff[npairs], tb = boff[npairs];
   int rc;
-  if ((rc = upload(ctx, ctx->in_fax, ax, (size_t)ta))) return rc;
-  if ((rc = upload(ctx, ctx->in_fay, ay, (size_t)ta))) return rc;
-  if ((rc = upload(ctx, ctx->in_aoff, aoff, (size_t)npairs + 1))) return rc;
-  if ((rc = upload(ctx, ctx->in_fbx, bx, (size_t)tb))) return rc;
-  if ((rc = upload(ctx, ctx->in_fby, by, (size_t)tb))) return rc;
-  if ((rc = upload(ctx, ctx->in_boff, boff, (size_t)npairs + 1))) return rc;
+  const void *const src[6] = {ax, ay, aoff, bx, by, boff};
+  const size_t bytes[6] = {(size_t)ta * 8, (size_t)ta * 8, ((size_t)npairs + 1) * 4, (size_t)tb * 8, (size_t)tb * 8, ((size_t)npairs + 1) * 4};
+  const char *dev[6];
+  bool packed = false;
+  if ((rc = upload_packed(ctx, src, bytes, dev, packed))) return rc;
+  if (!packed) {
+    if ((rc = upload(ctx, ctx->in_fax, ax, (size_t)ta))) return rc;
+    if ((rc = upload(ctx, ctx->in_fay, ay, (size_t)ta))) return rc;
+    if ((rc = upload(ctx, ctx->in_aoff, aoff, (size_t)npairs + 1))) return rc;
+    if ((rc = upload(ctx, ctx->in_fbx, bx, (size_t)tb))) return rc;
+    if ((rc = upload(ctx, ctx->in_fby, by, (size_t)tb))) return rc;
+    if ((rc = upload(ctx, ctx->in_boff, boff, (size_t)npairs + 1))) return rc;
+    dev[0] = (const char *)ctx->in_fax.p; dev[1] = (const char *)ctx->in_fay.p; dev[2] = (const char *)ctx->in_aoff.p;
+    dev[3] = (const char *)ctx->in_fbx.p; dev[4] = (const char *)ctx->in_fby.p; dev[5] = (const char *)ctx->in_boff.p;
+  }
   ClipArgs a;
   memset(&a, 0, sizeof(a));
   if ((rc = prepare(ctx, npairs, ta + tb, a))) return rc;
-  a.fax = (const double *)ctx->in_fax.p; a.fay = (const double *)ctx->in_fay.p;
-  a.fbx = (const double *)ctx->in_fbx.p; a.fby = (const double *)ctx->in_fby.p;
-  a.aoff = (const int *)ctx->in_aoff.p; a.boff = (const int *)ctx->in_boff.p;
+  a.fax = (const double *)dev[0]; a.fay = (const double *)dev[1];
+  a.fbx = (const double *)dev[3]; a.fby = (const double *)dev[4];
+  a.aoff = (const int *)dev[2]; a.boff = (const int *)dev[5];
   a.method = method; a.fill_s = SZ_FILL_EVENODD; a.fill_c = SZ_FILL_EVENODD;
   if ((rc = run(ctx, a, nullptr))) return rc;
   return gather<double>(ctx, a, outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);

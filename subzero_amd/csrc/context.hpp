@@ -39,6 +39,7 @@ struct szContext {
   DevBuf ws, ovx, ovy, oroff, ov_base, or_base, nrings, status, retry_list, counters;
   DevBuf clip_meta, clip_lists;      // front pass -> sweep pass (clip.hip)
   HostStage h_in, h_out;             // staging of the post-step entries (corners.hip ...)
+  HostStage h_cnt;                   // the clip batch's counters on their way in and out (clip.hip: three slots of 16 words)
   DevBuf d_in, d_out;
   bool clip_lds_set = false;         // the clip kernels' dynamic-LDS limit has been raised on this context's device
   // Three side streams for everything in the library that runs kernels side by side (the sweep passes of the clip batch,

@@ -14,13 +14,19 @@ namespace {
 struct EulEnt { double x, y; int src, pad; };
 enum { EUL_FIELDS = 18, EUL_CAP = 2048, EUL_PAR = 192 };   // fields; potential floes of a cell held in LDS; ... summed by a thread per output
 
-__global__ void k_eul_extent(Floes F, double *ext2) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// (the extents, positions and live flags of all floes in ONE block -- one copy to the host instead of four -- and the
+// result array cleared on the way: `zero` doubles, the overflow flag behind them included)
+__global__ void k_eul_extent(Floes F, double *ext2, double *xs, double *ys, int *live, double *zero, long long nzero) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+  for (long long k = t; k < nzero; k += nt) zero[k] = 0.0;
+  const int i = (int)t;
   if (i >= F.n) return;
   const int v0 = F.vert_off[i], nv = F.vert_off[i + 1] - v0;
+  const double X = F.Xi[i], Y = F.Yi[i];
   double mx = 0, my = 0;
-  for (int k = 0; k < nv; ++k) { mx = szc::maxd(mx, szs::absd(F.cax[v0 + k] + F.Xi[i])); my = szc::maxd(my, szs::absd(F.cay[v0 + k] + F.Yi[i])); }
+  for (int k = 0; k < nv; ++k) { mx = szc::maxd(mx, szs::absd(F.cax[v0 + k] + X)); my = szc::maxd(my, szs::absd(F.cay[v0 + k] + Y)); }
   ext2[2 * i] = mx; ext2[2 * i + 1] = my;
+  xs[i] = X; ys[i] = Y; live[i] = F.alive[i];
 }
 
 __device__ inline double nz(double v) { return v != v ? 0.0 : v; }
@@ -214,21 +220,24 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   hipStream_t st = ctx->stream;
   const int n = S->n;
   int rc;
-  DevBuf &d_ext = S->post[24]; DevBuf &d_ent = S->post[25]; DevBuf &d_grid = S->post[26]; DevBuf &d_out = S->post[27]; DevBuf &d_flag = S->post[28];
-  auto cleanup = [&]() { (void)d_ext; (void)d_ent; (void)d_grid; (void)d_out; (void)d_flag; };
-  if ((rc = sz_reserve(ctx, d_ext, (size_t)n * 16 + 16))) return rc;
-  hipLaunchKernelGGL(k_eul_extent, grid_for(n, 256), dim3(256), 0, st, S->F, (double *)d_ext.p);
+  DevBuf &d_ext = S->post[24]; DevBuf &d_ent = S->post[25]; DevBuf &d_grid = S->post[26]; DevBuf &d_out = S->post[27];
+  auto cleanup = [&]() { (void)d_ext; (void)d_ent; (void)d_grid; (void)d_out; };
   // (read back into the context's pinned staging buffer: a copy to pageable memory is staged by the runtime, tens of
-  // microseconds each)
+  // microseconds each; the device block has the layout of the staging block)
   Packer back;
   const size_t b_ext = back.add((size_t)2 * n * 8), b_x = back.add((size_t)n * 8), b_y = back.add((size_t)n * 8), b_al = back.add((size_t)n * 4);
+  const size_t cells = (size_t)Nx * Ny;
+  const size_t out_bytes = EUL_FIELDS * cells * 8;        // (+ 16: the overflow flag travels behind the result)
+  if ((rc = sz_reserve(ctx, d_ext, back.at + 16)) || (rc = sz_reserve(ctx, d_out, out_bytes + 16))) return rc;
   if ((rc = sz_stage_reserve(ctx, ctx->h_out, back.at))) return rc;
+  int *const d_flag = (int *)((char *)d_out.p + out_bytes);
+  const i64 nzero = (i64)(out_bytes / 8 + 2), threads = std::max<i64>(n, std::min<i64>(nzero, 1 << 16));     // (a thread per floe; the clearing strides)
+  hipLaunchKernelGGL(k_eul_extent, grid_for(threads, 256), dim3(256), 0, st, S->F, (double *)((char *)d_ext.p + b_ext),
+                     (double *)((char *)d_ext.p + b_x), (double *)((char *)d_ext.p + b_y), (int *)((char *)d_ext.p + b_al), (double *)d_out.p, (long long)nzero);
   const double *ext = (const double *)(ctx->h_out.p + b_ext), *x = (const double *)(ctx->h_out.p + b_x), *y = (const double *)(ctx->h_out.p + b_y);
   const int *alive = (const int *)(ctx->h_out.p + b_al);
-  hipError_t he = hipMemcpyAsync(ctx->h_out.p + b_ext, d_ext.p, (size_t)2 * n * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p + b_x, S->F.Xi, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p + b_y, S->F.Yi, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p + b_al, S->F.alive, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_out.p, d_ext.p, back.at, hipMemcpyDeviceToHost, st);
   if (he == hipSuccess) he = hipStreamSynchronize(st);
   if (he != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szEulerianData: %s", hipGetErrorString(he)); }
   double Lx = c2b[0], Ly = c2b[1], xmin = c2b[0], ymin = c2b[1];
@@ -259,7 +268,6 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
   xg[Nx] = Lx; yg[0] = Ly;
   const double dx = absd(xg[1] - xg[0]), dy = absd(yg[1] - yg[0]);
   const double r_max = ::sqrt((dx / 2) * (dx / 2) + (dy / 2) * (dy / 2));
-  const size_t cells = (size_t)Nx * Ny;
   // ---- cells that meet the topography (Nb > 0): box = subtract(box, boundaries), overlap = intersect(box, poly) (:141-154)
   // through the clip kernel (szClipPathsBatch: the polyshape operations restated by the fixed-point clip, as polyclip.m
   // uses it).  Only a cell whose rectangle meets the bounding box of a topography floe can lose anything.
@@ -395,27 +403,26 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
       ov.cell = (const int *)d_ovc.p; ov.off = (const int *)d_ovo.p; ov.ent = (const int *)d_ove.p; ov.area = (const double *)d_ova.p; ov.abox = (const double *)d_ovb.p;
     }
   }
-  if ((rc = sz_reserve(ctx, d_ent, (size_t)(M + 1) * sizeof(EulEnt))) || (rc = sz_reserve(ctx, d_grid, grid.size() * 8)) ||
-      (rc = sz_reserve(ctx, d_out, EUL_FIELDS * cells * 8)) || (rc = sz_reserve(ctx, d_flag, 16))) { cleanup(); cleanup2(); return rc; }
+  if ((rc = sz_reserve(ctx, d_ent, (size_t)(M + 1) * sizeof(EulEnt))) || (rc = sz_reserve(ctx, d_grid, grid.size() * 8))) { cleanup(); cleanup2(); return rc; }
   // (entities, grid lines and the result through the pinned staging buffer, as the read-back above)
   Packer up;
-  const size_t u_ent = up.add((size_t)(M + 1) * sizeof(EulEnt)), u_grid = up.add(grid.size() * 8), u_out = up.add(EUL_FIELDS * cells * 8);
+  const size_t u_ent = up.add((size_t)(M + 1) * sizeof(EulEnt)), u_grid = up.add(grid.size() * 8), u_out = up.add(out_bytes + 16);
   if ((rc = sz_stage_reserve(ctx, ctx->h_in, up.at))) { cleanup(); cleanup2(); return rc; }
   if (M) memcpy(ctx->h_in.p + u_ent, E.data(), (size_t)M * sizeof(EulEnt));
   memcpy(ctx->h_in.p + u_grid, grid.data(), grid.size() * 8);
   he = hipMemcpyAsync(d_ent.p, ctx->h_in.p + u_ent, (size_t)M * sizeof(EulEnt), hipMemcpyHostToDevice, st);
   if (he == hipSuccess) he = hipMemcpyAsync(d_grid.p, ctx->h_in.p + u_grid, grid.size() * 8, hipMemcpyHostToDevice, st);
-  if (he == hipSuccess) he = hipMemsetAsync(d_out.p, 0, EUL_FIELDS * cells * 8, st);
-  if (he == hipSuccess) he = hipMemsetAsync(d_flag.p, 0, 16, st);
+  // (the result and the flag were cleared by k_eul_extent; both come back in one copy behind the kernel: one wait)
   if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
   if (he == hipSuccess && M > 0)
     hipLaunchKernelGGL(k_eul_cells, dim3((unsigned)cells), dim3(256), 0, st, S->F, (const EulEnt *)d_ent.p, M, Nx, Ny,
-                       (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p, ov,
+                       (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, d_flag, ov,
                        (int *)nullptr, (double *)nullptr, 0);
   if (he == hipSuccess) he = hipEventRecord(ctx->ev1, st);
-  int over = 0;
-  if (he == hipSuccess) he = hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st);
+  const int *const h_flag = (const int *)(ctx->h_in.p + u_out + out_bytes);
+  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_in.p + u_out, d_out.p, out_bytes + 16, hipMemcpyDeviceToHost, st);
   if (he == hipSuccess) he = hipStreamSynchronize(st);
+  int over = (he == hipSuccess) ? h_flag[0] : 0;
   if (he == hipSuccess && over) {
     // a cell holds more potential floes than the LDS lists: once more with the lists in HBM (the reference
     // has no limit; a 1 x 1 grid over 1e4 floes is a legitimate domain average).  Twice M entries per cell: list + sort room.
@@ -423,20 +430,18 @@ extern "C" int szEulerianData(szContext *ctx, int Nx, int Ny, int Nb, const doub
     if (cells * per * 12 > ((size_t)2 << 30)) { cleanup(); cleanup2(); return sz_fail(ctx, SZ_ERR_WORKSPACE, "szEulerianData: a grid cell has more than %d potential floes and the lists of all %zu cells would not fit 2 GB", (int)EUL_CAP, cells); }
     DevBuf &d_se = S->post[34]; DevBuf &d_sa = S->post[35];
     if ((rc = sz_reserve(ctx, d_se, cells * per * 4)) || (rc = sz_reserve(ctx, d_sa, cells * per * 8))) { cleanup(); cleanup2(); return rc; }
-    he = hipMemsetAsync(d_out.p, 0, EUL_FIELDS * cells * 8, st);
-    if (he == hipSuccess) he = hipMemsetAsync(d_flag.p, 0, 16, st);
+    he = hipMemsetAsync(d_out.p, 0, out_bytes + 16, st);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev0, st);
     if (he == hipSuccess)
       hipLaunchKernelGGL(k_eul_cells, dim3((unsigned)cells), dim3(256), 0, st, S->F, (const EulEnt *)d_ent.p, M, Nx, Ny,
-                         (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, (int *)d_flag.p, ov,
+                         (const double *)d_grid.p, (const double *)d_grid.p + Nx + 1, r_max, (double *)d_out.p, d_flag, ov,
                          (int *)d_se.p, (double *)d_sa.p, (int)per);
     if (he == hipSuccess) he = hipEventRecord(ctx->ev1, st);
-    if (he == hipSuccess) he = hipMemcpyAsync(&over, d_flag.p, 4, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_in.p + u_out, d_out.p, out_bytes + 16, hipMemcpyDeviceToHost, st);
     if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he == hipSuccess) over = h_flag[0];
   }
-  if (he == hipSuccess) he = hipMemcpyAsync(ctx->h_in.p + u_out, d_out.p, EUL_FIELDS * cells * 8, hipMemcpyDeviceToHost, st);
-  if (he == hipSuccess) he = hipStreamSynchronize(st);
-  if (he == hipSuccess) memcpy(out, ctx->h_in.p + u_out, EUL_FIELDS * cells * 8);
+  if (he == hipSuccess) memcpy(out, ctx->h_in.p + u_out, out_bytes);
   float ms = 0;
   if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   cleanup(); cleanup2();

@@ -127,14 +127,21 @@ extern "C" int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, in
                          (void)d_chg; (void)d_sc; (void)d_len; (void)d_ox; (void)d_oy; };
 #define FR_TRY(expr) do { if ((rc = (expr))) { cleanup(); return rc; } } while (0)
 #define FR_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return sz_fail(ctx, SZ_ERR_HIP, "szFractureDeform: %s", hipGetErrorString(e_)); } } while (0)
+  // (every transfer through the context's pinned staging buffers, one block per direction and phase: a copy from or to
+  // pageable memory is staged by the runtime, tens of microseconds each -- there were ten of them)
   FR_TRY(sz_reserve(ctx, d_ids, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_pick, (size_t)nsel * sizeof(Pick)));
-  FR_HIP(hipMemcpyAsync(d_ids.p, ids, (size_t)nsel * 4, hipMemcpyHostToDevice, st));
+  FR_TRY(sz_stage_reserve(ctx, ctx->h_in, (size_t)3 * (nsel + 4) * 4 + 64)); FR_TRY(sz_stage_reserve(ctx, ctx->h_out, (size_t)nsel * sizeof(Pick)));
+  memcpy(ctx->h_in.p, ids, (size_t)nsel * 4);
+  FR_HIP(hipMemcpyAsync(d_ids.p, ctx->h_in.p, (size_t)nsel * 4, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_frac_pick, grid_for(nsel, 64), dim3(64), 0, st, S->F, S->W, (const int *)d_ids.p, nsel, (Pick *)d_pick.p);
-  std::vector<Pick> pick((size_t)nsel);
-  FR_HIP(hipMemcpyAsync(pick.data(), d_pick.p, (size_t)nsel * sizeof(Pick), hipMemcpyDeviceToHost, st));
+  FR_HIP(hipMemcpyAsync(ctx->h_out.p, d_pick.p, (size_t)nsel * sizeof(Pick), hipMemcpyDeviceToHost, st));
   FR_HIP(hipStreamSynchronize(st));
+  std::vector<Pick> pick((const Pick *)ctx->h_out.p, (const Pick *)ctx->h_out.p + nsel);
   // operand layout: the floe's stored ring, its partner's stored ring (none: empty)
-  std::vector<int> aoff((size_t)nsel + 1, 0), boff((size_t)nsel + 1, 0), ooff((size_t)nsel + 1, 0);
+  Packer offs;
+  const size_t o_a = offs.add((size_t)(nsel + 1) * 4), o_b = offs.add((size_t)(nsel + 1) * 4), o_o = offs.add((size_t)(nsel + 1) * 4);
+  int *aoff = (int *)(ctx->h_in.p + o_a), *boff = (int *)(ctx->h_in.p + o_b), *ooff = (int *)(ctx->h_in.p + o_o);   // (nothing of the first phase is pending: the stream is idle)
+  aoff[0] = boff[0] = ooff[0] = 0;
   for (int s = 0; s < nsel; ++s) {
     const int na = S->h_vert_off[ids[s]] - S->h_vert_off[ids[s] - 1];
     const int nb = pick[s].partner >= 0 ? S->h_vert_off[pick[s].partner + 1] - S->h_vert_off[pick[s].partner] : 0;
@@ -142,43 +149,44 @@ extern "C" int szFractureDeform(szContext *ctx, const int32_t *ids, int nsel, in
     ooff[s + 1] = ooff[s] + (nb ? 2 * (na + nb) + 8 : 0);
   }
   const i64 ta = aoff[nsel], tb = boff[nsel], to = ooff[nsel];
-  FR_TRY(sz_reserve(ctx, d_aoff, (size_t)(nsel + 1) * 4)); FR_TRY(sz_reserve(ctx, d_boff, (size_t)(nsel + 1) * 4)); FR_TRY(sz_reserve(ctx, d_ooff, (size_t)(nsel + 1) * 4));
+  // the results in one device block: ox | oy | Xi, Yi, area | changed | length
+  Packer res;
+  const size_t r_ox = res.add((size_t)to * 8 + 16), r_oy = res.add((size_t)to * 8 + 16), r_sc = res.add((size_t)nsel * 24), r_chg = res.add((size_t)nsel * 4), r_len = res.add((size_t)nsel * 4);
+  FR_TRY(sz_reserve(ctx, d_aoff, offs.at));
   FR_TRY(sz_reserve(ctx, ctx->in_fax, (size_t)ta * 8 + 16)); FR_TRY(sz_reserve(ctx, ctx->in_fay, (size_t)ta * 8 + 16));
   FR_TRY(sz_reserve(ctx, ctx->in_fbx, (size_t)tb * 8 + 16)); FR_TRY(sz_reserve(ctx, ctx->in_fby, (size_t)tb * 8 + 16));
-  FR_TRY(sz_reserve(ctx, d_stage, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_chg, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_len, (size_t)nsel * 4));
-  FR_TRY(sz_reserve(ctx, d_sc, (size_t)nsel * 24)); FR_TRY(sz_reserve(ctx, d_ox, (size_t)to * 8 + 16)); FR_TRY(sz_reserve(ctx, d_oy, (size_t)to * 8 + 16));
-  FR_HIP(hipMemcpyAsync(d_aoff.p, aoff.data(), (size_t)(nsel + 1) * 4, hipMemcpyHostToDevice, st));
-  FR_HIP(hipMemcpyAsync(d_boff.p, boff.data(), (size_t)(nsel + 1) * 4, hipMemcpyHostToDevice, st));
-  FR_HIP(hipMemcpyAsync(d_ooff.p, ooff.data(), (size_t)(nsel + 1) * 4, hipMemcpyHostToDevice, st));
+  FR_TRY(sz_reserve(ctx, d_stage, (size_t)nsel * 4)); FR_TRY(sz_reserve(ctx, d_ox, res.at));
+  FR_TRY(sz_stage_reserve(ctx, ctx->h_out, res.at));
+  FR_HIP(hipMemcpyAsync(d_aoff.p, ctx->h_in.p, offs.at, hipMemcpyHostToDevice, st));
+  const int *const dv_aoff = (const int *)((char *)d_aoff.p + o_a), *const dv_boff = (const int *)((char *)d_aoff.p + o_b), *const dv_ooff = (const int *)((char *)d_aoff.p + o_o);
   double *ax = (double *)ctx->in_fax.p, *ay = (double *)ctx->in_fay.p, *bx = (double *)ctx->in_fbx.p, *by = (double *)ctx->in_fby.p;
   hipLaunchKernelGGL(k_frac_rings, dim3((unsigned)nsel), dim3(64), 0, st, S->F, (const int *)d_ids.p, nsel, (const Pick *)d_pick.p,
-                     (const int *)d_aoff.p, (const int *)d_boff.p, ax, ay, bx, by);
+                     dv_aoff, dv_boff, ax, ay, bx, by);
   FR_HIP(hipGetLastError());
   // the two clips; a floe without a partner is an empty second operand: the clip of it is skipped by its stage flag
   szb::ClipArgs a;
   memset(&a, 0, sizeof(a));
   FR_TRY(szb::prepare(ctx, nsel, ta + tb, a));
-  a.fax = ax; a.fay = ay; a.fbx = bx; a.fby = by; a.aoff = (const int *)d_aoff.p; a.boff = (const int *)d_boff.p;
+  a.fax = ax; a.fay = ay; a.fbx = bx; a.fby = by; a.aoff = dv_aoff; a.boff = dv_boff;
   a.method = SZ_CLIP_INTERSECTION; a.fill_s = SZ_FILL_EVENODD; a.fill_c = SZ_FILL_EVENODD;
   FR_TRY(szb::run(ctx, a, nullptr));
-  hipLaunchKernelGGL(k_frac_shift, grid_for(nsel, 64), dim3(64), 0, st, a, nsel, (const Pick *)d_pick.p, (const int *)d_boff.p, bx, by, (int *)d_stage.p);
+  hipLaunchKernelGGL(k_frac_shift, grid_for(nsel, 64), dim3(64), 0, st, a, nsel, (const Pick *)d_pick.p, dv_boff, bx, by, (int *)d_stage.p);
   FR_HIP(hipGetLastError());
   szb::ClipArgs b;
   memset(&b, 0, sizeof(b));
   FR_TRY(szb::prepare(ctx, nsel, ta + tb, b));
-  b.fax = ax; b.fay = ay; b.fbx = bx; b.fby = by; b.aoff = (const int *)d_aoff.p; b.boff = (const int *)d_boff.p;
+  b.fax = ax; b.fay = ay; b.fbx = bx; b.fby = by; b.aoff = dv_aoff; b.boff = dv_boff;
   b.method = SZ_CLIP_DIFFERENCE; b.fill_s = SZ_FILL_EVENODD; b.fill_c = SZ_FILL_EVENODD;
   FR_TRY(szb::run(ctx, b, nullptr));
-  double *sc = (double *)d_sc.p;
-  hipLaunchKernelGGL(k_frac_finish, grid_for(nsel, 64), dim3(64), 0, st, b, S->F, (const int *)d_ids.p, nsel, (const int *)d_stage.p, (const int *)d_ooff.p,
-                     (int *)d_chg.p, sc, sc + nsel, sc + 2 * (size_t)nsel, (int *)d_len.p, (double *)d_ox.p, (double *)d_oy.p);
+  double *sc = (double *)((char *)d_ox.p + r_sc);
+  hipLaunchKernelGGL(k_frac_finish, grid_for(nsel, 64), dim3(64), 0, st, b, S->F, (const int *)d_ids.p, nsel, (const int *)d_stage.p, dv_ooff,
+                     (int *)((char *)d_ox.p + r_chg), sc, sc + nsel, sc + 2 * (size_t)nsel, (int *)((char *)d_ox.p + r_len), (double *)((char *)d_ox.p + r_ox), (double *)((char *)d_ox.p + r_oy));
   FR_HIP(hipGetLastError());
-  std::vector<int> chg, len;
-  std::vector<double> scal, hx, hy;
-  FR_TRY(fetch(ctx, chg, d_chg.p, (size_t)nsel)); FR_TRY(fetch(ctx, len, d_len.p, (size_t)nsel)); FR_TRY(fetch(ctx, scal, d_sc.p, (size_t)3 * nsel));
-  FR_TRY(fetch(ctx, hx, d_ox.p, (size_t)to)); FR_TRY(fetch(ctx, hy, d_oy.p, (size_t)to));
+  FR_HIP(hipMemcpyAsync(ctx->h_out.p, d_ox.p, res.at, hipMemcpyDeviceToHost, st));
   FR_HIP(hipStreamSynchronize(st));
   cleanup();
+  const int *chg = (const int *)(ctx->h_out.p + r_chg), *len = (const int *)(ctx->h_out.p + r_len);
+  const double *scal = (const double *)(ctx->h_out.p + r_sc), *hx = (const double *)(ctx->h_out.p + r_ox), *hy = (const double *)(ctx->h_out.p + r_oy);
   int64_t at = 0;
   for (int s = 0; s < nsel; ++s) {
     if (chg[s] == -2) return sz_fail(ctx, SZ_ERR_HIP, "szFractureDeform: floe %d: the reference's \"Clipper Error.\" condition", (int)ids[s]);
