@@ -44,14 +44,14 @@ def main():
     ctx = capi.Context(0)
     for n, gen in ((1, convex_pairs), (8, convex_pairs), (64, convex_pairs), (1, pairs), (8, pairs), (64, pairs)):
         a = gen(n)
-        for _ in range(10): out = ctx.polyclip_batch(*a, 0)
+        for _ in range(10): out = ctx.polyclip_batch(*a, 1)
         t0 = time.perf_counter()
-        for _ in range(reps): out = ctx.polyclip_batch(*a, 0)
+        for _ in range(reps): out = ctx.polyclip_batch(*a, 1)
         dt = (time.perf_counter() - t0) / reps
         fx = [np.round(v * 4294967296.0).astype(np.int64) for v in (a[0], a[1], a[3], a[4])]
-        for _ in range(10): ctx.clip_batch(fx[0], fx[1], a[2], fx[2], fx[3], a[5], 0)
+        for _ in range(10): ctx.clip_batch(fx[0], fx[1], a[2], fx[2], fx[3], a[5], 1)
         t0 = time.perf_counter()
-        for _ in range(reps): ctx.clip_batch(fx[0], fx[1], a[2], fx[2], fx[3], a[5], 0)
+        for _ in range(reps): ctx.clip_batch(fx[0], fx[1], a[2], fx[2], fx[3], a[5], 1)
         dt2 = (time.perf_counter() - t0) / reps
         print("pairs per call %3d  vertices in %5d  rings out %3d : szPolyclipBatch %.1f us/call, szClipBatch %.1f us/call (Python wrapper included)"
               % (n, len(a[0]) + len(a[3]), int(out[3][-1]), dt * 1e6, dt2 * 1e6), flush=True)

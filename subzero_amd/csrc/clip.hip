@@ -28,6 +28,7 @@ __device__ int sz_ph_k[1 << 16];
 #include "clip_batch.hpp"
 #include "offset.hpp"
 #include "trim.hpp"
+#include "teamclip.hpp"
 
 using szb::ClipArgs;
 
@@ -292,10 +293,47 @@ __global__ void __launch_bounds__(64) k_clip_front(ClipArgs a) {
   }
   const i64 nv = s.nv;
   RingI64 ra = {a.ax + a0, a.ay + a0}, rb = {a.bx + b0, a.by + b0};
+  const bool evenodd = a.fill_s == szv::FILL_EVENODD && a.fill_c == szv::FILL_EVENODD;
+  // Two short rings (what a Voronoi field hands polyclip 'int', floe_interactions.m:29): the team form of the clip
+  // first -- teamclip.hpp, the clip inside the step's pair kernel: one scanline per lane of a 32-lane team, a few
+  // microseconds where the sweep of one lane takes 70+.  It answers the plain case (two convex rings in general
+  // position, bit-identical to the reference's Execute: tests/test_team_clip_gpu.py) and hands everything else on.
+  if (a.method == szv::OP_INTERSECTION && evenodd && !a.no_team && na >= 3 && nb >= 3 && na <= (int)sztm::T_NV + 1 && nb <= (int)sztm::T_NV + 1) {
+    __shared__ sztm::ClipScratch team_scr;
+    __shared__ i64 team_ox[sztm::T_CAPV], team_oy[sztm::T_CAPV];
+    __shared__ int team_res[2];
+    int ea = na, eb = nb;
+    if (ra.x[ea - 1] == ra.x[0] && ra.y[ea - 1] == ra.y[0]) --ea;
+    if (rb.x[eb - 1] == rb.x[0] && rb.y[eb - 1] == rb.y[0]) --eb;
+    if (ea <= (int)sztm::T_NV && eb <= (int)sztm::T_NV) {
+      if (lane < 32) {
+        const sztm::Team<32> T = sztm::Team<32>::here();
+        for (int i = T.lane; i < ea; i += 32) { team_scr.fx[0][i] = ra.x[i]; team_scr.fy[0][i] = ra.y[i]; }
+        for (int i = T.lane; i < eb; i += 32) { team_scr.fx[1][i] = rb.x[i]; team_scr.fy[1][i] = rb.y[i]; }
+        T.sync(TEAM_SITE);
+        int n = 0;
+        const int st = sztm::team_clip(T, &team_scr, ea, eb, team_ox, team_oy, &n);
+        T.sync(TEAM_SITE);
+        if (T.lane == 0) { team_res[0] = st; team_res[1] = n; }
+      }
+      __syncthreads();
+      const int st = team_res[0], n = team_res[1];
+      if (st == szv::ST_OK && (i64)n <= s.cv && s.cr >= 2) {
+        for (int i = lane; i < n; i += 64) { a.ovx[s.voff + i] = team_ox[i]; a.ovy[s.voff + i] = team_oy[i]; }
+        if (lane == 0) {
+          a.oroff[s.roff] = 0;
+          if (n) a.oroff[s.roff + 1] = n;
+          a.ov_base[p] = s.voff; a.or_base[p] = s.roff;
+          a.status[p] = szv::ST_OK; a.nrings[p] = n ? 1 : 0;
+        }
+        return;
+      }
+      __syncthreads();
+    }
+  }
   i64 *tx = (i64 *)(a.ws + s.woff + s.wbytes - 16 * nv), *ty = tx + (na + nb);
   int ta = na, tb = nb;
   bool apart = false, tail = false;
-  const bool evenodd = a.fill_s == szv::FILL_EVENODD && a.fill_c == szv::FILL_EVENODD;
   const bool staged = a.method == szv::OP_INTERSECTION && na > 0 && nb > 0 && 16 * nv <= (i64)a.lds_per_lane;
   if (staged) {
     i64 *sx = (i64 *)clip_lds, *sy = sx + (na + nb);
@@ -551,6 +589,8 @@ int szb::run(szContext *ctx, ClipArgs &a, szClipStats *stats) {
   // per lane, as few pairs per wave as still give each of the 1024 SIMDs its two waves (252 VGPRs).
   a.lanes = clip_lanes(a.npairs);
   a.lds_per_lane = clip_lds_per_lane();
+  static const bool no_team = getenv("SUBZERO_CLIP_NO_TEAM") != nullptr;
+  a.no_team = no_team ? 1 : 0;
   const bool classes = a.lds_per_lane > 0 && !getenv("SUBZERO_CLIP_LANES") && !a.aring && !a.fax;
   if (!classes && !getenv("SUBZERO_CLIP_LDS")) a.lds_per_lane = 0;
   if ((i64)a.lds_per_lane * a.lanes > 160 * 1024) a.lds_per_lane = (160 * 1024 / a.lanes) & ~15;

@@ -20,6 +20,7 @@ struct ClipArgs {
   int mult;
   int lanes;                    // pairs per 64-lane wave (the rest of the lanes idle: fewer divergent sweeps per wave)
   int lds_per_lane;             // bytes of LDS per lane for the sweep's records (0: the HBM workspace only)
+  int no_team;                  // k_clip_front does not try the team form of the clip on short rings (SUBZERO_CLIP_NO_TEAM: comparisons)
   char *ws; i64 ws_cap;         // workspace arena
   i64 *ovx, *ovy; i64 ov_cap;   // result vertices
   int *oroff; i64 or_cap;       // result ring offsets (local to the pair's vertex slot)
