@@ -663,6 +663,15 @@ int upload(szContext *ctx, DevBuf &b, const T *src, size_t n) {
   return SZ_OK;
 }
 
+// polyclip.m:63-66 for a whole batch: the rings in metres -> Clipper's fixed point, so that a batch of doubles takes the
+// front pass and the sweeps of szClipBatch (the same to_fixed the per-access conversion of RingF64 applies)
+__global__ void k_rings_to_fixed(const double *fax, const double *fay, const double *fbx, const double *fby, i64 ta, i64 tb,
+                                 i64 *ax, i64 *ay, i64 *bx, i64 *by) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ta) { ax[i] = to_fixed(fax[i]); ay[i] = to_fixed(fay[i]); }
+  if (i < tb) { bx[i] = to_fixed(fbx[i]); by[i] = to_fixed(fby[i]); }
+}
+
 // A small batch (a pair or two per call is how polyclip.m calls the reference's mex): the six input arrays through the
 // pinned staging buffer into ONE device block with one copy, instead of six copies the runtime stages one by one.
 static int upload_packed(szContext *ctx, const void *const src[6], const size_t bytes[6], const char *dev[6], bool &done) {
@@ -914,8 +923,15 @@ int szPolyclipBatch(szContext *ctx, int npairs, const double *ax, const double *
   ClipArgs a;
   memset(&a, 0, sizeof(a));
   if ((rc = prepare(ctx, npairs, ta + tb, a))) return rc;
-  a.fax = (const double *)dev[0]; a.fay = (const double *)dev[1];
-  a.fbx = (const double *)dev[3]; a.fby = (const double *)dev[4];
+  if ((rc = sz_reserve(ctx, ctx->in_ax, (size_t)ta * 8 + 16)) || (rc = sz_reserve(ctx, ctx->in_ay, (size_t)ta * 8 + 16)) ||
+      (rc = sz_reserve(ctx, ctx->in_bx, (size_t)tb * 8 + 16)) || (rc = sz_reserve(ctx, ctx->in_by, (size_t)tb * 8 + 16))) return rc;
+  if (ta > 0 || tb > 0) {
+    const i64 m = ta > tb ? ta : tb;
+    hipLaunchKernelGGL(k_rings_to_fixed, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)dev[0], (const double *)dev[1],
+                       (const double *)dev[3], (const double *)dev[4], ta, tb, (i64 *)ctx->in_ax.p, (i64 *)ctx->in_ay.p, (i64 *)ctx->in_bx.p, (i64 *)ctx->in_by.p);
+    SZ_HIP(ctx, hipGetLastError());
+  }
+  a.ax = (const i64 *)ctx->in_ax.p; a.ay = (const i64 *)ctx->in_ay.p; a.bx = (const i64 *)ctx->in_bx.p; a.by = (const i64 *)ctx->in_by.p;
   a.aoff = (const int *)dev[2]; a.boff = (const int *)dev[5];
   a.method = method; a.fill_s = SZ_FILL_EVENODD; a.fill_c = SZ_FILL_EVENODD;
   if ((rc = run(ctx, a, nullptr))) return rc;

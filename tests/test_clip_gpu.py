@@ -57,6 +57,24 @@ def test_polyclip_doubles(ctx):
     assert np.array_equal(ox[:nv], r.x[:nv] / g.SCALE) and np.array_equal(oy[:nv], r.y[:nv] / g.SCALE)
 
 
+@pytest.mark.parametrize("gen,n", [(g.convex_pairs, 2000), (g.neighbour_pairs, 1500), (g.lattice_pairs, 1500), (g.shape_pairs, 250)])
+def test_polyclip_doubles_against_the_reference(ctx, gen, n):
+    # szPolyclipBatch converts the whole batch on the device (k_rings_to_fixed) and takes the front pass and the sweeps of
+    # szClipBatch (round 4): against the reference's own Clipper on the rings as polyclip.m:63-66 would convert them
+    ps = gen(n, seed=77)
+    ax, ay, aoff, bx, by, boff = ps.arrays()
+    fl = [v.astype(np.float64) / g.SCALE for v in (ax, ay, bx, by)]
+    fx = [np.rint(v * g.SCALE).astype(np.int64) for v in fl]
+    ps2 = g.ArraysPairSet((fx[0], fx[1], aoff, fx[2], fx[3], boff))
+    for m in range(4):
+        ox, oy, roff, proff, st = ctx.polyclip_batch(fl[0], fl[1], aoff, fl[2], fl[3], boff, m)
+        chk = g.run_ref(ps2, m) if g.ref_lib() is not None else g.run_host(ps2, m)
+        nr = chk.pair_ring_off[len(ps2)]; nv = chk.ring_off[nr]
+        assert np.array_equal(st, chk.status[:len(ps2)])
+        assert np.array_equal(proff, chk.pair_ring_off) and np.array_equal(roff[:nr + 1], chk.ring_off[:nr + 1])
+        assert np.array_equal(ox[:nv], chk.x[:nv] / g.SCALE) and np.array_equal(oy[:nv], chk.y[:nv] / g.SCALE)
+
+
 def test_empty_and_degenerate(ctx):
     ps = g.PairSet()
     sq = np.array([[0, 0], [4, 0], [4, 4], [0, 4]], np.int64) << 32
