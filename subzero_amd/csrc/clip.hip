@@ -849,6 +849,14 @@ int szClipPathsBatch(szContext *ctx, int npairs, const int64_t *ax, const int64_
     ring_off[0] = 0;
     return SZ_OK;
   }
+  // One contour per operand in every pair -- floe against floe, the way floe_interactions.m:29 calls polyclip and
+  // polyclip.m:73 the mex -- is szClipBatch's case (the ring CSR is then the pair CSR): front pass with the team form of
+  // the clip for short rings, trimming, sweeps with their records in LDS.
+  bool single = npairs > 0 && a_pair_off[0] == 0 && b_pair_off[0] == 0 && a_ring_off[0] == 0 && b_ring_off[0] == 0;
+  for (int p = 0; single && p < npairs; ++p) single = a_pair_off[p + 1] == p + 1 && b_pair_off[p + 1] == p + 1;
+  if (single)
+    return szClipBatch(ctx, npairs, ax, ay, a_ring_off, bx, by, b_ring_off, method, subj_fill, clip_fill, outx, outy, out_cap, ring_off, ring_cap,
+                       pair_ring_off, status);
   return clip_paths_host(ctx, npairs, ax, ay, a_ring_off, a_pair_off, bx, by, b_ring_off, b_pair_off, method, subj_fill, clip_fill,
                          outx, outy, out_cap, ring_off, ring_cap, pair_ring_off, status);
 }
